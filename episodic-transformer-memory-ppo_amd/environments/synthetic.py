@@ -1,0 +1,155 @@
+"""Synthetic environments used for the throughput metric and for parity tests.
+
+Two forms that generate *identical* streams:
+
+* ``SyntheticEnv`` -- one env with the reference's per-worker env API
+  (``reset() -> obs``; ``step(action) -> (obs, reward, done, info-or-None)``;
+  properties ``observation_space``, ``action_space``, ``max_episode_steps``;
+  cf. /root/reference/worker.py:20-34, README.md:216).  Used behind the pipe
+  ``Worker`` and when the real reference is driven for golden vectors.
+* ``SyntheticVecEnv`` -- the batched in-process form the MI355X trainer steps
+  (one call per rollout step for all workers, observations written straight
+  into a caller-provided -- normally pinned -- host buffer).
+
+Workload (BASELINE.md section 3 / SURVEY.md section 8d): observation ~ U[0,1) float32 of
+``obs_shape`` from ``numpy.random.default_rng(seed + worker_id)``, reward
+Bernoulli(0.05), done when the episode reaches ``max_episode_steps`` or with
+probability ``p_done`` per step.  Observations are drawn once per worker into
+a ring of ``pool`` frames at construction and then replayed (one frame per
+emitted observation), so that RNG cost -- which is not what the metric is about
+-- stays out of the timed region while every step still hands a fresh host
+buffer to the trainer.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+_CHUNK = 4096
+
+
+class _WorkerStream:
+    """Per-worker RNG state: frame ring + chunked (reward, done) uniforms."""
+
+    def __init__(self, worker_id, obs_shape, seed, pool):
+        self.rng = np.random.default_rng(seed + worker_id)
+        self.frames = self.rng.random((pool,) + tuple(obs_shape), dtype=np.float32)
+        self.u = None
+        self.upos = _CHUNK
+
+    def next_uniforms(self):
+        if self.upos >= _CHUNK:
+            self.u = self.rng.random((_CHUNK, 2))
+            self.upos = 0
+        row = self.u[self.upos]
+        self.upos += 1
+        return row
+
+
+class SyntheticEnv:
+    """Single env, reference env API.  ``worker_id`` selects the RNG stream."""
+
+    def __init__(self, obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=0, worker_id=0,
+                 p_reward=0.05, p_done=0.02, pool=64):
+        self._shape = tuple(obs_shape)
+        self._n_act = int(num_actions)
+        self._T = int(max_episode_steps)
+        self._p_r, self._p_d = float(p_reward), float(p_done)
+        self._s = _WorkerStream(worker_id, self._shape, seed, pool)
+        self._pool = pool
+        self._cursor = 0
+        self._t = 0
+        self._ret = 0.0
+
+    @property
+    def observation_space(self):
+        return SimpleNamespace(shape=self._shape, low=0.0, high=1.0, dtype=np.float32)
+
+    @property
+    def action_space(self):
+        return SimpleNamespace(n=self._n_act)
+
+    @property
+    def max_episode_steps(self):
+        return self._T
+
+    def _emit(self):
+        frame = self._s.frames[self._cursor % self._pool]
+        self._cursor += 1
+        return frame
+
+    def reset(self, **kwargs):
+        self._t = 0
+        self._ret = 0.0
+        return self._emit()
+
+    def step(self, action):
+        u_r, u_d = self._s.next_uniforms()
+        reward = 1.0 if u_r < self._p_r else 0.0
+        self._t += 1
+        self._ret += reward
+        done = bool(self._t >= self._T or u_d < self._p_d)
+        if done:
+            # terminal observation is never consumed by the trainer (it resets immediately): no frame is spent
+            return np.zeros(self._shape, dtype=np.float32), reward, True, {"reward": self._ret, "length": self._t}
+        return self._emit(), reward, False, None
+
+    def close(self):
+        return None
+
+
+class SyntheticVecEnv:
+    """Batched form of ``num_envs`` ``SyntheticEnv`` instances (same streams, auto-reset on done)."""
+
+    def __init__(self, num_envs, obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=0,
+                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0):
+        self.num_envs = int(num_envs)
+        self.observation_space_shape = tuple(obs_shape)
+        self.num_actions = int(num_actions)
+        self.max_episode_steps = int(max_episode_steps)
+        self._p_r, self._p_d = float(p_reward), float(p_done)
+        self._pool = pool
+        streams = [_WorkerStream(first_worker_id + w, obs_shape, seed, pool) for w in range(self.num_envs)]
+        self._rngs = [s.rng for s in streams]
+        # [W, pool, *obs]: one strided copy per step (all cursors advance in lock-step)
+        self._frames = np.stack([s.frames for s in streams], axis=0)
+        self._u = np.empty((self.num_envs, _CHUNK, 2))
+        self._upos = _CHUNK
+        self._cursor = 0
+        self._t = np.zeros(self.num_envs, dtype=np.int64)
+        self._ret = np.zeros(self.num_envs, dtype=np.float64)
+
+    def _emit(self, out):
+        frame = self._frames[:, self._cursor % self._pool]
+        self._cursor += 1
+        if out is None:
+            return frame.copy()
+        np.copyto(out, frame)
+        return out
+
+    def reset(self, out=None):
+        self._t[:] = 0
+        self._ret[:] = 0.0
+        return self._emit(out)
+
+    def step(self, actions, out=None):
+        if self._upos >= _CHUNK:
+            for w, rng in enumerate(self._rngs):
+                self._u[w] = rng.random((_CHUNK, 2))
+            self._upos = 0
+        u = self._u[:, self._upos]
+        self._upos += 1
+        rewards = (u[:, 0] < self._p_r).astype(np.float32)
+        self._t += 1
+        self._ret += rewards
+        dones = (self._t >= self.max_episode_steps) | (u[:, 1] < self._p_d)
+        infos = [None] * self.num_envs
+        if dones.any():
+            for w in np.flatnonzero(dones):
+                infos[w] = {"reward": float(self._ret[w]), "length": int(self._t[w])}
+            self._t[dones] = 0
+            self._ret[dones] = 0.0
+        obs = self._emit(out)  # for finished workers this frame *is* the reset observation
+        return obs, rewards, dones, infos
+
+    def close(self):
+        return None
