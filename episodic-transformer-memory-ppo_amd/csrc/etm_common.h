@@ -1,0 +1,34 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA f32 32x32x2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/etm_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ETM_WAVE 64
+
+// C/D fragment of v_mfma_f32_32x32x2_f32: lane holds column (lane & 31); register r holds row
+//   (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)          (cdna_hip_programming.md section 3)
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+static inline int etm_launch_status() { return (int)hipGetLastError(); }

@@ -1,0 +1,502 @@
+// Kernel #1 (backward) for gfx950: gradients of the fused episodic-memory attention wrt q, Wk, Wv
+// (+ norm_kv gain/bias and a learned positional table).  The window itself is detached in the reference
+// (/root/reference transformer.py:248), so nothing flows into the memory bank.
+//
+// With K = X Wk^T, V = X Wv^T, e = K q, a = softmax(fill(e) / sqrt(D)), ctx = a V   (per sample n, head h):
+//   B1  scores  : da[l] = V[l].dctx ; ds = a (da - a.da) ; dE[l] = mask[l] ? ds / sqrt(D) : 0 ; dq = sum_l dE[l] K[l]
+//   B2  weights : dWk = sum_{n,l} (dE[n,h,l] q[n,:])^T X[n,l,:]      dWv = sum_{n,l} (a[n,h,l] dctx[n,:])^T X[n,l,:]
+//                 -- the dense [2D, N*L] x [N*L, D] contraction, fp32 MFMA, split-K over the window rows.  The
+//                 left operand (dK | dV, rank-1 per sample and head) is generated on the fly while staging to LDS,
+//                 the right operand is re-gathered from the memory bank; neither is materialised in HBM.
+//   B3  (pre-LN / learned positions only): dX[n,l,:] = sum_h dE[n,h,l] (Wk_h^T q_h) + a[n,h,l] (Wv_h^T dctx_h)
+//                 -> LayerNorm backward -> d gain, d bias, d pos rows.
+#include "etm_common.h"
+
+namespace {
+
+constexpr int TM = 128;  // dW tile: output-feature rows (o over [Wk ; Wv] = 2D)
+constexpr int TN = 128;  // dW tile: input-feature cols (i over D)
+constexpr int RB = 32;   // window rows per reduction chunk (one chunk never straddles two samples)
+
+struct BwdParams {
+  const float *bank;
+  long long ep_stride, row_stride;
+  const long long *ep, *win, *pidx;
+  const unsigned char *mask;
+  const float *pos, *ln_g, *ln_b;
+  const float *q, *wk, *wv, *att, *k_save, *v_save, *ln_stats, *d_ctx;
+  float *d_q, *d_e, *d_wk, *d_wv, *d_ln_g, *d_ln_b, *d_pos;
+  float *partial;  // [splits, 2D, D]
+  float *uw;       // [2, N, H, D]
+  int N, L, Lp, D, H, hd;
+  int splits, chunks, chunks_per_split, tiles_m, tiles_n;
+  float sqrt_d;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// B1: one workgroup per sample.
+__global__ __launch_bounds__(256) void bwd_scores_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int L = p.L, D = p.D, H = p.H, hd = p.hd;
+  float *dctx_s = sm;            // D
+  float *att_s = dctx_s + D;     // H*L
+  float *datt_s = att_s + H * L; // H*L
+  float *de_s = datt_s + H * L;  // H*L
+  for (int i = tid; i < D; i += 256) dctx_s[i] = p.d_ctx[(long long)n * D + i];
+  for (int i = tid; i < H * L; i += 256) att_s[i] = p.att[(long long)n * H * L + i];
+  __syncthreads();
+
+  // da[h][l] = V[n,l,h,:] . dctx[n,h,:]   (8 lanes per (l,h) pair; pairs are contiguous in memory)
+  const int pairs = L * H;
+  const int sub = lane & 7;
+  for (int p0 = 0; p0 < pairs; p0 += 32) {
+    const int pr = p0 + wave * 8 + (lane >> 3);
+    float s = 0.f;
+    if (pr < pairs) {
+      const int l = pr / H, h = pr - l * H;
+      const float *vrow = p.v_save + ((long long)n * L + l) * D + h * hd;
+      for (int c = sub * 4; c < hd; c += 32) {
+        const float4 v = *reinterpret_cast<const float4 *>(vrow + c);
+        const float4 d = *reinterpret_cast<const float4 *>(dctx_s + h * hd + c);
+        s += v.x * d.x + v.y * d.y + v.z * d.z + v.w * d.w;
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (pr < pairs && sub == 0) {
+      const int l = pr / H, h = pr - l * H;
+      datt_s[h * L + l] = s;
+    }
+  }
+  __syncthreads();
+
+  // softmax backward + mask, one wave per head
+  for (int h = wave; h < H; h += 4) {
+    float a[2], da[2];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int l = lane + 64 * j;
+      a[j] = (l < L) ? att_s[h * L + l] : 0.f;
+      da[j] = (l < L) ? datt_s[h * L + l] : 0.f;
+      dot += a[j] * da[j];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int l = lane + 64 * j;
+      if (l < L) {
+        float de = a[j] * (da[j] - dot) / p.sqrt_d;
+        if (p.mask[(long long)n * L + l] == 0) de = 0.f;  // masked_fill blocks the gradient
+        de_s[h * L + l] = de;
+        p.d_e[((long long)n * H + h) * L + l] = de;
+      }
+    }
+  }
+  __syncthreads();
+
+  // dq[d] = sum_l dE[h(d)][l] * K[n,l,d]
+  for (int d = tid; d < D; d += 256) {
+    const int h = d / hd;
+    const float *kcol = p.k_save + (long long)n * L * D + d;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int l = 0;
+    for (; l + 4 <= L; l += 4) {
+      s0 += de_s[h * L + l] * kcol[(long long)l * D];
+      s1 += de_s[h * L + l + 1] * kcol[(long long)(l + 1) * D];
+      s2 += de_s[h * L + l + 2] * kcol[(long long)(l + 2) * D];
+      s3 += de_s[h * L + l + 3] * kcol[(long long)(l + 3) * D];
+    }
+    for (; l < L; ++l) s0 += de_s[h * L + l] * kcol[(long long)l * D];
+    p.d_q[(long long)n * D + d] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B2: split-K MFMA contraction.  Workgroup = 4 waves in a 2x2 arrangement, each wave a 64x64 block of the
+// 128x128 output tile (2x2 accumulators of 32x32).
+struct RowIdx {          // per-thread description of its 4 staged rows of a chunk
+  long long xoff[4];     // offset of the window row in the bank, -1 if the row does not exist (padding / n >= N)
+  long long poff[4];     // offset of the positional row
+  float mu[4], rs[4];    // LayerNorm statistics
+  float scal[4];         // dE[n,h,l] (Wk half) or att[n,h,l] (Wv half) for this thread's output-feature group
+  int n;
+};
+
+template <bool HAS_LN, bool HAS_POS>
+__global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float As[RB * TM];
+  __shared__ __attribute__((aligned(16))) float Bs[RB * TN];
+
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int split = blockIdx.x / tiles;
+  const int tile = blockIdx.x - split * tiles;
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int o0 = tm * TM, i0 = tn * TN;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int L = p.L, Lp = p.Lp, D = p.D, H = p.H, N = p.N;
+
+  // staging role: float4 column c4 (of 32) and rows rr + 8 i
+  const int c4 = tid & 31, rr = tid >> 5;
+  const int o = o0 + c4 * 4;             // output feature of the G (left) operand
+  const bool o_ok = o < 2 * D;
+  const bool v_half = o >= D;            // false: Wk rows (dE * q), true: Wv rows (att * dctx)
+  const int oo = o - (v_half ? D : 0);
+  const int h_o = o_ok ? oo / p.hd : 0;
+  const float *vec_src = v_half ? p.d_ctx : p.q;
+  const float *scal_src = v_half ? p.att : p.d_e;
+  const int ii = i0 + c4 * 4;            // input feature of the X (right) operand
+  const bool i_ok = ii < D;
+
+  float4 lng = make_float4(0.f, 0.f, 0.f, 0.f), lnb = lng;
+  if (HAS_LN && i_ok) {
+    lng = *reinterpret_cast<const float4 *>(p.ln_g + ii);
+    lnb = *reinterpret_cast<const float4 *>(p.ln_b + ii);
+  }
+
+  auto load_idx = [&](int c, RowIdx &I) {
+    const long long R0 = (long long)c * RB;
+    const int n = (int)(R0 / Lp);
+    const int lbase = (int)(R0 - (long long)n * Lp);
+    I.n = n;
+    const long long e = (n < N) ? (p.ep ? p.ep[n] : n) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int l = lbase + rr + 8 * i;
+      I.xoff[i] = -1;
+      I.poff[i] = 0;
+      I.mu[i] = 0.f;
+      I.rs[i] = 0.f;
+      I.scal[i] = 0.f;
+      if (n < N && l < L) {
+        const long long row = (long long)n * L + l;
+        I.xoff[i] = e * p.ep_stride + p.win[row] * p.row_stride;
+        if (HAS_POS) I.poff[i] = p.pidx[row] * D;
+        if (HAS_LN) {
+          I.mu[i] = p.ln_stats[row * 2];
+          I.rs[i] = p.ln_stats[row * 2 + 1];
+        }
+        if (o_ok) I.scal[i] = scal_src[((long long)n * H + h_o) * L + l];
+      }
+    }
+  };
+
+  float4 ga[4], xb[4];
+  auto load_data = [&](const RowIdx &I) {
+    float4 vec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o_ok && I.n < N) vec = *reinterpret_cast<const float4 *>(vec_src + (long long)I.n * D + oo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ga[i] = make_float4(vec.x * I.scal[i], vec.y * I.scal[i], vec.z * I.scal[i], vec.w * I.scal[i]);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i_ok && I.xoff[i] >= 0) {
+        v = *reinterpret_cast<const float4 *>(p.bank + I.xoff[i] + ii);
+        if (HAS_POS) {
+          const float4 pv = *reinterpret_cast<const float4 *>(p.pos + I.poff[i] + ii);
+          v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+        }
+        if (HAS_LN) {
+          v.x = (v.x - I.mu[i]) * I.rs[i] * lng.x + lnb.x;
+          v.y = (v.y - I.mu[i]) * I.rs[i] * lng.y + lnb.y;
+          v.z = (v.z - I.mu[i]) * I.rs[i] * lng.z + lnb.z;
+          v.w = (v.w - I.mu[i]) * I.rs[i] * lng.w + lnb.w;
+        }
+      }
+      xb[i] = v;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (c_begin < c_end) {
+    RowIdx I;
+    load_idx(c_begin, I);
+    load_data(I);
+    if (c_begin + 1 < c_end) load_idx(c_begin + 1, I);
+    for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float4 *>(&As[(rr + 8 * i) * TM + c4 * 4]) = ga[i];
+        *reinterpret_cast<float4 *>(&Bs[(rr + 8 * i) * TN + c4 * 4]) = xb[i];
+      }
+      __syncthreads();
+      if (c + 1 < c_end) {
+        load_data(I);                           // rows of chunk c+1 (indices fetched one iteration ago)
+        if (c + 2 < c_end) load_idx(c + 2, I);  // indices of chunk c+2
+      }
+#pragma unroll
+      for (int s = 0; s < RB / 2; ++s) {
+        const int r = 2 * s + half;
+        const float a0 = As[r * TM + wm * 64 + col];
+        const float a1 = As[r * TM + wm * 64 + 32 + col];
+        const float b0 = Bs[r * TN + wn * 64 + col];
+        const float b1 = Bs[r * TN + wn * 64 + 32 + col];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // partial[split][o][i]
+  float *out = p.partial + (long long)split * 2 * D * D;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int icol = i0 + wn * 64 + b * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = o0 + wm * 64 + a * 32 + mfma32_row(r, lane);
+        if (orow < 2 * D && icol < D) out[(long long)orow * D + icol] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void bwd_dw_reduce_kernel(const float *partial, float *d_wk, float *d_wv, int splits, int D) {
+  const long long per = (long long)2 * D * D;
+  const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx >= per) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4 *>(partial + (long long)k * per + idx);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const long long half_sz = (long long)D * D;
+  float *dst = (idx < half_sz) ? d_wk + idx : d_wv + (idx - half_sz);
+  *reinterpret_cast<float4 *>(dst) = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B3a: u[n,h,:] = Wk_h^T q[n,h,:], w[n,h,:] = Wv_h^T dctx[n,h,:]   (8 samples per workgroup share the weight reads)
+__global__ __launch_bounds__(256) void bwd_uw_kernel(const BwdParams p) {
+  constexpr int SB = 8;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = p.D, H = p.H, hd = p.hd, N = p.N;
+  const int which = blockIdx.y;  // 0: u from (q, Wk); 1: w from (dctx, Wv)
+  const float *vec = which ? p.d_ctx : p.q;
+  const float *W = which ? p.wv : p.wk;
+  float *out = p.uw + (long long)which * N * H * D;
+  const int n0 = blockIdx.x * SB, tid = threadIdx.x;
+  float *vs = sm;  // [SB][D]
+  for (int i = tid; i < SB * D; i += 256) {
+    const int s = i / D, c = i - s * D;
+    vs[i] = (n0 + s < N) ? vec[(long long)(n0 + s) * D + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += 256) {
+    for (int h = 0; h < H; ++h) {
+      float acc[SB];
+#pragma unroll
+      for (int s = 0; s < SB; ++s) acc[s] = 0.f;
+      for (int c = 0; c < hd; ++c) {
+        const int orow = h * hd + c;
+        const float wv = W[(long long)orow * D + i];
+#pragma unroll
+        for (int s = 0; s < SB; ++s) acc[s] += vs[s * D + orow] * wv;
+      }
+#pragma unroll
+      for (int s = 0; s < SB; ++s)
+        if (n0 + s < N) out[((long long)(n0 + s) * H + h) * D + i] = acc[s];
+    }
+  }
+}
+
+// B3b: one workgroup per sample; wave per window row.  dy = dX row; accumulates d gain / d bias; scatters d pos.
+template <bool HAS_LN>
+__global__ __launch_bounds__(256) void bwd_dx_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int L = p.L, D = p.D, H = p.H, N = p.N;
+  float *u_s = sm;               // [H][D]
+  float *w_s = u_s + H * D;      // [H][D]
+  float *red = w_s + H * D;      // [4][2][D]  per-wave partial d gain / d bias
+  for (int i = tid; i < H * D; i += 256) {
+    u_s[i] = p.uw[(long long)n * H * D + i];
+    w_s[i] = p.uw[(long long)N * H * D + (long long)n * H * D + i];
+  }
+  __syncthreads();
+  float dg[16], db[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dg[j] = db[j] = 0.f;
+  const long long e = p.ep ? p.ep[n] : n;
+  for (int l = wave; l < L; l += 4) {
+    const long long row = (long long)n * L + l;
+    const float *xp = p.bank + e * p.ep_stride + p.win[row] * p.row_stride;
+    const float *pp = p.pos ? p.pos + p.pidx[row] * D : nullptr;
+    float mu = 0.f, rs = 1.f;
+    if (HAS_LN) {
+      mu = p.ln_stats[row * 2];
+      rs = p.ln_stats[row * 2 + 1];
+    }
+    float dy[16], xh[16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + 64 * j;
+      dy[j] = 0.f;
+      xh[j] = 0.f;
+      if (c < D) {
+        float acc = 0.f;
+        for (int h = 0; h < H; ++h)
+          acc += p.d_e[((long long)n * H + h) * L + l] * u_s[h * D + c] + p.att[((long long)n * H + h) * L + l] * w_s[h * D + c];
+        dy[j] = acc;
+        if (HAS_LN) {
+          float x = xp[c];
+          if (pp) x += pp[c];
+          xh[j] = (x - mu) * rs;
+          dg[j] += acc * xh[j];
+          db[j] += acc;
+          const float gdy = acc * p.ln_g[c];
+          s1 += gdy;
+          s2 += gdy * xh[j];
+        }
+      }
+    }
+    if (p.d_pos) {
+      float m1 = 0.f, m2 = 0.f;
+      if (HAS_LN) {
+        m1 = wave_sum(s1) / (float)D;
+        m2 = wave_sum(s2) / (float)D;
+      }
+      float *dp = p.d_pos + p.pidx[row] * D;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int c = lane + 64 * j;
+        if (c < D) {
+          float dx = dy[j];
+          if (HAS_LN) dx = rs * (dy[j] * p.ln_g[c] - m1 - xh[j] * m2);
+          atomicAdd(dp + c, dx);
+        }
+      }
+    }
+  }
+  if (HAS_LN && p.d_ln_g) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = lane + 64 * j;
+      if (c < D) {
+        red[(wave * 2 + 0) * D + c] = dg[j];
+        red[(wave * 2 + 1) * D + c] = db[j];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += 256) {
+      float g = 0.f, b = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        g += red[(w * 2 + 0) * D + c];
+        b += red[(w * 2 + 1) * D + c];
+      }
+      atomicAdd(p.d_ln_g + c, g);
+      atomicAdd(p.d_ln_b + c, b);
+    }
+  }
+}
+
+struct DwPlan {
+  int Lp, chunks, tiles_m, tiles_n, splits, chunks_per_split;
+};
+
+DwPlan plan_dw(int N, int L, int D) {
+  DwPlan pl;
+  pl.Lp = ((L + 31) / 32) * 32;
+  pl.chunks = (int)(((long long)N * pl.Lp) / RB);
+  pl.tiles_m = (2 * D + TM - 1) / TM;
+  pl.tiles_n = (D + TN - 1) / TN;
+  const int tiles = pl.tiles_m * pl.tiles_n;
+  int splits = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU on 256 CUs
+  if (splits > pl.chunks) splits = pl.chunks;
+  if (splits < 1) splits = 1;
+  pl.chunks_per_split = (pl.chunks + splits - 1) / splits;
+  pl.splits = (pl.chunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" int64_t etm_mha_bwd_workspace_bytes(int N, int L, int D) {
+  if (N <= 0 || L <= 0 || D <= 0) return 0;
+  const DwPlan pl = plan_dw(N, L, D);
+  // split-K partials + (u, w) vectors for the LayerNorm / positional path (H <= D/32 heads, bounded by D)
+  return ((int64_t)pl.splits * 2 * D * D + (int64_t)2 * N * D * (D / 32)) * (int64_t)sizeof(float);
+}
+
+extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                           const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,
+                           const float *q, const float *wk, const float *wv, const float *att, const float *k_save,
+                           const float *v_save, const float *ln_stats, const float *d_ctx, float *d_q, float *d_e, float *d_wk,
+                           float *d_wv, float *d_ln_g, float *d_ln_b, float *d_pos, void *workspace, int64_t workspace_bytes,
+                           int N, int L, int D, int H, void *stream) {
+  if (!bank || !win || !mask || !q || !wk || !wv || !att || !k_save || !v_save || !d_ctx || !d_q || !d_e || !d_wk || !d_wv ||
+      !workspace)
+    return ETM_EINVAL;
+  if (N <= 0 || L <= 0 || D <= 0 || H <= 0 || D % H != 0) return ETM_EINVAL;
+  if ((pos != nullptr) != (pidx != nullptr)) return ETM_EINVAL;
+  if ((ln_g != nullptr) != (ln_b != nullptr)) return ETM_EINVAL;
+  if (ln_g && !ln_stats) return ETM_EINVAL;
+  if ((d_ln_g != nullptr) != (d_ln_b != nullptr)) return ETM_EINVAL;
+  if (d_ln_g && !ln_g) return ETM_EINVAL;
+  if (d_pos && !pos) return ETM_EINVAL;
+  const int hd = D / H;
+  if (D % 32 != 0 || hd % 32 != 0 || hd > 128 || L > 128 || D > 1024) return ETM_EUNSUPPORTED;
+  if (workspace_bytes < etm_mha_bwd_workspace_bytes(N, L, D)) return ETM_EWORKSPACE;
+  if ((size_t)(2 * H * D + 8 * D) * sizeof(float) > 64 * 1024 || (size_t)(D + 3 * H * L) * sizeof(float) > 64 * 1024)
+    return ETM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const DwPlan pl = plan_dw(N, L, D);
+
+  BwdParams p;
+  p.bank = bank; p.ep_stride = ep_stride; p.row_stride = row_stride;
+  p.ep = (const long long *)ep; p.win = (const long long *)win; p.pidx = (const long long *)pidx;
+  p.mask = mask; p.pos = pos; p.ln_g = ln_g; p.ln_b = ln_b;
+  p.q = q; p.wk = wk; p.wv = wv; p.att = att; p.k_save = k_save; p.v_save = v_save; p.ln_stats = ln_stats; p.d_ctx = d_ctx;
+  p.d_q = d_q; p.d_e = d_e; p.d_wk = d_wk; p.d_wv = d_wv; p.d_ln_g = d_ln_g; p.d_ln_b = d_ln_b; p.d_pos = d_pos;
+  p.partial = (float *)workspace;
+  p.uw = p.partial + (long long)pl.splits * 2 * D * D;
+  p.N = N; p.L = L; p.Lp = pl.Lp; p.D = D; p.H = H; p.hd = hd;
+  p.splits = pl.splits; p.chunks = pl.chunks; p.chunks_per_split = pl.chunks_per_split;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.sqrt_d = (float)sqrt((double)D);
+
+  int rc;
+  // B1
+  const size_t sm1 = (size_t)(D + 3 * H * L) * sizeof(float);
+  hipLaunchKernelGGL(bwd_scores_kernel, dim3(N), dim3(256), sm1, st, p);
+  if ((rc = etm_launch_status())) return rc;
+  // B2
+  const dim3 g2((unsigned)(pl.splits * pl.tiles_m * pl.tiles_n));
+  const bool has_ln = ln_g != nullptr, has_pos = pos != nullptr;
+  if (has_ln && has_pos) hipLaunchKernelGGL((bwd_dw_kernel<true, true>), g2, dim3(256), 0, st, p);
+  else if (has_ln) hipLaunchKernelGGL((bwd_dw_kernel<true, false>), g2, dim3(256), 0, st, p);
+  else if (has_pos) hipLaunchKernelGGL((bwd_dw_kernel<false, true>), g2, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((bwd_dw_kernel<false, false>), g2, dim3(256), 0, st, p);
+  if ((rc = etm_launch_status())) return rc;
+  const long long per = (long long)2 * D * D;
+  hipLaunchKernelGGL(bwd_dw_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, st, p.partial, d_wk, d_wv,
+                     pl.splits, D);
+  if ((rc = etm_launch_status())) return rc;
+  // B3
+  if (d_ln_g || d_pos) {
+    hipLaunchKernelGGL(bwd_uw_kernel, dim3((unsigned)((N + 7) / 8), 2), dim3(256), (size_t)8 * D * sizeof(float), st, p);
+    if ((rc = etm_launch_status())) return rc;
+    const size_t sm3 = (size_t)(2 * H * D + 8 * D) * sizeof(float);
+    if (has_ln) hipLaunchKernelGGL((bwd_dx_kernel<true>), dim3(N), dim3(256), sm3, st, p);
+    else hipLaunchKernelGGL((bwd_dx_kernel<false>), dim3(N), dim3(256), sm3, st, p);
+    if ((rc = etm_launch_status())) return rc;
+  }
+  return ETM_OK;
+}

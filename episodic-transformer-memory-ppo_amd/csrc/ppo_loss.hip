@@ -1,0 +1,189 @@
+// Kernel #3: PPO clipped surrogate + clipped value loss + entropy bonus, forward and backward in one pass
+// (replaces /root/reference trainer.py:276-304 and :315-316 for one action branch).
+//
+// Sample-parallel, coalesced; per-workgroup partial sums go to a scratch buffer and a one-workgroup finalize kernel
+// produces the six statistics, so results are deterministic (no float atomics).  Tie handling of torch.min /
+// torch.max (gradient split in half) and the inclusive range of torch.clamp's backward are reproduced.
+// HBM traffic: 28 + 8 A bytes per sample.
+#include "etm_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict__ adv, int N, float *__restrict__ stats3) {
+  __shared__ float red[16];
+  __shared__ float mean_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f;
+  for (int i = tid; i < N; i += 1024) s += adv[i];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    mean_s = t / (float)N;
+  }
+  __syncthreads();
+  const float mean = mean_s;
+  float m2 = 0.f;
+  for (int i = tid; i < N; i += 1024) {
+    const float d = adv[i] - mean;
+    m2 += d * d;
+  }
+  m2 = wave_sum(m2);
+  __syncthreads();
+  if (lane == 0) red[wave] = m2;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    stats3[0] = (float)N;
+    stats3[1] = mean;
+    stats3[2] = t;
+  }
+}
+
+struct LossParams {
+  const float *logits;
+  const long long *actions;
+  long long action_stride;
+  const float *old_logp;
+  long long logp_stride;
+  const float *adv, *old_value, *value, *adv_stats3;
+  float clip, clip_lo, clip_hi, vf_coef, beta, pol_scale, ent_scale, val_scale;
+  int include_value;
+  float *d_logits, *d_value, *partials;
+  int N, A;
+};
+
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p) {
+  __shared__ float red[4][5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * 256 + tid;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // policy, value, entropy, kl, clip fraction
+  if (n < p.N) {
+    const int A = p.A;
+    const float cnt = p.adv_stats3[0], mean = p.adv_stats3[1], m2 = p.adv_stats3[2];
+    const float stdv = sqrtf(m2 / (cnt - 1.0f));            // torch.std: unbiased
+    const float a_raw = p.adv[n];
+    const float a_n = (a_raw - mean) / (stdv + 1e-8f);
+    const float *lg = p.logits + (long long)n * A;
+    float mx = -INFINITY;
+    for (int j = 0; j < A; ++j) mx = fmaxf(mx, lg[j]);
+    float se = 0.f;
+    for (int j = 0; j < A; ++j) se += expf(lg[j] - mx);
+    const float lse = mx + logf(se);
+    const int act = (int)p.actions[(long long)n * p.action_stride];
+    const float lp = lg[act] - lse;
+    float ent = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float l = lg[j] - lse;
+      ent -= expf(l) * l;
+    }
+    const float log_ratio = lp - p.old_logp[(long long)n * p.logp_stride];
+    const float ratio = expf(log_ratio);
+    const bool in_range = (ratio >= p.clip_lo) && (ratio <= p.clip_hi);
+    const float s1 = ratio * a_n;
+    const float s2 = fminf(fmaxf(ratio, p.clip_lo), p.clip_hi) * a_n;
+    acc[0] = fminf(s1, s2);
+    float g_ratio;  // d min(s1, s2) / d ratio
+    if (s1 < s2) g_ratio = a_n;
+    else if (s1 > s2) g_ratio = in_range ? a_n : 0.f;
+    else g_ratio = 0.5f * a_n + (in_range ? 0.5f * a_n : 0.f);
+    acc[2] = ent;
+    acc[3] = (ratio - 1.0f) - log_ratio;
+    acc[4] = (fabsf(ratio - 1.0f) > p.clip) ? 1.f : 0.f;
+    // d loss / d logits
+    const float cpol = -p.pol_scale * g_ratio * ratio;
+    const float cent = -p.beta * p.ent_scale;
+    float *dl = p.d_logits + (long long)n * A;
+    for (int j = 0; j < A; ++j) {
+      const float l = lg[j] - lse;
+      const float pj = expf(l);
+      const float d_lp = ((j == act) ? 1.f : 0.f) - pj;   // d log p[act] / d logit_j
+      const float d_ent = -pj * (l + ent);                // d entropy / d logit_j
+      dl[j] = cpol * d_lp + cent * d_ent;
+    }
+    if (p.include_value) {
+      const float v = p.value[n], vo = p.old_value[n];
+      const float ret = vo + a_raw;
+      const float dv = v - vo;
+      const bool in_v = (dv >= -p.clip) && (dv <= p.clip);
+      const float vc = vo + fminf(fmaxf(dv, -p.clip), p.clip);
+      const float e1 = v - ret, e2 = vc - ret;
+      const float v1 = e1 * e1, v2 = e2 * e2;
+      acc[1] = fmaxf(v1, v2);
+      const float g2 = in_v ? 2.f * e2 : 0.f;
+      float gv;
+      if (v1 > v2) gv = 2.f * e1;
+      else if (v1 < v2) gv = g2;
+      else gv = e1 + 0.5f * g2;
+      p.d_value[n] = p.vf_coef * p.val_scale * gv;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (tid < 5) p.partials[(long long)blockIdx.x * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ __launch_bounds__(64) void ppo_finalize_kernel(const float *__restrict__ partials, int n_blocks, float vf_coef, float beta,
+                                                          float pol_scale, float ent_scale, float val_scale, float *__restrict__ out8) {
+  const int lane = threadIdx.x;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = lane; b < n_blocks; b += 64)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] += partials[(long long)b * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+    const float pol = acc[0] * pol_scale, val = acc[1] * val_scale, ent = acc[2] * ent_scale;
+    out8[0] = pol;
+    out8[1] = val;
+    out8[2] = -(pol - vf_coef * val + beta * ent);
+    out8[3] = ent;
+    out8[4] = acc[3] * pol_scale;
+    out8[5] = acc[4] * pol_scale;
+    out8[6] = 0.f;
+    out8[7] = 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int etm_adv_stats(const float *adv, int N, float *stats3, void *stream) {
+  if (!adv || !stats3 || N <= 0) return ETM_EINVAL;
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, adv, N, stats3);
+  return etm_launch_status();
+}
+
+extern "C" int64_t etm_ppo_loss_workspace_bytes(int N) { return N <= 0 ? 0 : (int64_t)((N + 255) / 256) * 8 * sizeof(float); }
+
+extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t action_stride, const float *old_logp,
+                            int64_t logp_stride, const float *adv, const float *old_value, const float *value,
+                            const float *adv_stats3, double clip, float vf_coef, float beta, float pol_scale, float ent_scale,
+                            float val_scale, int include_value, float *out8, float *d_logits, float *d_value, void *partials,
+                            int64_t partials_bytes, int N, int A, void *stream) {
+  if (!logits || !actions || !old_logp || !adv || !adv_stats3 || !out8 || !d_logits || !partials) return ETM_EINVAL;
+  if (include_value && (!old_value || !value || !d_value)) return ETM_EINVAL;
+  if (N <= 0 || A <= 0) return ETM_EINVAL;
+  if (partials_bytes < etm_ppo_loss_workspace_bytes(N)) return ETM_EWORKSPACE;
+  LossParams p;
+  p.logits = logits; p.actions = (const long long *)actions; p.action_stride = action_stride;
+  p.old_logp = old_logp; p.logp_stride = logp_stride; p.adv = adv; p.old_value = old_value; p.value = value;
+  p.adv_stats3 = adv_stats3;
+  p.clip = (float)clip; p.clip_lo = (float)(1.0 - clip); p.clip_hi = (float)(1.0 + clip);
+  p.vf_coef = vf_coef; p.beta = beta; p.pol_scale = pol_scale; p.ent_scale = ent_scale; p.val_scale = val_scale;
+  p.include_value = include_value; p.d_logits = d_logits; p.d_value = d_value; p.partials = (float *)partials;
+  p.N = N; p.A = A;
+  const int nb = (N + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(256), 0, st, p);
+  int rc = etm_launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(ppo_finalize_kernel, dim3(1), dim3(64), 0, st, (const float *)partials, nb, vf_coef, beta, pol_scale, ent_scale,
+                     val_scale, out8);
+  return etm_launch_status();
+}

@@ -1,0 +1,116 @@
+"""Vectorised environment front-ends for the trainer.
+
+``VecEnv`` protocol (what ``PPOTrainer`` steps):
+    num_envs, observation_space_shape, num_actions, max_episode_steps
+    reset(out=None) -> obs [W, *obs_shape] float32
+    step(actions [W] or [W, B], out=None) -> (obs, rewards [W] f32, dones [W] bool, infos [W] (dict or None))
+with auto-reset: for a finished worker the returned observation is already the first one of the next episode, which
+is exactly what upstream's loop does by hand (trainer.py:195-201).
+
+* ``SerialVecEnv``  -- wraps in-process single envs with the upstream env API.
+* ``PipeVecEnv``    -- wraps upstream-protocol ``Worker`` subprocesses (worker.py), one pipe round trip per step.
+* ``environments.synthetic.SyntheticVecEnv`` implements the protocol natively.
+"""
+import numpy as np
+
+
+class _VecBase:
+    def _alloc(self, out):
+        return out if out is not None else np.zeros((self.num_envs,) + self.observation_space_shape, dtype=np.float32)
+
+
+class SerialVecEnv(_VecBase):
+    def __init__(self, envs):
+        self.envs = list(envs)
+        self.num_envs = len(self.envs)
+        e = self.envs[0]
+        self.observation_space_shape = tuple(e.observation_space.shape)
+        self.num_actions = int(e.action_space.n)
+        self.max_episode_steps = int(e.max_episode_steps)
+
+    def reset(self, out=None):
+        out = self._alloc(out)
+        for w, e in enumerate(self.envs):
+            out[w] = e.reset()
+        return out
+
+    def step(self, actions, out=None):
+        out = self._alloc(out)
+        actions = np.asarray(actions).reshape(self.num_envs, -1)
+        rewards = np.zeros(self.num_envs, dtype=np.float32)
+        dones = np.zeros(self.num_envs, dtype=bool)
+        infos = [None] * self.num_envs
+        for w, e in enumerate(self.envs):
+            obs, rewards[w], dones[w], info = e.step(actions[w])
+            if info:
+                infos[w] = info
+                obs = e.reset()
+            out[w] = obs
+        return out, rewards, dones, infos
+
+    def close(self):
+        for e in self.envs:
+            e.close()
+
+
+class PipeVecEnv(_VecBase):
+    """One subprocess per env, upstream (cmd, data) pipe protocol; actions are sent to all workers before any
+    result is received so the environments step concurrently."""
+
+    def __init__(self, env_config: dict, num_envs: int, first_worker_id: int = 0):
+        from utils import create_env
+        from worker import Worker
+        probe = create_env(env_config)
+        self.observation_space_shape = tuple(probe.observation_space.shape)
+        self.num_actions = int(probe.action_space.n)
+        self.max_episode_steps = int(probe.max_episode_steps)
+        probe.close()
+        self.num_envs = num_envs
+        self.workers = [Worker(env_config, worker_id=first_worker_id + w) for w in range(num_envs)]
+
+    def reset(self, out=None):
+        out = self._alloc(out)
+        for wk in self.workers:
+            wk.child.send(("reset", None))
+        for w, wk in enumerate(self.workers):
+            out[w] = wk.child.recv()
+        return out
+
+    def step(self, actions, out=None):
+        out = self._alloc(out)
+        actions = np.asarray(actions).reshape(self.num_envs, -1)
+        for w, wk in enumerate(self.workers):
+            wk.child.send(("step", actions[w]))
+        rewards = np.zeros(self.num_envs, dtype=np.float32)
+        dones = np.zeros(self.num_envs, dtype=bool)
+        infos = [None] * self.num_envs
+        for w, wk in enumerate(self.workers):
+            obs, rewards[w], dones[w], info = wk.child.recv()
+            if info:
+                infos[w] = info
+                wk.child.send(("reset", None))
+                obs = wk.child.recv()
+            out[w] = obs
+        return out, rewards, dones, infos
+
+    def close(self):
+        for wk in self.workers:
+            try:
+                wk.child.send(("close", None))
+            except Exception:
+                pass
+
+
+def make_vec_env(env_config: dict, num_envs: int, first_worker_id: int = 0):
+    """Pick the front-end for ``env_config["type"]``."""
+    if env_config["type"] == "Synthetic":
+        from environments.synthetic import SyntheticVecEnv
+        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool")
+        kw = {k: env_config[k] for k in keys if k in env_config}
+        if "obs_shape" in kw:
+            kw["obs_shape"] = tuple(kw["obs_shape"])
+        return SyntheticVecEnv(num_envs, first_worker_id=first_worker_id, **kw)
+    if env_config.get("vectorize", "pipe") == "serial":
+        from utils import create_env
+        return SerialVecEnv([create_env(env_config, worker_id=first_worker_id + w) for w in range(num_envs)])
+    return PipeVecEnv(env_config, num_envs, first_worker_id)

@@ -1,0 +1,93 @@
+"""Data-parallel plumbing: one process per GPU, gradients all-reduced with RCCL over xGMI (torch.distributed,
+backend "nccl" on ROCm) -- the exchange step the upstream code does not have.
+
+Design: workers (environments) are partitioned across ranks; each rank owns its rollout shard, memory bank and a
+full model replica.  Per minibatch there is ONE collective on ONE flat fp32 bucket that aliases every ``p.grad``
+(no per-parameter launches, message = 4 * n_params bytes), placed between ``backward()`` and gradient clipping
+(upstream trainer.py:310-311), plus an 3-float all-gather so the advantage normalisation uses global-minibatch
+statistics.  With the gloo backend the same code runs on CPU tensors (tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, device=None, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        self.flat = None
+        if self.world > 1 and not dist.is_initialized():
+            if backend is None:
+                backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = torch.device(device)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def shard(self, total: int):
+        """Contiguous shard of ``total`` items for this rank -> (first, count); total must divide evenly."""
+        if total % self.world != 0:
+            raise ValueError(f"{total} items do not divide over {self.world} ranks")
+        per = total // self.world
+        return self.rank * per, per
+
+    def broadcast_parameters(self, module: torch.nn.Module):
+        if not self.active:
+            return
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=0)
+
+    def attach_flat_grads(self, params):
+        """Allocate one flat fp32 buffer and make every ``p.grad`` a view into it."""
+        params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = self.flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        return self.flat
+
+    def all_reduce_grads(self):
+        """Sum the flat gradient bucket over ranks and average (one RCCL all-reduce)."""
+        if self.active:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(self.world)
+
+    def merge_adv_stats(self, stats3: torch.Tensor) -> torch.Tensor:
+        """Merge per-rank (count, mean, M2) into global statistics (Chan et al. pairwise update)."""
+        if not self.active:
+            return stats3
+        gathered = [torch.empty_like(stats3) for _ in range(self.world)]
+        dist.all_gather(gathered, stats3)
+        allst = torch.stack(gathered)               # [world, 3]
+        n, mean, m2 = allst[:, 0], allst[:, 1], allst[:, 2]
+        tot = n.sum()
+        gmean = (n * mean).sum() / tot
+        gm2 = (m2 + n * (mean - gmean) ** 2).sum()
+        return torch.stack([tot, gmean, gm2])
+
+    def max_over_ranks(self, value: float) -> float:
+        if not self.active:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        if self.active:
+            dist.barrier()
+
+    def close(self):
+        if self.active and dist.is_initialized():
+            dist.destroy_process_group()

@@ -1,0 +1,55 @@
+"""ctypes loader for libetm_hip.so.  Fails loudly: there is no CPU or eager fallback for the kernels."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libetm_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+_D = ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/etm_hip.h one to one
+SIGNATURES = {
+    "etm_abi_version": (_I, []),
+    "etm_error_string": (ctypes.c_char_p, [_I]),
+    "etm_mha_fwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "etm_mha_bwd_workspace_bytes": (_L, [_I, _I, _I]),
+    "etm_mha_bwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                         _P, _L, _I, _I, _I, _I, _P]),
+    "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),
+    "etm_adv_stats": (_I, [_P, _I, _P, _P]),
+    "etm_ppo_loss_workspace_bytes": (_L, [_I]),
+    "etm_ppo_loss": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P, _D, _F, _F, _F, _F, _F, _I, _P, _P, _P, _P, _L, _I, _I, _P]),
+}
+
+
+def load():
+    """Return the loaded library (cached).  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X kernels are not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C episodic-transformer-memory-ppo_amd/csrc`. There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.etm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libetm_hip.so ABI {lib.etm_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().etm_error_string(rc)
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

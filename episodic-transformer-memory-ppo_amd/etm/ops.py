@@ -1,0 +1,274 @@
+"""torch-facing wrappers (autograd glue) around the C ABI of libetm_hip.so.
+
+PyTorch is plumbing here: it owns the device buffers and the stream; the math of the three hot ops runs in the
+hand-written kernels.  Every entry point requires HIP device tensors and raises otherwise -- no CPU/eager fallback.
+"""
+import torch
+
+from . import lib as _lib
+
+_workspaces = {}
+_timing_hook = None  # set by bench.py: callable(name, meta) -> context manager
+
+
+def set_timing_hook(hook):
+    global _timing_hook
+    _timing_hook = hook
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _timed(name, **meta):
+    return _timing_hook(name, meta) if _timing_hook is not None else _NullCtx()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("etm ops need tensors on the MI355X (HIP) device; there is no CPU path in this build "
+                               "(the CPU oracle lives under oracle/ and is test-only)")
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def workspace(nbytes, device, tag="ws"):
+    key = (tag, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+class WindowSpec:
+    """Where the memory-window rows of a batch live: X[n, l] = bank[ep[n], win[n, l], block, :].
+
+    bank_ptr/ep_stride/row_stride/block_stride are in float32 elements.  ``ep`` may be None (ep[n] = n).
+    """
+
+    __slots__ = ("bank", "ep_stride", "row_stride", "block_stride", "ep", "win", "pidx", "mask", "N", "L")
+
+    def __init__(self, bank, ep_stride, row_stride, block_stride, ep, win, pidx, mask):
+        _need_dev(bank, ep, win, pidx, mask)
+        if bank.dtype != torch.float32 or bank.stride(-1) != 1:
+            raise TypeError("memory bank must be float32 with a contiguous feature dimension")
+        for s in (ep_stride, row_stride, block_stride):
+            if s % 4 != 0:
+                raise ValueError("memory bank strides must be multiples of 4 floats (16-byte rows)")
+        if bank.data_ptr() % 16 != 0:
+            raise ValueError("memory bank must be 16-byte aligned")
+        self.bank = bank
+        self.ep_stride, self.row_stride, self.block_stride = int(ep_stride), int(row_stride), int(block_stride)
+        self.N, self.L = int(win.shape[0]), int(win.shape[1])
+        self.ep = None if ep is None else ep.to(torch.int64).contiguous()
+        self.win = win.to(torch.int64).contiguous()
+        self.pidx = None if pidx is None else pidx.to(torch.int64).contiguous()
+        if mask.dtype == torch.bool:
+            m = mask.contiguous().view(torch.uint8)
+        elif mask.dtype == torch.uint8:
+            m = mask.contiguous()
+        else:
+            m = (mask != 0).to(torch.uint8)  # reference semantics: `mask == 0` is masked (transformer.py:66)
+        self.mask = m
+
+    @classmethod
+    def from_bank(cls, bank, ep, win, pidx, mask):
+        """bank: [E, T, nb, D] episode bank."""
+        return cls(bank, bank.stride(0), bank.stride(1), bank.stride(2), ep, win, pidx, mask)
+
+    @classmethod
+    def from_windows(cls, memories, pidx, mask):
+        """memories: pre-gathered windows [N, L, nb, D] (the reference's calling convention) or [N, L, D]."""
+        n, l = memories.shape[0], memories.shape[1]
+        win = torch.arange(l, device=memories.device, dtype=torch.int64).unsqueeze(0).expand(n, l)
+        bstride = memories.stride(2) if memories.dim() == 4 else 0
+        return cls(memories, memories.stride(0), memories.stride(1), bstride, None, win, pidx, mask)
+
+    def block_ptr(self, block):
+        return self.bank.data_ptr() + 4 * block * self.block_stride
+
+
+class _MhaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, wk, wv, ln_g, ln_b, pos, spec, block, num_heads, ln_eps):
+        lib = _lib.load()
+        _need_dev(q, wk, wv, ln_g, ln_b, pos)
+        q, wk, wv = _f32c(q, "q"), _f32c(wk, "wk"), _f32c(wv, "wv")
+        ln_g, ln_b, pos = _f32c(ln_g, "ln_g"), _f32c(ln_b, "ln_b"), _f32c(pos, "pos")
+        N, D = q.shape
+        L, H = spec.L, int(num_heads)
+        if N != spec.N:
+            raise ValueError("query batch and window batch differ")
+        need_grad = any(ctx.needs_input_grad[:6])
+        dev = q.device
+        out = torch.empty((N, D), dtype=torch.float32, device=dev)
+        att = torch.empty((N, H, L), dtype=torch.float32, device=dev)
+        k_save = v_save = None
+        if need_grad:
+            k_save = torch.empty((N, L, D), dtype=torch.float32, device=dev)
+            v_save = torch.empty((N, L, D), dtype=torch.float32, device=dev)
+        ln_stats = torch.empty((N, L, 2), dtype=torch.float32, device=dev) if ln_g is not None else None
+        pidx = spec.pidx if pos is not None else None
+        with _timed("mha_fwd", N=N, L=L, D=D, H=H, train=need_grad):
+            rc = lib.etm_mha_fwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                 _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), float(ln_eps), _ptr(q), _ptr(wk), _ptr(wv),
+                                 _ptr(out), _ptr(att), _ptr(k_save), _ptr(v_save), _ptr(ln_stats), N, L, D, H, _stream())
+        _lib.check(rc, "etm_mha_fwd")
+        if need_grad:
+            ctx.spec, ctx.block, ctx.H = spec, block, H
+            ctx.has_ln, ctx.has_pos = ln_g is not None, pos is not None
+            saved = [q, wk, wv, att, k_save, v_save]
+            if ln_g is not None:
+                saved += [ln_g, ln_b, ln_stats]
+            if pos is not None:
+                saved += [pos]
+            ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, d_out, _d_att):
+        lib = _lib.load()
+        spec, block, H = ctx.spec, ctx.block, ctx.H
+        saved = list(ctx.saved_tensors)
+        q, wk, wv, att, k_save, v_save = saved[:6]
+        rest = saved[6:]
+        ln_g = ln_b = ln_stats = pos = None
+        if ctx.has_ln:
+            ln_g, ln_b, ln_stats = rest[:3]
+            rest = rest[3:]
+        if ctx.has_pos:
+            pos = rest[0]
+        N, D = q.shape
+        L = spec.L
+        dev = q.device
+        d_out = _f32c(d_out, "d_ctx")
+        d_q = torch.empty_like(q)
+        d_e = torch.empty((N, H, L), dtype=torch.float32, device=dev)
+        d_wk = torch.empty_like(wk)
+        d_wv = torch.empty_like(wv)
+        want_ln = ctx.has_ln and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        want_pos = ctx.has_pos and ctx.needs_input_grad[5]
+        d_ln_g = torch.zeros_like(ln_g) if want_ln else None
+        d_ln_b = torch.zeros_like(ln_b) if want_ln else None
+        d_pos = torch.zeros_like(pos) if want_pos else None
+        nbytes = lib.etm_mha_bwd_workspace_bytes(N, L, D)
+        ws = workspace(nbytes, dev, "mha_bwd")
+        pidx = spec.pidx if pos is not None else None
+        with _timed("mha_bwd", N=N, L=L, D=D, H=H):
+            rc = lib.etm_mha_bwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                 _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), _ptr(q), _ptr(wk), _ptr(wv), _ptr(att),
+                                 _ptr(k_save), _ptr(v_save), _ptr(ln_stats), _ptr(d_out), _ptr(d_q), _ptr(d_e), _ptr(d_wk), _ptr(d_wv),
+                                 _ptr(d_ln_g), _ptr(d_ln_b), _ptr(d_pos), _ptr(ws), nbytes, N, L, D, H, _stream())
+        _lib.check(rc, "etm_mha_bwd")
+        return d_q, d_wk, d_wv, d_ln_g, d_ln_b, d_pos, None, None, None, None
+
+
+def mha(q, wk, wv, spec, block, num_heads, ln_g=None, ln_b=None, pos=None, ln_eps=1e-5):
+    """Fused window attention.  q [N,D] projected queries -> (ctx [N,D] before fc_out, attention [N,H,L])."""
+    return _MhaFn.apply(q, wk, wv, ln_g, ln_b, pos, spec, block, num_heads, ln_eps)
+
+
+def gae(rewards, dones, values, last_value, gamma, lamda, out=None):
+    """Generalized advantage estimation on device; [W,S] row-major like the reference buffer."""
+    lib = _lib.load()
+    _need_dev(rewards, dones, values, last_value)
+    rewards, values, last_value = _f32c(rewards, "rewards"), _f32c(values, "values"), _f32c(last_value, "last_value")
+    d = dones.contiguous()
+    d = d.view(torch.uint8) if d.dtype == torch.bool else d.to(torch.uint8)
+    W, S = values.shape
+    if out is None:
+        out = torch.empty_like(values)
+    elif not out.is_contiguous() or out.dtype != torch.float32:
+        raise TypeError("advantages output must be contiguous float32")
+    g32 = float(torch.tensor(float(gamma), dtype=torch.float32))
+    gl32 = float(torch.tensor(float(gamma) * float(lamda), dtype=torch.float32))  # python-float product, then fp32 (buffer.py:111)
+    with _timed("gae", W=W, S=S):
+        rc = lib.etm_gae(_ptr(rewards), _ptr(d), _ptr(values), _ptr(last_value), g32, gl32, _ptr(out), W, S, _stream())
+    _lib.check(rc, "etm_gae")
+    return out
+
+
+def adv_stats(adv):
+    """(count, mean, M2) of a flat advantage vector as a 3-element device tensor."""
+    lib = _lib.load()
+    _need_dev(adv)
+    adv = _f32c(adv.reshape(-1), "adv")
+    stats = torch.empty(3, dtype=torch.float32, device=adv.device)
+    _lib.check(lib.etm_adv_stats(_ptr(adv), adv.numel(), _ptr(stats), _stream()), "etm_adv_stats")
+    return stats
+
+
+class _PpoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, value, actions, old_logp, adv, old_value, stats3, branch, n_branches, clip, vf_coef, beta,
+                include_value):
+        lib = _lib.load()
+        _need_dev(logits, value, actions, old_logp, adv, old_value, stats3)
+        logits = _f32c(logits, "logits")
+        value = _f32c(value, "value")
+        adv, old_value = _f32c(adv, "adv"), _f32c(old_value, "old_value")
+        if actions.dtype != torch.int64 or old_logp.dtype != torch.float32:
+            raise TypeError("actions must be int64 and old log-probs float32")
+        actions, old_logp = actions.contiguous(), old_logp.contiguous()
+        N, A = logits.shape
+        B = actions.shape[1] if actions.dim() == 2 else 1
+        dev = logits.device
+        out8 = torch.empty(8, dtype=torch.float32, device=dev)
+        d_logits = torch.empty_like(logits)
+        d_value = torch.empty_like(value)
+        nbytes = lib.etm_ppo_loss_workspace_bytes(N)
+        ws = workspace(nbytes, dev, "ppo")
+        with _timed("ppo_loss", N=N, A=A):
+            rc = lib.etm_ppo_loss(_ptr(logits), actions.data_ptr() + 8 * branch, B, old_logp.data_ptr() + 4 * branch, B, _ptr(adv),
+                                  _ptr(old_value), _ptr(value), _ptr(stats3), float(clip), float(vf_coef), float(beta),
+                                  1.0 / (N * n_branches), 1.0 / N, 1.0 / N, 1 if include_value else 0, _ptr(out8), _ptr(d_logits),
+                                  _ptr(d_value), _ptr(ws), nbytes, N, A, _stream())
+        _lib.check(rc, "etm_ppo_loss")
+        ctx.save_for_backward(d_logits, d_value)
+        ctx.include_value = include_value
+        ctx.mark_non_differentiable(out8)
+        return out8[2].clone(), out8
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        d_logits, d_value = ctx.saved_tensors
+        gv = d_value * g_loss if ctx.include_value else None
+        return d_logits * g_loss, gv, None, None, None, None, None, None, None, None, None, None, None
+
+
+def ppo_loss(logits_list, value, actions, old_logp, adv, old_value, clip, vf_coef, beta, stats3=None):
+    """PPO loss over all action branches.  Returns (loss scalar with grad, stats[6] device tensor in trainer.py:318-323 order)."""
+    if stats3 is None:
+        stats3 = adv_stats(adv)
+    nb = len(logits_list)
+    loss, st = _PpoLossFn.apply(logits_list[0], value, actions, old_logp, adv, old_value, stats3, 0, nb, clip, vf_coef, beta, True)
+    if nb == 1:
+        return loss, st[:6]
+    pol, ent, kl, cf = st[0], st[3], st[4], st[5]
+    total = loss
+    for b in range(1, nb):
+        l_b, s_b = _PpoLossFn.apply(logits_list[b], value, actions, old_logp, adv, old_value, stats3, b, nb, clip, vf_coef, beta, False)
+        total = total + l_b
+        pol, ent, kl, cf = pol + s_b[0], ent + s_b[3], kl + s_b[4], cf + s_b[5]
+    return total, torch.stack([pol, st[1], total.detach(), ent, kl, cf])

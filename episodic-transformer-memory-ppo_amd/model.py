@@ -1,0 +1,107 @@
+"""Actor-critic with the episodic-memory transformer (API of upstream model.py:10-166).
+
+``forward(obs, memory, memory_mask, memory_indices)`` keeps the upstream convention (pre-gathered memory windows);
+``forward_banked(obs, spec)`` is the trainer's entry: windows are read in place from the episode bank.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Categorical
+from torch.nn import functional as F
+
+from etm.ops import WindowSpec
+from transformer import Transformer
+
+
+class ActorCriticModel(nn.Module):
+    def __init__(self, config, observation_space, action_space_shape, max_episode_length):
+        super().__init__()
+        self.hidden_size = config["hidden_layer_size"]
+        self.memory_layer_size = config["transformer"]["embed_dim"]
+        self.observation_space_shape = tuple(observation_space.shape)
+        self.max_episode_length = max_episode_length
+        self.visual = len(self.observation_space_shape) > 1
+        if self.visual:
+            c = self.observation_space_shape[0]
+            self.conv1 = nn.Conv2d(c, 32, 8, 4)
+            self.conv2 = nn.Conv2d(32, 64, 4, 2, 0)
+            self.conv3 = nn.Conv2d(64, 64, 3, 1, 0)
+            for conv in (self.conv1, self.conv2, self.conv3):
+                nn.init.orthogonal_(conv.weight, math.sqrt(2))
+            self.conv_out_size = self.get_conv_output(self.observation_space_shape)
+            feat = self.conv_out_size
+        else:
+            feat = self.observation_space_shape[0]
+        self.lin_hidden = nn.Linear(feat, self.memory_layer_size)
+        nn.init.orthogonal_(self.lin_hidden.weight, math.sqrt(2))
+        self.transformer = Transformer(config["transformer"], self.memory_layer_size, self.max_episode_length)
+        self.lin_policy = nn.Linear(self.memory_layer_size, self.hidden_size)
+        nn.init.orthogonal_(self.lin_policy.weight, math.sqrt(2))
+        self.lin_value = nn.Linear(self.memory_layer_size, self.hidden_size)
+        nn.init.orthogonal_(self.lin_value.weight, math.sqrt(2))
+        self.policy_branches = nn.ModuleList()
+        for num_actions in action_space_shape:
+            branch = nn.Linear(in_features=self.hidden_size, out_features=num_actions)
+            nn.init.orthogonal_(branch.weight, math.sqrt(0.01))
+            self.policy_branches.append(branch)
+        self.value = nn.Linear(self.hidden_size, 1)
+        nn.init.orthogonal_(self.value.weight, 1)
+
+    # ------------------------------------------------------------------ forward
+    def _encode(self, obs):
+        h = obs
+        if self.visual:
+            h = F.relu(self.conv1(h))
+            h = F.relu(self.conv2(h))
+            h = F.relu(self.conv3(h))
+            h = h.reshape(h.shape[0], -1)
+        return F.relu(self.lin_hidden(h))
+
+    def forward_logits(self, obs, spec: WindowSpec):
+        """-> (list of raw logits per branch, value [N], new memory items [N, blocks, D])."""
+        h, memory = self.transformer.forward_window(self._encode(obs), spec)
+        h_policy = F.relu(self.lin_policy(h))
+        h_value = F.relu(self.lin_value(h))
+        value = self.value(h_value).reshape(-1)
+        return [branch(h_policy) for branch in self.policy_branches], value, memory
+
+    def forward_banked(self, obs, spec: WindowSpec):
+        logits, value, memory = self.forward_logits(obs, spec)
+        return [Categorical(logits=l, validate_args=False) for l in logits], value, memory
+
+    def forward(self, obs, memory, memory_mask, memory_indices):
+        """Upstream signature; memory [N, L, blocks, D] is the pre-gathered window."""
+        return self.forward_banked(obs, WindowSpec.from_windows(memory, memory_indices, memory_mask))
+
+    def get_conv_output(self, shape) -> int:
+        with torch.no_grad():
+            o = self.conv3(self.conv2(self.conv1(torch.zeros(1, *shape))))
+        return int(np.prod(o.size()))
+
+    # ------------------------------------------------------------------ gradient monitoring (keys of upstream :128-151)
+    def _grad_groups(self):
+        groups = {}
+        if self.visual:
+            groups["encoder"] = [self.conv1, self.conv2, self.conv3]
+        groups["linear_layer"] = [self.lin_hidden]
+        for i, block in enumerate(self.transformer.transformer_blocks):
+            groups["transformer_block_" + str(i)] = [block]
+        for i, head in enumerate(self.policy_branches):
+            groups["policy_head_" + str(i)] = [head]
+        groups["lin_policy"] = [self.lin_policy]
+        groups["value"] = [self.lin_value, self.value]
+        groups["model"] = [self, self.value]
+        return groups
+
+    def grad_norms_device(self):
+        """{key: 0-dim device tensor}: no host synchronisation (the trainer syncs once per update)."""
+        out = {}
+        for key, modules in self._grad_groups().items():
+            grads = [p.grad.reshape(-1) for m in modules for p in m.parameters() if p.grad is not None]
+            out[key] = torch.linalg.norm(torch.cat(grads)) if grads else None
+        return out
+
+    def get_grad_norm(self):
+        return {k: (v.item() if v is not None else None) for k, v in self.grad_norms_device().items()}

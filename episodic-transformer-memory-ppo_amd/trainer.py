@@ -1,0 +1,345 @@
+"""PPO trainer with TransformerXL episodic memory on one MI355X per process.
+
+Keeps upstream's ``PPOTrainer`` surface (trainer.py:17 ctor, :101 run_training, :145 _sample_training_data,
+:227 get_last_value, :239 _train_epochs, :258 _train_mini_batch, :364 close) and its bookkeeping semantics --
+mask / window-index tables (bit-exact, :78, :88-90), per-step window rule (:165-166), the different window of
+``get_last_value`` (:230-236, quirk Q5), episode hand-over on ``done`` (:195-213) -- while the data path is redesigned
+for the GPU:
+
+* rollout state (episode bank, tables, buffer) is HBM-resident; per step there is ONE pinned host->device
+  observation upload and ONE device->host action download (upstream: one ``.cpu()`` per worker, :190);
+* memory windows are never gathered: the attention kernel reads the bank through (slot, row) indices;
+* GAE and the PPO loss (+ its backward) are single fused kernels; loss statistics stay on the device and are
+  fetched once per update (upstream: 6 host syncs per minibatch, :318-323);
+* data parallelism (absent upstream): ``dp`` all-reduces one flat gradient bucket with RCCL between ``backward()``
+  and gradient clipping (:310-311) and merges advantage statistics so normalisation is over the global minibatch.
+
+There is no CPU path: constructing the trainer without a HIP device raises.
+"""
+import os
+import pickle
+import time
+from collections import deque
+
+import numpy as np
+import torch
+from torch import optim
+
+from buffer import Buffer
+from environments.vec_env import make_vec_env
+from etm import lib as etm_lib
+from etm import ops
+from etm.ops import WindowSpec
+from model import ActorCriticModel
+from utils import polynomial_decay, process_episode_info
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def _make_writer(run_id):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+    except Exception:
+        return _NullWriter()
+    os.makedirs("./summaries", exist_ok=True)
+    return SummaryWriter("./summaries/" + run_id + time.strftime("/%Y%m%d-%H%M%S/"))
+
+
+def build_window_tables(memory_length: int, max_episode_length: int):
+    """Attention-mask table [L, L] and sliding-window index table [T, L] (upstream trainer.py:78, :88-90).
+
+    Integer/0-1 valued, built on the host: row s of the index table is the window used at episode step s
+    ([0..L-1] while s < L-1, then [s-L+1..s]); mask row r has its first r entries set.
+    """
+    L, T = int(memory_length), int(max_episode_length)
+    if T < L:
+        raise ValueError(f"max_episode_steps ({T}) must be >= memory_length ({L})")
+    mask = torch.tril(torch.ones((L, L), dtype=torch.float32), diagonal=-1)
+    first = torch.clamp(torch.arange(T, dtype=torch.int64) - (L - 1), min=0)
+    indices = first.unsqueeze(1) + torch.arange(L, dtype=torch.int64).unsqueeze(0)
+    return mask, indices
+
+
+class PPOTrainer:
+    def __init__(self, config: dict, run_id: str = "run", device: torch.device = None, env=None, dp=None,
+                 first_worker_id: int = 0, tensorboard: bool = True) -> None:
+        if device is None:
+            device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("PPOTrainer needs an MI355X (HIP) device: this build has no CPU training path "
+                               "(the CPU restatement under oracle/ is test infrastructure only)")
+        etm_lib.load()  # fail loudly if the kernels are not built
+        self.config = config
+        self.device = device
+        self.run_id = run_id
+        self.dp = dp
+        self.num_workers = config["n_workers"]
+        self.lr_schedule = config["learning_rate_schedule"]
+        self.beta_schedule = config["beta_schedule"]
+        self.cr_schedule = config["clip_range_schedule"]
+        t = config["transformer"]
+        self.memory_length, self.num_blocks, self.embed_dim = t["memory_length"], t["num_blocks"], t["embed_dim"]
+        self.writer = _make_writer(run_id) if tensorboard else _NullWriter()
+
+        # environments (batched front-end over the upstream per-worker protocol)
+        self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id)
+        W = self.num_workers
+        obs_shape = tuple(self.env.observation_space_shape)
+        self.observation_space = type("Space", (), {"shape": obs_shape})()
+        self.action_space_shape = (self.env.num_actions,)  # one branch, like upstream (trainer.py:47)
+        self.max_episode_length = self.env.max_episode_steps
+
+        self.buffer = Buffer(config, self.observation_space, self.action_space_shape, self.max_episode_length, device)
+        self.model = ActorCriticModel(config, self.observation_space, self.action_space_shape, self.max_episode_length).to(device)
+        self.model.train()
+        if self.dp is not None:
+            self.dp.broadcast_parameters(self.model)
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = optim.AdamW(self.params, lr=self.lr_schedule["initial"], fused=True)
+        # one flat gradient bucket aliased by every p.grad (the all-reduce message; also makes clipping 3 launches)
+        total = sum(p.numel() for p in self.params)
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grads[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        if self.dp is not None:
+            self.dp.flat = self.flat_grads
+        self._build_grad_groups()
+
+        # host <-> device staging (pinned)
+        self._obs_pin = torch.zeros((W,) + obs_shape, dtype=torch.float32).pin_memory()
+        self.obs = self._obs_pin.numpy()
+        self._act_pin = torch.zeros((W, len(self.action_space_shape)), dtype=torch.int64).pin_memory()
+        self._step_pin = torch.zeros((W,), dtype=torch.int64).pin_memory()
+        self._slot_pin = torch.zeros((W,), dtype=torch.int64).pin_memory()
+        self.worker_current_episode_step = self._step_pin.numpy()   # host truth, mirrored on device each step
+        self.worker_episode_slot = self._slot_pin.numpy()
+        self.worker_episode_slot[:] = np.arange(W)
+        self._step_dev = torch.zeros((W,), dtype=torch.int64, device=device)
+        self._slot_dev = torch.arange(W, dtype=torch.int64, device=device)
+        self.env.reset(out=self.obs)
+
+        mask, indices = build_window_tables(self.memory_length, self.max_episode_length)
+        self.memory_mask, self.memory_indices = mask, indices                       # host copies (upstream names)
+        self._mask_table = mask.bool().to(device)
+        self._index_table = indices.to(device)
+        self.last_update_timing = {}
+
+    # ------------------------------------------------------------------ properties mirroring upstream members
+    @property
+    def memory(self):
+        """[W, T, blocks, D] live episodic memory of every worker (upstream ``self.memory``); a gathered copy."""
+        return self.buffer.bank.index_select(0, self._slot_dev)
+
+    # ------------------------------------------------------------------ training loop
+    def run_training(self) -> None:
+        print("Step 6: Starting training using " + str(self.device))
+        episode_infos = deque(maxlen=100)
+        for update in range(self.config["updates"]):
+            lr, beta, clip = self.schedules(update)
+            t0 = time.perf_counter()
+            sampled_episode_info = self._sample_training_data()
+            self.buffer.prepare_batch_dict()
+            training_stats, grad_info = self._train_epochs(lr, clip, beta)
+            torch.cuda.synchronize(self.device)
+            dt = time.perf_counter() - t0
+            training_stats = np.mean(training_stats, axis=0)
+            episode_infos.extend(sampled_episode_info)
+            episode_result = process_episode_info(episode_infos)
+            steps_per_s = self.num_workers * self.config["worker_steps"] / dt
+            vmean, amean = torch.mean(self.buffer.values).item(), torch.mean(self.buffer.advantages).item()
+            if episode_result:
+                head = "{:4} reward={:.2f} std={:.2f} length={:.1f} std={:.2f}".format(
+                    update, episode_result["reward_mean"], episode_result["reward_std"], episode_result["length_mean"],
+                    episode_result["length_std"])
+            else:
+                head = "{:4} (no finished episode yet)".format(update)
+            if "success_percent" in episode_result:
+                head += " success={:.2f}".format(episode_result["success_percent"])
+            print(head + " pi_loss={:3f} v_loss={:3f} entropy={:.3f} loss={:3f} value={:.3f} advantage={:.3f} steps/s={:.0f}".format(
+                training_stats[0], training_stats[1], training_stats[3], training_stats[2], vmean, amean, steps_per_s))
+            self._write_gradient_summary(update, grad_info)
+            self._write_training_summary(update, training_stats, episode_result, vmean, amean, steps_per_s)
+        self._save_model()
+
+    def schedules(self, update: int):
+        s = lambda c: polynomial_decay(c["initial"], c["final"], c["max_decay_steps"], c["power"], update)
+        return s(self.lr_schedule), s(self.beta_schedule), s(self.cr_schedule)
+
+    # ------------------------------------------------------------------ rollout
+    def _sample_training_data(self, forced_actions=None) -> list:
+        """Runs all workers for ``worker_steps`` steps; fills the buffer; returns finished-episode infos.
+
+        ``forced_actions`` [W, S] (optional) replays recorded actions instead of sampling (teacher forcing for
+        parity tests -- CPU and GPU RNG streams differ)."""
+        buf, W, S, L = self.buffer, self.num_workers, self.config["worker_steps"], self.memory_length
+        stream = torch.cuda.current_stream(self.device)
+        episode_infos = []
+        buf.begin_rollout(self._slot_dev)
+        self.worker_episode_slot[:] = np.arange(W)
+        self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+        if forced_actions is not None:
+            forced = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).to(self.device)
+        t_env = 0.0
+        for t in range(S):
+            with torch.no_grad():
+                obs_t = buf.obs[:, t]
+                obs_t.copy_(self._obs_pin, non_blocking=True)
+                mask_t = self._mask_table[torch.clamp(self._step_dev, 0, L - 1)]
+                win_t = self._index_table[self._step_dev]
+                buf.memory_mask[:, t] = mask_t
+                buf.memory_indices[:, t] = win_t
+                spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
+                logits, value, item = self.model.forward_logits(obs_t, spec)
+                buf.bank[self._slot_dev, self._step_dev] = item          # new memory item (upstream :174)
+                acts, logps = [], []
+                for b, lg in enumerate(logits):
+                    lsm = torch.log_softmax(lg, dim=-1)
+                    a = forced[:, t] if forced_actions is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
+                    acts.append(a)
+                    logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
+                actions = torch.stack(acts, dim=1)
+                buf.actions[:, t] = actions
+                buf.log_probs[:, t] = torch.stack(logps, dim=1)
+                buf.values[:, t] = value
+                self._act_pin.copy_(actions, non_blocking=True)
+            stream.synchronize()  # actions are on the host; the observation upload has been consumed
+            te = time.perf_counter()
+            _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
+            t_env += time.perf_counter() - te
+            buf.rewards[:, t] = rewards
+            buf.dones[:, t] = dones
+            self.worker_current_episode_step += 1
+            if dones.any():
+                for w in np.flatnonzero(dones):
+                    self.worker_current_episode_step[w] = 0
+                    episode_infos.append(infos[w])
+                    slot = buf.open_episode()                  # fresh zero memory for the next episode (upstream :208-213)
+                    self.worker_episode_slot[w] = slot
+                    if t < S - 1:
+                        buf.memory_index_host[w, t + 1:] = slot
+                self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+            self._step_dev.copy_(self._step_pin, non_blocking=True)
+        last_value = self.get_last_value()
+        buf.calc_advantages(last_value, self.config["gamma"], self.config["lamda"])
+        self.last_update_timing["env_s"] = t_env
+        return episode_infos
+
+    def get_last_value(self):
+        """Value of the observation after the last step (bootstrap for GAE), with upstream's window rule:
+        rows [clip(step - L, 0), clip(step, L)) and positional indices of the last stored step (trainer.py:230-236)."""
+        L = self.memory_length
+        step = torch.from_numpy(self.worker_current_episode_step.copy())
+        start = torch.clamp(step - L, min=0)
+        rows = (start.unsqueeze(1) + torch.arange(L, dtype=torch.int64).unsqueeze(0)).to(self.device)
+        with torch.no_grad():
+            mask = self._mask_table[torch.clamp(self._step_dev, 0, L - 1)]
+            obs = self._obs_pin.to(self.device, non_blocking=True)
+            spec = WindowSpec.from_bank(self.buffer.bank, self._slot_dev, rows, self.buffer.memory_indices[:, -1], mask)
+            _, last_value, _ = self.model.forward_logits(obs, spec)
+        return last_value
+
+    # ------------------------------------------------------------------ optimisation
+    def _train_epochs(self, learning_rate: float, clip_range: float, beta: float, perms=None):
+        """``epochs`` passes over shuffled minibatches.  Returns (list of 6-stat rows, {grad key: [norms]})."""
+        stats, norms = [], []
+        monitor = self.config.get("monitor_gradients", True)
+        for epoch in range(self.config["epochs"]):
+            indices = None if perms is None else perms[epoch]
+            for mini_batch in self.buffer.mini_batch_generator(indices):
+                stats.append(self._train_mini_batch(mini_batch, learning_rate, clip_range, beta))
+                if monitor:
+                    norms.append(self._grad_group_norms())
+        train_info = torch.stack(stats).cpu().numpy()          # the only host sync of the optimisation phase
+        grad_info = {}
+        if norms:
+            allnorms = torch.stack(norms).cpu().numpy()
+            grad_info = {k: allnorms[:, i].tolist() for i, k in enumerate(self._grad_keys)}
+        return [row for row in train_info], grad_info
+
+    def _train_mini_batch(self, samples: dict, learning_rate: float, clip_range: float, beta: float):
+        """One optimiser step on one minibatch.  Returns a device tensor [policy, value, loss, entropy, kl, clip_frac]."""
+        ep = samples.get("memory_index")  # None: upstream layout, ``memories`` already gathered per sample
+        spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
+                                    samples["memory_mask"])
+        logits, value, _ = self.model.forward_logits(samples["obs"], spec)
+        stats3 = ops.adv_stats(samples["advantages"])
+        if self.dp is not None:
+            stats3 = self.dp.merge_adv_stats(stats3)
+        loss, stats = ops.ppo_loss(logits, value, samples["actions"], samples["log_probs"], samples["advantages"],
+                                   samples["values"], clip_range, self.config["value_loss_coefficient"], beta, stats3)
+        for pg in self.optimizer.param_groups:
+            pg["lr"] = learning_rate
+        self.flat_grads.zero_()
+        loss.backward()
+        if self.dp is not None:
+            self.dp.all_reduce_grads()
+        # global-norm clipping, same rule as torch.nn.utils.clip_grad_norm_ (upstream :311), on the flat bucket
+        total_norm = torch.linalg.vector_norm(self.flat_grads)
+        self.flat_grads.mul_(torch.clamp(self.config["max_grad_norm"] / (total_norm + 1e-6), max=1.0))
+        self.optimizer.step()
+        return stats
+
+    def _build_grad_groups(self):
+        """Group-membership matrix so all monitored gradient norms come from one pass over per-parameter norms."""
+        groups = self.model._grad_groups()
+        index = {id(p): i for i, p in enumerate(self.params)}
+        self._grad_keys = list(groups.keys())
+        member = torch.zeros((len(groups), len(self.params)), dtype=torch.float32)
+        for g, modules in enumerate(groups.values()):
+            for m in modules:
+                for p in m.parameters():
+                    member[g, index[id(p)]] += 1.0   # upstream concatenates, so a parameter listed twice counts twice
+        self._grad_member = member.to(self.device)
+
+    def _grad_group_norms(self):
+        sq = torch.stack(torch._foreach_norm([p.grad for p in self.params])) ** 2
+        return torch.sqrt(self._grad_member @ sq)
+
+    # ------------------------------------------------------------------ logging / checkpoint
+    def _write_training_summary(self, update, training_stats, episode_result, value_mean, advantage_mean, steps_per_s) -> None:
+        if episode_result:
+            for key in episode_result:
+                if "std" not in key:
+                    self.writer.add_scalar("episode/" + key, episode_result[key], update)
+        self.writer.add_scalar("losses/loss", training_stats[2], update)
+        self.writer.add_scalar("losses/policy_loss", training_stats[0], update)
+        self.writer.add_scalar("losses/value_loss", training_stats[1], update)
+        self.writer.add_scalar("losses/entropy", training_stats[3], update)
+        self.writer.add_scalar("training/value_mean", value_mean, update)
+        self.writer.add_scalar("training/advantage_mean", advantage_mean, update)
+        # upstream swaps these two tags (trainer.py:343-344 vs :322-323); written correctly here
+        self.writer.add_scalar("other/kl", training_stats[4], update)
+        self.writer.add_scalar("other/clip_fraction", training_stats[5], update)
+        self.writer.add_scalar("other/env_steps_per_second", steps_per_s, update)
+
+    def _write_gradient_summary(self, update, grad_info):
+        for key, value in grad_info.items():
+            self.writer.add_scalar("gradients/" + key, np.mean(value), update)
+
+    def _save_model(self) -> None:
+        """``pickle((state_dict, config))`` to ./models/<run_id>.nn -- upstream's checkpoint format (trainer.py:356-362)."""
+        os.makedirs("./models", exist_ok=True)
+        state = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        with open("./models/" + self.run_id + ".nn", "wb") as f:
+            pickle.dump((state, self.config), f)
+        print("Model saved to " + "./models/" + self.run_id + ".nn")
+
+    def close(self, exit_process: bool = False) -> None:
+        """Releases environments and the summary writer (upstream also ``exit(0)``s; opt in with exit_process)."""
+        for closer in (self.env.close, self.writer.close):
+            try:
+                closer()
+            except Exception:
+                pass
+        if exit_process:
+            time.sleep(1.0)
+            raise SystemExit(0)

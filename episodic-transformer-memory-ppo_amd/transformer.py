@@ -1,0 +1,172 @@
+"""TransformerXL-style episodic memory encoder on the MI355X kernels.
+
+Same public classes, constructor arguments, forward signatures and ``state_dict`` keys as the upstream
+``transformer.py`` (MultiHeadAttention :8-86, TransformerBlock :88-172, SinusoidalPosition :174-186,
+Transformer :188-253, GRUGate :255-298), but the window attention of every block -- gather of the memory window,
+positional rows, ``norm_kv``, K/V projection, masked softmax, attention-weighted sum -- is ONE fused HIP kernel
+(``etm.ops.mha``) that reads the episodic memory bank in place.  The small [N, D] x [D, D] maps around it (query
+projection, ``fc_out``, feed-forward, GRU gates) are library GEMMs.
+
+Besides the upstream calling convention (pre-gathered ``memories`` [N, L, blocks, D]) every level also accepts a
+``WindowSpec`` that addresses the windows inside the whole-episode bank, which is what the trainer uses so the
+[N, L, blocks, D] tensor is never materialised.
+"""
+import math
+
+import torch
+from torch import nn
+
+from etm import ops
+from etm.ops import WindowSpec
+from utils import Module
+
+
+class MultiHeadAttention(nn.Module):
+    """Single-query multi-head attention over a memory window (no dropout)."""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise AssertionError("Embedding dimension needs to be divisible by the number of heads")
+        self.embed_dim, self.num_heads, self.head_size = embed_dim, num_heads, embed_dim // num_heads
+        self.values = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.keys = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.queries = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.fc_out = nn.Linear(embed_dim, embed_dim)
+
+    def attend(self, query, spec: WindowSpec, block=0, pos=None, norm_kv=None):
+        """query [N, D] -> (output [N, D], attention [N, H, L]); window rows come from ``spec``."""
+        q = self.queries(query)
+        ln_g = ln_b = None
+        eps = 1e-5
+        if norm_kv is not None:
+            ln_g, ln_b, eps = norm_kv.weight, norm_kv.bias, norm_kv.eps
+        ctx, att = ops.mha(q, self.keys.weight, self.values.weight, spec, block, self.num_heads, ln_g, ln_b, pos, eps)
+        return self.fc_out(ctx), att
+
+    def forward(self, values, keys, queries, mask):
+        """Upstream signature: values/keys [N, L, D], queries [N, 1, D], mask [N, L] -> ([N, 1, D], [N, H, 1, L])."""
+        if keys.data_ptr() != values.data_ptr() or keys.shape != values.shape or keys.stride() != values.stride():
+            raise NotImplementedError("the fused kernel projects keys and values from the same memory window "
+                                      "(the only way the upstream model calls it, transformer.py:249)")
+        if queries.shape[1] != 1:
+            raise NotImplementedError("episodic attention is single-query (query_len == 1)")
+        if mask is None:
+            mask = torch.ones(values.shape[:2], dtype=torch.bool, device=values.device)
+        spec = WindowSpec.from_windows(values, None, mask)
+        out, att = self.attend(queries[:, 0], spec)
+        return out.unsqueeze(1), att.unsqueeze(2)
+
+
+class GRUGate(nn.Module):
+    """GTrXL gating unit: r, z gates and candidate from six bias-free maps (+ gate bias ``bg``)."""
+
+    def __init__(self, input_dim: int, bg: float = 0.0):
+        super().__init__()
+        for name in ("Wr", "Ur", "Wz", "Uz", "Wg", "Ug"):
+            lin = nn.Linear(input_dim, input_dim, bias=False)
+            setattr(self, name, lin)
+        self.bg = nn.Parameter(torch.full([input_dim], float(bg)))
+        for name in ("Wr", "Ur", "Wz", "Uz", "Wg", "Ug"):
+            nn.init.xavier_uniform_(getattr(self, name).weight)
+
+    def forward(self, x, y):
+        r = torch.sigmoid(self.Wr(y) + self.Ur(x))
+        z = torch.sigmoid(self.Wz(y) + self.Uz(x) - self.bg)
+        cand = torch.tanh(self.Wg(y) + self.Ug(r * x))
+        return (1 - z) * x + z * cand
+
+
+class TransformerBlock(Module):
+    def __init__(self, embed_dim, num_heads, config):
+        super().__init__()
+        self.attention = MultiHeadAttention(embed_dim, num_heads)
+        self.use_gtrxl = bool(config["gtrxl"]) if "gtrxl" in config else False
+        if self.use_gtrxl:
+            self.gate1 = GRUGate(embed_dim, config["gtrxl_bias"])
+            self.gate2 = GRUGate(embed_dim, config["gtrxl_bias"])
+        self.layer_norm = config["layer_norm"]
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        if self.layer_norm == "pre":
+            self.norm_kv = nn.LayerNorm(embed_dim)
+        self.fc = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.ReLU())
+
+    def forward_window(self, h, spec: WindowSpec, block=0, pos=None):
+        """h [N, D] query state; returns (new state [N, D], attention [N, H, L])."""
+        pre, post = self.layer_norm == "pre", self.layer_norm == "post"
+        q_in = self.norm1(h) if pre else h
+        att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
+        x = self.gate1(h, att_out) if self.use_gtrxl else att_out + h
+        if post:
+            x = self.norm1(x)
+        f = self.fc(self.norm2(x) if pre else x)
+        out = self.gate2(x, f) if self.use_gtrxl else f + x
+        if post:
+            out = self.norm2(out)
+        return out, att_w
+
+    def forward(self, value, key, query, mask):
+        """Upstream signature: value/key [N, L, D] (same tensor), query [N, 1, D], mask [N, L]."""
+        if key.data_ptr() != value.data_ptr():
+            raise NotImplementedError("keys and values must be the same memory window")
+        spec = WindowSpec.from_windows(value, None, mask)
+        out, att = self.forward_window(query[:, 0], spec)
+        return out.unsqueeze(1), att.unsqueeze(2)
+
+
+class SinusoidalPosition(nn.Module):
+    """Reversed absolute sinusoid ("relative" option): row i of the table encodes position seq_len - 1 - i."""
+
+    def __init__(self, dim, min_timescale=2.0, max_timescale=1e4):
+        super().__init__()
+        freqs = torch.arange(0, dim, min_timescale)
+        self.register_buffer("inv_freqs", max_timescale ** (-freqs / dim))
+
+    def forward(self, seq_len):
+        seq = torch.arange(seq_len - 1, -1, -1.0, device=self.inv_freqs.device)
+        ang = seq.unsqueeze(1) * self.inv_freqs.unsqueeze(0)
+        return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+class Transformer(nn.Module):
+    def __init__(self, config, input_dim, max_episode_steps) -> None:
+        super().__init__()
+        self.config = config
+        self.num_blocks = config["num_blocks"]
+        self.embed_dim = config["embed_dim"]
+        self.num_heads = config["num_heads"]
+        self.max_episode_steps = max_episode_steps
+        self.activation = nn.ReLU()
+        self.linear_embedding = nn.Linear(input_dim, self.embed_dim)
+        nn.init.orthogonal_(self.linear_embedding.weight, math.sqrt(2))
+        self.pos_kind = config["positional_encoding"]
+        if self.pos_kind == "relative":
+            self.pos_embedding = SinusoidalPosition(dim=self.embed_dim)
+            # table is evaluated once on the host with the same expression as upstream (bit-identical rows)
+            self.register_buffer("_pos_table", self.pos_embedding(max_episode_steps).contiguous(), persistent=False)
+        elif self.pos_kind == "learned":
+            self.pos_embedding = nn.Parameter(torch.randn(self.max_episode_steps, self.embed_dim))
+        self.transformer_blocks = nn.ModuleList(
+            [TransformerBlock(self.embed_dim, self.num_heads, config) for _ in range(self.num_blocks)])
+
+    def _pos(self):
+        if self.pos_kind == "relative":
+            return self._pos_table
+        if self.pos_kind == "learned":
+            return self.pos_embedding
+        return None
+
+    def forward_window(self, h, spec: WindowSpec):
+        """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D])."""
+        h = self.activation(self.linear_embedding(h))
+        pos = self._pos()
+        items = []
+        for i, blk in enumerate(self.transformer_blocks):
+            items.append(h.detach())
+            h, _ = blk.forward_window(h, spec, i, pos)
+        return h, torch.stack(items, dim=1)
+
+    def forward(self, h, memories, mask, memory_indices):
+        """Upstream signature: memories [N, L, blocks, D] pre-gathered, mask [N, L], memory_indices [N, L] (long)."""
+        return self.forward_window(h, WindowSpec.from_windows(memories, memory_indices, mask))

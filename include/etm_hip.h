@@ -1,0 +1,153 @@
+/*
+ * etm_hip.h -- C ABI of libetm_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * PPO + TransformerXL episodic-memory training path.
+ *
+ * The reference (MarcoMeter/episodic-transformer-memory-ppo) has no native/FFI layer; each entry point
+ * below replaces a stock-PyTorch op sequence of the reference (cited as file:line into the upstream
+ * repository) and is what a reference-side ctypes binding would call.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the library borrows it for the
+ *     duration of the enqueue and allocates nothing;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no synchronisation;
+ *   - return value: 0 on success, a hipError_t (> 0) from the launch, or a negative ETM_E* code for
+ *     argument errors; nothing throws across the ABI;
+ *   - fp32 tensors are dense row-major unless strides are given; indices are int64 (torch.long);
+ *     masks are one byte per element (0 = masked);
+ *   - thread-safety: calls are re-entrant; ordering is the stream's.
+ */
+#ifndef ETM_HIP_H
+#define ETM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETM_OK 0
+#define ETM_EINVAL (-1)      /* bad dimension / null pointer */
+#define ETM_EUNSUPPORTED (-2) /* shape outside what the gfx950 kernels are built for */
+#define ETM_EWORKSPACE (-3)  /* workspace too small */
+
+/* ABI version of this header (bumped on any signature change). */
+int etm_abi_version(void);
+
+/* Human-readable name for a negative ETM_E* code or a hipError_t. Static storage. */
+const char *etm_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel #1: episodic single-query multi-head attention over the sliding memory window.
+ *
+ * Replaces, for one transformer block, the reference sequence
+ *   utils.py:52-75 batched_index_select (window gather, [N,L,nb,D] materialised)
+ *   transformer.py:237-242 (+ positional rows indexed by the absolute episode index)
+ *   transformer.py:131      (pre-LN: LayerNorm `norm_kv` over the window)
+ *   transformer.py:50-51    (K = X Wk^T, V = X Wv^T  -- the dense [N*L, D] x [D, D] contractions)
+ *   transformer.py:59-75    (energy = Q.K, masked_fill(mask == 0, -1e20), softmax(energy / sqrt(D)), att.V)
+ * The query projection (transformer.py:52) and fc_out (:83) stay plain library GEMMs on the caller side.
+ *
+ * Window row (n, l) of the block is
+ *     X[n,l,:] = bank[ep[n] * ep_stride + win[n,l] * row_stride + 0..D)   (+ pos[pidx[n,l], :])   (then LayerNorm)
+ * so the caller passes `bank` already offset to the block (bank_base + block * D).
+ *
+ *   ep      [N]     episode slot per sample, or NULL for ep[n] = n
+ *   win     [N,L]   row inside the episode (memory_indices of the reference)
+ *   pidx    [N,L]   positional row (== win in training; differs in get_last_value, trainer.py:236), NULL iff pos == NULL
+ *   mask    [N,L]   0 => masked (transformer.py:66)
+ *   pos     [P,D]   positional table or NULL
+ *   ln_g/ln_b [D]   norm_kv gain / bias or both NULL; ln_eps = 1e-5 in the reference
+ *   q       [N,D]   projected queries
+ *   wk, wv  [D,D]   torch Linear layout [out, in]
+ * outputs
+ *   ctx     [N,D]   attention output before fc_out
+ *   att     [N,H,L] attention weights (the reference returns [N,H,1,L])
+ *   k_save, v_save [N,L,D]  projected keys / values kept for the backward pass, or both NULL (inference)
+ *   ln_stats [N,L,2] (mean, rstd) per window row: scratch written by a pre-pass, required iff ln_g != NULL
+ *                    (kept by the caller for the backward pass)
+ *
+ * Shape support: D % 32 == 0, head_dim = D / H in {32,64,96,128}, 1 <= L <= 128.
+ */
+int etm_mha_fwd(const float *bank, int64_t ep_stride, int64_t row_stride,
+                const int64_t *ep, const int64_t *win, const int64_t *pidx, const uint8_t *mask,
+                const float *pos, const float *ln_g, const float *ln_b, float ln_eps,
+                const float *q, const float *wk, const float *wv,
+                float *ctx, float *att, float *k_save, float *v_save, float *ln_stats,
+                int N, int L, int D, int H, void *stream);
+
+/* Backward of etm_mha_fwd wrt q, Wk, Wv (and optionally norm_kv gain/bias and a learned positional
+ * table).  The memory window itself is detached in the reference (transformer.py:248), so there is no
+ * gradient into `bank`.
+ *
+ *   d_ctx  [N,D]    gradient wrt ctx
+ *   att, k_save, v_save, ln_stats: as produced by the forward
+ * outputs (all overwritten, not accumulated, except d_pos / d_ln_* which are ACCUMULATED into)
+ *   d_q    [N,D]
+ *   d_e    [N,H,L]  scratch/output: gradient wrt the masked, unscaled energies
+ *   d_wk, d_wv [D,D]
+ *   d_ln_g, d_ln_b [D]  or NULL   (accumulated; caller zero-fills)
+ *   d_pos  [P,D]        or NULL   (accumulated; only for the learned table, transformer.py:213)
+ *   workspace: etm_mha_bwd_workspace_bytes(N, L, D) bytes of scratch
+ */
+int64_t etm_mha_bwd_workspace_bytes(int N, int L, int D);
+
+int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_stride,
+                const int64_t *ep, const int64_t *win, const int64_t *pidx, const uint8_t *mask,
+                const float *pos, const float *ln_g, const float *ln_b,
+                const float *q, const float *wk, const float *wv,
+                const float *att, const float *k_save, const float *v_save, const float *ln_stats,
+                const float *d_ctx,
+                float *d_q, float *d_e, float *d_wk, float *d_wv,
+                float *d_ln_g, float *d_ln_b, float *d_pos,
+                void *workspace, int64_t workspace_bytes,
+                int N, int L, int D, int H, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).
+ *   rewards, values, advantages [W,S] fp32 row-major (time contiguous, the reference layout)
+ *   dones [W,S] one byte each; last_value [W]
+ * The per-worker recurrence is evaluated in the reference's operation order without FMA contraction,
+ * so the result is bit-identical to the reference loop.  gamma_lambda = (float)(gamma * lamda) with
+ * the product formed in double precision by the caller (python float semantics of buffer.py:111).
+ */
+int etm_gae(const float *rewards, const uint8_t *dones, const float *values, const float *last_value,
+            float gamma, float gamma_lambda, float *advantages, int W, int S, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel #3: PPO clipped-surrogate + clipped value + entropy loss, forward and backward in one pass.
+ * Replaces trainer.py:276-304 and :315-316 for ONE action branch.
+ *
+ * etm_adv_stats: (count, mean, M2 = sum (a - mean)^2) of `adv` -> stats[3] (fp32).  Kept separate so a
+ *   data-parallel caller can merge per-rank statistics before normalising.
+ * etm_ppo_loss:
+ *   logits [N,A]; actions [N] (stride `action_stride` int64 elements); old_logp [N] (stride
+ *   `logp_stride`); adv, old_value, value [N]
+ *   adv_stats3 [3]    device scalars (count, mean, M2) of the (global) minibatch, as written by etm_adv_stats;
+ *                     the kernel normalises with the unbiased std sqrt(M2 / (count - 1)) + 1e-8 (trainer.py:285)
+ *   clip (double: the bounds 1 -/+ clip are formed in double like the reference's python floats), vf_coef, beta:
+ *                     hyper-parameters of trainer.py:289-304
+ *   pol_scale = 1 / (N * branches), ent_scale = val_scale = 1 / N  (the `.mean()`s of the reference)
+ *   include_value: 0 to skip the value term (2nd.. branch of a multi-discrete policy)
+ * outputs
+ *   out[8]   : policy, value_loss, loss, entropy, kl, clip_fraction, 0, 0   (trainer.py:318-323 order)
+ *   d_logits [N,A], d_value [N] : gradient of `loss` (d_value untouched when include_value == 0)
+ *   partials : scratch of etm_ppo_loss_workspace_bytes(N) bytes
+ */
+int etm_adv_stats(const float *adv, int N, float *stats3, void *stream);
+
+int64_t etm_ppo_loss_workspace_bytes(int N);
+
+int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t action_stride,
+                 const float *old_logp, int64_t logp_stride,
+                 const float *adv, const float *old_value, const float *value,
+                 const float *adv_stats3,
+                 double clip, float vf_coef, float beta,
+                 float pol_scale, float ent_scale, float val_scale, int include_value,
+                 float *out8, float *d_logits, float *d_value,
+                 void *partials, int64_t partials_bytes,
+                 int N, int A, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ETM_HIP_H */

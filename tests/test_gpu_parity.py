@@ -1,0 +1,391 @@
+"""-m gpu: the HIP path (through libetm_hip.so) against golden vectors from the reference and against the oracle.
+
+Tolerances (fp32; differences come only from summation order and libm-vs-device exp): forward 2e-5 abs + 1e-4 rel
+(values up to O(10)), attention weights 2e-6, gradients 2e-4 of the tensor norm, window indices / masks / GAE: exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import detgen as dg
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def shapes_of(z, tag):
+    keys = [str(k) for k in z[tag + "keys"]]
+    shapes = [tuple(int(x) for x in str(s).split(",") if x) for s in z[tag + "shapes"]]
+    return keys, shapes
+
+
+def load_det(module, case, keys, shapes):
+    gen = dg.det_state_dict(case, keys, shapes)
+    sd = module.state_dict()
+    assert list(sd.keys()) == keys, "state_dict keys differ from the reference"
+    module.load_state_dict({k: (torch.from_numpy(gen[k]) if k in gen else sd[k]) for k in keys})
+
+
+def close(a, b, atol=2e-5, rtol=1e-4, what=""):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    assert (err <= atol + rtol * np.abs(b)).all(), f"{what}: max err {err.max():.3e} (ref max {np.abs(b).max():.3e})"
+
+
+def grad_close(g, z, tag, key, n_sample, rel=2e-4):
+    g = g.detach().cpu().numpy()
+    norm = float(z[tag + "grad_norm/" + key])
+    tol = rel * max(norm, 1e-6)
+    assert abs(float(np.linalg.norm(g.astype(np.float64))) - norm) <= 10 * tol, (key, np.linalg.norm(g), norm)
+    close(dg.sample(g, n_sample), z[tag + "grad_sample/" + key], atol=tol, rtol=1e-3, what=key)
+
+
+def test_library_loaded_and_no_fallback():
+    from etm import lib, ops
+    h = lib.load()
+    assert h.etm_abi_version() == lib.ABI_VERSION
+    with pytest.raises(RuntimeError):
+        ops.gae(torch.zeros(2, 2), torch.zeros(2, 2, dtype=torch.bool), torch.zeros(2, 2), torch.zeros(2), 0.9, 0.9)
+
+
+# ------------------------------------------------------------------ kernel #1 vs reference golden
+def test_mha_module_vs_reference(golden_dir):
+    from transformer import MultiHeadAttention
+    dev = _dev()
+    z = load(golden_dir, "mha.npz")
+    for case in sorted({k.split("/")[0] for k in z.files}):
+        tag = case + "/"
+        D, H, L, n = (int(x) for x in z[tag + "dims"])
+        keys, shapes = shapes_of(z, tag)
+        m = MultiHeadAttention(D, H)
+        load_det(m, case, keys, shapes)
+        m.to(dev)
+        kv = torch.from_numpy(dg.det_normal(case, "kv", (n, L, D))).to(dev)
+        q = torch.from_numpy(dg.det_normal(case, "q", (n, 1, D))).to(dev).requires_grad_(True)
+        mask = torch.from_numpy(dg.leading_mask(case, n, L)).to(dev)
+        out, att = m(kv, kv, q, mask)
+        assert out.shape == (n, 1, D) and att.shape == (n, H, 1, L)
+        close(out, z[tag + "out"], what=case + " out")
+        close(att, z[tag + "att"], atol=2e-6, rtol=1e-4, what=case + " att")
+        go = torch.from_numpy(dg.det_normal(case, "gout", (n, 1, D))).to(dev)
+        (out * go).sum().backward()
+        close(q.grad, z[tag + "gq"], atol=2e-5, rtol=1e-3, what=case + " gq")
+        for k, p in m.named_parameters():
+            grad_close(p.grad, z, tag, k, 384)
+
+
+def test_transformer_variants_vs_reference(golden_dir):
+    from transformer import Transformer
+    dev = _dev()
+    z = load(golden_dir, "transformer.npz")
+    cases = sorted({k.split("/")[0] for k in z.files}, key=lambda s: int(s.split("_v")[1]))
+    assert len(cases) == 27
+    for case in cases:
+        tag = case + "/"
+        info = json.loads(str(z[tag + "cfg_json"]))
+        cfg, T, n = info["cfg"], info["T"], info["n"]
+        D, L, nb = cfg["embed_dim"], cfg["memory_length"], cfg["num_blocks"]
+        keys, shapes = shapes_of(z, tag)
+        tr = Transformer(cfg, D, T)
+        load_det(tr, case, keys, shapes)
+        tr.to(dev)
+        h = torch.from_numpy(dg.det_normal(case, "h", (n, D))).to(dev)
+        mem = torch.from_numpy(dg.det_normal(case, "mem", (n, L, nb, D), 0.5)).to(dev)
+        mask = torch.from_numpy(dg.leading_mask(case, n, L)).to(dev)
+        idx = torch.from_numpy(dg.window_indices(case, n, L, T)).to(dev)
+        out, new_mem = tr(h, mem, mask, idx)
+        assert out.shape == (n, D) and new_mem.shape == (n, nb, D)
+        close(out, z[tag + "out"], atol=5e-5, what=case + " out")
+        close(new_mem, z[tag + "new_mem"], atol=5e-5, what=case + " new_mem")
+        go = torch.from_numpy(dg.det_normal(case, "gout", (n, D))).to(dev)
+        (out * go).sum().backward()
+        for k, p in tr.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            grad_close(g, z, tag, k, 96, rel=3e-4)
+
+
+def test_actor_critic_vs_reference(golden_dir):
+    from types import SimpleNamespace
+    from model import ActorCriticModel
+    dev = _dev()
+    z = load(golden_dir, "model.npz")
+    for case in ("model_vec", "model_img", "model_img_post"):
+        tag = case + "/"
+        info = json.loads(str(z[tag + "cfg_json"]))
+        cfg, T, n, obs_shape = info["cfg"], info["T"], info["n"], tuple(info["obs_shape"])
+        t = cfg["transformer"]
+        keys, shapes = shapes_of(z, tag)
+        m = ActorCriticModel(cfg, SimpleNamespace(shape=obs_shape), tuple(info["act"]), T)
+        load_det(m, case, keys, shapes)
+        m.to(dev)
+        obs = torch.from_numpy(np.abs(dg.det_normal(case, "obs", (n,) + obs_shape, 0.4)).clip(0, 1)).to(dev)
+        mem = torch.from_numpy(dg.det_normal(case, "mem", (n, t["memory_length"], t["num_blocks"], t["embed_dim"]), 0.3)).to(dev)
+        mask = torch.from_numpy(dg.leading_mask(case, n, t["memory_length"])).to(dev)
+        idx = torch.from_numpy(dg.window_indices(case, n, t["memory_length"], T)).to(dev)
+        pi, value, new_mem = m(obs, mem, mask, idx)
+        close(pi[0].logits, z[tag + "log_probs_all"], atol=1e-4, what=case + " logp")
+        close(value, z[tag + "value"], atol=1e-4, what=case + " value")
+        close(new_mem, z[tag + "new_mem"], atol=1e-4, what=case + " mem")
+        loss = (pi[0].logits * torch.from_numpy(dg.det_normal(case, "gl", tuple(pi[0].logits.shape))).to(dev)).sum() + \
+               (value * torch.from_numpy(dg.det_normal(case, "gv", tuple(value.shape))).to(dev)).sum()
+        loss.backward()
+        for k, p in m.named_parameters():
+            grad_close(p.grad, z, tag, k, 96, rel=1e-3)
+
+
+# ------------------------------------------------------------------ kernel #1 vs the oracle: banked gather, LN, positions, Q5
+@pytest.mark.parametrize("D,H,L,N,ln,pos", [(384, 4, 64, 37, False, True), (384, 4, 128, 9, True, True), (128, 1, 32, 50, True, False),
+                                            (64, 1, 32, 7, True, True), (256, 4, 96, 6, False, False), (384, 4, 118, 5, True, True),
+                                            (96, 3, 5, 11, False, True)])
+def test_mha_banked_vs_oracle(D, H, L, N, ln, pos):
+    from etm import ops
+    from oracle import ref_model as rm
+    dev = _dev()
+    g = torch.Generator().manual_seed(D + L + N)
+    E, T, nb, blk = 6, L + 9, 3, 1
+    bank = torch.randn((E, T, nb, D), generator=g)
+    ep = torch.randint(0, E, (N,), generator=g)
+    win = (torch.randint(0, T - L + 1, (N,), generator=g)[:, None] + torch.arange(L)[None, :]).long()
+    pidx = (torch.randint(0, T - L + 1, (N,), generator=g)[:, None] + torch.arange(L)[None, :]).long()  # != win (Q5)
+    cnt = torch.randint(0, L + 1, (N,), generator=g)
+    cnt[0] = 0
+    mask = torch.arange(L)[None, :] < cnt[:, None]
+    table = torch.randn((T, D), generator=g) * 0.5
+    wk = (torch.randn((D, D), generator=g) / D ** 0.5).requires_grad_(True)
+    wv = (torch.randn((D, D), generator=g) / D ** 0.5).requires_grad_(True)
+    lg = (1 + 0.1 * torch.randn((D,), generator=g)).requires_grad_(True)
+    lb = (0.1 * torch.randn((D,), generator=g)).requires_grad_(True)
+    pt = table.clone().requires_grad_(True)
+    q = torch.randn((N, D), generator=g).requires_grad_(True)
+    gout = torch.randn((N, D), generator=g)
+    # oracle: explicit gather -> (+pos) -> (LN) -> projections -> attention (ref_model.mha without q-proj / fc_out)
+    x = bank[ep][torch.arange(N)[:, None], win][:, :, blk]
+    if pos:
+        x = x + pt[pidx]
+    if ln:
+        x = torch.nn.functional.layer_norm(x, (D,), lg, lb, 1e-5)
+    hd = D // H
+    k = (x @ wk.t()).reshape(N, L, H, hd)
+    v = (x @ wv.t()).reshape(N, L, H, hd)
+    e = torch.einsum("nhd,nkhd->nhk", q.reshape(N, H, hd), k)
+    e = e.masked_fill(mask[:, None, :] == 0, float("-1e20"))
+    a = torch.softmax(e / (D ** 0.5), dim=2)
+    ctx = torch.einsum("nhl,nlhd->nhd", a, v).reshape(N, D)
+    (ctx * gout).sum().backward()
+    ref = dict(ctx=ctx.detach(), att=a.detach(), q=q.grad, wk=wk.grad, wv=wv.grad, lg=lg.grad, lb=lb.grad, pt=pt.grad)
+
+    d = lambda t: t.detach().clone().to(dev)
+    qd, wkd, wvd = d(q).requires_grad_(True), d(wk).requires_grad_(True), d(wv).requires_grad_(True)
+    lgd, lbd, ptd = d(lg).requires_grad_(True), d(lb).requires_grad_(True), d(pt).requires_grad_(True)
+    spec = ops.WindowSpec.from_bank(bank.to(dev), ep.to(dev), win.to(dev), pidx.to(dev) if pos else None, mask.to(dev))
+    out, att = ops.mha(qd, wkd, wvd, spec, blk, H, lgd if ln else None, lbd if ln else None, ptd if pos else None)
+    close(out, ref["ctx"], what="ctx")
+    close(att, ref["att"], atol=2e-6, what="att")
+    assert torch.allclose(att[0].cpu(), torch.full((H, L), 1.0 / L), atol=1e-6)  # fully masked row -> uniform (Q2)
+    (out * gout.to(dev)).sum().backward()
+
+    def gclose(got, want, name, rel=2e-4):
+        tol = rel * float(want.double().norm()) + 1e-7
+        close(got, want.numpy(), atol=tol, rtol=1e-3, what=name)
+    gclose(qd.grad, ref["q"], "dq")
+    gclose(wkd.grad, ref["wk"], "dwk")
+    gclose(wvd.grad, ref["wv"], "dwv")
+    if ln:
+        gclose(lgd.grad, ref["lg"], "dln_g", 5e-4)
+        gclose(lbd.grad, ref["lb"], "dln_b", 5e-4)
+    if pos:
+        gclose(ptd.grad, ref["pt"], "dpos", 5e-4)
+
+
+def test_mha_full_size_vs_torch_on_device():
+    """BASELINE config (3) training shape (N=2048, L=64, D=384, H=4, 3 blocks in the bank) against plain torch ops
+    on the same device, plus size-independent properties (rows of the attention sum to 1, masked slots are 0)."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(0)
+    N, L, D, H, T, nb, E = 2048, 64, 384, 4, 96, 3, 416
+    bank = torch.randn((E, T, nb, D), device=dev)
+    ep = torch.randint(0, E, (N,), device=dev)
+    win = torch.randint(0, T - L + 1, (N, 1), device=dev) + torch.arange(L, device=dev)[None, :]
+    cnt = torch.randint(0, L, (N,), device=dev)
+    mask = torch.arange(L, device=dev)[None, :] < cnt[:, None]
+    pos = torch.randn((T, D), device=dev) * 0.5
+    wk = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
+    wv = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
+    q = torch.randn((N, D), device=dev).requires_grad_(True)
+    gout = torch.randn((N, D), device=dev)
+    spec = ops.WindowSpec.from_bank(bank, ep, win, win, mask)
+    out, att = ops.mha(q, wk, wv, spec, 2, H, pos=pos)
+    (out * gout).sum().backward()
+    got = [t.detach().clone() for t in (out, att, q.grad, wk.grad, wv.grad)]
+    q.grad = wk.grad = wv.grad = None
+    torch.backends.cuda.matmul.allow_tf32 = False
+    x = bank[ep[:, None], win][:, :, 2] + pos[win]
+    hd = D // H
+    k = (x @ wk.t()).reshape(N, L, H, hd)
+    v = (x @ wv.t()).reshape(N, L, H, hd)
+    e = torch.einsum("nhd,nkhd->nhk", q.reshape(N, H, hd), k).masked_fill(mask[:, None, :] == 0, float("-1e20"))
+    a = torch.softmax(e / (D ** 0.5), dim=2)
+    ctx = torch.einsum("nhl,nlhd->nhd", a, v).reshape(N, D)
+    (ctx * gout).sum().backward()
+    want = [ctx, a, q.grad, wk.grad, wv.grad]
+    for name, g_, w_ in zip(("ctx", "att", "dq", "dwk", "dwv"), got, want):
+        tol = 2e-4 * float(w_.double().norm()) / max(1.0, float(w_.numel()) ** 0.5) + 2e-5
+        err = (g_ - w_).abs().max().item()
+        assert err <= tol * 50, f"{name}: max err {err:.3e} vs tol {tol * 50:.3e}"
+        assert (g_ - w_).double().norm() <= 2e-4 * w_.double().norm() + 1e-6, name
+    assert torch.allclose(got[1].sum(-1), torch.ones((N, H), device=dev), atol=1e-5)
+    nonfull = cnt > 0
+    assert (got[1][nonfull] * (~mask[nonfull])[:, None, :]).abs().max() == 0
+
+
+# ------------------------------------------------------------------ kernel #2
+def test_gae_bit_exact(golden_dir):
+    from etm import ops
+    from oracle import ref_algo as ra
+    dev = _dev()
+    z = load(golden_dir, "gae.npz")
+    for case in sorted({k.split("/")[0] for k in z.files}):
+        t = lambda k: torch.from_numpy(z[f"{case}/{k}"]).to(dev)
+        adv = ops.gae(t("rewards"), t("dones"), t("values"), t("last_value"), float(z[case + "/gamma"]), float(z[case + "/lamda"]))
+        assert np.array_equal(adv.cpu().numpy(), z[case + "/adv"]), case
+    rng = np.random.default_rng(3)
+    for W, S in ((256, 512), (1000, 77), (1, 1), (65, 33)):
+        r = rng.normal(size=(W, S)).astype(np.float32)
+        d = rng.random((W, S)) < 0.03
+        v = rng.normal(size=(W, S)).astype(np.float32)
+        lv = rng.normal(size=(W,)).astype(np.float32)
+        adv = ops.gae(torch.from_numpy(r).to(dev), torch.from_numpy(d).to(dev), torch.from_numpy(v).to(dev), torch.from_numpy(lv).to(dev), 0.995, 0.95)
+        assert np.array_equal(adv.cpu().numpy(), ra.gae(r, d, v, lv, 0.995, 0.95).numpy()), (W, S)
+
+
+# ------------------------------------------------------------------ kernel #3
+def test_ppo_loss_vs_reference(golden_dir):
+    from etm import ops
+    dev = _dev()
+    z = load(golden_dir, "loss.npz")
+    for case in sorted({k.split("/")[0] for k in z.files}):
+        t = lambda k: torch.from_numpy(z[f"{case}/{k}"]).to(dev)
+        logits = t("logits").requires_grad_(True)
+        value = t("value").requires_grad_(True)
+        clip, cv, beta = (float(x) for x in z[f"{case}/hp"])
+        loss, stats = ops.ppo_loss([logits], value, t("actions"), t("old_logp"), t("adv"), t("old_v"), clip, cv, beta)
+        loss.backward()
+        close(stats, z[f"{case}/stats"], atol=2e-6, rtol=1e-4, what=case + " stats")
+        assert abs(loss.item() - float(z[f"{case}/stats"][2])) < 1e-5
+        close(logits.grad, z[f"{case}/glogits"], atol=1e-8, rtol=2e-3, what=case + " glogits")
+        close(value.grad, z[f"{case}/gvalue"], atol=1e-8, rtol=2e-3, what=case + " gvalue")
+
+
+def test_ppo_loss_multi_branch_vs_oracle():
+    from etm import ops
+    from oracle import ref_algo as ra
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    N = 300
+    lg = [torch.randn((N, a), generator=g).requires_grad_(True) for a in (3, 5)]
+    value = torch.randn((N,), generator=g).requires_grad_(True)
+    actions = torch.stack([torch.randint(0, 3, (N,), generator=g), torch.randint(0, 5, (N,), generator=g)], 1)
+    old = torch.randn((N, 2), generator=g) * 0.1 - 1.2
+    adv, oldv = torch.randn((N,), generator=g), torch.randn((N,), generator=g)
+    loss, stats = ra.ppo_loss(lg, value, actions, old, adv, oldv, 0.2, 0.3, 0.01)
+    loss.backward()
+    lgd = [t.detach().to(dev).requires_grad_(True) for t in lg]
+    vd = value.detach().to(dev).requires_grad_(True)
+    l2, s2 = ops.ppo_loss(lgd, vd, actions.to(dev), old.to(dev), adv.to(dev), oldv.to(dev), 0.2, 0.3, 0.01)
+    l2.backward()
+    close(s2, stats.numpy(), atol=2e-6, rtol=1e-4, what="stats")
+    for a, b in zip(lgd, lg):
+        close(a.grad, b.grad.numpy(), atol=1e-8, rtol=2e-3, what="glogits")
+    close(vd.grad, value.grad.numpy(), atol=1e-8, rtol=2e-3, what="gvalue")
+
+
+# ------------------------------------------------------------------ whole path: teacher-forced rollout + updates vs the reference
+@pytest.mark.parametrize("name", ["vec", "gtrxl"])
+def test_trainer_teacher_forced_vs_reference(golden_dir, name):
+    from environments.synthetic import SyntheticVecEnv
+    from trainer import PPOTrainer
+    dev = _dev()
+    z = load(golden_dir, f"rollout_{name}.npz")
+    info = json.loads(str(z["cfg_json"]))
+    cfg, envk = info["cfg"], info["env"]
+    env = SyntheticVecEnv(cfg["n_workers"], **{**envk, "obs_shape": tuple(envk["obs_shape"])})
+    tr = PPOTrainer(cfg, run_id="parity", device=dev, env=env, tensorboard=False)
+    keys, shapes = shapes_of(z, "")
+    load_det(tr.model, "rollout_" + name, keys, shapes)
+    W, S = cfg["n_workers"], cfg["worker_steps"]
+    for upd in range(cfg["updates"]):
+        tag = f"u{upd}/"
+        tr._sample_training_data(forced_actions=z[tag + "actions"][:, :, 0])
+        tr.buffer.prepare_batch_dict()
+        b = tr.buffer
+        # memory-window bookkeeping: bit exact
+        assert np.array_equal(b.memory_mask.cpu().numpy(), z[tag + "memory_mask"])
+        assert np.array_equal(b.memory_indices.cpu().numpy(), z[tag + "memory_indices"])
+        assert np.array_equal(b.memory_index.cpu().numpy(), z[tag + "memory_index"])
+        assert np.array_equal(b.dones, z[tag + "dones"]) and np.array_equal(b.rewards, z[tag + "rewards"])
+        assert np.array_equal(tr.worker_current_episode_step, z[tag + "ep_step_after"])
+        assert np.array_equal(b.obs.cpu().numpy(), z[tag + "obs"])
+        close(b.values, z[tag + "values"], atol=1e-4, what="values")
+        close(b.log_probs, z[tag + "log_probs"], atol=1e-4, what="log_probs")
+        close(b.advantages, z[tag + "advantages"], atol=5e-4, what="advantages")
+        e_ref = z[tag + "memories"].shape[0]
+        assert b.num_episodes >= e_ref
+        close(b.memories[:e_ref], z[tag + "memories"], atol=1e-4, what="memories")
+        lr, clip, beta = (float(x) for x in z[tag + "hp"])
+        assert (lr, beta, clip) == tuple(float(x) for x in tr.schedules(upd))
+        stats, _ = tr._train_epochs(lr, clip, beta, perms=z[tag + "perms"])
+        close(np.asarray(stats), z[tag + "stats"], atol=1e-4, rtol=5e-3, what="stats")
+        sd = tr.model.state_dict()
+        for k in keys:
+            if k.endswith("inv_freqs"):
+                continue
+            close(dg.sample(sd[k].cpu().numpy(), 64), z[tag + "sd_after_sample/" + k], atol=1e-4, rtol=5e-3, what="param " + k)
+    tr.close()
+
+
+def test_trainer_self_consistency_and_free_run():
+    """Recomputed values from the buffer equal the rollout values for every sample with a non-empty mask row
+    (SURVEY quirk Q10), and a free-running update produces finite statistics."""
+    from trainer import PPOTrainer
+    from etm.ops import WindowSpec
+    dev = _dev()
+    cfg = dict(environment=dict(type="Synthetic", obs_shape=[3, 84, 84], num_actions=3, max_episode_steps=40, seed=1, p_done=0.03, pool=8),
+               gamma=0.995, lamda=0.95, updates=1, epochs=2, n_workers=8, worker_steps=96, n_mini_batch=4, value_loss_coefficient=0.5,
+               hidden_layer_size=128, max_grad_norm=0.5,
+               transformer=dict(num_blocks=3, embed_dim=128, num_heads=4, memory_length=32, positional_encoding="relative",
+                                layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
+               learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
+               beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
+               clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
+    torch.manual_seed(0)
+    tr = PPOTrainer(cfg, run_id="selfcheck", device=dev, tensorboard=False)
+    for _ in range(2):
+        infos = tr._sample_training_data()
+        tr.buffer.prepare_batch_dict()
+        flat = tr.buffer.samples_flat
+        with torch.no_grad():
+            spec = WindowSpec.from_bank(tr.buffer.memories, flat["memory_index"], flat["memory_indices"], flat["memory_indices"], flat["memory_mask"])
+            _, value, _ = tr.model.forward_logits(flat["obs"], spec)
+        keep = flat["memory_mask"].any(dim=1)
+        assert keep.sum() > 0.8 * keep.numel()
+        assert torch.allclose(value[keep], flat["values"][keep], atol=2e-4), (value[keep] - flat["values"][keep]).abs().max()
+        stats, grads = tr._train_epochs(3e-4, 0.1, 1e-3)
+        assert np.isfinite(np.asarray(stats)).all() and len(stats) == 8
+        assert set(grads) == {"encoder", "linear_layer", "transformer_block_0", "transformer_block_1", "transformer_block_2",
+                              "policy_head_0", "lin_policy", "value", "model"}
+    assert len(infos) > 0 and all({"reward", "length"} <= set(i) for i in infos)
+    tr.close()

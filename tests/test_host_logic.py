@@ -1,0 +1,134 @@
+"""CPU-side checks of the product's host logic: window tables (bit-exact vs the reference's), schedules, config
+surface, the C-ABI library (loads, exports every symbol include/etm_hip.h declares), loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_window_tables_bit_exact_vs_reference(golden_dir):
+    from trainer import build_window_tables
+    z = np.load(os.path.join(golden_dir, "tables.npz"))
+    for k in [k for k in z.files if k.startswith("mask_")]:
+        L, T = (int(x[1:]) for x in k.split("_")[1:])
+        mask, idx = build_window_tables(L, T)
+        assert mask.dtype == torch.float32 and idx.dtype == torch.int64
+        assert np.array_equal(mask.numpy(), z[k]) and np.array_equal(idx.numpy(), z[f"index_L{L}_T{T}"])
+    with pytest.raises(ValueError):
+        build_window_tables(8, 7)
+
+
+def test_polynomial_decay_vs_reference(golden_dir):
+    from utils import polynomial_decay
+    z = np.load(os.path.join(golden_dir, "decay.npz"))
+    for k in [k for k in z.files if k.endswith("/steps")]:
+        base = k[:-len("steps")]
+        ini, fin, mx, pw = z[base + "params"]
+        got = [polynomial_decay(float(ini), float(fin), int(mx), float(pw), int(s)) for s in z[k]]
+        assert got == list(z[base + "values"]), base
+
+
+def test_batched_index_select_matches_gather():
+    from utils import batched_index_select
+    x = torch.randn(5, 9, 2, 4)
+    idx = torch.randint(0, 9, (5, 3))
+    out = batched_index_select(x, 1, idx)
+    assert out.shape == (5, 3, 2, 4)
+    for b in range(5):
+        assert torch.equal(out[b], x[b, idx[b]])
+
+
+def test_state_dict_keys_and_param_counts(golden_dir):
+    import yaml
+    from types import SimpleNamespace
+    from model import ActorCriticModel
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg_dir = os.path.join(here, "..", "episodic-transformer-memory-ppo_amd", "configs")
+    z = np.load(os.path.join(golden_dir, "model.npz"))
+    for cname, obs_shape, n_act, T in (("minigrid", (3, 84, 84), 3, 96), ("cartpole", (4,), 2, 200),
+                                        ("poc_memory_env", (3,), 2, 32), ("mortar_mayhem_grid", (3, 84, 84), 4, 128)):
+        cfg = yaml.safe_load(open(os.path.join(cfg_dir, cname + ".yaml")))
+        m = ActorCriticModel(cfg, SimpleNamespace(shape=obs_shape), (n_act,), T)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [str(k) for k in z[f"keys/{cname}"]]
+        assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in z[f"shapes/{cname}"]]
+        assert sum(p.numel() for p in m.parameters()) == int(z[f"nparams/{cname}"])
+
+
+def test_yaml_surface_and_parser():
+    from yaml_parser import YamlParser
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = YamlParser(os.path.join(here, "..", "episodic-transformer-memory-ppo_amd", "configs", "minigrid.yaml")).get_config()
+    assert cfg["n_workers"] == 16 and cfg["worker_steps"] == 512 and cfg["epochs"] == 5 and cfg["n_mini_batch"] == 8
+    assert cfg["transformer"] == {"num_blocks": 3, "embed_dim": 384, "num_heads": 4, "memory_length": 64,
+                                  "positional_encoding": "relative", "layer_norm": "post", "gtrxl": False, "gtrxl_bias": 0.0}
+    syn = YamlParser(os.path.join(here, "..", "episodic-transformer-memory-ppo_amd", "configs", "synthetic_minigrid.yaml")).get_config()
+    assert syn["n_workers"] == 32 and syn["environment"]["type"] == "Synthetic" and syn["transformer"] == cfg["transformer"]
+
+
+def test_library_exports_every_declared_symbol():
+    from etm import lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    header = open(os.path.join(here, "..", "include", "etm_hip.h")).read()
+    declared = set(re.findall(r"\b(etm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    handle = lib.load()                       # dlopen works without a GPU; no kernel is launched here
+    for name in declared:
+        assert hasattr(handle, name)
+    assert handle.etm_abi_version() == lib.ABI_VERSION
+    assert b"not supported" in handle.etm_error_string(-2)
+    assert handle.etm_mha_bwd_workspace_bytes(2048, 64, 384) > 0 and handle.etm_ppo_loss_workspace_bytes(2048) == 8 * 8 * 4
+
+
+def test_product_path_refuses_cpu():
+    from etm import ops
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.gae(torch.zeros(2, 3), torch.zeros(2, 3, dtype=torch.bool), torch.zeros(2, 3), torch.zeros(2), 0.99, 0.95)
+    if not torch.cuda.is_available():
+        from trainer import PPOTrainer
+        with pytest.raises(RuntimeError, match="no CPU"):
+            PPOTrainer({"n_workers": 1}, device=torch.device("cpu"))
+
+
+def test_product_does_not_import_oracle():
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(here, "..", "episodic-transformer-memory-ppo_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_synthetic_env_single_and_vector_streams_agree():
+    from environments.synthetic import SyntheticEnv, SyntheticVecEnv
+    kw = dict(obs_shape=(2, 3), num_actions=3, max_episode_steps=7, seed=5, p_done=0.2, p_reward=0.4, pool=5)
+    vec = SyntheticVecEnv(3, **kw)
+    singles = [SyntheticEnv(worker_id=w, **kw) for w in range(3)]
+    obs_v = vec.reset()
+    obs_s = np.stack([e.reset() for e in singles])
+    assert np.array_equal(obs_v, obs_s)
+    for t in range(60):
+        o, r, d, info = vec.step(np.zeros(3, dtype=np.int64))
+        for w, e in enumerate(singles):
+            so, sr, sd, si = e.step([0])
+            if si:
+                so = e.reset()
+            assert np.array_equal(o[w], so) and r[w] == sr and d[w] == sd and info[w] == si
+
+
+def test_poc_memory_env_protocol():
+    from environments.poc_memory_env import PocMemoryEnv
+    env = PocMemoryEnv(glob=False, freeze=True, max_episode_steps=32, seed=0)
+    obs = env.reset()
+    assert obs.shape == (3,) and set(np.abs(obs[[0, 2]])) == {1.0}
+    total, steps, done = 0.0, 0, False
+    while not done:
+        obs, r, done, info = env.step([1])
+        steps += 1
+        total += r
+        if steps > 2 and not done:
+            assert obs[0] == 0.0 and obs[2] == 0.0       # goals hidden after the first two steps
+    assert info["length"] == steps and abs(info["reward"] - total) < 1e-6 and steps <= 32
