@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Throughput bench of the MI355X PPO + TransformerXL path (driver contract: see the repo prompt / DESIGN.md).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full PPO update of BASELINE config (3)/(4): a rollout of n_workers x worker_steps = 32 x 512
+environment steps per GPU on synthetic 3x84x84 observations, GAE, and epochs x n_mini_batch = 5 x 8 optimiser steps
+on minibatches of 2048 samples (configs/synthetic_minigrid.yaml).  Weak scaling: every rank owns its own 32
+environments; gradients are all-reduced with RCCL.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     the dominant kernel's achieved rate from HIP events recorded around its launches inside the timed
+               region (libetm_hip.so's etm_profile_* facility), against the fp32 MFMA peak of gfx950;
+  cpu_baseline the CPU oracle (oracle/ref_algo.OracleTrainer, a validated restatement of the reference trainer)
+               timed on this host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "episodic-transformer-memory-ppo_amd")
+for _p in (REPO, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def load_config():
+    from yaml_parser import YamlParser
+    return YamlParser(os.path.join(PKG, "configs", "synthetic_minigrid.yaml")).get_config()
+
+
+def kernel_flops(name, N, L, D, H):
+    """Algorithmic flops one launch of a kernel performs at the training shape (DESIGN.md section 'Kernels')."""
+    if name == "mha_fwd_kernel":      # K and V projections of the window + QK^T + att.V
+        return N * 2.0 * (2 * L * D * D + 2 * L * D)
+    if name == "bwd_dw_kernel":       # dWk and dWv: [2D, N*L] x [N*L, D]
+        return N * 2.0 * (2 * L * D * D)
+    return None
+
+
+def cpu_baseline(cfg, seed=0):
+    """Oracle trainer on host cores, bounded sample: 32 workers x 64 steps, 5 epochs x 1 minibatch of 2048."""
+    from environments.vec_env import make_vec_env
+    from oracle.ref_algo import OracleTrainer
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        c = json.loads(json.dumps(cfg))
+        c["worker_steps"] = 64
+        c["n_mini_batch"] = 1
+        env = make_vec_env(c["environment"], c["n_workers"])
+        torch.manual_seed(seed)
+        tr = OracleTrainer(c, env, seed=seed)
+        t0 = time.perf_counter()
+        _, _, split = tr.update(0)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(prev)
+    steps = c["n_workers"] * c["worker_steps"]
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 update of {c['n_workers']} workers x {c['worker_steps']} steps (= {steps} env steps) with {c['epochs']} epochs x 1 "
+                      f"minibatch of {steps} samples: same per-env-step work as the full config (minibatch 2048, 5 epochs); "
+                      f"{dt:.1f} s (rollout {split['rollout_s']:.1f} s, train {split['train_s']:.1f} s) on {threads} torch threads "
+                      f"of {cores} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
+                             f"--nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the MI355X path; no HIP device is visible (there is no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from etm import lib as etm_lib
+    from etm.dist import DataParallel
+    from trainer import PPOTrainer
+    lib = etm_lib.load()
+
+    cfg = load_config()
+    dp = DataParallel(device) if world > 1 else None
+    torch.manual_seed(0)
+    np.random.seed(0)
+    trainer = PPOTrainer(cfg, run_id="bench", device=device, dp=dp, first_worker_id=rank * cfg["n_workers"], tensorboard=False)
+
+    def one_update(i):
+        lr, beta, clip = trainer.schedules(i)
+        t0 = time.perf_counter()
+        lib.etm_profile_set_tag(0)
+        trainer._sample_training_data()
+        trainer.buffer.prepare_batch_dict()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        lib.etm_profile_set_tag(1)
+        trainer._train_epochs(lr, clip, beta)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    for i in range(args.warmup):
+        one_update(i)
+    if not args.no_profile:
+        etm_lib.profile_collect()
+        lib.etm_profile_enable(1)
+    if dp is not None:
+        dp.barrier()
+    torch.cuda.synchronize(device)
+    t_start = time.perf_counter()
+    phase = np.zeros(2)
+    env_s = 0.0
+    for i in range(args.steps):
+        r, tr_s = one_update(args.warmup + i)
+        phase += (r, tr_s)
+        env_s += trainer.last_update_timing.get("env_s", 0.0)
+    torch.cuda.synchronize(device)
+    if dp is not None:
+        dp.barrier()
+    elapsed = time.perf_counter() - t_start
+    lib.etm_profile_enable(0)
+    prof = etm_lib.profile_collect() if not args.no_profile else {}
+    if dp is not None:
+        elapsed = dp.max_over_ranks(elapsed)
+
+    W, S = cfg["n_workers"], cfg["worker_steps"]
+    t = cfg["transformer"]
+    L, D, H, nb = t["memory_length"], t["embed_dim"], t["num_heads"], t["num_blocks"]
+    N = W * S // cfg["n_mini_batch"]
+    total_env_steps = world * W * S * args.steps
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (training-tag launches, minibatch shape)
+        kernels = {}
+        for (tag, name), (ms, cnt) in prof.items():
+            if tag != 1:
+                continue
+            entry = {"launches": cnt, "avg_ms": ms / cnt, "total_ms": ms}
+            fl = kernel_flops(name, N, L, D, H)
+            if fl:
+                entry["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
+            kernels[name] = entry
+        roofline = None
+        cand = [k for k in ("mha_fwd_kernel", "bwd_dw_kernel") if k in kernels]
+        if cand:
+            dom = max(cand, key=lambda k: kernels[k]["total_ms"])
+            ach = kernels[dom]["tflops"]
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": kernels[dom]["avg_ms"],
+                        "flops_per_launch": kernel_flops(dom, N, L, D, H), "launches": kernels[dom]["launches"],
+                        "shape": {"N": N, "L": L, "D": D, "H": H}, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
+        out = {
+            "metric": "env-steps/sec (whole node) MinigridMemory 3x84x84",
+            "value": total_env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config (3)/(4): configs/synthetic_minigrid.yaml -- per GPU n_workers=32 x worker_steps=512 "
+                                   "= 16384 env steps per update, 5 epochs x 8 minibatches of 2048, TrXL 3 blocks D=384 H=4 L=64, "
+                                   "synthetic U[0,1) 3x84x84 observations, random-init weights",
+                       "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}"},
+            "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
+            "roofline": roofline,
+            "kernels_train": kernels,
+            "kernels_rollout": rollout_k,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    trainer.close()
+    if dp is not None:
+        dp.close()
+
+
+if __name__ == "__main__":
+    main()

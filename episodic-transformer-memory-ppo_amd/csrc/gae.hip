@@ -67,6 +67,7 @@ extern "C" int etm_gae(const float *rewards, const uint8_t *dones, const float *
                        float gamma_lambda, float *advantages, int W, int S, void *stream) {
   if (!rewards || !dones || !values || !last_value || !advantages) return ETM_EINVAL;
   if (W <= 0 || S <= 0) return ETM_EINVAL;
+  EtmProfScope prof(ETM_K_GAE, (hipStream_t)stream);
   hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rewards, dones, values,
                      last_value, gamma, gamma_lambda, advantages, W, S);
   return etm_launch_status();

@@ -475,27 +475,42 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   int rc;
   // B1
   const size_t sm1 = (size_t)(D + 3 * H * L) * sizeof(float);
-  hipLaunchKernelGGL(bwd_scores_kernel, dim3(N), dim3(256), sm1, st, p);
+  {
+    EtmProfScope prof(ETM_K_BWD_SCORES, st);
+    hipLaunchKernelGGL(bwd_scores_kernel, dim3(N), dim3(256), sm1, st, p);
+  }
   if ((rc = etm_launch_status())) return rc;
   // B2
   const dim3 g2((unsigned)(pl.splits * pl.tiles_m * pl.tiles_n));
   const bool has_ln = ln_g != nullptr, has_pos = pos != nullptr;
-  if (has_ln && has_pos) hipLaunchKernelGGL((bwd_dw_kernel<true, true>), g2, dim3(256), 0, st, p);
-  else if (has_ln) hipLaunchKernelGGL((bwd_dw_kernel<true, false>), g2, dim3(256), 0, st, p);
-  else if (has_pos) hipLaunchKernelGGL((bwd_dw_kernel<false, true>), g2, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((bwd_dw_kernel<false, false>), g2, dim3(256), 0, st, p);
+  {
+    EtmProfScope prof(ETM_K_BWD_DW, st);
+    if (has_ln && has_pos) hipLaunchKernelGGL((bwd_dw_kernel<true, true>), g2, dim3(256), 0, st, p);
+    else if (has_ln) hipLaunchKernelGGL((bwd_dw_kernel<true, false>), g2, dim3(256), 0, st, p);
+    else if (has_pos) hipLaunchKernelGGL((bwd_dw_kernel<false, true>), g2, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((bwd_dw_kernel<false, false>), g2, dim3(256), 0, st, p);
+  }
   if ((rc = etm_launch_status())) return rc;
   const long long per = (long long)2 * D * D;
-  hipLaunchKernelGGL(bwd_dw_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, st, p.partial, d_wk, d_wv,
-                     pl.splits, D);
+  {
+    EtmProfScope prof(ETM_K_BWD_REDUCE, st);
+    hipLaunchKernelGGL(bwd_dw_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, st, p.partial, d_wk, d_wv,
+                       pl.splits, D);
+  }
   if ((rc = etm_launch_status())) return rc;
   // B3
   if (d_ln_g || d_pos) {
-    hipLaunchKernelGGL(bwd_uw_kernel, dim3((unsigned)((N + 7) / 8), 2), dim3(256), (size_t)8 * D * sizeof(float), st, p);
+    {
+      EtmProfScope prof(ETM_K_BWD_UW, st);
+      hipLaunchKernelGGL(bwd_uw_kernel, dim3((unsigned)((N + 7) / 8), 2), dim3(256), (size_t)8 * D * sizeof(float), st, p);
+    }
     if ((rc = etm_launch_status())) return rc;
     const size_t sm3 = (size_t)(2 * H * D + 8 * D) * sizeof(float);
-    if (has_ln) hipLaunchKernelGGL((bwd_dx_kernel<true>), dim3(N), dim3(256), sm3, st, p);
-    else hipLaunchKernelGGL((bwd_dx_kernel<false>), dim3(N), dim3(256), sm3, st, p);
+    {
+      EtmProfScope prof(ETM_K_BWD_DX, st);
+      if (has_ln) hipLaunchKernelGGL((bwd_dx_kernel<true>), dim3(N), dim3(256), sm3, st, p);
+      else hipLaunchKernelGGL((bwd_dx_kernel<false>), dim3(N), dim3(256), sm3, st, p);
+    }
     if ((rc = etm_launch_status())) return rc;
   }
   return ETM_OK;

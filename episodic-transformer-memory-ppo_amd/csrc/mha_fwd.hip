@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
 template <int HT>
 int launch_fwd(const FwdParams &p, bool has_ln, bool has_pos, hipStream_t st) {
   const dim3 grid(((p.n_tiles + 7) / 8) * 8 * p.H), block(256);
+  EtmProfScope prof(ETM_K_MHA_FWD, st);
   if (has_ln && has_pos) hipLaunchKernelGGL((mha_fwd_kernel<HT, true, true>), grid, block, 0, st, p);
   else if (has_ln) hipLaunchKernelGGL((mha_fwd_kernel<HT, true, false>), grid, block, 0, st, p);
   else if (has_pos) hipLaunchKernelGGL((mha_fwd_kernel<HT, false, true>), grid, block, 0, st, p);
@@ -320,9 +321,12 @@ extern "C" int etm_mha_fwd(const float *bank, int64_t ep_stride, int64_t row_str
 
   if (ln_g) {
     const long long rows = (long long)N * L;
-    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, bank, (long long)ep_stride,
-                       (long long)row_stride, (const long long *)ep, (const long long *)win, (const long long *)pidx, pos, ln_eps,
-                       ln_stats, N, L, D);
+    {
+      EtmProfScope prof(ETM_K_LN_STATS, st);
+      hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, bank, (long long)ep_stride,
+                         (long long)row_stride, (const long long *)ep, (const long long *)win, (const long long *)pidx, pos, ln_eps,
+                         ln_stats, N, L, D);
+    }
     int rc = etm_launch_status();
     if (rc) return rc;
   }

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(64) void ppo_finalize_kernel(const float *__restric
 
 extern "C" int etm_adv_stats(const float *adv, int N, float *stats3, void *stream) {
   if (!adv || !stats3 || N <= 0) return ETM_EINVAL;
+  EtmProfScope prof(ETM_K_ADV_STATS, (hipStream_t)stream);
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, adv, N, stats3);
   return etm_launch_status();
 }
@@ -180,10 +181,16 @@ extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t
   p.N = N; p.A = A;
   const int nb = (N + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(256), 0, st, p);
+  {
+    EtmProfScope prof(ETM_K_PPO_LOSS, st);
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(256), 0, st, p);
+  }
   int rc = etm_launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(ppo_finalize_kernel, dim3(1), dim3(64), 0, st, (const float *)partials, nb, vf_coef, beta, pol_scale, ent_scale,
-                     val_scale, out8);
+  {
+    EtmProfScope prof(ETM_K_PPO_FINAL, st);
+    hipLaunchKernelGGL(ppo_finalize_kernel, dim3(1), dim3(64), 0, st, (const float *)partials, nb, vf_coef, beta, pol_scale, ent_scale,
+                       val_scale, out8);
+  }
   return etm_launch_status();
 }

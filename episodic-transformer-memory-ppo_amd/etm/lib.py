@@ -25,6 +25,11 @@ SIGNATURES = {
     "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),
     "etm_adv_stats": (_I, [_P, _I, _P, _P]),
     "etm_ppo_loss_workspace_bytes": (_L, [_I]),
+    "etm_profile_enable": (_I, [_I]),
+    "etm_profile_set_tag": (_I, [_I]),
+    "etm_profile_kernel_count": (_I, []),
+    "etm_profile_kernel_name": (ctypes.c_char_p, [_I]),
+    "etm_profile_collect": (_I, [_P, _P]),
     "etm_ppo_loss": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P, _D, _F, _F, _F, _F, _F, _I, _P, _P, _P, _P, _L, _I, _I, _P]),
 }
 
@@ -53,3 +58,19 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().etm_error_string(rc)
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def profile_collect():
+    """{(tag, kernel_name): (total_ms, launches)} for everything recorded since the last call."""
+    import numpy as np
+    lib = load()
+    k = lib.etm_profile_kernel_count()
+    ms = np.zeros(2 * k, dtype=np.float64)
+    cnt = np.zeros(2 * k, dtype=np.int64)
+    check(lib.etm_profile_collect(ms.ctypes.data, cnt.ctypes.data), "etm_profile_collect")
+    out = {}
+    for tag in (0, 1):
+        for i in range(k):
+            if cnt[tag * k + i]:
+                out[(tag, lib.etm_profile_kernel_name(i).decode())] = (float(ms[tag * k + i]), int(cnt[tag * k + i]))
+    return out

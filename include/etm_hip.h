@@ -147,6 +147,20 @@ int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t action_str
                  void *partials, int64_t partials_bytes,
                  int N, int A, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline numbers).
+ *   etm_profile_enable(1/0)      start/stop recording an event pair around every internal kernel launch
+ *   etm_profile_set_tag(0/1)     tag subsequent launches (bench: 0 = rollout/inference, 1 = training minibatch)
+ *   etm_profile_kernel_count()   number K of internal kernels; etm_profile_kernel_name(k) their names
+ *   etm_profile_collect(total_ms[2*K], count[2*K])  synchronise the recorded events, sum per (tag, kernel), reset
+ * Not thread-safe; off by default (zero overhead when off apart from one branch per launch).
+ */
+int etm_profile_enable(int on);
+int etm_profile_set_tag(int tag);
+int etm_profile_kernel_count(void);
+const char *etm_profile_kernel_name(int kernel);
+int etm_profile_collect(double *total_ms, int64_t *count);
+
 #ifdef __cplusplus
 }
 #endif

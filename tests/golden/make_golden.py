@@ -363,7 +363,7 @@ def golden_rollout():
         "vec": dict(env=dict(obs_shape=(6,), num_actions=3, max_episode_steps=12, seed=3, p_done=0.08, p_reward=0.3, pool=16),
                     cfg=dict(gamma=0.99, lamda=0.95, updates=2, epochs=2, n_workers=4, worker_steps=40, n_mini_batch=2,
                              value_loss_coefficient=0.25, hidden_layer_size=32, max_grad_norm=0.5,
-                             transformer=dict(num_blocks=2, embed_dim=32, num_heads=2, memory_length=8,
+                             transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8,
                                               positional_encoding="relative", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))),
         "gtrxl": dict(env=dict(obs_shape=(5,), num_actions=2, max_episode_steps=10, seed=9, p_done=0.1, p_reward=0.3, pool=16),
                       cfg=dict(gamma=0.99, lamda=0.95, updates=2, epochs=1, n_workers=3, worker_steps=32, n_mini_batch=2,

@@ -1,0 +1,81 @@
+"""Data-parallel plumbing (etm/dist.py) on CPU: world_size 2 over gloo, 127.0.0.1 rendezvous."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "episodic-transformer-memory-ppo_amd")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, PKG)
+    from etm.dist import DataParallel
+    dp = DataParallel(device=torch.device("cpu"), backend="gloo")
+    assert dp.active and dp.rank == rank and dp.world == world
+    first, count = dp.shard(64)
+    assert (first, count) == (rank * 32, 32)
+
+    # replicas start identical after the broadcast
+    torch.manual_seed(100 + rank)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    dp.broadcast_parameters(model)
+    params = list(model.parameters())
+    flat = dp.attach_flat_grads(params)
+    assert flat.numel() == sum(p.numel() for p in params)
+
+    # shard the same global batch; averaged shard gradients == gradient of the global mean loss
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((64, 5), generator=g)
+    y = torch.randn((64, 3), generator=g)
+    flat.zero_()
+    loss = ((model(x[first:first + count]) - y[first:first + count]) ** 2).mean()
+    loss.backward()
+    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in params)   # grads still alias the bucket
+    dp.all_reduce_grads()
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    ref.load_state_dict(model.state_dict())
+    ((ref(x) - y) ** 2).mean().backward()
+    ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    assert torch.allclose(flat, ref_flat, atol=1e-6), (flat - ref_flat).abs().max()
+
+    # advantage statistics: merged (count, mean, M2) == statistics of the concatenated minibatch
+    adv = torch.randn((100,), generator=g) * 3 + 1
+    mine = adv[rank * 50:(rank + 1) * 50]
+    local = torch.stack([torch.tensor(50.0), mine.mean(), ((mine - mine.mean()) ** 2).sum()])
+    merged = dp.merge_adv_stats(local)
+    assert torch.allclose(merged, torch.stack([torch.tensor(100.0), adv.mean(), ((adv - adv.mean()) ** 2).sum()]), rtol=1e-5)
+    assert abs(float(torch.sqrt(merged[2] / (merged[0] - 1))) - float(adv.std())) < 1e-5
+
+    assert dp.max_over_ranks(float(rank + 1)) == float(world)
+    dp.barrier()
+    dp.close()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_data_parallel_world_size_2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_single_process_is_passthrough():
+    sys.path.insert(0, PKG)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    from etm.dist import DataParallel
+    dp = DataParallel(device=torch.device("cpu"))
+    assert not dp.active and dp.shard(32) == (0, 32)
+    s = torch.tensor([4.0, 1.0, 2.0])
+    assert dp.merge_adv_stats(s) is s and dp.max_over_ranks(3.5) == 3.5
