@@ -38,13 +38,13 @@ hipEvent_t take_event() {
 void etm_prof_begin(int kid, hipStream_t st) {
   if (!g_prof_on || g_recs.size() >= kMaxRecs) { g_cur_start = nullptr; return; }
   g_cur_start = take_event();
-  if (g_cur_start) hipEventRecord(g_cur_start, st);
+  if (g_cur_start) (void)hipEventRecord(g_cur_start, st);
 }
 void etm_prof_end(int kid, hipStream_t st) {
   if (!g_cur_start) return;
   hipEvent_t b = take_event();
   if (!b) { g_free.push_back(g_cur_start); g_cur_start = nullptr; return; }
-  hipEventRecord(b, st);
+  (void)hipEventRecord(b, st);
   g_recs.push_back({kid, g_prof_tag, g_cur_start, b});
   g_cur_start = nullptr;
 }

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(64) void gae_kernel(const float *__restrict__ rewar
 
 extern "C" int etm_gae(const float *rewards, const uint8_t *dones, const float *values, const float *last_value, float gamma,
                        float gamma_lambda, float *advantages, int W, int S, void *stream) {
+  (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated runtime calls
   if (!rewards || !dones || !values || !last_value || !advantages) return ETM_EINVAL;
   if (W <= 0 || S <= 0) return ETM_EINVAL;
   EtmProfScope prof(ETM_K_GAE, (hipStream_t)stream);

@@ -441,6 +441,7 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
                            const float *v_save, const float *ln_stats, const float *d_ctx, float *d_q, float *d_e, float *d_wk,
                            float *d_wv, float *d_ln_g, float *d_ln_b, float *d_pos, void *workspace, int64_t workspace_bytes,
                            int N, int L, int D, int H, void *stream) {
+  (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated runtime calls
   if (!bank || !win || !mask || !q || !wk || !wv || !att || !k_save || !v_save || !d_ctx || !d_q || !d_e || !d_wk || !d_wv ||
       !workspace)
     return ETM_EINVAL;

@@ -309,6 +309,7 @@ extern "C" int etm_mha_fwd(const float *bank, int64_t ep_stride, int64_t row_str
                            const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,
                            float ln_eps, const float *q, const float *wk, const float *wv, float *ctx, float *att,
                            float *k_save, float *v_save, float *ln_stats, int N, int L, int D, int H, void *stream) {
+  (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated runtime calls
   if (!bank || !win || !mask || !q || !wk || !wv || !ctx || !att) return ETM_EINVAL;
   if (N <= 0 || L <= 0 || D <= 0 || H <= 0 || D % H != 0) return ETM_EINVAL;
   if ((pos != nullptr) != (pidx != nullptr)) return ETM_EINVAL;

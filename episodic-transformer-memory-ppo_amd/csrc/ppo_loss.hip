@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64) void ppo_finalize_kernel(const float *__restric
 }  // namespace
 
 extern "C" int etm_adv_stats(const float *adv, int N, float *stats3, void *stream) {
+  (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated runtime calls
   if (!adv || !stats3 || N <= 0) return ETM_EINVAL;
   EtmProfScope prof(ETM_K_ADV_STATS, (hipStream_t)stream);
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, adv, N, stats3);
@@ -167,6 +168,7 @@ extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t
                             const float *adv_stats3, double clip, float vf_coef, float beta, float pol_scale, float ent_scale,
                             float val_scale, int include_value, float *out8, float *d_logits, float *d_value, void *partials,
                             int64_t partials_bytes, int N, int A, void *stream) {
+  (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated runtime calls
   if (!logits || !actions || !old_logp || !adv || !adv_stats3 || !out8 || !d_logits || !partials) return ETM_EINVAL;
   if (include_value && (!old_value || !value || !d_value)) return ETM_EINVAL;
   if (N <= 0 || A <= 0) return ETM_EINVAL;

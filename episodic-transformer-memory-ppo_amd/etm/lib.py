@@ -2,6 +2,9 @@
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its own libamdhip64; loading ours first would put a
+#                             second HIP runtime in the process (kernels would then launch on a runtime with no device)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")
 ABI_VERSION = 1
