@@ -57,7 +57,9 @@ class Buffer:
         self.memory_indices = torch.zeros((W, S, L), dtype=torch.long, device=dev)
 
         # whole-episode memory bank: slot e holds one episode's [T, blocks, D] items
-        cap = config.get("episode_bank_capacity", W + max(W, self.batch_size // 8))
+        # default capacity = worst case (every step ends an episode): the bank then never reallocates, which keeps its
+        # address stable for the captured rollout graph; 288 GB of HBM make this affordable (7.3 GB at BASELINE config 3)
+        cap = config.get("episode_bank_capacity", W + self.batch_size)
         self.bank = torch.zeros((cap, max_episode_length, self.num_blocks, self.embed_dim), dtype=torch.float32, device=dev)
         self.num_episodes = W
         self.samples_flat = None

@@ -36,7 +36,10 @@ hipEvent_t take_event() {
 }  // namespace
 
 void etm_prof_begin(int kid, hipStream_t st) {
-  if (!g_prof_on || g_recs.size() >= kMaxRecs) { g_cur_start = nullptr; return; }
+  g_cur_start = nullptr;
+  if (!g_prof_on || g_recs.size() >= kMaxRecs) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;  // timing events are not capturable
   g_cur_start = take_event();
   if (g_cur_start) (void)hipEventRecord(g_cur_start, st);
 }

@@ -127,6 +127,20 @@ class PPOTrainer:
         self._slot_dev = torch.arange(W, dtype=torch.int64, device=device)
         self.env.reset(out=self.obs)
 
+        # fixed-address operands of the rollout step (HIP-graph friendly) and time-major staging of the step outputs
+        S, L, B = config["worker_steps"], self.memory_length, len(self.action_space_shape)
+        self._obs_dev = torch.zeros((W,) + obs_shape, dtype=torch.float32, device=device)
+        self._t_dev = torch.zeros((), dtype=torch.int64, device=device)
+        self._stage = {
+            "obs": torch.zeros((S, W) + obs_shape, dtype=torch.float32, device=device),
+            "memory_mask": torch.zeros((S, W, L), dtype=torch.bool, device=device),
+            "memory_indices": torch.zeros((S, W, L), dtype=torch.int64, device=device),
+            "actions": torch.zeros((S, W, B), dtype=torch.int64, device=device),
+            "log_probs": torch.zeros((S, W, B), dtype=torch.float32, device=device),
+            "values": torch.zeros((S, W), dtype=torch.float32, device=device),
+        }
+        self._step_graph = None
+
         mask, indices = build_window_tables(self.memory_length, self.max_episode_length)
         self.memory_mask, self.memory_indices = mask, indices                       # host copies (upstream names)
         self._mask_table = mask.bool().to(device)
@@ -178,39 +192,31 @@ class PPOTrainer:
     def _sample_training_data(self, forced_actions=None) -> list:
         """Runs all workers for ``worker_steps`` steps; fills the buffer; returns finished-episode infos.
 
-        ``forced_actions`` [W, S] (optional) replays recorded actions instead of sampling (teacher forcing for
-        parity tests -- CPU and GPU RNG streams differ)."""
-        buf, W, S, L = self.buffer, self.num_workers, self.config["worker_steps"], self.memory_length
+        The device work of one step (observation upload, window lookup, model forward, memory write, action sampling,
+        staging of the step's buffer rows, action download) is captured ONCE in a HIP graph and replayed per step, so
+        the host issues one launch instead of ~75 (``hip_graph_rollout: false`` in the config selects the eager path).
+        ``forced_actions`` [W, S] (optional) replays recorded actions instead of sampling (teacher forcing for parity
+        tests -- CPU and GPU RNG streams differ); it always uses the eager path."""
+        buf, W, S = self.buffer, self.num_workers, self.config["worker_steps"]
         stream = torch.cuda.current_stream(self.device)
+        use_graph = forced_actions is None and self.config.get("hip_graph_rollout", True)
         episode_infos = []
         buf.begin_rollout(self._slot_dev)
         self.worker_episode_slot[:] = np.arange(W)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+        forced = None
         if forced_actions is not None:
             forced = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).to(self.device)
+        if use_graph and self._step_graph is None:
+            self._capture_step_graph()
+        self._t_dev.zero_()
         t_env = 0.0
         for t in range(S):
-            with torch.no_grad():
-                obs_t = buf.obs[:, t]
-                obs_t.copy_(self._obs_pin, non_blocking=True)
-                mask_t = self._mask_table[torch.clamp(self._step_dev, 0, L - 1)]
-                win_t = self._index_table[self._step_dev]
-                buf.memory_mask[:, t] = mask_t
-                buf.memory_indices[:, t] = win_t
-                spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
-                logits, value, item = self.model.forward_logits(obs_t, spec)
-                buf.bank[self._slot_dev, self._step_dev] = item          # new memory item (upstream :174)
-                acts, logps = [], []
-                for b, lg in enumerate(logits):
-                    lsm = torch.log_softmax(lg, dim=-1)
-                    a = forced[:, t] if forced_actions is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
-                    acts.append(a)
-                    logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
-                actions = torch.stack(acts, dim=1)
-                buf.actions[:, t] = actions
-                buf.log_probs[:, t] = torch.stack(logps, dim=1)
-                buf.values[:, t] = value
-                self._act_pin.copy_(actions, non_blocking=True)
+            if use_graph:
+                self._step_graph.replay()
+            else:
+                with torch.no_grad():
+                    self._rollout_step_device(forced[:, t] if forced is not None else None)
             stream.synchronize()  # actions are on the host; the observation upload has been consumed
             te = time.perf_counter()
             _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
@@ -226,12 +232,62 @@ class PPOTrainer:
                     self.worker_episode_slot[w] = slot
                     if t < S - 1:
                         buf.memory_index_host[w, t + 1:] = slot
-                self._slot_dev.copy_(self._slot_pin, non_blocking=True)
-            self._step_dev.copy_(self._step_pin, non_blocking=True)
+        # time-major staging -> the buffer's [W, S, ...] fields (one strided copy per field)
+        self._step_dev.copy_(self._step_pin, non_blocking=True)
+        self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+        for name, stage in self._stage.items():
+            getattr(buf, name).copy_(stage.transpose(0, 1))
         last_value = self.get_last_value()
         buf.calc_advantages(last_value, self.config["gamma"], self.config["lamda"])
         self.last_update_timing["env_s"] = t_env
         return episode_infos
+
+    def _rollout_step_device(self, forced_t=None):
+        """Device side of one rollout step (upstream trainer.py:161-186); every operand has a fixed address so the
+        sequence can be captured in a HIP graph.  Reads the pinned host mirrors (observation, episode step, episode
+        slot), writes row ``t`` of the time-major staging arrays and the pinned action buffer."""
+        buf, L = self.buffer, self.memory_length
+        self._obs_dev.copy_(self._obs_pin, non_blocking=True)
+        self._step_dev.copy_(self._step_pin, non_blocking=True)
+        self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+        mask_t = self._mask_table[torch.clamp(self._step_dev, 0, L - 1)]
+        win_t = self._index_table[self._step_dev]
+        spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
+        logits, value, item = self.model.forward_logits(self._obs_dev, spec)
+        buf.bank[self._slot_dev, self._step_dev] = item          # new memory item (upstream :174)
+        acts, logps = [], []
+        for lg in logits:
+            lsm = torch.log_softmax(lg, dim=-1)
+            a = forced_t if forced_t is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
+            acts.append(a)
+            logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
+        actions = torch.stack(acts, dim=1)
+        row = self._t_dev.view(1)
+        st = self._stage
+        st["obs"].index_copy_(0, row, self._obs_dev.unsqueeze(0))
+        st["memory_mask"].index_copy_(0, row, mask_t.unsqueeze(0))
+        st["memory_indices"].index_copy_(0, row, win_t.unsqueeze(0))
+        st["actions"].index_copy_(0, row, actions.unsqueeze(0))
+        st["log_probs"].index_copy_(0, row, torch.stack(logps, dim=1).unsqueeze(0))
+        st["values"].index_copy_(0, row, value.unsqueeze(0))
+        self._t_dev.add_(1)
+        self._act_pin.copy_(actions, non_blocking=True)
+
+    def _capture_step_graph(self):
+        """Warm the step up on a side stream (library handles, MIOpen find, allocator), then capture it."""
+        self._t_dev.zero_()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(3):
+                self._rollout_step_device()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            self._rollout_step_device()
+        self._step_graph = graph
+        self._t_dev.zero_()
 
     def get_last_value(self):
         """Value of the observation after the last step (bootstrap for GAE), with upstream's window rule:
