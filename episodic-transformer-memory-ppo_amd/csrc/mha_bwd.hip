@@ -116,15 +116,9 @@ __global__ __launch_bounds__(256) void bwd_scores_kernel(const BwdParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // B2: split-K MFMA contraction.  Workgroup = 4 waves in a 2x2 arrangement, each wave a 64x64 block of the
-// 128x128 output tile (2x2 accumulators of 32x32).
-struct RowIdx {          // per-thread description of its 4 staged rows of a chunk
-  long long xoff[4];     // offset of the window row in the bank, -1 if the row does not exist (padding / n >= N)
-  long long poff[4];     // offset of the positional row
-  float mu[4], rs[4];    // LayerNorm statistics
-  float scal[4];         // dE[n,h,l] (Wk half) or att[n,h,l] (Wv half) for this thread's output-feature group
-  int n;
-};
-
+// 128x128 output tile (2x2 accumulators of 32x32).  Staging is straight-line and unconditional (indices clamped,
+// non-existent rows zeroed when stored) so that the row indices of chunk c+2 and the operands of chunk c+1 stay in
+// flight under the MFMAs of chunk c.
 template <bool HAS_LN, bool HAS_POS>
 __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
   __shared__ __attribute__((aligned(16))) float As[RB * TM];
@@ -147,70 +141,63 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
   const int o = o0 + c4 * 4;             // output feature of the G (left) operand
   const bool o_ok = o < 2 * D;
   const bool v_half = o >= D;            // false: Wk rows (dE * q), true: Wv rows (att * dctx)
-  const int oo = o - (v_half ? D : 0);
-  const int h_o = o_ok ? oo / p.hd : 0;
-  const float *vec_src = v_half ? p.d_ctx : p.q;
-  const float *scal_src = v_half ? p.att : p.d_e;
+  const int oo = o_ok ? o - (v_half ? D : 0) : 0;
+  const int h_o = oo / p.hd;
+  const float *vec_src = (v_half ? p.d_ctx : p.q) + oo;
+  const float *scal_src = (v_half ? p.att : p.d_e) + (long long)h_o * L;
   const int ii = i0 + c4 * 4;            // input feature of the X (right) operand
   const bool i_ok = ii < D;
+  const int ii_c = i_ok ? ii : 0;
+  const float *xbase = p.bank + ii_c;
+  const float *pbase = HAS_POS ? p.pos + ii_c : nullptr;
 
-  float4 lng = make_float4(0.f, 0.f, 0.f, 0.f), lnb = lng;
-  if (HAS_LN && i_ok) {
-    lng = *reinterpret_cast<const float4 *>(p.ln_g + ii);
-    lnb = *reinterpret_cast<const float4 *>(p.ln_b + ii);
+  f32x4 lng = {0.f, 0.f, 0.f, 0.f}, lnb = {0.f, 0.f, 0.f, 0.f};
+  if (HAS_LN) {
+    lng = *reinterpret_cast<const f32x4 *>(p.ln_g + ii_c);
+    lnb = *reinterpret_cast<const f32x4 *>(p.ln_b + ii_c);
   }
 
-  auto load_idx = [&](int c, RowIdx &I) {
-    const long long R0 = (long long)c * RB;
-    const int n = (int)(R0 / Lp);
-    const int lbase = (int)(R0 - (long long)n * Lp);
-    I.n = n;
-    const long long e = (n < N) ? (p.ep ? p.ep[n] : n) : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int l = lbase + rr + 8 * i;
-      I.xoff[i] = -1;
-      I.poff[i] = 0;
-      I.mu[i] = 0.f;
-      I.rs[i] = 0.f;
-      I.scal[i] = 0.f;
-      if (n < N && l < L) {
-        const long long row = (long long)n * L + l;
-        I.xoff[i] = e * p.ep_stride + p.win[row] * p.row_stride;
-        if (HAS_POS) I.poff[i] = p.pidx[row] * D;
-        if (HAS_LN) {
-          I.mu[i] = p.ln_stats[row * 2];
-          I.rs[i] = p.ln_stats[row * 2 + 1];
-        }
-        if (o_ok) I.scal[i] = scal_src[((long long)n * H + h_o) * L + l];
-      }
-    }
-  };
+  // raw indices of the chunk whose operands are fetched next (pure loads: nothing here is consumed until the next
+  // iteration, so the loads never have to be waited for right after they are issued)
+  long long e_raw = 0, win_raw[4], pidx_raw[4];
+  float mu[4], rs[4], scal[4];
+  bool rvalid[4];
+  long long vec_off = 0;
+  // operands of the chunk that is stored to LDS next (+ what is needed to finish them at store time)
+  f32x4 xraw[4], praw[4], vec;
+  float d_mu[4], d_rs[4], d_scal[4];
+  bool d_valid[4];
 
-  float4 ga[4], xb[4];
-  auto load_data = [&](const RowIdx &I) {
-    float4 vec = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (o_ok && I.n < N) vec = *reinterpret_cast<const float4 *>(vec_src + (long long)I.n * D + oo);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ga[i] = make_float4(vec.x * I.scal[i], vec.y * I.scal[i], vec.z * I.scal[i], vec.w * I.scal[i]);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i_ok && I.xoff[i] >= 0) {
-        v = *reinterpret_cast<const float4 *>(p.bank + I.xoff[i] + ii);
-        if (HAS_POS) {
-          const float4 pv = *reinterpret_cast<const float4 *>(p.pos + I.poff[i] + ii);
-          v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
-        }
-        if (HAS_LN) {
-          v.x = (v.x - I.mu[i]) * I.rs[i] * lng.x + lnb.x;
-          v.y = (v.y - I.mu[i]) * I.rs[i] * lng.y + lnb.y;
-          v.z = (v.z - I.mu[i]) * I.rs[i] * lng.z + lnb.z;
-          v.w = (v.w - I.mu[i]) * I.rs[i] * lng.w + lnb.w;
-        }
-      }
-      xb[i] = v;
-    }
-  };
+#define ETM_ISSUE_IDX(c_)                                                                           \
+  {                                                                                                 \
+    const unsigned cps_ = (unsigned)Lp / RB; /* chunks per (padded) sample: 32-bit division only */  \
+    const int n_ = (int)((unsigned)(c_) / cps_);                                                    \
+    const int lbase_ = ((c_) - n_ * (int)cps_) * RB;                                                \
+    const int nc_ = n_ < N ? n_ : N - 1;                                                            \
+    e_raw = p.ep ? p.ep[nc_] : nc_;                                                                 \
+    vec_off = (long long)nc_ * D;                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+      const int l_ = lbase_ + rr + 8 * i;                                                           \
+      const int lc_ = l_ < L ? l_ : L - 1;                                                          \
+      rvalid[i] = (n_ < N) && (l_ < L);                                                             \
+      const long long row_ = (long long)nc_ * L + lc_;                                              \
+      win_raw[i] = p.win[row_];                                                                     \
+      pidx_raw[i] = HAS_POS ? p.pidx[row_] : 0;                                                     \
+      mu[i] = HAS_LN ? p.ln_stats[row_ * 2] : 0.f;                                                  \
+      rs[i] = HAS_LN ? p.ln_stats[row_ * 2 + 1] : 0.f;                                              \
+      scal[i] = scal_src[(long long)nc_ * H * L + lc_];                                             \
+    }                                                                                               \
+  }
+
+#define ETM_ISSUE_DATA()                                                                            \
+  {                                                                                                 \
+    vec = *reinterpret_cast<const f32x4 *>(vec_src + vec_off);                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+      xraw[i] = *reinterpret_cast<const f32x4 *>(xbase + e_raw * p.ep_stride + win_raw[i] * p.row_stride); \
+      if (HAS_POS) praw[i] = *reinterpret_cast<const f32x4 *>(pbase + pidx_raw[i] * D);             \
+      d_mu[i] = mu[i]; d_rs[i] = rs[i]; d_scal[i] = scal[i]; d_valid[i] = rvalid[i];                \
+    }                                                                                               \
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -221,36 +208,53 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   if (c_begin < c_end) {
-    RowIdx I;
-    load_idx(c_begin, I);
-    load_data(I);
-    if (c_begin + 1 < c_end) load_idx(c_begin + 1, I);
+    const int c_last = c_end - 1;
+    ETM_ISSUE_IDX(c_begin)
+    ETM_ISSUE_DATA()
+    ETM_ISSUE_IDX(min(c_begin + 1, c_last))
     for (int c = c_begin; c < c_end; ++c) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<float4 *>(&As[(rr + 8 * i) * TM + c4 * 4]) = ga[i];
-        *reinterpret_cast<float4 *>(&Bs[(rr + 8 * i) * TN + c4 * 4]) = xb[i];
+        const float sc = (d_valid[i] && o_ok) ? d_scal[i] : 0.f;
+        const f32x4 g = vec * sc;
+        f32x4 v = xraw[i];
+        if (HAS_POS) v += praw[i];
+        if (HAS_LN) v = (v - d_mu[i]) * d_rs[i] * lng + lnb;
+        if (!(d_valid[i] && i_ok)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(&As[(rr + 8 * i) * TM + c4 * 4]) = g;
+        *reinterpret_cast<f32x4 *>(&Bs[(rr + 8 * i) * TN + c4 * 4]) = v;
       }
       __syncthreads();
-      if (c + 1 < c_end) {
-        load_data(I);                           // rows of chunk c+1 (indices fetched one iteration ago)
-        if (c + 2 < c_end) load_idx(c + 2, I);  // indices of chunk c+2
-      }
+      // unconditional prefetch (chunk ids clamped to the split's last chunk: the final iterations re-fetch it, which is
+      // harmless) -- a conditional prefetch makes the compiler drain every outstanding load at the join point
+      ETM_ISSUE_DATA()                           // operands of chunk c+1 (indices fetched one iteration ago)
+      ETM_ISSUE_IDX(min(c + 2, c_last))          // indices of chunk c+2
+
+      // software-pipelined operand reads: fragments of k-step s+1 are read while the MFMAs of k-step s issue
+      const float *ap = As + half * TM + wm * 64 + col;
+      const float *bp = Bs + half * TN + wn * 64 + col;
+      float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
 #pragma unroll
       for (int s = 0; s < RB / 2; ++s) {
-        const int r = 2 * s + half;
-        const float a0 = As[r * TM + wm * 64 + col];
-        const float a1 = As[r * TM + wm * 64 + 32 + col];
-        const float b0 = Bs[r * TN + wn * 64 + col];
-        const float b1 = Bs[r * TN + wn * 64 + 32 + col];
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        if (s + 1 < RB / 2) {
+          na0 = ap[(2 * s + 2) * TM];
+          na1 = ap[(2 * s + 2) * TM + 32];
+          nb0 = bp[(2 * s + 2) * TN];
+          nb1 = bp[(2 * s + 2) * TN + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the next fragments' LDS reads ahead of this step's MFMAs
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
       }
       __syncthreads();
     }
   }
+#undef ETM_ISSUE_IDX
+#undef ETM_ISSUE_DATA
 
   // partial[split][o][i]
   float *out = p.partial + (long long)split * 2 * D * D;

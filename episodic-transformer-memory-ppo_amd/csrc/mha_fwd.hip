@@ -102,64 +102,52 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
   const int wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int L = p.L, Lp = p.Lp, D = p.D, N = p.N;
 
-  // ---- per-thread staging descriptors: thread stages rows r0 + 32 i (i < 4), float4 column c4 of every chunk
+  // ---- per-thread staging descriptors: thread stages rows r0 + 32 i (i < 4), float4 column c4 of every chunk.
+  // Rows that do not exist (padding up to Lp, samples past N) read a valid dummy address and are zeroed when stored, so
+  // every load is unconditional: the compiler can keep the whole next chunk in flight under the MFMAs.
   const int c4 = tid & 7, r0 = tid >> 3;
   const float *xptr[4];
   const float *pptr[4];
+  bool valid[4];
   float mu[4], rs[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + 32 * i;
     const int s = r / Lp, l = r - s * Lp;
     const int n = tile * p.spw + s;
-    xptr[i] = nullptr;
-    pptr[i] = nullptr;
-    mu[i] = 0.f;
-    rs[i] = 0.f;
-    if (s < p.spw && n < N && l < L) {
-      const long long row = (long long)n * L + l;
-      const long long e = p.ep ? p.ep[n] : n;
-      xptr[i] = p.bank + e * p.ep_stride + p.win[row] * p.row_stride;
-      if (HAS_POS) pptr[i] = p.pos + p.pidx[row] * D;
-      if (HAS_LN) {
-        mu[i] = p.ln_stats[row * 2];
-        rs[i] = p.ln_stats[row * 2 + 1];
-      }
-    }
+    valid[i] = (s < p.spw) && (n < N) && (l < L);
+    const long long row = valid[i] ? (long long)n * L + l : 0;
+    const long long e = p.ep ? p.ep[valid[i] ? n : 0] : (valid[i] ? n : 0);
+    xptr[i] = p.bank + e * p.ep_stride + p.win[row] * p.row_stride + c4 * 4;
+    pptr[i] = HAS_POS ? p.pos + p.pidx[row] * D + c4 * 4 : nullptr;
+    mu[i] = HAS_LN ? p.ln_stats[row * 2] : 0.f;
+    rs[i] = HAS_LN ? p.ln_stats[row * 2 + 1] : 0.f;
   }
-  const float *wptr[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int wrow = r0 + 32 * j;  // [0, HD): K_h rows, [HD, 2HD): V_h rows
-    wptr[j] = (wrow < HD) ? p.wk + (long long)(head * HD + wrow) * D : p.wv + (long long)(head * HD + wrow - HD) * D;
-  }
+  // weight rows r0 + 32 j: [0, HD) are K_h rows of Wk, [HD, 2HD) V_h rows of Wv
+  const float *wk_row = p.wk + (long long)(head * HD + r0) * D + c4 * 4;
+  const float *wv_row = p.wv + (long long)(head * HD + r0) * D + c4 * 4;
+  const long long wstep = (long long)32 * D;
 
-  float4 xr[4], wr[NT];
-  auto load_chunk = [&](int kb) {
-    const int k0 = kb * BK + c4 * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xptr[i]) {
-        v = *reinterpret_cast<const float4 *>(xptr[i] + k0);
-        if (HAS_POS) {
-          const float4 pv = *reinterpret_cast<const float4 *>(pptr[i] + k0);
-          v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
-        }
-        if (HAS_LN) {
-          const float4 g = *reinterpret_cast<const float4 *>(p.ln_g + k0);
-          const float4 bb = *reinterpret_cast<const float4 *>(p.ln_b + k0);
-          v.x = (v.x - mu[i]) * rs[i] * g.x + bb.x;
-          v.y = (v.y - mu[i]) * rs[i] * g.y + bb.y;
-          v.z = (v.z - mu[i]) * rs[i] * g.z + bb.z;
-          v.w = (v.w - mu[i]) * rs[i] * g.w + bb.w;
-        }
-      }
-      xr[i] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wr[j] = *reinterpret_cast<const float4 *>(wptr[j] + k0);
-  };
+  float4 xr[4], pr[4], lg, lb;
+  f32x4 wr[NT];
+  lg = lb = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define ETM_ISSUE_LOADS(kb_)                                                                        \
+  {                                                                                                 \
+    const int k0_ = (kb_) * BK;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+      xr[i] = *reinterpret_cast<const float4 *>(xptr[i] + k0_);                                     \
+      if (HAS_POS) pr[i] = *reinterpret_cast<const float4 *>(pptr[i] + k0_);                        \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < HT; ++j) {                                                \
+      wr[j] = *reinterpret_cast<const f32x4 *>(wk_row + j * wstep + k0_);                           \
+      wr[HT + j] = *reinterpret_cast<const f32x4 *>(wv_row + j * wstep + k0_);                      \
+    }                                                                                               \
+    if (HAS_LN) {                                                                                   \
+      lg = *reinterpret_cast<const float4 *>(p.ln_g + k0_ + c4 * 4);                                \
+      lb = *reinterpret_cast<const float4 *>(p.ln_b + k0_ + c4 * 4);                                \
+    }                                                                                               \
+  }
 
   f32x16 acc[NT];
 #pragma unroll
@@ -168,15 +156,26 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nk = D / BK;
-  load_chunk(0);
+  ETM_ISSUE_LOADS(0)
   for (int kb = 0; kb < nk; ++kb) {
-    // registers -> LDS (previous chunk's readers are past the trailing barrier)
+    // registers -> LDS: positional add / LayerNorm / zeroing of non-existent rows happen here, at the first use
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&Xs[(r0 + 32 * i) * LDP + c4 * 4]) = xr[i];
+    for (int i = 0; i < 4; ++i) {
+      float4 v = xr[i];
+      if (HAS_POS) { v.x += pr[i].x; v.y += pr[i].y; v.z += pr[i].z; v.w += pr[i].w; }
+      if (HAS_LN) {
+        v.x = (v.x - mu[i]) * rs[i] * lg.x + lb.x;
+        v.y = (v.y - mu[i]) * rs[i] * lg.y + lb.y;
+        v.z = (v.z - mu[i]) * rs[i] * lg.z + lb.z;
+        v.w = (v.w - mu[i]) * rs[i] * lg.w + lb.w;
+      }
+      if (!valid[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&Xs[(r0 + 32 * i) * LDP + c4 * 4]) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * j) * LDP + c4 * 4]) = wr[j];
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4 *>(&Ws[(r0 + 32 * j) * LDP + c4 * 4]) = wr[j];
     __syncthreads();
-    if (kb + 1 < nk) load_chunk(kb + 1);  // global loads in flight under the MFMAs below
+    if (kb + 1 < nk) ETM_ISSUE_LOADS(kb + 1)  // global loads stay in flight under the MFMAs below
 
     // lane supplies A[row = 32 wave + col][k] and B[k][col'] with k = 8 kk + 4 half + j (same pairing on both sides)
 #pragma unroll
@@ -196,6 +195,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
     }
     __syncthreads();
   }
+#undef ETM_ISSUE_LOADS
 
   // ---- epilogue.  All 32 rows of a wave belong to one sample (Lp is a multiple of 32).
   const int srow0 = wave * 32;
