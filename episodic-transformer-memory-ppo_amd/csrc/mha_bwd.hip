@@ -115,14 +115,22 @@ __global__ __launch_bounds__(256) void bwd_scores_kernel(const BwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// B2: split-K MFMA contraction.  Workgroup = 4 waves in a 2x2 arrangement, each wave a 64x64 block of the
-// 128x128 output tile (2x2 accumulators of 32x32).  Staging is straight-line and unconditional (indices clamped,
-// non-existent rows zeroed when stored) so that the row indices of chunk c+2 and the operands of chunk c+1 stay in
-// flight under the MFMAs of chunk c.
+// B2: split-K MFMA contraction, ping-pong scheduled.
+//
+// Workgroup = 8 waves = two GROUPS of 4 waves.  Each group is a complete 128 x 128 tile engine (2 x 2 waves, each wave
+// 64 x 64 outputs = 2 x 2 accumulators of 32x32) with its own LDS operand buffers, and the groups take alternate
+// 32-row chunks of the workgroup's row range.  The groups run in ANTIPHASE under workgroup-wide barriers: while one
+// group issues its 64 MFMAs per wave, the other converts its prefetched registers into LDS operands (left operand
+// dK|dV generated on the fly, right operand = gathered window rows) and issues the global loads of its next chunk.
+// Every SIMD hosts one wave of each group, so its matrix pipe always has a wave in an MFMA segment -- two independent
+// 4-wave workgroups per CU fall into lockstep instead (both stage, then both contend for the pipe: ~55 % busy).
+// At the end group 1 hands its accumulators to group 0 through LDS; one partial tile per workgroup is written.
+//
+// Staging is straight-line and unconditional (indices clamped, non-existent rows zeroed when stored) so that the row
+// indices two chunks ahead and the operands one chunk ahead stay in flight under the MFMAs.
 template <bool HAS_LN, bool HAS_POS>
-__global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
-  __shared__ __attribute__((aligned(16))) float As[RB * TM];
-  __shared__ __attribute__((aligned(16))) float Bs[RB * TN];
+__global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * RB * (TM + TN)];
 
   const int tiles = p.tiles_m * p.tiles_n;
   const int split = blockIdx.x / tiles;
@@ -132,9 +140,17 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
   const int c_begin = split * p.chunks_per_split;
   const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int grp = threadIdx.x >> 8;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int L = p.L, Lp = p.Lp, D = p.D, H = p.H, N = p.N;
+  float *As = smem + grp * RB * (TM + TN);
+  float *Bs = As + RB * TM;
+
+  // this group's chunks: c_begin + grp + 2 k, k < n_my
+  const int n_all = max(c_end - c_begin, 0);
+  const int n_max = (n_all + 1) / 2;            // group 0's count (>= group 1's)
+  const int c_first = c_begin + grp;
 
   // staging role: float4 column c4 (of 32) and rows rr + 8 i
   const int c4 = tid & 31, rr = tid >> 5;
@@ -157,8 +173,8 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
     lnb = *reinterpret_cast<const f32x4 *>(p.ln_b + ii_c);
   }
 
-  // raw indices of the chunk whose operands are fetched next (pure loads: nothing here is consumed until the next
-  // iteration, so the loads never have to be waited for right after they are issued)
+  // raw indices of the chunk whose operands are fetched next (pure loads: nothing here is consumed until the group's
+  // next staging phase, so the loads never have to be waited for right after they are issued)
   long long e_raw = 0, win_raw[4], pidx_raw[4];
   float mu[4], rs[4], scal[4];
   bool rvalid[4];
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
       const int l_ = lbase_ + rr + 8 * i;                                                           \
       const int lc_ = l_ < L ? l_ : L - 1;                                                          \
-      rvalid[i] = (n_ < N) && (l_ < L);                                                             \
+      rvalid[i] = (n_ < N) && (l_ < L) && ((c_) < c_end);                                           \
       const long long row_ = (long long)nc_ * L + lc_;                                              \
       win_raw[i] = p.win[row_];                                                                     \
       pidx_raw[i] = HAS_POS ? p.pidx[row_] : 0;                                                     \
@@ -207,68 +223,84 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const BwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  if (c_begin < c_end) {
-    const int c_last = c_end - 1;
-    ETM_ISSUE_IDX(c_begin)
-    ETM_ISSUE_DATA()
-    ETM_ISSUE_IDX(min(c_begin + 1, c_last))
-    for (int c = c_begin; c < c_end; ++c) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float sc = (d_valid[i] && o_ok) ? d_scal[i] : 0.f;
-        const f32x4 g = vec * sc;
-        f32x4 v = xraw[i];
-        if (HAS_POS) v += praw[i];
-        if (HAS_LN) v = (v - d_mu[i]) * d_rs[i] * lng + lnb;
-        if (!(d_valid[i] && i_ok)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4 *>(&As[(rr + 8 * i) * TM + c4 * 4]) = g;
-        *reinterpret_cast<f32x4 *>(&Bs[(rr + 8 * i) * TN + c4 * 4]) = v;
-      }
-      __syncthreads();
-      // unconditional prefetch (chunk ids clamped to the split's last chunk: the final iterations re-fetch it, which is
-      // harmless) -- a conditional prefetch makes the compiler drain every outstanding load at the join point
-      ETM_ISSUE_DATA()                           // operands of chunk c+1 (indices fetched one iteration ago)
-      ETM_ISSUE_IDX(min(c + 2, c_last))          // indices of chunk c+2
+  ETM_ISSUE_IDX(c_first)
+  ETM_ISSUE_DATA()
+  ETM_ISSUE_IDX(c_first + 2)
 
-      // software-pipelined operand reads: fragments of k-step s+1 are read while the MFMAs of k-step s issue
-      const float *ap = As + half * TM + wm * 64 + col;
-      const float *bp = Bs + half * TN + wn * 64 + col;
-      float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+  // Both groups run the SAME straight-line loop body (stage, barrier, multiply, barrier); group 1 enters it one barrier
+  // later, which puts its staging segments under group 0's MFMA segments and vice versa.  (s_barrier only counts
+  // arrivals, so waves may meet at different barrier instructions.)  A group that has run out of chunks stages zeros
+  // (rvalid is false past c_end; chunk ids past the array are clamped inside ETM_ISSUE_IDX), so no branch guards the
+  // loads and nothing forces the compiler to drain them early.
+  if (grp == 1) __syncthreads();
+  for (int k = 0; k < n_max; ++k) {
+    // ---- staging segment: registers -> LDS, then refill the registers for this group's next chunks
 #pragma unroll
-      for (int s = 0; s < RB / 2; ++s) {
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        if (s + 1 < RB / 2) {
-          na0 = ap[(2 * s + 2) * TM];
-          na1 = ap[(2 * s + 2) * TM + 32];
-          nb0 = bp[(2 * s + 2) * TN];
-          nb1 = bp[(2 * s + 2) * TN + 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the next fragments' LDS reads ahead of this step's MFMAs
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-      }
-      __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      const float sc = (d_valid[i] && o_ok) ? d_scal[i] : 0.f;
+      const f32x4 g = vec * sc;
+      f32x4 v = xraw[i];
+      if (HAS_POS) v += praw[i];
+      if (HAS_LN) v = (v - d_mu[i]) * d_rs[i] * lng + lnb;
+      if (!(d_valid[i] && i_ok)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4 *>(&As[(rr + 8 * i) * TM + c4 * 4]) = g;
+      *reinterpret_cast<f32x4 *>(&Bs[(rr + 8 * i) * TN + c4 * 4]) = v;
     }
+    ETM_ISSUE_DATA()                             // operands of this group's chunk k+1
+    ETM_ISSUE_IDX(c_first + 2 * (k + 2))         // indices of this group's chunk k+2
+    __syncthreads();
+
+    // ---- MFMA segment; fragments of k-step s+1 are read while the MFMAs of k-step s issue
+    const float *ap = As + half * TM + wm * 64 + col;
+    const float *bp = Bs + half * TN + wn * 64 + col;
+    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+#pragma unroll
+    for (int s = 0; s < RB / 2; ++s) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (s + 1 < RB / 2) {
+        na0 = ap[(2 * s + 2) * TM];
+        na1 = ap[(2 * s + 2) * TM + 32];
+        nb0 = bp[(2 * s + 2) * TN];
+        nb1 = bp[(2 * s + 2) * TN + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the next fragments' LDS reads ahead of this step's MFMAs
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    __syncthreads();
   }
+  if (grp == 0) __syncthreads();
 #undef ETM_ISSUE_IDX
 #undef ETM_ISSUE_DATA
 
-  // partial[split][o][i]
-  float *out = p.partial + (long long)split * 2 * D * D;
+  // group 1 -> group 0 through LDS (lane-contiguous layout: conflict-free), then one partial tile per workgroup
+  if (grp == 1) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int icol = i0 + wn * 64 + b * 32 + col;
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int orow = o0 + wm * 64 + a * 32 + mfma32_row(r, lane);
-        if (orow < 2 * D && icol < D) out[(long long)orow * D + icol] = acc[a][b][r];
+        for (int r = 0; r < 16; ++r) smem[((wave * 4 + a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (grp == 0) {
+    float *out = p.partial + (long long)split * 2 * D * D;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int icol = i0 + wn * 64 + b * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int orow = o0 + wm * 64 + a * 32 + mfma32_row(r, lane);
+          const float v = acc[a][b][r] + smem[((wave * 4 + a * 2 + b) * 16 + r) * 64 + lane];
+          if (orow < 2 * D && icol < D) out[(long long)orow * D + icol] = v;
+        }
       }
-    }
+  }
 }
 
 __global__ __launch_bounds__(256) void bwd_dw_reduce_kernel(const float *partial, float *d_wk, float *d_wv, int splits, int D) {
@@ -422,7 +454,7 @@ DwPlan plan_dw(int N, int L, int D) {
   pl.tiles_m = (2 * D + TM - 1) / TM;
   pl.tiles_n = (D + TN - 1) / TN;
   const int tiles = pl.tiles_m * pl.tiles_n;
-  int splits = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU on 256 CUs
+  int splits = 256 / tiles;                // one 8-wave workgroup per CU on 256 CUs, a single round
   if (splits > pl.chunks) splits = pl.chunks;
   if (splits < 1) splits = 1;
   pl.chunks_per_split = (pl.chunks + splits - 1) / splits;
@@ -490,10 +522,10 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   const bool has_ln = ln_g != nullptr, has_pos = pos != nullptr;
   {
     EtmProfScope prof(ETM_K_BWD_DW, st);
-    if (has_ln && has_pos) hipLaunchKernelGGL((bwd_dw_kernel<true, true>), g2, dim3(256), 0, st, p);
-    else if (has_ln) hipLaunchKernelGGL((bwd_dw_kernel<true, false>), g2, dim3(256), 0, st, p);
-    else if (has_pos) hipLaunchKernelGGL((bwd_dw_kernel<false, true>), g2, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((bwd_dw_kernel<false, false>), g2, dim3(256), 0, st, p);
+    if (has_ln && has_pos) hipLaunchKernelGGL((bwd_dw_kernel<true, true>), g2, dim3(512), 0, st, p);
+    else if (has_ln) hipLaunchKernelGGL((bwd_dw_kernel<true, false>), g2, dim3(512), 0, st, p);
+    else if (has_pos) hipLaunchKernelGGL((bwd_dw_kernel<false, true>), g2, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((bwd_dw_kernel<false, false>), g2, dim3(512), 0, st, p);
   }
   if ((rc = etm_launch_status())) return rc;
   const long long per = (long long)2 * D * D;

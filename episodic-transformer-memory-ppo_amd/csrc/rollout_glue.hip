@@ -1,0 +1,129 @@
+// Small fused kernels for the per-step glue of the rollout (/root/reference trainer.py:161-186).  At n_workers = 32 a
+// step is bound by the NUMBER of launches (each tiny kernel costs ~4-5 us on the device even inside a HIP graph), so
+// the window-table lookup, the categorical sampling + staging of the step's buffer rows, and residual-add + LayerNorm
+// are each one launch here instead of ~8, ~17 and 2 framework launches.
+#include "etm_common.h"
+
+namespace {
+
+// mask_t[w,:] = mask_table[clip(step[w],0,L-1),:], win_t[w,:] = index_table[step[w],:]   (trainer.py:165-166),
+// also written to row t of the time-major staging arrays.
+__global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__restrict__ step, const unsigned char *__restrict__ mask_table,
+                                                             const long long *__restrict__ index_table, const long long *__restrict__ t_dev,
+                                                             unsigned char *__restrict__ mask_t, long long *__restrict__ win_t,
+                                                             unsigned char *__restrict__ st_mask, long long *__restrict__ st_idx, int W, int L) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * L) return;
+  const int w = i / L, l = i - w * L;
+  const long long s = step[w];
+  const long long r = s < 0 ? 0 : (s > L - 1 ? L - 1 : s);
+  const unsigned char m = mask_table[r * L + l];
+  const long long idx = index_table[s * L + l];
+  const long long t = *t_dev;
+  mask_t[i] = m;
+  win_t[i] = idx;
+  st_mask[t * W * L + i] = m;
+  st_idx[t * W * L + i] = idx;
+}
+
+// One thread per worker: log-softmax, inverse-CDF sample with the pre-drawn uniform of (t, w) (or a forced action),
+// log-prob, staging of actions / log_probs / values for step t; finally t += 1.
+__global__ __launch_bounds__(1024) void rollout_sample_kernel(const float *__restrict__ logits, const float *__restrict__ value,
+                                                              const float *__restrict__ uniforms, const long long *__restrict__ forced,
+                                                              long long *__restrict__ t_dev, long long *__restrict__ actions,
+                                                              long long *__restrict__ st_actions, float *__restrict__ st_logp,
+                                                              float *__restrict__ st_values, int W, int A) {
+  const long long t = *t_dev;
+  for (int w = threadIdx.x; w < W; w += 1024) {
+    const float *lg = logits + (long long)w * A;
+    float mx = -INFINITY;
+    for (int j = 0; j < A; ++j) mx = fmaxf(mx, lg[j]);
+    float se = 0.f;
+    for (int j = 0; j < A; ++j) se += expf(lg[j] - mx);
+    const float lse = mx + logf(se);
+    int a;
+    if (forced) {
+      a = (int)forced[w];
+    } else {
+      const float u = uniforms[t * W + w];
+      float c = 0.f;
+      a = A - 1;
+      for (int j = 0; j < A; ++j) {
+        c += expf(lg[j] - lse);
+        if (u < c) { a = j; break; }
+      }
+    }
+    actions[w] = a;
+    st_actions[t * W + w] = a;
+    st_logp[t * W + w] = lg[a] - lse;
+    st_values[t * W + w] = value[w];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *t_dev = t + 1;
+}
+
+// out = LayerNorm(a + b) * gamma + beta, one wave per row (post-LN blocks, transformer.py:143-149 / :164-170), forward only.
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps, float *__restrict__ out, int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float *pa = a + (long long)row * D, *pb = b + (long long)row * D;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = (c < D) ? pa[c] + pb[c] : 0.f;
+    s += v[j];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + 64 * j;
+    const float d = (c < D) ? v[j] - mean : 0.f;
+    m2 += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(m2) / (float)D + eps);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D) out[(long long)row * D + c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+}  // namespace
+
+extern "C" int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
+                                  uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int W, int L, void *stream) {
+  (void)hipGetLastError();
+  if (!step || !mask_table || !index_table || !t_dev || !mask_t || !win_t || !st_mask || !st_idx || W <= 0 || L <= 0) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_ROLLOUT_WINDOW, st);
+  hipLaunchKernelGGL(rollout_window_kernel, dim3((unsigned)((W * L + 255) / 256)), dim3(256), 0, st, (const long long *)step, mask_table,
+                     (const long long *)index_table, (const long long *)t_dev, mask_t, (long long *)win_t, st_mask, (long long *)st_idx, W, L);
+  return etm_launch_status();
+}
+
+extern "C" int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
+                                  int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream) {
+  (void)hipGetLastError();
+  if (!logits || !value || (!uniforms && !forced) || !t_dev || !actions || !st_actions || !st_logp || !st_values || W <= 0 || A <= 0)
+    return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_ROLLOUT_SAMPLE, st);
+  hipLaunchKernelGGL(rollout_sample_kernel, dim3(1), dim3(1024), 0, st, logits, value, uniforms, (const long long *)forced, (long long *)t_dev,
+                     (long long *)actions, (long long *)st_actions, st_logp, st_values, W, A);
+  return etm_launch_status();
+}
+
+extern "C" int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
+                                 void *stream) {
+  (void)hipGetLastError();
+  if (!a || !b || !gamma || !beta || !out || N <= 0 || D <= 0) return ETM_EINVAL;
+  if (D > 1024) return ETM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_ADD_LN, st);
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, a, b, gamma, beta, eps, out, N, D);
+  return etm_launch_status();
+}

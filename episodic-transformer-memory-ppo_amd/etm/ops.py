@@ -189,6 +189,85 @@ def mha(q, wk, wv, spec, block, num_heads, ln_g=None, ln_b=None, pos=None, ln_ep
     return _MhaFn.apply(q, wk, wv, ln_g, ln_b, pos, spec, block, num_heads, ln_eps)
 
 
+def attn_cached(q, kv_spec, block, num_heads, want_att=False):
+    """Inference-only window attention over cached projections.  ``kv_spec`` addresses a cache [W, T, blocks, 2D]
+    (K | V per row).  q [N, D] projected queries -> ctx [N, D] (and attention [N, H, L] if asked)."""
+    lib = _lib.load()
+    _need_dev(q)
+    if torch.is_grad_enabled() and q.requires_grad:
+        raise RuntimeError("attn_cached is the rollout (no-grad) path; training uses ops.mha")
+    q = _f32c(q, "q")
+    N, D = q.shape
+    L, H = kv_spec.L, int(num_heads)
+    ctx = torch.empty((N, D), dtype=torch.float32, device=q.device)
+    att = torch.empty((N, H, L), dtype=torch.float32, device=q.device) if want_att else None
+    rc = lib.etm_attn_cached(kv_spec.block_ptr(block), kv_spec.ep_stride, kv_spec.row_stride, _ptr(kv_spec.ep), _ptr(kv_spec.win),
+                             _ptr(kv_spec.mask), _ptr(q), _ptr(ctx), _ptr(att), N, L, D, H, _stream())
+    _lib.check(rc, "etm_attn_cached")
+    return ctx, att
+
+
+def reset_rows(dst, init, step):
+    """dst[w] = init for every w with step[w] == 0 (dst [W, ...], init [...], step [W] int64), in place."""
+    lib = _lib.load()
+    _need_dev(dst, init, step)
+    if not dst.is_contiguous() or not init.is_contiguous() or step.dtype != torch.int64:
+        raise TypeError("reset_rows needs contiguous float32 tensors and an int64 step vector")
+    _lib.check(lib.etm_reset_rows(_ptr(dst), _ptr(init), _ptr(step), dst.shape[0], init.numel(), _stream()), "etm_reset_rows")
+    return dst
+
+
+def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx):
+    """Window-table lookup of one rollout step + staging (all outputs preallocated, in place)."""
+    lib = _lib.load()
+    W, L = win_t.shape
+    _lib.check(lib.etm_rollout_window(_ptr(step), _ptr(mask_table), _ptr(index_table), _ptr(t_dev), _ptr(mask_t), _ptr(win_t),
+                                      _ptr(st_mask), _ptr(st_idx), W, L, _stream()), "etm_rollout_window")
+
+
+def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values):
+    """Categorical sampling + staging of one rollout step for a single-branch policy (in place; increments t_dev)."""
+    lib = _lib.load()
+    W, A = logits.shape
+    logits, value = _f32c(logits, "logits"), _f32c(value, "value")
+    _lib.check(lib.etm_rollout_sample(_ptr(logits), _ptr(value), _ptr(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions),
+                                      _ptr(st_actions), _ptr(st_logp), _ptr(st_values), W, A, _stream()), "etm_rollout_sample")
+
+
+def add_layernorm(a, b, norm):
+    """LayerNorm(a + b) with ``norm``'s affine parameters; forward only (rollout path)."""
+    lib = _lib.load()
+    _need_dev(a, b)
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    N, D = a.shape
+    out = torch.empty_like(a)
+    _lib.check(lib.etm_add_layernorm(_ptr(a), _ptr(b), _ptr(norm.weight), _ptr(norm.bias), float(norm.eps), _ptr(out), N, D, _stream()),
+               "etm_add_layernorm")
+    return out
+
+
+_fused_linear_relu = None  # None: untested, True/False after the first call
+
+
+def linear_relu(lin, x):
+    """relu(lin(x)).  In the no-grad rollout path the ReLU rides in the GEMM epilogue (hipBLASLt through
+    ``torch._addmm_activation``), saving one launch per layer; with autograd enabled it is the plain two-op form."""
+    global _fused_linear_relu
+    if torch.is_grad_enabled() or _fused_linear_relu is False or x.dim() != 2:
+        return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+    if _fused_linear_relu is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+        try:
+            y = torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
+            ref = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+            _fused_linear_relu = bool(torch.allclose(y, ref, atol=1e-5, rtol=1e-5))
+        except Exception:
+            _fused_linear_relu = False
+        return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+    return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
+
+
 def gae(rewards, dones, values, last_value, gamma, lamda, out=None):
     """Generalized advantage estimation on device; [W,S] row-major like the reference buffer."""
     lib = _lib.load()

@@ -11,6 +11,7 @@ from torch import nn
 from torch.distributions import Categorical
 from torch.nn import functional as F
 
+from etm import ops
 from etm.ops import WindowSpec
 from transformer import Transformer
 
@@ -57,13 +58,21 @@ class ActorCriticModel(nn.Module):
             h = F.relu(self.conv2(h))
             h = F.relu(self.conv3(h))
             h = h.reshape(h.shape[0], -1)
-        return F.relu(self.lin_hidden(h))
+        return ops.linear_relu(self.lin_hidden, h)
 
     def forward_logits(self, obs, spec: WindowSpec):
         """-> (list of raw logits per branch, value [N], new memory items [N, blocks, D])."""
         h, memory = self.transformer.forward_window(self._encode(obs), spec)
-        h_policy = F.relu(self.lin_policy(h))
-        h_value = F.relu(self.lin_value(h))
+        h_policy = ops.linear_relu(self.lin_policy, h)
+        h_value = ops.linear_relu(self.lin_value, h)
+        value = self.value(h_value).reshape(-1)
+        return [branch(h_policy) for branch in self.policy_branches], value, memory
+
+    def forward_logits_cached(self, obs, kv_spec: WindowSpec):
+        """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache."""
+        h, memory = self.transformer.forward_cached(self._encode(obs), kv_spec)
+        h_policy = ops.linear_relu(self.lin_policy, h)
+        h_value = ops.linear_relu(self.lin_value, h)
         value = self.value(h_value).reshape(-1)
         return [branch(h_policy) for branch in self.policy_branches], value, memory
 

@@ -139,12 +139,23 @@ class PPOTrainer:
             "log_probs": torch.zeros((S, W, B), dtype=torch.float32, device=device),
             "values": torch.zeros((S, W), dtype=torch.float32, device=device),
         }
+        self._mask_t = torch.zeros((W, L), dtype=torch.bool, device=device)
+        self._win_t = torch.zeros((W, L), dtype=torch.int64, device=device)
+        self._act_dev = torch.zeros((W, B), dtype=torch.int64, device=device)
+        self._uniforms = torch.zeros((S, W), dtype=torch.float32, device=device)
         self._step_graph = None
+        # rollout K/V cache (weights are frozen while sampling): per worker [T, blocks, 2D] projections of its episode
+        self._use_kv_cache = bool(config.get("kv_cache_rollout", True))
+        T, nb, D = self.max_episode_length, self.num_blocks, self.embed_dim
+        self._kv_cache = torch.zeros((W, T, nb, 2 * D), dtype=torch.float32, device=device)
+        self._kv_init = torch.zeros((T, nb, 2 * D), dtype=torch.float32, device=device)
+        self._kv_weights = None
+        self._worker_ids = torch.arange(W, dtype=torch.int64, device=device)
 
         mask, indices = build_window_tables(self.memory_length, self.max_episode_length)
         self.memory_mask, self.memory_indices = mask, indices                       # host copies (upstream names)
-        self._mask_table = mask.bool().to(device)
-        self._index_table = indices.to(device)
+        self._mask_table = mask.bool().contiguous().to(device)
+        self._index_table = indices.contiguous().to(device)
         self.last_update_timing = {}
 
     # ------------------------------------------------------------------ properties mirroring upstream members
@@ -204,19 +215,22 @@ class PPOTrainer:
         buf.begin_rollout(self._slot_dev)
         self.worker_episode_slot[:] = np.arange(W)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+        if self._use_kv_cache:
+            self._refresh_kv_cache()
         forced = None
         if forced_actions is not None:
             forced = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).to(self.device)
         if use_graph and self._step_graph is None:
             self._capture_step_graph()
         self._t_dev.zero_()
+        self._uniforms.uniform_()                # one draw per (step, worker) for the whole rollout
         t_env = 0.0
         for t in range(S):
             if use_graph:
                 self._step_graph.replay()
             else:
                 with torch.no_grad():
-                    self._rollout_step_device(forced[:, t] if forced is not None else None)
+                    self._rollout_step_device(forced[:, t].contiguous() if forced is not None else None)
             stream.synchronize()  # actions are on the host; the observation upload has been consumed
             te = time.perf_counter()
             _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
@@ -250,28 +264,64 @@ class PPOTrainer:
         self._obs_dev.copy_(self._obs_pin, non_blocking=True)
         self._step_dev.copy_(self._step_pin, non_blocking=True)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
-        mask_t = self._mask_table[torch.clamp(self._step_dev, 0, L - 1)]
-        win_t = self._index_table[self._step_dev]
-        spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
-        logits, value, item = self.model.forward_logits(self._obs_dev, spec)
-        buf.bank[self._slot_dev, self._step_dev] = item          # new memory item (upstream :174)
-        acts, logps = [], []
-        for lg in logits:
-            lsm = torch.log_softmax(lg, dim=-1)
-            a = forced_t if forced_t is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
-            acts.append(a)
-            logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
-        actions = torch.stack(acts, dim=1)
-        row = self._t_dev.view(1)
         st = self._stage
+        single = len(self.action_space_shape) == 1
+        mask_t, win_t = self._mask_t, self._win_t
+        ops.rollout_window(self._step_dev, self._mask_table, self._index_table, self._t_dev, mask_t, win_t,
+                           st["memory_mask"], st["memory_indices"])
+        if self._use_kv_cache:
+            # a worker at episode step 0 starts from the projection of an empty memory
+            ops.reset_rows(self._kv_cache, self._kv_init, self._step_dev)
+            kv_spec = WindowSpec.from_bank(self._kv_cache, None, win_t, None, mask_t)
+            logits, value, item = self.model.forward_logits_cached(self._obs_dev, kv_spec)
+            tr = self.model.transformer
+            pos = tr._pos()
+            pos_rows = pos.index_select(0, self._step_dev) if pos is not None else None
+            self._kv_cache[self._worker_ids, self._step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
+        else:
+            spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
+            logits, value, item = self.model.forward_logits(self._obs_dev, spec)
+        buf.bank[self._slot_dev, self._step_dev] = item          # new memory item (upstream :174)
+        row = self._t_dev.view(1)
         st["obs"].index_copy_(0, row, self._obs_dev.unsqueeze(0))
-        st["memory_mask"].index_copy_(0, row, mask_t.unsqueeze(0))
-        st["memory_indices"].index_copy_(0, row, win_t.unsqueeze(0))
-        st["actions"].index_copy_(0, row, actions.unsqueeze(0))
-        st["log_probs"].index_copy_(0, row, torch.stack(logps, dim=1).unsqueeze(0))
-        st["values"].index_copy_(0, row, value.unsqueeze(0))
-        self._t_dev.add_(1)
-        self._act_pin.copy_(actions, non_blocking=True)
+        if single:
+            # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
+            ops.rollout_sample(logits[0], value, self._uniforms, forced_t, self._t_dev, self._act_dev,
+                               st["actions"], st["log_probs"], st["values"])
+        else:
+            acts, logps = [], []
+            for lg in logits:
+                lsm = torch.log_softmax(lg, dim=-1)
+                a = forced_t if forced_t is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
+                acts.append(a)
+                logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
+            self._act_dev.copy_(torch.stack(acts, dim=1))
+            st["actions"].index_copy_(0, row, self._act_dev.unsqueeze(0))
+            st["log_probs"].index_copy_(0, row, torch.stack(logps, dim=1).unsqueeze(0))
+            st["values"].index_copy_(0, row, value.unsqueeze(0))
+            self._t_dev.add_(1)
+        self._act_pin.copy_(self._act_dev, non_blocking=True)
+
+    def _refresh_kv_cache(self):
+        """Start of a rollout: re-project every live episode's memory with the CURRENT weights (they changed in the
+        last optimisation phase) into the per-worker K/V cache [W, T, blocks, 2D]; rows that are not written yet hold the
+        projection of a zero item, which is also the initial state of every episode that starts during the rollout."""
+        W, T = self.num_workers, self.max_episode_length
+        tr = self.model.transformer
+        with torch.no_grad():
+            fresh = tr.kv_projection_weights()
+            if self._kv_weights is None:      # fixed-address buffers: the captured step graph reads them every replay
+                self._kv_weights = tuple(t.clone() if torch.is_tensor(t) else t for t in fresh)
+            else:
+                for dst, src in zip(self._kv_weights, fresh):
+                    if torch.is_tensor(dst):
+                        dst.copy_(src)
+            pos = tr._pos()
+            live = self.buffer.bank[:W].reshape(W * T, self.num_blocks, self.embed_dim)
+            pos_all = pos.repeat(W, 1) if pos is not None else None
+            self._kv_cache.copy_(tr.project_memory(live, pos_all, self._kv_weights).reshape(self._kv_cache.shape))
+            zeros = torch.zeros((T, self.num_blocks, self.embed_dim), dtype=torch.float32, device=self.device)
+            self._kv_init.copy_(tr.project_memory(zeros, pos, self._kv_weights))
 
     def _capture_step_graph(self):
         """Warm the step up on a side stream (library handles, MIOpen find, allocator), then capture it."""

@@ -94,17 +94,31 @@ class TransformerBlock(Module):
 
     def forward_window(self, h, spec: WindowSpec, block=0, pos=None):
         """h [N, D] query state; returns (new state [N, D], attention [N, H, L])."""
-        pre, post = self.layer_norm == "pre", self.layer_norm == "post"
+        pre = self.layer_norm == "pre"
         q_in = self.norm1(h) if pre else h
         att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
+        return self._after_attention(h, att_out), att_w
+
+    def forward_cached(self, h, kv_spec: WindowSpec, block=0):
+        """Rollout path: attention over cached K/V projections (no grad)."""
+        q_in = self.norm1(h) if self.layer_norm == "pre" else h
+        ctx, _ = ops.attn_cached(self.attention.queries(q_in), kv_spec, block, self.attention.num_heads)
+        return self._after_attention(h, self.attention.fc_out(ctx))
+
+    def _after_attention(self, h, att_out):
+        pre, post = self.layer_norm == "pre", self.layer_norm == "post"
+        if post and not self.use_gtrxl and not torch.is_grad_enabled():
+            # rollout: residual + LayerNorm and Linear + ReLU are one launch each
+            x = ops.add_layernorm(att_out, h, self.norm1)
+            return ops.add_layernorm(ops.linear_relu(self.fc[0], x), x, self.norm2)
         x = self.gate1(h, att_out) if self.use_gtrxl else att_out + h
         if post:
             x = self.norm1(x)
-        f = self.fc(self.norm2(x) if pre else x)
+        f = ops.linear_relu(self.fc[0], self.norm2(x) if pre else x)
         out = self.gate2(x, f) if self.use_gtrxl else f + x
         if post:
             out = self.norm2(out)
-        return out, att_w
+        return out
 
     def forward(self, value, key, query, mask):
         """Upstream signature: value/key [N, L, D] (same tensor), query [N, 1, D], mask [N, L]."""
@@ -159,12 +173,40 @@ class Transformer(nn.Module):
 
     def forward_window(self, h, spec: WindowSpec):
         """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D])."""
-        h = self.activation(self.linear_embedding(h))
+        h = ops.linear_relu(self.linear_embedding, h)
         pos = self._pos()
         items = []
         for i, blk in enumerate(self.transformer_blocks):
             items.append(h.detach())
             h, _ = blk.forward_window(h, spec, i, pos)
+        return h, torch.stack(items, dim=1)
+
+    # ---------------------------------------------------------------- rollout K/V cache (weights frozen while sampling)
+    def kv_projection_weights(self):
+        """[blocks, D, 2D]: per block [Wk ; Wv]^T, plus norm_kv gains/biases [blocks, D] (or None)."""
+        blocks = self.transformer_blocks
+        w = torch.stack([torch.cat((b.attention.keys.weight, b.attention.values.weight), dim=0).t() for b in blocks])
+        if blocks[0].layer_norm == "pre":
+            g = torch.stack([b.norm_kv.weight for b in blocks])
+            bb = torch.stack([b.norm_kv.bias for b in blocks])
+            return w.contiguous(), g, bb, blocks[0].norm_kv.eps
+        return w.contiguous(), None, None, 0.0
+
+    def project_memory(self, items, pos_rows, weights):
+        """items [M, blocks, D] memory items, pos_rows [M, D] (or None) -> cached projections [M, blocks, 2D] (K | V)."""
+        w, g, bb, eps = weights
+        x = items if pos_rows is None else items + pos_rows.unsqueeze(1)
+        if g is not None:
+            x = torch.nn.functional.layer_norm(x, (x.shape[-1],), None, None, eps) * g + bb
+        return torch.bmm(x.transpose(0, 1), w).transpose(0, 1)
+
+    def forward_cached(self, h, kv_spec: WindowSpec):
+        """Rollout path of ``forward_window``: attention reads the K/V cache addressed by ``kv_spec``."""
+        h = ops.linear_relu(self.linear_embedding, h)
+        items = []
+        for i, blk in enumerate(self.transformer_blocks):
+            items.append(h.detach())
+            h = blk.forward_cached(h, kv_spec, i)
         return h, torch.stack(items, dim=1)
 
     def forward(self, h, memories, mask, memory_indices):

@@ -103,6 +103,38 @@ int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_stride,
                 int N, int L, int D, int H, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Rollout-time variant of kernel #1 over CACHED key/value projections (inference only, no backward).
+ * During sampling the weights are frozen and an item's positional row is fixed by its absolute episode index
+ * (transformer.py:237-239), so the trainer projects each new memory item once (library GEMM) into a cache
+ * [W, T, blocks, 2D] (K in [0,D), V in [D,2D)) and this kernel performs transformer.py:59-75 for the single query.
+ *   kv: cache already offset to the block (base + block * 2D); ep_stride/row_stride in floats; ep NULL => ep[n] = n
+ *   ctx [N,D]; att [N,H,L] or NULL.   Shape support: head_dim % 4 == 0, head_dim <= 256, L <= 128.
+ * etm_reset_rows: dst[w, 0..row_elems) = init[0..row_elems) for every w with step[w] == 0 (a new episode starts from
+ * the projection of an all-zero memory); touches only the flagged workers.
+ */
+int etm_attn_cached(const float *kv, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                    const uint8_t *mask, const float *q, float *ctx, float *att, int N, int L, int D, int H, void *stream);
+int etm_reset_rows(float *dst, const float *init, const int64_t *step, int W, int64_t row_elems, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rollout-step glue (trainer.py:161-186).  At n_workers = 32 a step is bound by the number of launches, so these fuse
+ * what would be ~8 / ~17 / 2 framework launches into one each.  All operands have fixed addresses (HIP-graph friendly);
+ * `t_dev` is a device-resident step counter, staging arrays are time-major [S, W, ...].
+ *   etm_rollout_window: mask_t[w] = mask_table[clip(step[w], 0, L-1)], win_t[w] = index_table[step[w]] (trainer.py:165-166),
+ *                       also stored to row *t_dev of st_mask / st_idx.
+ *   etm_rollout_sample: per worker log-softmax of logits [W,A], categorical sample by inverse CDF with the pre-drawn
+ *                       uniform uniforms[*t_dev, w] (or forced[w] if non-NULL), log-prob; writes actions [W] and row *t_dev
+ *                       of st_actions / st_logp / st_values, then *t_dev += 1 (trainer.py:179-186).
+ *   etm_add_layernorm:  out = LayerNorm(a + b) (residual + post-LN, transformer.py:145-149 / :166-170), forward only, D <= 1024.
+ */
+int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
+                       uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int W, int L, void *stream);
+int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
+                       int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
+int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).
  *   rewards, values, advantages [W,S] fp32 row-major (time contiguous, the reference layout)
  *   dones [W,S] one byte each; last_value [W]

@@ -397,3 +397,80 @@ def test_trainer_self_consistency_and_free_run():
                               "policy_head_0", "lin_policy", "value", "model"}
     assert len(infos) > 0 and all({"reward", "length"} <= set(i) for i in infos)
     tr.close()
+
+
+# ------------------------------------------------------------------ rollout K/V cache path
+def test_attn_cached_matches_fused_kernel():
+    """Cached-projection attention (rollout) == the fused projection+attention kernel on the same window."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    for (W, T, nb, D, H, L, ln) in ((9, 40, 3, 384, 4, 32, False), (5, 130, 2, 128, 1, 128, True), (7, 20, 2, 64, 2, 7, True)):
+        bank = torch.randn((W, T, nb, D), device=dev)
+        pos = torch.randn((T, D), device=dev) * 0.5
+        wk = torch.randn((D, D), device=dev) / D ** 0.5
+        wv = torch.randn((D, D), device=dev) / D ** 0.5
+        g = 1 + 0.1 * torch.randn((D,), device=dev)
+        b = 0.1 * torch.randn((D,), device=dev)
+        q = torch.randn((W, D), device=dev)
+        win = torch.randint(0, T - L + 1, (W, 1), device=dev) + torch.arange(L, device=dev)[None, :]
+        cnt = torch.randint(0, L + 1, (W,), device=dev)
+        cnt[0] = 0
+        mask = torch.arange(L, device=dev)[None, :] < cnt[:, None]
+        blk = nb - 1
+        spec = ops.WindowSpec.from_bank(bank, None, win, win, mask)
+        with torch.no_grad():
+            ref, ref_att = ops.mha(q, wk, wv, spec, blk, H, g if ln else None, b if ln else None, pos)
+            x = bank[:, :, blk] + pos[None]
+            if ln:
+                x = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
+            cache = torch.zeros((W, T, nb, 2 * D), device=dev)
+            cache[:, :, blk, :D] = x @ wk.t()
+            cache[:, :, blk, D:] = x @ wv.t()
+            kv_spec = ops.WindowSpec.from_bank(cache, None, win, None, mask)
+            ctx, att = ops.attn_cached(q, kv_spec, blk, H, want_att=True)
+        close(ctx, ref.cpu().numpy(), atol=5e-5, rtol=1e-4, what="ctx")
+        close(att, ref_att.cpu().numpy(), atol=2e-6, rtol=1e-4, what="att")
+    # reset_rows touches only workers at episode step 0
+    dst = torch.ones((4, 6, 8), device=dev)
+    init = torch.arange(48, dtype=torch.float32, device=dev).reshape(6, 8)
+    ops.reset_rows(dst, init, torch.tensor([0, 3, 0, 1], device=dev))
+    assert torch.equal(dst[0], init) and torch.equal(dst[2], init) and bool((dst[1] == 1).all()) and bool((dst[3] == 1).all())
+
+
+def test_rollout_cache_and_graph_paths_agree():
+    """Same seeds, same recorded actions: rollout with K/V cache (eager), without it, must fill the buffer identically
+    (up to fp32 summation order), including episode bookkeeping."""
+    from trainer import PPOTrainer
+    dev = _dev()
+    base = dict(environment=dict(type="Synthetic", obs_shape=[6], num_actions=3, max_episode_steps=24, seed=2, p_done=0.06, pool=8),
+                gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=6, worker_steps=48, n_mini_batch=2, value_loss_coefficient=0.5,
+                hidden_layer_size=64, max_grad_norm=0.5,
+                transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=16, positional_encoding="relative",
+                                 layer_norm="pre", gtrxl=True, gtrxl_bias=0.0),
+                learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
+                beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
+                clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 3, size=(2, 6, 48))
+    results = []
+    for use_cache in (True, False):
+        cfg = json.loads(json.dumps(base))
+        cfg["kv_cache_rollout"] = use_cache
+        torch.manual_seed(11)
+        tr = PPOTrainer(cfg, run_id="cache", device=dev, tensorboard=False)
+        snap = []
+        for u in range(2):   # second rollout starts with live episodes whose cache must be re-projected
+            tr._sample_training_data(forced_actions=acts[u])
+            tr.buffer.prepare_batch_dict()
+            b = tr.buffer
+            snap.append({k: getattr(b, k).clone() for k in ("values", "log_probs", "advantages", "memory_mask", "memory_indices", "memory_index")})
+            snap[-1]["memories"] = b.memories.clone()
+            tr._train_epochs(3e-4, 0.1, 1e-3, perms=[np.arange(6 * 48)])
+        results.append(snap)
+        tr.close()
+    for a, b in zip(*results):
+        for k in ("memory_mask", "memory_indices", "memory_index"):
+            assert torch.equal(a[k], b[k]), k
+        for k in ("values", "log_probs", "advantages", "memories"):
+            assert torch.allclose(a[k], b[k], atol=2e-4, rtol=1e-3), (k, (a[k] - b[k]).abs().max())
