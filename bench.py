@@ -97,6 +97,7 @@ def main():
         raise SystemExit("bench.py measures the MI355X path; no HIP device is visible (there is no CPU fallback)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))  # host side is a single python loop per rank
 
     from etm import lib as etm_lib
     from etm.dist import DataParallel

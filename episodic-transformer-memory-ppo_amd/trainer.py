@@ -334,7 +334,8 @@ class PPOTrainer:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
+        # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
+        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._rollout_step_device()
         self._step_graph = graph
         self._t_dev.zero_()

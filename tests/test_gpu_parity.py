@@ -476,3 +476,70 @@ def test_rollout_cache_and_graph_paths_agree():
             assert torch.equal(a[k], b[k]), k
         for k in ("values", "log_probs", "advantages", "memories"):
             assert torch.allclose(a[k], b[k], atol=2e-4, rtol=1e-3), (k, (a[k] - b[k]).abs().max())
+
+
+# ------------------------------------------------------------------ other BASELINE config shapes + RCCL plumbing on one device
+@pytest.mark.parametrize("cfg_name,over", [
+    ("synthetic_cartpole", dict(n_workers=8, worker_steps=64, n_mini_batch=2, epochs=1)),              # config (2): GTrXL, pre-LN, D=128 H=1
+    ("synthetic_mortar_gtrxl", dict(n_workers=4, worker_steps=160, n_mini_batch=2, epochs=1)),         # config (5): GTrXL 4 blocks, L=128, pre-LN
+    ("synthetic_minigrid", dict(n_workers=4, worker_steps=128, n_mini_batch=2, epochs=1)),             # config (3)
+])
+def test_baseline_config_shapes_train(cfg_name, over):
+    """One rollout + optimisation pass at the model shapes of BASELINE configs (2), (3), (5) (fewer workers/steps):
+    the buffer self-consistency check (quirk Q10) must hold and every parameter must receive a finite gradient."""
+    from yaml_parser import YamlParser
+    from trainer import PPOTrainer
+    from etm.ops import WindowSpec
+    dev = _dev()
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = YamlParser(os.path.join(here, "..", "episodic-transformer-memory-ppo_amd", "configs", cfg_name + ".yaml")).get_config()
+    cfg.update(over)
+    cfg["environment"] = dict(cfg["environment"], pool=4)
+    torch.manual_seed(0)
+    tr = PPOTrainer(cfg, run_id="shapes", device=dev, tensorboard=False)
+    tr._sample_training_data()
+    tr.buffer.prepare_batch_dict()
+    flat = tr.buffer.samples_flat
+    with torch.no_grad():
+        spec = WindowSpec.from_bank(tr.buffer.memories, flat["memory_index"], flat["memory_indices"], flat["memory_indices"], flat["memory_mask"])
+        _, value, _ = tr.model.forward_logits(flat["obs"], spec)
+    keep = flat["memory_mask"].any(dim=1)
+    assert torch.allclose(value[keep], flat["values"][keep], atol=5e-4), (value[keep] - flat["values"][keep]).abs().max()
+    stats, _ = tr._train_epochs(1e-4, 0.1, 1e-3)
+    assert np.isfinite(np.asarray(stats)).all()
+    for name, p_ in tr.model.named_parameters():
+        assert torch.isfinite(p_.grad).all(), name
+        assert torch.isfinite(p_).all(), name
+    tr.close()
+
+
+def test_rccl_single_rank_plumbing(tmp_path):
+    """The data-parallel path with the real RCCL backend on one device (world size 1 forced): communicator creation,
+    flat-bucket all-reduce, merged advantage statistics, rank-max -- what every rank does in the multi-GPU bench."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(here, "..", "episodic-transformer-memory-ppo_amd")
+    code = f"""
+import os, sys
+sys.path.insert(0, {pkg!r})
+import torch, torch.distributed as dist
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+from etm.dist import DataParallel
+dp = DataParallel(dev)
+dp.world = 1
+flat = torch.arange(1000, dtype=torch.float32, device=dev)
+dist.all_reduce(flat)                       # RCCL all-reduce on the device
+assert float(flat[999]) == 999.0
+g = [torch.empty(3, device=dev)]
+dist.all_gather(g, torch.tensor([4.0, 1.0, 2.0], device=dev))
+assert g[0].tolist() == [4.0, 1.0, 2.0]
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert "rccl-ok" in out.stdout, out.stderr[-2000:]
