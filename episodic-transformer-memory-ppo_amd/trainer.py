@@ -144,6 +144,9 @@ class PPOTrainer:
         self._act_dev = torch.zeros((W, B), dtype=torch.int64, device=device)
         self._uniforms = torch.zeros((S, W), dtype=torch.float32, device=device)
         self._step_graph = None
+        self._act_ready = torch.cuda.Event()
+        self._t_row = torch.zeros((), dtype=torch.int64, device=device)
+        self._item = torch.zeros((W, self.num_blocks, self.embed_dim), dtype=torch.float32, device=device)
         # rollout K/V cache (weights are frozen while sampling): per worker [T, blocks, 2D] projections of its episode
         self._use_kv_cache = bool(config.get("kv_cache_rollout", True))
         T, nb, D = self.max_episode_length, self.num_blocks, self.embed_dim
@@ -227,11 +230,15 @@ class PPOTrainer:
         t_env = 0.0
         for t in range(S):
             if use_graph:
-                self._step_graph.replay()
+                self._step_graph[0].replay()
+                self._act_ready.record(stream)       # actions are in pinned memory once this event completes
+                self._step_graph[1].replay()         # tail runs while the host steps the environments
             else:
                 with torch.no_grad():
-                    self._rollout_step_device(forced[:, t].contiguous() if forced is not None else None)
-            stream.synchronize()  # actions are on the host; the observation upload has been consumed
+                    carry = self._rollout_step_head(forced[:, t].contiguous() if forced is not None else None)
+                    self._act_ready.record(stream)
+                    self._rollout_step_tail(carry)
+            self._act_ready.synchronize()
             te = time.perf_counter()
             _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
             t_env += time.perf_counter() - te
@@ -257,10 +264,15 @@ class PPOTrainer:
         return episode_infos
 
     def _rollout_step_device(self, forced_t=None):
-        """Device side of one rollout step (upstream trainer.py:161-186); every operand has a fixed address so the
-        sequence can be captured in a HIP graph.  Reads the pinned host mirrors (observation, episode step, episode
-        slot), writes row ``t`` of the time-major staging arrays and the pinned action buffer."""
-        buf, L = self.buffer, self.memory_length
+        """Device side of one rollout step (upstream trainer.py:161-186) = head + tail."""
+        carry = self._rollout_step_head(forced_t)
+        self._rollout_step_tail(carry)
+
+    def _rollout_step_head(self, forced_t=None):
+        """Everything the ACTIONS depend on: observation / step / slot upload, window lookup, model forward, sampling,
+        staging of the step's rows, action download.  Every operand has a fixed address (HIP-graph capturable).
+        Returns what the tail needs (the new memory item)."""
+        buf = self.buffer
         self._obs_dev.copy_(self._obs_pin, non_blocking=True)
         self._step_dev.copy_(self._step_pin, non_blocking=True)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
@@ -274,21 +286,16 @@ class PPOTrainer:
             ops.reset_rows(self._kv_cache, self._kv_init, self._step_dev)
             kv_spec = WindowSpec.from_bank(self._kv_cache, None, win_t, None, mask_t)
             logits, value, item = self.model.forward_logits_cached(self._obs_dev, kv_spec)
-            tr = self.model.transformer
-            pos = tr._pos()
-            pos_rows = pos.index_select(0, self._step_dev) if pos is not None else None
-            self._kv_cache[self._worker_ids, self._step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
         else:
             spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
             logits, value, item = self.model.forward_logits(self._obs_dev, spec)
-        buf.bank[self._slot_dev, self._step_dev] = item          # new memory item (upstream :174)
-        row = self._t_dev.view(1)
-        st["obs"].index_copy_(0, row, self._obs_dev.unsqueeze(0))
+        self._t_row.copy_(self._t_dev)               # row index of this step for the tail (t_dev is incremented below)
         if single:
             # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
             ops.rollout_sample(logits[0], value, self._uniforms, forced_t, self._t_dev, self._act_dev,
                                st["actions"], st["log_probs"], st["values"])
         else:
+            row = self._t_row.view(1)
             acts, logps = [], []
             for lg in logits:
                 lsm = torch.log_softmax(lg, dim=-1)
@@ -301,6 +308,20 @@ class PPOTrainer:
             st["values"].index_copy_(0, row, value.unsqueeze(0))
             self._t_dev.add_(1)
         self._act_pin.copy_(self._act_dev, non_blocking=True)
+        self._item.copy_(item)
+        return self._item
+
+    def _rollout_step_tail(self, item):
+        """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
+        K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
+        buf, st = self.buffer, self._stage
+        buf.bank[self._slot_dev, self._step_dev] = item
+        if self._use_kv_cache:
+            tr = self.model.transformer
+            pos = tr._pos()
+            pos_rows = pos.index_select(0, self._step_dev) if pos is not None else None
+            self._kv_cache[self._worker_ids, self._step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
+        st["obs"].index_copy_(0, self._t_row.view(1), self._obs_dev.unsqueeze(0))
 
     def _refresh_kv_cache(self):
         """Start of a rollout: re-project every live episode's memory with the CURRENT weights (they changed in the
@@ -324,7 +345,8 @@ class PPOTrainer:
             self._kv_init.copy_(tr.project_memory(zeros, pos, self._kv_weights))
 
     def _capture_step_graph(self):
-        """Warm the step up on a side stream (library handles, MIOpen find, allocator), then capture it."""
+        """Warm the step up on a side stream (library handles, MIOpen find, allocator), then capture it as TWO graphs:
+        the head (ends with the action download) and the tail (bank / cache / staging writes)."""
         self._t_dev.zero_()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -333,11 +355,14 @@ class PPOTrainer:
                 self._rollout_step_device()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
-        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._rollout_step_device()
-        self._step_graph = graph
+        with torch.no_grad(), torch.cuda.graph(head, pool=pool, capture_error_mode="thread_local"):
+            self._rollout_step_head()
+        with torch.no_grad(), torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
+            self._rollout_step_tail(self._item)
+        self._step_graph = (head, tail)
         self._t_dev.zero_()
 
     def get_last_value(self):

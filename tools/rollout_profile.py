@@ -32,12 +32,16 @@ t00 = time.perf_counter()
 for t in range(S):
     a = time.perf_counter()
     if tr._step_graph is not None:
-        tr._step_graph.replay()
+        tr._step_graph[0].replay()
+        tr._act_ready.record(stream)
+        tr._step_graph[1].replay()
     else:
         with torch.no_grad():
-            tr._rollout_step_device()
+            carry = tr._rollout_step_head()
+            tr._act_ready.record(stream)
+            tr._rollout_step_tail(carry)
     b = time.perf_counter()
-    stream.synchronize()
+    tr._act_ready.synchronize()
     c = time.perf_counter()
     _, rewards, dones, infos = tr.env.step(tr._act_pin.numpy()[:, 0], out=tr.obs)
     d = time.perf_counter()
