@@ -49,6 +49,21 @@ def kernel_flops(name, N, L, D, H):
     return None
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of ``kernel`` at the training shape from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary.json, produced by tools/run_pmc.sh in separate --pmc passes): FETCH_SIZE KiB x 2 (gfx950 reports
+    half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KiB.  None if no profile is present."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)[kernel]
+        return {"bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"]["mean"] + 1024 * k["WRITE_SIZE"]["mean"],
+                "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, N=2048 L=64 D=384 H=4)",
+                "mfma_busy_fraction_pmc": k.get("derived", {}).get("mfma_busy_fraction")}
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, seed=0):
     """Oracle trainer on host cores, bounded sample: 32 workers x 64 steps, 5 epochs x 1 minibatch of 2048."""
     from environments.vec_env import make_vec_env
@@ -171,7 +186,7 @@ def main():
             dom = max(cand, key=lambda k: kernels[k]["total_ms"])
             ach = kernels[dom]["tflops"]
             roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": kernels[dom]["avg_ms"],
+                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom), "avg_launch_ms": kernels[dom]["avg_ms"],
                         "flops_per_launch": kernel_flops(dom, N, L, D, H), "launches": kernels[dom]["launches"],
                         "shape": {"N": N, "L": L, "D": D, "H": H}, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
