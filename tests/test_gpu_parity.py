@@ -543,3 +543,29 @@ print("rccl-ok")
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert "rccl-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_train_cli_and_checkpoint_format(tmp_path):
+    """`train.py --config ... --run-id ...` runs end to end and writes upstream's checkpoint format:
+    pickle((state_dict, config)) at ./models/<run_id>.nn with the reference's key names (trainer.py:356-362, enjoy.py:48-55)."""
+    import pickle
+    import subprocess
+    import sys
+    import yaml
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(here, "..", "episodic-transformer-memory-ppo_amd")
+    cfg = yaml.safe_load(open(os.path.join(pkg, "configs", "synthetic_cartpole.yaml")))
+    cfg.update(updates=2, n_workers=4, worker_steps=32, epochs=1, n_mini_batch=2)
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    out = subprocess.run([sys.executable, os.path.join(pkg, "train.py"), "--config", str(cfg_path), "--run-id", "clitest"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "steps/s" in out.stdout and "Model saved" in out.stdout
+    state, saved_cfg = pickle.load(open(tmp_path / "models" / "clitest.nn", "rb"))
+    assert saved_cfg["transformer"] == cfg["transformer"]
+    assert "transformer.transformer_blocks.0.attention.keys.weight" in state and "policy_branches.0.weight" in state
+    assert all(v.device.type == "cpu" for v in state.values())
+    bad = subprocess.run([sys.executable, os.path.join(pkg, "train.py"), "--config", str(cfg_path), "--cpu"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "no CPU trainer" in (bad.stderr + bad.stdout)
