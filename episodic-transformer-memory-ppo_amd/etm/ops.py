@@ -66,7 +66,7 @@ class WindowSpec:
     bank_ptr/ep_stride/row_stride/block_stride are in float32 elements.  ``ep`` may be None (ep[n] = n).
     """
 
-    __slots__ = ("bank", "ep_stride", "row_stride", "block_stride", "ep", "win", "pidx", "mask", "N", "L")
+    __slots__ = ("bank", "ep_stride", "row_stride", "block_stride", "ep", "win", "pidx", "mask", "N", "L", "pos_included")
 
     def __init__(self, bank, ep_stride, row_stride, block_stride, ep, win, pidx, mask):
         _need_dev(bank, ep, win, pidx, mask)
@@ -80,6 +80,7 @@ class WindowSpec:
         self.bank = bank
         self.ep_stride, self.row_stride, self.block_stride = int(ep_stride), int(row_stride), int(block_stride)
         self.N, self.L = int(win.shape[0]), int(win.shape[1])
+        self.pos_included = False   # True: the bank rows already contain their positional rows (see Transformer.bank_with_positions)
         self.ep = None if ep is None else ep.to(torch.int64).contiguous()
         self.win = win.to(torch.int64).contiguous()
         self.pidx = None if pidx is None else pidx.to(torch.int64).contiguous()

@@ -384,6 +384,10 @@ class PPOTrainer:
         """``epochs`` passes over shuffled minibatches.  Returns (list of 6-stat rows, {grad key: [norms]})."""
         stats, norms = [], []
         monitor = self.config.get("monitor_gradients", True)
+        # sinusoidal positions: add them to the (read-only) episode bank once per update instead of once per window row,
+        # block, minibatch and epoch inside the kernels (bit-identical sums; halves the kernels' window-row loads)
+        with torch.no_grad():
+            self._bank_pos = self.model.transformer.bank_with_positions(self.buffer.memories)
         for epoch in range(self.config["epochs"]):
             indices = None if perms is None else perms[epoch]
             for mini_batch in self.buffer.mini_batch_generator(indices):
@@ -391,6 +395,7 @@ class PPOTrainer:
                 if monitor:
                     norms.append(self._grad_group_norms())
         train_info = torch.stack(stats).cpu().numpy()          # the only host sync of the optimisation phase
+        self._bank_pos = None
         grad_info = {}
         if norms:
             allnorms = torch.stack(norms).cpu().numpy()
@@ -400,8 +405,13 @@ class PPOTrainer:
     def _train_mini_batch(self, samples: dict, learning_rate: float, clip_range: float, beta: float):
         """One optimiser step on one minibatch.  Returns a device tensor [policy, value, loss, entropy, kl, clip_frac]."""
         ep = samples.get("memory_index")  # None: upstream layout, ``memories`` already gathered per sample
-        spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
-                                    samples["memory_mask"])
+        bank_pos = getattr(self, "_bank_pos", None)
+        if bank_pos is not None and ep is not None and samples["memories"].data_ptr() == self.buffer.bank.data_ptr():
+            spec = WindowSpec.from_bank(bank_pos, ep, samples["memory_indices"], None, samples["memory_mask"])
+            spec.pos_included = True
+        else:
+            spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
+                                        samples["memory_mask"])
         logits, value, _ = self.model.forward_logits(samples["obs"], spec)
         stats3 = ops.adv_stats(samples["advantages"])
         if self.dp is not None:

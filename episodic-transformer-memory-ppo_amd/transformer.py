@@ -174,12 +174,20 @@ class Transformer(nn.Module):
     def forward_window(self, h, spec: WindowSpec):
         """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D])."""
         h = ops.linear_relu(self.linear_embedding, h)
-        pos = self._pos()
+        pos = None if spec.pos_included else self._pos()
         items = []
         for i, blk in enumerate(self.transformer_blocks):
             items.append(h.detach())
             h, _ = blk.forward_window(h, spec, i, pos)
         return h, torch.stack(items, dim=1)
+
+    def bank_with_positions(self, bank):
+        """[E, T, blocks, D] episode bank with every row's positional row already added (same fp32 add the kernel would
+        do per use).  Valid whenever a window's positional index equals its row index -- always the case in the
+        optimisation phase (upstream trainer.py:271-274) -- and the table is not trainable.  Returns None otherwise."""
+        if self.pos_kind != "relative":
+            return None
+        return bank + self._pos_table[None, : bank.shape[1], None, :]
 
     # ---------------------------------------------------------------- rollout K/V cache (weights frozen while sampling)
     def kv_projection_weights(self):
