@@ -66,6 +66,24 @@ def build_window_tables(memory_length: int, max_episode_length: int):
     return mask, indices
 
 
+def check_kernel_shapes(tcfg: dict):
+    """Fail early (before any environment or buffer is built) if the transformer shape is outside what the gfx950
+    kernels are built for; there is no fallback path."""
+    d, h, mem = tcfg["embed_dim"], tcfg["num_heads"], tcfg["memory_length"]
+    if d % h != 0:
+        raise ValueError("Embedding dimension needs to be divisible by the number of heads")
+    hd = d // h
+    problems = []
+    if d % 32 != 0 or d > 1024:
+        problems.append(f"embed_dim={d} (need a multiple of 32, <= 1024)")
+    if hd % 32 != 0 or hd > 128:
+        problems.append(f"head_dim={hd} (need 32, 64, 96 or 128)")
+    if mem > 128:
+        problems.append(f"memory_length={mem} (need <= 128)")
+    if problems:
+        raise ValueError("transformer shape not supported by the MI355X kernels: " + "; ".join(problems))
+
+
 class PPOTrainer:
     def __init__(self, config: dict, run_id: str = "run", device: torch.device = None, env=None, dp=None,
                  first_worker_id: int = 0, tensorboard: bool = True) -> None:
@@ -86,6 +104,7 @@ class PPOTrainer:
         self.cr_schedule = config["clip_range_schedule"]
         t = config["transformer"]
         self.memory_length, self.num_blocks, self.embed_dim = t["memory_length"], t["num_blocks"], t["embed_dim"]
+        check_kernel_shapes(t)
         self.writer = _make_writer(run_id) if tensorboard else _NullWriter()
 
         # environments (batched front-end over the upstream per-worker protocol)

@@ -112,7 +112,7 @@ def sd_arrays(module, prefix="sd/"):
 def golden_tables():
     """trainer.py:78,88-90 evaluated verbatim (same torch expressions the reference runs)."""
     out = {}
-    for L, T in [(4, 7), (6, 6), (8, 20), (32, 32), (32, 200), (64, 96), (118, 128), (128, 128)]:
+    for L, T in [(1, 1), (1, 3), (2, 2), (4, 7), (6, 6), (8, 20), (32, 32), (32, 200), (64, 96), (118, 128), (128, 128)]:
         mask = torch.tril(torch.ones((L, L)), diagonal=-1)
         rep = torch.repeat_interleave(torch.arange(0, L).unsqueeze(0), L - 1, dim=0).long()
         idx = torch.stack([torch.arange(i, i + L) for i in range(T - L + 1)]).long()

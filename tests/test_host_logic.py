@@ -132,3 +132,12 @@ def test_poc_memory_env_protocol():
         if steps > 2 and not done:
             assert obs[0] == 0.0 and obs[2] == 0.0       # goals hidden after the first two steps
     assert info["length"] == steps and abs(info["reward"] - total) < 1e-6 and steps <= 32
+
+
+def test_kernel_shape_validation_is_early_and_loud():
+    from trainer import check_kernel_shapes
+    ok = dict(embed_dim=384, num_heads=4, memory_length=64)
+    check_kernel_shapes(ok)
+    for bad in (dict(ok, embed_dim=100, num_heads=4), dict(ok, num_heads=8), dict(ok, memory_length=129), dict(ok, embed_dim=2048)):
+        with pytest.raises(ValueError):
+            check_kernel_shapes(bad)
