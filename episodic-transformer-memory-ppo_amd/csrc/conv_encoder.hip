@@ -1,0 +1,141 @@
+// Rollout-only encoder convolution: implicit GEMM on fp32 MFMA with fused bias + ReLU (forward, no grad).
+//
+// Replaces, on the no-grad path, one `relu(conv2d(x))` of /root/reference model.py:90-92 (MIOpen + bias + ReLU launches;
+// at n_workers = 32 the three layers cost ~110 us per rollout step, mostly launch overhead).  The optimisation phase
+// keeps the library convolution (it needs the backward).
+//
+//   out[m, co] = relu(bias[co] + sum_k A[m, k] * Wt[co, k]),   m = (n, oy, ox),  k = (segment, offset)
+// K is a list of memory-contiguous SEGMENTS of the input window of one output pixel:
+//   NCHW input (layer 1, as it arrives from the host): segment = (c, ky), length KW          -> weights in native layout
+//   NHWC input (layers 2, 3):                          segment = ky,      length KW * C      -> weights pre-permuted to
+//                                                                                               [Cout][KH][KW][C]
+// so every lane fetches its A fragment with 16-byte loads straight from global memory/L2 (no LDS staging, no barrier in
+// the main loop).  One workgroup = one tile of 32 output pixels x all Cout (NT = Cout/32 accumulator tiles); its four
+// waves split K (interleaved 8-wide k-groups) and are reduced through LDS, then bias + ReLU + store (NHWC for the next
+// layer, NCHW for the last one so that the flatten order of model.py:94 is unchanged).
+#include "etm_common.h"
+
+namespace {
+struct ConvParams {
+  const float *in, *w, *bias;
+  float *out;
+  int N, C, H, W, Cout, KH, KW, S, Ho, Wo;
+  int in_nhwc, out_nchw;
+  int seg_len, n_seg, groups;  // K = n_seg * seg_len, groups = K / 8
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_relu_kernel(const ConvParams p) {
+  __shared__ float red[4 * NT * 16 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int M = p.N * p.Ho * p.Wo;
+  const int m = min((int)blockIdx.x * 32 + col, M - 1);
+  const int n = m / (p.Ho * p.Wo);
+  const int rem = m - n * p.Ho * p.Wo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const int K = p.n_seg * p.seg_len;
+
+  // base offset of this lane's pixel; a segment s adds seg_stride_a * (its row) ... computed per group below
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float *wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wrow[t] = p.w + (long long)(t * 32 + col) * K + half * 4;
+
+  auto a_ptr = [&](int k0) -> const float * {
+    const int seg = k0 / p.seg_len, off = k0 - seg * p.seg_len;
+    long long base;
+    if (p.in_nhwc) {            // seg = ky
+      base = (((long long)n * p.H + oy * p.S + seg) * p.W + ox * p.S) * p.C;
+    } else {                    // seg = c * KH + ky
+      const int c = seg / p.KH, ky = seg - c * p.KH;
+      base = (((long long)n * p.C + c) * p.H + oy * p.S + ky) * p.W + ox * p.S;
+    }
+    return p.in + base + off + half * 4;
+  };
+
+  // wave w takes k-groups w, w+4, ...; two groups in flight
+  int g = wave;
+  for (; g + 4 < p.groups; g += 8) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a_ptr(g * 8));
+    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a_ptr((g + 4) * 8));
+    f32x4 b0[NT], b1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      b0[t] = *reinterpret_cast<const f32x4 *>(wrow[t] + g * 8);
+      b1[t] = *reinterpret_cast<const f32x4 *>(wrow[t] + (g + 4) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[t][j], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[t][j], acc[t], 0, 0, 0);
+  }
+  for (; g < p.groups; g += 4) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a_ptr(g * 8));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(wrow[t] + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[t], 0, 0, 0);
+    }
+  }
+
+  // reduce the four K-slices through LDS (lane-contiguous: conflict-free)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  // each thread finishes (t, r) pairs for its lane: NT*16 pairs over 4 waves
+  for (int pr = wave; pr < NT * 16; pr += 4) {
+    const int t = pr / 16, r = pr - t * 16;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * NT + t) * 16 + r) * 64 + lane];
+    const int row = mfma32_row(r, lane);
+    const int mm = (int)blockIdx.x * 32 + row;
+    if (mm < M) {
+      const int co = t * 32 + col;
+      v = fmaxf(v + p.bias[co], 0.f);
+      if (p.out_nchw) {
+        const int nn = mm / (p.Ho * p.Wo);
+        const int rr = mm - nn * p.Ho * p.Wo;
+        p.out[((long long)nn * p.Cout + co) * p.Ho * p.Wo + rr] = v;
+      } else {
+        p.out[(long long)mm * p.Cout + co] = v;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int etm_conv_relu(const float *in, const float *w, const float *bias, float *out, int N, int C, int H, int W, int Cout,
+                             int KH, int KW, int S, int in_nhwc, int out_nchw, void *stream) {
+  (void)hipGetLastError();
+  if (!in || !w || !bias || !out || N <= 0 || C <= 0 || H < KH || W < KW || Cout <= 0 || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
+  ConvParams p;
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.N = N; p.C = C; p.H = H; p.W = W; p.Cout = Cout; p.KH = KH; p.KW = KW; p.S = S;
+  p.Ho = (H - KH) / S + 1; p.Wo = (W - KW) / S + 1; p.in_nhwc = in_nhwc; p.out_nchw = out_nchw;
+  p.seg_len = in_nhwc ? KW * C : KW;
+  p.n_seg = in_nhwc ? KH : C * KH;
+  const int K = p.n_seg * p.seg_len;
+  // 16-byte loads: every segment start and the 8-wide k-groups must be 4-float aligned
+  const bool aligned = in_nhwc ? (C % 4 == 0) : (W % 4 == 0 && S % 4 == 0);
+  if (p.seg_len % 8 != 0 || K % 8 != 0 || !aligned || (Cout != 32 && Cout != 64)) return ETM_EUNSUPPORTED;
+  p.groups = K / 8;
+  const int M = N * p.Ho * p.Wo;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_CONV_RELU, st);
+  const dim3 grid((unsigned)((M + 31) / 32));
+  if (Cout == 32) hipLaunchKernelGGL((conv_relu_kernel<1>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_relu_kernel<2>), grid, dim3(256), 0, st, p);
+  return etm_launch_status();
+}

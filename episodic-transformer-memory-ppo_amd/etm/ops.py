@@ -247,6 +247,22 @@ def add_layernorm(a, b, norm):
     return out
 
 
+def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw):
+    """relu(conv2d(x) + bias) on the no-grad path (see etm_conv_relu).  ``weight2d`` [Cout, K] in the K order that matches
+    the input layout.  Returns NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
+    lib = _lib.load()
+    _need_dev(x, weight2d, bias)
+    x = _f32c(x, "x")
+    N, Cout = x.shape[0], weight2d.shape[0]
+    Ho, Wo = (H - KH) // S + 1, (W - KW) // S + 1
+    shape = (N, Cout, Ho, Wo) if out_nchw else (N, Ho, Wo, Cout)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    rc = lib.etm_conv_relu(_ptr(x), _ptr(weight2d), _ptr(bias), _ptr(out), N, C, H, W, Cout, KH, KW, S, 1 if in_nhwc else 0,
+                           1 if out_nchw else 0, _stream())
+    _lib.check(rc, "etm_conv_relu")
+    return out
+
+
 _fused_linear_relu = None  # None: untested, True/False after the first call
 
 

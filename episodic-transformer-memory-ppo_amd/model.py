@@ -25,6 +25,7 @@ class ActorCriticModel(nn.Module):
         self.max_episode_length = max_episode_length
         self.visual = len(self.observation_space_shape) > 1
         self.channels_last = bool(config.get("encoder_channels_last", True))
+        self.fused_encoder = bool(config.get("fused_rollout_encoder", True))
         if self.visual:
             c = self.observation_space_shape[0]
             self.conv1 = nn.Conv2d(c, 32, 8, 4)
@@ -52,8 +53,46 @@ class ActorCriticModel(nn.Module):
         nn.init.orthogonal_(self.value.weight, 1)
 
     # ------------------------------------------------------------------ forward
+    # ------------------------------------------------------------------ rollout encoder (no grad): MFMA conv + bias + ReLU
+    def _fused_encoder_ok(self, obs):
+        if not (self.visual and self.fused_encoder and obs.is_cuda and not torch.is_grad_enabled()):
+            return False
+        _, _, hh, ww = obs.shape
+        h1, w1 = (hh - 8) // 4 + 1, (ww - 8) // 4 + 1
+        return ww % 4 == 0 and obs.shape[1] * 1 >= 1 and h1 >= 4 and w1 >= 4 and ((h1 - 4) // 2 + 1) >= 3 and ((w1 - 4) // 2 + 1) >= 3
+
+    def refresh_rollout_weights(self):
+        """(Re)build the [Cout, KH*KW*C] weight copies the NHWC layers of the fused encoder read.  Buffers keep their address
+        (the captured rollout graph reads them); called by the trainer at the start of every rollout and lazily whenever a
+        weight's version counter moved."""
+        if not self.visual:
+            return
+        with torch.no_grad():
+            for name, conv in (("_w2p", self.conv2), ("_w3p", self.conv3)):
+                perm = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, -1)
+                buf = getattr(self, name, None)
+                if buf is None or buf.shape != perm.shape or buf.device != perm.device:
+                    setattr(self, name, perm.contiguous())
+                else:
+                    buf.copy_(perm)
+            self._wver = (self.conv2.weight._version, self.conv3.weight._version)
+
+    def _encode_fused(self, obs):
+        if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()
+                                                     and self._wver != (self.conv2.weight._version, self.conv3.weight._version)):
+            self.refresh_rollout_weights()
+        n, c, hh, ww = obs.shape
+        x = ops.conv_relu(obs, self.conv1.weight.reshape(32, -1), self.conv1.bias, c, hh, ww, 8, 8, 4, False, False)   # -> NHWC
+        h1, w1 = x.shape[1], x.shape[2]
+        x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)
+        h2, w2 = x.shape[1], x.shape[2]
+        x = ops.conv_relu(x, self._w3p, self.conv3.bias, 64, h2, w2, 3, 3, 1, True, True)                                # -> NCHW
+        return ops.linear_relu(self.lin_hidden, x.reshape(n, -1))
+
     def _encode(self, obs):
         h = obs
+        if self._fused_encoder_ok(obs):
+            return self._encode_fused(obs)
         if self.visual:
             if self.channels_last and h.is_cuda:
                 # NHWC activations: MIOpen's implicit-GEMM kernels run without layout transposes (1.35 vs 2.1 ms for

@@ -239,6 +239,7 @@ class PPOTrainer:
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
         if self._use_kv_cache:
             self._refresh_kv_cache()
+        self.model.refresh_rollout_weights()       # encoder weight copies for the fused rollout convolutions
         forced = None
         if forced_actions is not None:
             forced = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).to(self.device)

@@ -134,6 +134,14 @@ int etm_rollout_sample(const float *logits, const float *value, const float *uni
 int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
                       void *stream);
 
+/* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
+ * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C];
+ * w: [Cout, K] with K ordered (c, ky, kx) for NCHW input (= the native torch layout) or (ky, kx, c) for NHWC input;
+ * out: NHWC [N,Ho,Wo,Cout] or NCHW (out_nchw = 1).  Shape support: Cout in {32, 64}; NCHW input: KW % 8 == 0, W % 4 == 0,
+ * S % 4 == 0; NHWC input: (KW * C) % 8 == 0, C % 4 == 0.  (Covers the three layers of the Atari-style encoder.) */
+int etm_conv_relu(const float *in, const float *w, const float *bias, float *out, int N, int C, int H, int W, int Cout,
+                  int KH, int KW, int S, int in_nhwc, int out_nchw, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).
  *   rewards, values, advantages [W,S] fp32 row-major (time contiguous, the reference layout)

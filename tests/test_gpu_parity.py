@@ -569,3 +569,30 @@ def test_train_cli_and_checkpoint_format(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(pkg, "train.py"), "--config", str(cfg_path), "--cpu"], cwd=tmp_path,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "no CPU trainer" in (bad.stderr + bad.stdout)
+
+
+def test_fused_rollout_encoder_vs_library_convs():
+    """conv_relu_kernel (MFMA implicit GEMM + bias + ReLU, no-grad path) == relu(conv2d) of the library for the three
+    encoder layers, through ActorCriticModel._encode, including a weight update between calls (version tracking)."""
+    from types import SimpleNamespace
+    from model import ActorCriticModel
+    dev = _dev()
+    cfg = dict(hidden_layer_size=64, transformer=dict(num_blocks=1, embed_dim=64, num_heads=2, memory_length=8,
+                                                      positional_encoding="", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))
+    torch.manual_seed(2)
+    for shape, n in (((3, 84, 84), 32), ((3, 84, 84), 5), ((4, 64, 64), 3)):
+        m = ActorCriticModel(cfg, SimpleNamespace(shape=shape), (3,), 8).to(dev)
+        obs = torch.rand((n,) + shape, device=dev)
+        with torch.no_grad():
+            got = m._encode(obs)
+            m.fused_encoder = False
+            want = m._encode(obs)
+            m.fused_encoder = True
+            close(got, want.cpu().numpy(), atol=2e-5, rtol=1e-4, what=f"encoder {shape}")
+            for conv in (m.conv1, m.conv2, m.conv3):
+                conv.weight.mul_(1.1)
+            got2 = m._encode(obs)
+            m.fused_encoder = False
+            want2 = m._encode(obs)
+            close(got2, want2.cpu().numpy(), atol=2e-5, rtol=1e-4, what=f"encoder after update {shape}")
+        assert not torch.allclose(got, got2)
