@@ -28,6 +28,26 @@ __global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__
 
 // One thread per worker: log-softmax, inverse-CDF sample with the pre-drawn uniform of (t, w) (or a forced action),
 // log-prob, staging of actions / log_probs / values for step t; finally t += 1.
+// Output heads of the actor-critic for the rollout (model.py:108-110): logits[w, a] = Wp[a,:] . h_pol[w,:] + bp[a] and
+// value[w] = Wv . h_val[w,:] + bv, with h = [h_pol | h_val] rows of length 2*hid.  One wave per (worker, output).
+__global__ __launch_bounds__(256) void rollout_heads_kernel(const float *__restrict__ h, const float *__restrict__ wp, const float *__restrict__ bp,
+                                                            const float *__restrict__ wv, const float *__restrict__ bv, float *__restrict__ logits,
+                                                            float *__restrict__ value, int W, int A, int hid) {
+  const int lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (job >= W * (A + 1)) return;
+  const int w = job / (A + 1), o = job - w * (A + 1);
+  const float *x = h + (long long)w * 2 * hid + (o < A ? 0 : hid);
+  const float *wt = (o < A) ? wp + (long long)o * hid : wv;
+  float s = 0.f;
+  for (int c = lane; c < hid; c += 64) s += x[c] * wt[c];
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (o < A) logits[(long long)w * A + o] = s + bp[o];
+    else value[w] = s + bv[0];
+  }
+}
+
 __global__ __launch_bounds__(1024) void rollout_sample_kernel(const float *__restrict__ logits, const float *__restrict__ value,
                                                               const float *__restrict__ uniforms, const long long *__restrict__ forced,
                                                               long long *__restrict__ t_dev, long long *__restrict__ actions,
@@ -114,6 +134,16 @@ extern "C" int etm_rollout_sample(const float *logits, const float *value, const
   EtmProfScope prof(ETM_K_ROLLOUT_SAMPLE, st);
   hipLaunchKernelGGL(rollout_sample_kernel, dim3(1), dim3(1024), 0, st, logits, value, uniforms, (const long long *)forced, (long long *)t_dev,
                      (long long *)actions, (long long *)st_actions, st_logp, st_values, W, A);
+  return etm_launch_status();
+}
+
+extern "C" int etm_rollout_heads(const float *h, const float *wp, const float *bp, const float *wv, const float *bv, float *logits,
+                                 float *value, int W, int A, int hid, void *stream) {
+  (void)hipGetLastError();
+  if (!h || !wp || !bp || !wv || !bv || !logits || !value || W <= 0 || A <= 0 || hid <= 0) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_ROLLOUT_HEADS, st);
+  hipLaunchKernelGGL(rollout_heads_kernel, dim3((unsigned)((W * (A + 1) + 3) / 4)), dim3(256), 0, st, h, wp, bp, wv, bv, logits, value, W, A, hid);
   return etm_launch_status();
 }
 

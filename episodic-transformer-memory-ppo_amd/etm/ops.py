@@ -235,6 +235,19 @@ def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, 
                                       _ptr(st_actions), _ptr(st_logp), _ptr(st_values), W, A, _stream()), "etm_rollout_sample")
 
 
+def rollout_heads(h2, branch, value_head):
+    """logits [W,A] and value [W] from h2 = [relu(lin_policy(h)) | relu(lin_value(h))] ([W, 2*hid]); no-grad path."""
+    lib = _lib.load()
+    h2 = _f32c(h2, "h2")
+    W, hid = h2.shape[0], h2.shape[1] // 2
+    A = branch.weight.shape[0]
+    logits = torch.empty((W, A), dtype=torch.float32, device=h2.device)
+    value = torch.empty((W,), dtype=torch.float32, device=h2.device)
+    _lib.check(lib.etm_rollout_heads(_ptr(h2), _ptr(branch.weight), _ptr(branch.bias), _ptr(value_head.weight), _ptr(value_head.bias),
+                                     _ptr(logits), _ptr(value), W, A, hid, _stream()), "etm_rollout_heads")
+    return logits, value
+
+
 def add_layernorm(a, b, norm):
     """LayerNorm(a + b) with ``norm``'s affine parameters; forward only (rollout path)."""
     lib = _lib.load()

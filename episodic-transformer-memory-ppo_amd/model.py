@@ -65,6 +65,17 @@ class ActorCriticModel(nn.Module):
         """(Re)build the [Cout, KH*KW*C] weight copies the NHWC layers of the fused encoder read.  Buffers keep their address
         (the captured rollout graph reads them); called by the trainer at the start of every rollout and lazily whenever a
         weight's version counter moved."""
+        with torch.no_grad():
+            # concatenated hidden heads [lin_policy ; lin_value]: fixed-address copies read by the captured rollout graph
+            w = torch.cat((self.lin_policy.weight, self.lin_value.weight), dim=0)
+            b = torch.cat((self.lin_policy.bias, self.lin_value.bias), dim=0)
+            if getattr(self, "_w_heads", None) is None or self._w_heads.device != w.device:
+                self._w_heads, self._b_heads = w.contiguous(), b.contiguous()
+                self._heads_lin = type("HeadsLinear", (), {})()
+                self._heads_lin.weight, self._heads_lin.bias = self._w_heads, self._b_heads
+            else:
+                self._w_heads.copy_(w)
+                self._b_heads.copy_(b)
         if not self.visual:
             return
         with torch.no_grad():
@@ -115,6 +126,11 @@ class ActorCriticModel(nn.Module):
     def forward_logits_cached(self, obs, kv_spec: WindowSpec):
         """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache."""
         h, memory = self.transformer.forward_cached(self._encode(obs), kv_spec)
+        if len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled():
+            # [lin_policy ; lin_value] as ONE GEMM (+ReLU epilogue), then both output heads in one small kernel
+            h2 = ops.linear_relu(self._heads_lin, h)
+            logits, value = ops.rollout_heads(h2, self.policy_branches[0], self.value)
+            return [logits], value, memory
         h_policy = ops.linear_relu(self.lin_policy, h)
         h_value = ops.linear_relu(self.lin_value, h)
         value = self.value(h_value).reshape(-1)

@@ -133,6 +133,10 @@ int etm_rollout_sample(const float *logits, const float *value, const float *uni
                        int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
 int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
                       void *stream);
+/* Output heads on the rollout path (model.py:108-110): h [W, 2*hid] = [relu(lin_policy) | relu(lin_value)] rows;
+ * logits [W,A] = h_pol Wp^T + bp, value [W] = h_val . wv + bv.  One launch instead of two small library GEMMs. */
+int etm_rollout_heads(const float *h, const float *wp, const float *bp, const float *wv, const float *bv, float *logits, float *value,
+                      int W, int A, int hid, void *stream);
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
  * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C];
