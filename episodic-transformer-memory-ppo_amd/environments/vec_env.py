@@ -73,7 +73,7 @@ class PipeVecEnv(_VecBase):
         for wk in self.workers:
             wk.child.send(("reset", None))
         for w, wk in enumerate(self.workers):
-            out[w] = wk.child.recv()
+            out[w] = self._recv(wk)
         return out
 
     def step(self, actions, out=None):
@@ -85,13 +85,20 @@ class PipeVecEnv(_VecBase):
         dones = np.zeros(self.num_envs, dtype=bool)
         infos = [None] * self.num_envs
         for w, wk in enumerate(self.workers):
-            obs, rewards[w], dones[w], info = wk.child.recv()
+            obs, rewards[w], dones[w], info = self._recv(wk)
             if info:
                 infos[w] = info
                 wk.child.send(("reset", None))
-                obs = wk.child.recv()
+                obs = self._recv(wk)
             out[w] = obs
         return out, rewards, dones, infos
+
+    @staticmethod
+    def _recv(wk):
+        msg = wk.child.recv()
+        if isinstance(msg, Exception):
+            raise msg
+        return msg
 
     def close(self):
         for wk in self.workers:

@@ -141,3 +141,31 @@ def test_kernel_shape_validation_is_early_and_loud():
     for bad in (dict(ok, embed_dim=100, num_heads=4), dict(ok, num_heads=8), dict(ok, memory_length=129), dict(ok, embed_dim=2048)):
         with pytest.raises(ValueError):
             check_kernel_shapes(bad)
+
+
+def test_pipe_worker_protocol_and_vec_env():
+    """Upstream pipe protocol (cmd, data) through real subprocesses, batched by PipeVecEnv; env errors reach the parent."""
+    from environments.vec_env import PipeVecEnv, SerialVecEnv
+    from utils import create_env
+    from worker import Worker, WorkerException
+    cfg = {"type": "Synthetic", "obs_shape": [5], "num_actions": 2, "max_episode_steps": 6, "seed": 3, "p_done": 0.3, "pool": 4}
+    w = Worker(cfg, worker_id=1)
+    w.child.send(("reset", None))
+    first = w.child.recv()
+    assert first.shape == (5,)
+    w.child.send(("step", [0]))
+    obs, r, d, info = w.child.recv()
+    assert obs.shape == (5,) and isinstance(d, bool)
+    w.child.send(("bogus", None))
+    assert isinstance(w.child.recv(), WorkerException)
+    w.child.send(("close", None))
+    w.child.recv()
+    pipe_env = PipeVecEnv(cfg, 3)
+    serial = SerialVecEnv([create_env(cfg, worker_id=i) for i in range(3)])
+    a, b = pipe_env.reset(), serial.reset()
+    assert np.array_equal(a, b)
+    for _ in range(20):
+        oa, ra, da, ia = pipe_env.step(np.zeros(3, dtype=np.int64))
+        ob, rb, db, ib = serial.step(np.zeros(3, dtype=np.int64))
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db) and ia == ib
+    pipe_env.close()
