@@ -132,9 +132,16 @@ template <bool HAS_LN, bool HAS_POS>
 __global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * RB * (TM + TN)];
 
+  // XCD-aware work assignment: block b runs on XCD b % 8 (observed dispatch rule; used for speed only).  Logical work
+  // ids are handed out so that each XCD owns a CONTIGUOUS range of (split, tile) pairs in split-major order: the 18 tile
+  // workgroups that read the same window rows then share one L2 (at most two) instead of being spread over all eight.
   const int tiles = p.tiles_m * p.tiles_n;
-  const int split = blockIdx.x / tiles;
-  const int tile = blockIdx.x - split * tiles;
+  const int nwg = (int)gridDim.x;
+  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;                       // bijective for any grid size
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+  const int split = logical / tiles;
+  const int tile = logical - split * tiles;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int o0 = tm * TM, i0 = tn * TN;
   const int c_begin = split * p.chunks_per_split;
