@@ -498,8 +498,8 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   const int hd = D / H;
   if (D % 32 != 0 || hd % 32 != 0 || hd > 128 || L > 128 || D > 1024) return ETM_EUNSUPPORTED;
   if (workspace_bytes < etm_mha_bwd_workspace_bytes(N, L, D)) return ETM_EWORKSPACE;
-  if ((size_t)(2 * H * D + 8 * D) * sizeof(float) > 64 * 1024 || (size_t)(D + 3 * H * L) * sizeof(float) > 64 * 1024)
-    return ETM_EUNSUPPORTED;
+  if ((size_t)(2 * H * D + 8 * D) * sizeof(float) > 160 * 1024 || (size_t)(D + 3 * H * L) * sizeof(float) > 160 * 1024)
+    return ETM_EUNSUPPORTED;  // more than one CU's LDS
   hipStream_t st = (hipStream_t)stream;
   const DwPlan pl = plan_dw(N, L, D);
 
@@ -519,6 +519,8 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   int rc;
   // B1
   const size_t sm1 = (size_t)(D + 3 * H * L) * sizeof(float);
+  if (sm1 > 48 * 1024)
+    (void)hipFuncSetAttribute((const void *)bwd_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
   {
     EtmProfScope prof(ETM_K_BWD_SCORES, st);
     hipLaunchKernelGGL(bwd_scores_kernel, dim3(N), dim3(256), sm1, st, p);
@@ -550,6 +552,10 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
     }
     if ((rc = etm_launch_status())) return rc;
     const size_t sm3 = (size_t)(2 * H * D + 8 * D) * sizeof(float);
+    if (sm3 > 48 * 1024) {
+      (void)hipFuncSetAttribute((const void *)bwd_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);
+      (void)hipFuncSetAttribute((const void *)bwd_dx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);
+    }
     {
       EtmProfScope prof(ETM_K_BWD_DX, st);
       if (has_ln) hipLaunchKernelGGL((bwd_dx_kernel<true>), dim3(N), dim3(256), sm3, st, p);

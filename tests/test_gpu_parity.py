@@ -159,7 +159,8 @@ def test_actor_critic_vs_reference(golden_dir):
 # ------------------------------------------------------------------ kernel #1 vs the oracle: banked gather, LN, positions, Q5
 @pytest.mark.parametrize("D,H,L,N,ln,pos", [(384, 4, 64, 37, False, True), (384, 4, 128, 9, True, True), (128, 1, 32, 50, True, False),
                                             (64, 1, 32, 7, True, True), (256, 4, 96, 6, False, False), (384, 4, 118, 5, True, True),
-                                            (96, 3, 5, 11, False, True)])
+                                            (96, 3, 5, 11, False, True), (1024, 8, 16, 3, True, True), (32, 1, 1, 1, False, False),
+                                            (128, 1, 128, 2, True, True), (64, 2, 33, 130, False, True), (512, 4, 64, 1, True, False)])
 def test_mha_banked_vs_oracle(D, H, L, N, ln, pos):
     from etm import ops
     from oracle import ref_model as rm
