@@ -157,3 +157,53 @@ extern "C" int etm_add_layernorm(const float *a, const float *b, const float *ga
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, a, b, gamma, beta, eps, out, N, D);
   return etm_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// GTrXL GRU gate on the rollout path (/root/reference transformer.py:287-298), elementwise parts.  With the three y-maps
+// and the two x-maps concatenated into two library GEMMs (a = y [Wr;Wz;Wg]^T  [N,3D],  b = x [Ur;Uz]^T  [N,2D]):
+//   gate_rz : r = sigmoid(a_r + b_r);  z = sigmoid(a_z + b_z - bg);  rx = r * x          -> rx, z
+//   (library GEMM  c = rx Ug^T)
+//   gate_out: h = tanh(a_g + c);  out = (1 - z) * x + z * h
+// 5 launches per gate instead of ~14.
+namespace {
+__global__ __launch_bounds__(256) void gru_gate_rz_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ bg,
+                                                          const float *__restrict__ x, float *__restrict__ rx, float *__restrict__ z, int N, int D) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)N * D) return;
+  const int n = (int)(i / D), d = (int)(i - (long long)n * D);
+  const float ar = a[(long long)n * 3 * D + d], az = a[(long long)n * 3 * D + D + d];
+  const float br = b[(long long)n * 2 * D + d], bz = b[(long long)n * 2 * D + D + d];
+  const float r = 1.0f / (1.0f + expf(-(ar + br)));
+  z[i] = 1.0f / (1.0f + expf(-(az + bz - bg[d])));
+  rx[i] = r * x[i];
+}
+
+__global__ __launch_bounds__(256) void gru_gate_out_kernel(const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ z,
+                                                           const float *__restrict__ x, float *__restrict__ out, int N, int D) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)N * D) return;
+  const int n = (int)(i / D), d = (int)(i - (long long)n * D);
+  const float h = tanhf(a[(long long)n * 3 * D + 2 * D + d] + c[i]);
+  const float zz = z[i];
+  out[i] = (1.0f - zz) * x[i] + zz * h;
+}
+}  // namespace
+
+extern "C" int etm_gru_gate_rz(const float *a, const float *b, const float *bg, const float *x, float *rx, float *z, int N, int D,
+                               void *stream) {
+  (void)hipGetLastError();
+  if (!a || !b || !bg || !x || !rx || !z || N <= 0 || D <= 0) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_GRU_GATE, st);
+  hipLaunchKernelGGL(gru_gate_rz_kernel, dim3((unsigned)(((long long)N * D + 255) / 256)), dim3(256), 0, st, a, b, bg, x, rx, z, N, D);
+  return etm_launch_status();
+}
+
+extern "C" int etm_gru_gate_out(const float *a, const float *c, const float *z, const float *x, float *out, int N, int D, void *stream) {
+  (void)hipGetLastError();
+  if (!a || !c || !z || !x || !out || N <= 0 || D <= 0) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_GRU_GATE, st);
+  hipLaunchKernelGGL(gru_gate_out_kernel, dim3((unsigned)(((long long)N * D + 255) / 256)), dim3(256), 0, st, a, c, z, x, out, N, D);
+  return etm_launch_status();
+}

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -32,6 +32,8 @@ SIGNATURES = {
     "etm_add_layernorm": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "etm_conv_relu": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "etm_gru_gate_rz": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "etm_gru_gate_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),
     "etm_adv_stats": (_I, [_P, _I, _P, _P]),
     "etm_ppo_loss_workspace_bytes": (_L, [_I]),

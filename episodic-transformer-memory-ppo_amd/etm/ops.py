@@ -248,6 +248,23 @@ def rollout_heads(h2, branch, value_head):
     return logits, value
 
 
+def gru_gate(x, y, wy, ux, ug, bg):
+    """GTrXL gate on the no-grad path: wy = [Wr;Wz;Wg] ([3D,D]), ux = [Ur;Uz] ([2D,D]), ug [D,D], bg [D].
+    Three library GEMMs + two elementwise kernels."""
+    lib = _lib.load()
+    x, y = _f32c(x, "x"), _f32c(y, "y")
+    N, D = x.shape
+    a = torch.nn.functional.linear(y, wy)
+    b = torch.nn.functional.linear(x, ux)
+    rx = torch.empty_like(x)
+    z = torch.empty_like(x)
+    _lib.check(lib.etm_gru_gate_rz(_ptr(a), _ptr(b), _ptr(bg), _ptr(x), _ptr(rx), _ptr(z), N, D, _stream()), "etm_gru_gate_rz")
+    c = torch.nn.functional.linear(rx, ug)
+    out = torch.empty_like(x)
+    _lib.check(lib.etm_gru_gate_out(_ptr(a), _ptr(c), _ptr(z), _ptr(x), _ptr(out), N, D, _stream()), "etm_gru_gate_out")
+    return out
+
+
 def add_layernorm(a, b, norm):
     """LayerNorm(a + b) with ``norm``'s affine parameters; forward only (rollout path)."""
     lib = _lib.load()

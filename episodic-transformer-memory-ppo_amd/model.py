@@ -65,6 +65,9 @@ class ActorCriticModel(nn.Module):
         """(Re)build the [Cout, KH*KW*C] weight copies the NHWC layers of the fused encoder read.  Buffers keep their address
         (the captured rollout graph reads them); called by the trainer at the start of every rollout and lazily whenever a
         weight's version counter moved."""
+        for mod in self.modules():
+            if mod is not self and hasattr(mod, "refresh_rollout_weights"):
+                mod.refresh_rollout_weights()
         with torch.no_grad():
             # concatenated hidden heads [lin_policy ; lin_value]: fixed-address copies read by the captured rollout graph
             w = torch.cat((self.lin_policy.weight, self.lin_value.weight), dim=0)

@@ -70,7 +70,26 @@ class GRUGate(nn.Module):
         for name in ("Wr", "Ur", "Wz", "Uz", "Wg", "Ug"):
             nn.init.xavier_uniform_(getattr(self, name).weight)
 
+    def refresh_rollout_weights(self):
+        """Concatenated gate maps for the fused no-grad path; buffers keep their address (captured rollout graph)."""
+        with torch.no_grad():
+            wy = torch.cat((self.Wr.weight, self.Wz.weight, self.Wg.weight), dim=0)
+            ux = torch.cat((self.Ur.weight, self.Uz.weight), dim=0)
+            if getattr(self, "_wy", None) is None or self._wy.device != wy.device:
+                self._wy, self._ux = wy.contiguous(), ux.contiguous()
+            else:
+                self._wy.copy_(wy)
+                self._ux.copy_(ux)
+            self._wver = self._versions()
+
+    def _versions(self):
+        return tuple(m.weight._version for m in (self.Wr, self.Wz, self.Wg, self.Ur, self.Uz))
+
     def forward(self, x, y):
+        if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and getattr(self, "_wy", None) is not None:
+            if not torch.cuda.is_current_stream_capturing() and self._wver != self._versions():
+                self.refresh_rollout_weights()       # weights moved since the copies were made (optimizer step, load)
+            return ops.gru_gate(x, y, self._wy, self._ux, self.Ug.weight, self.bg)
         r = torch.sigmoid(self.Wr(y) + self.Ur(x))
         z = torch.sigmoid(self.Wz(y) + self.Uz(x) - self.bg)
         cand = torch.tanh(self.Wg(y) + self.Ug(r * x))

@@ -133,6 +133,12 @@ int etm_rollout_sample(const float *logits, const float *value, const float *uni
                        int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
 int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
                       void *stream);
+/* Elementwise parts of the GTrXL GRU gate on the rollout path (transformer.py:287-298), around concatenated library GEMMs
+ * a = y [Wr;Wz;Wg]^T [N,3D], b = x [Ur;Uz]^T [N,2D], c = rx Ug^T [N,D]:
+ *   etm_gru_gate_rz : r = sigmoid(a_r + b_r); z = sigmoid(a_z + b_z - bg); rx = r * x        (writes rx, z)
+ *   etm_gru_gate_out: out = (1 - z) * x + z * tanh(a_g + c) */
+int etm_gru_gate_rz(const float *a, const float *b, const float *bg, const float *x, float *rx, float *z, int N, int D, void *stream);
+int etm_gru_gate_out(const float *a, const float *c, const float *z, const float *x, float *out, int N, int D, void *stream);
 /* Output heads on the rollout path (model.py:108-110): h [W, 2*hid] = [relu(lin_policy) | relu(lin_value)] rows;
  * logits [W,A] = h_pol Wp^T + bp, value [W] = h_val . wv + bv.  One launch instead of two small library GEMMs. */
 int etm_rollout_heads(const float *h, const float *wp, const float *bp, const float *wv, const float *bv, float *logits, float *value,

@@ -597,3 +597,26 @@ def test_fused_rollout_encoder_vs_library_convs():
             want2 = m._encode(obs)
             close(got2, want2.cpu().numpy(), atol=2e-5, rtol=1e-4, what=f"encoder after update {shape}")
         assert not torch.allclose(got, got2)
+
+
+def test_fused_gru_gate_vs_module_ops():
+    """Rollout GRU gate (concatenated GEMMs + two elementwise kernels) == the six-map formulation, also after a weight change."""
+    from transformer import GRUGate
+    dev = _dev()
+    torch.manual_seed(9)
+    for D, N, bias in ((384, 32, 0.0), (128, 5, 2.0), (64, 1, 0.0)):
+        gate = GRUGate(D, bias).to(dev)
+        x = torch.randn((N, D), device=dev)
+        y = torch.randn((N, D), device=dev)
+        with torch.no_grad():
+            want = gate(x, y)                      # copies not built yet -> reference formulation
+            gate.refresh_rollout_weights()
+            got = gate(x, y)
+            close(got, want.cpu().numpy(), atol=2e-6, rtol=1e-5, what=f"gate D={D}")
+            gate.Wz.weight.mul_(0.5)
+            gate.bg.add_(0.3)
+            got2 = gate(x, y)                      # version tracking refreshes the concatenated copies
+            r = torch.sigmoid(gate.Wr(y) + gate.Ur(x))
+            z = torch.sigmoid(gate.Wz(y) + gate.Uz(x) - gate.bg)
+            h = torch.tanh(gate.Wg(y) + gate.Ug(r * x))
+            close(got2, ((1 - z) * x + z * h).cpu().numpy(), atol=2e-6, rtol=1e-5, what=f"gate updated D={D}")

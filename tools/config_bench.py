@@ -1,0 +1,26 @@
+"""Time full PPO updates for any config of configs/ (whole-path env-steps/s, phases).  python tools/config_bench.py NAME [updates]"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
+import torch
+from yaml_parser import YamlParser
+from trainer import PPOTrainer
+name = sys.argv[1]
+n_upd = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", name + ".yaml")).get_config()
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+tr = PPOTrainer(cfg, run_id="cfgbench", device=dev, tensorboard=False)
+def upd(i):
+    lr, beta, clip = tr.schedules(i)
+    t0 = time.perf_counter(); tr._sample_training_data(); tr.buffer.prepare_batch_dict(); torch.cuda.synchronize()
+    t1 = time.perf_counter(); tr._train_epochs(lr, clip, beta); torch.cuda.synchronize()
+    return t1 - t0, time.perf_counter() - t1
+upd(0)
+r = t = 0.0
+for i in range(n_upd):
+    a, b = upd(1 + i); r += a; t += b
+steps = cfg["n_workers"] * cfg["worker_steps"]
+print(f"{name}: {steps * n_upd / (r + t):.0f} env-steps/s  (rollout {r / n_upd:.3f} s, train {t / n_upd:.3f} s per update of {steps} steps; "
+      f"D={cfg['transformer']['embed_dim']} L={cfg['transformer']['memory_length']} blocks={cfg['transformer']['num_blocks']} "
+      f"gtrxl={cfg['transformer']['gtrxl']} ln={cfg['transformer']['layer_norm']!r})")
