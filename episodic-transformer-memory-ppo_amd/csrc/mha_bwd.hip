@@ -325,9 +325,10 @@ __global__ __launch_bounds__(256) void bwd_dw_reduce_kernel(const float *partial
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// B3a: u[n,h,:] = Wk_h^T q[n,h,:], w[n,h,:] = Wv_h^T dctx[n,h,:]   (8 samples per workgroup share the weight reads)
+// B3a: u[n,h,:] = Wk_h^T q[n,h,:], w[n,h,:] = Wv_h^T dctx[n,h,:]   (16 samples per workgroup share the weight reads)
+constexpr int UW_SB = 16;
 __global__ __launch_bounds__(256) void bwd_uw_kernel(const BwdParams p) {
-  constexpr int SB = 8;
+  constexpr int SB = UW_SB;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int D = p.D, H = p.H, hd = p.hd, N = p.N;
   const int which = blockIdx.y;  // 0: u from (q, Wk); 1: w from (dctx, Wv)
@@ -346,11 +347,18 @@ __global__ __launch_bounds__(256) void bwd_uw_kernel(const BwdParams p) {
       float acc[SB];
 #pragma unroll
       for (int s = 0; s < SB; ++s) acc[s] = 0.f;
-      for (int c = 0; c < hd; ++c) {
-        const int orow = h * hd + c;
-        const float wv = W[(long long)orow * D + i];
+      // hd is a multiple of 32: 8 independent weight loads in flight per pass (the loop is otherwise one L2 round trip
+      // per iteration)
+      for (int c0 = 0; c0 < hd; c0 += 8) {
+        float wv[8];
 #pragma unroll
-        for (int s = 0; s < SB; ++s) acc[s] += vs[s * D + orow] * wv;
+        for (int u = 0; u < 8; ++u) wv[u] = W[(long long)(h * hd + c0 + u) * D + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int orow = h * hd + c0 + u;
+#pragma unroll
+          for (int s = 0; s < SB; ++s) acc[s] += vs[s * D + orow] * wv[u];
+        }
       }
 #pragma unroll
       for (int s = 0; s < SB; ++s)
@@ -368,9 +376,15 @@ __global__ __launch_bounds__(256) void bwd_dx_kernel(const BwdParams p) {
   float *u_s = sm;               // [H][D]
   float *w_s = u_s + H * D;      // [H][D]
   float *red = w_s + H * D;      // [4][2][D]  per-wave partial d gain / d bias
+  float *de_s = red + 8 * D;     // [H][L]  dE of this sample
+  float *at_s = de_s + H * L;    // [H][L]  attention of this sample
   for (int i = tid; i < H * D; i += 256) {
     u_s[i] = p.uw[(long long)n * H * D + i];
     w_s[i] = p.uw[(long long)N * H * D + (long long)n * H * D + i];
+  }
+  for (int i = tid; i < H * L; i += 256) {
+    de_s[i] = p.d_e[(long long)n * H * L + i];
+    at_s[i] = p.att[(long long)n * H * L + i];
   }
   __syncthreads();
   float dg[16], db[16];
@@ -395,8 +409,7 @@ __global__ __launch_bounds__(256) void bwd_dx_kernel(const BwdParams p) {
       xh[j] = 0.f;
       if (c < D) {
         float acc = 0.f;
-        for (int h = 0; h < H; ++h)
-          acc += p.d_e[((long long)n * H + h) * L + l] * u_s[h * D + c] + p.att[((long long)n * H + h) * L + l] * w_s[h * D + c];
+        for (int h = 0; h < H; ++h) acc += de_s[h * L + l] * u_s[h * D + c] + at_s[h * L + l] * w_s[h * D + c];
         dy[j] = acc;
         if (HAS_LN) {
           float x = xp[c];
@@ -498,7 +511,7 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   const int hd = D / H;
   if (D % 32 != 0 || hd % 32 != 0 || hd > 128 || L > 128 || D > 1024) return ETM_EUNSUPPORTED;
   if (workspace_bytes < etm_mha_bwd_workspace_bytes(N, L, D)) return ETM_EWORKSPACE;
-  if ((size_t)(2 * H * D + 8 * D) * sizeof(float) > 160 * 1024 || (size_t)(D + 3 * H * L) * sizeof(float) > 160 * 1024)
+  if ((size_t)(2 * H * D + 8 * D + 2 * H * L) * sizeof(float) > 160 * 1024 || (size_t)(D + 3 * H * L) * sizeof(float) > 160 * 1024)
     return ETM_EUNSUPPORTED;  // more than one CU's LDS
   hipStream_t st = (hipStream_t)stream;
   const DwPlan pl = plan_dw(N, L, D);
@@ -548,10 +561,10 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   if (d_ln_g || d_pos) {
     {
       EtmProfScope prof(ETM_K_BWD_UW, st);
-      hipLaunchKernelGGL(bwd_uw_kernel, dim3((unsigned)((N + 7) / 8), 2), dim3(256), (size_t)8 * D * sizeof(float), st, p);
+      hipLaunchKernelGGL(bwd_uw_kernel, dim3((unsigned)((N + UW_SB - 1) / UW_SB), 2), dim3(256), (size_t)UW_SB * D * sizeof(float), st, p);
     }
     if ((rc = etm_launch_status())) return rc;
-    const size_t sm3 = (size_t)(2 * H * D + 8 * D) * sizeof(float);
+    const size_t sm3 = (size_t)(2 * H * D + 8 * D + 2 * H * L) * sizeof(float);
     if (sm3 > 48 * 1024) {
       (void)hipFuncSetAttribute((const void *)bwd_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);
       (void)hipFuncSetAttribute((const void *)bwd_dx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);

@@ -8,24 +8,6 @@ import torch
 from . import lib as _lib
 
 _workspaces = {}
-_timing_hook = None  # set by bench.py: callable(name, meta) -> context manager
-
-
-def set_timing_hook(hook):
-    global _timing_hook
-    _timing_hook = hook
-
-
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-
-def _timed(name, **meta):
-    return _timing_hook(name, meta) if _timing_hook is not None else _NullCtx()
 
 
 def _stream():
@@ -130,10 +112,9 @@ class _MhaFn(torch.autograd.Function):
             v_save = torch.empty((N, L, D), dtype=torch.float32, device=dev)
         ln_stats = torch.empty((N, L, 2), dtype=torch.float32, device=dev) if ln_g is not None else None
         pidx = spec.pidx if pos is not None else None
-        with _timed("mha_fwd", N=N, L=L, D=D, H=H, train=need_grad):
-            rc = lib.etm_mha_fwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
-                                 _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), float(ln_eps), _ptr(q), _ptr(wk), _ptr(wv),
-                                 _ptr(out), _ptr(att), _ptr(k_save), _ptr(v_save), _ptr(ln_stats), N, L, D, H, _stream())
+        rc = lib.etm_mha_fwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                             _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), float(ln_eps), _ptr(q), _ptr(wk), _ptr(wv),
+                             _ptr(out), _ptr(att), _ptr(k_save), _ptr(v_save), _ptr(ln_stats), N, L, D, H, _stream())
         _lib.check(rc, "etm_mha_fwd")
         if need_grad:
             ctx.spec, ctx.block, ctx.H = spec, block, H
@@ -176,11 +157,10 @@ class _MhaFn(torch.autograd.Function):
         nbytes = lib.etm_mha_bwd_workspace_bytes(N, L, D)
         ws = workspace(nbytes, dev, "mha_bwd")
         pidx = spec.pidx if pos is not None else None
-        with _timed("mha_bwd", N=N, L=L, D=D, H=H):
-            rc = lib.etm_mha_bwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
-                                 _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), _ptr(q), _ptr(wk), _ptr(wv), _ptr(att),
-                                 _ptr(k_save), _ptr(v_save), _ptr(ln_stats), _ptr(d_out), _ptr(d_q), _ptr(d_e), _ptr(d_wk), _ptr(d_wv),
-                                 _ptr(d_ln_g), _ptr(d_ln_b), _ptr(d_pos), _ptr(ws), nbytes, N, L, D, H, _stream())
+        rc = lib.etm_mha_bwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                             _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), _ptr(q), _ptr(wk), _ptr(wv), _ptr(att),
+                             _ptr(k_save), _ptr(v_save), _ptr(ln_stats), _ptr(d_out), _ptr(d_q), _ptr(d_e), _ptr(d_wk), _ptr(d_wv),
+                             _ptr(d_ln_g), _ptr(d_ln_b), _ptr(d_pos), _ptr(ws), nbytes, N, L, D, H, _stream())
         _lib.check(rc, "etm_mha_bwd")
         return d_q, d_wk, d_wv, d_ln_g, d_ln_b, d_pos, None, None, None, None
 
@@ -329,8 +309,7 @@ def gae(rewards, dones, values, last_value, gamma, lamda, out=None):
         raise TypeError("advantages output must be contiguous float32")
     g32 = float(torch.tensor(float(gamma), dtype=torch.float32))
     gl32 = float(torch.tensor(float(gamma) * float(lamda), dtype=torch.float32))  # python-float product, then fp32 (buffer.py:111)
-    with _timed("gae", W=W, S=S):
-        rc = lib.etm_gae(_ptr(rewards), _ptr(d), _ptr(values), _ptr(last_value), g32, gl32, _ptr(out), W, S, _stream())
+    rc = lib.etm_gae(_ptr(rewards), _ptr(d), _ptr(values), _ptr(last_value), g32, gl32, _ptr(out), W, S, _stream())
     _lib.check(rc, "etm_gae")
     return out
 
@@ -365,11 +344,10 @@ class _PpoLossFn(torch.autograd.Function):
         d_value = torch.empty_like(value)
         nbytes = lib.etm_ppo_loss_workspace_bytes(N)
         ws = workspace(nbytes, dev, "ppo")
-        with _timed("ppo_loss", N=N, A=A):
-            rc = lib.etm_ppo_loss(_ptr(logits), actions.data_ptr() + 8 * branch, B, old_logp.data_ptr() + 4 * branch, B, _ptr(adv),
-                                  _ptr(old_value), _ptr(value), _ptr(stats3), float(clip), float(vf_coef), float(beta),
-                                  1.0 / (N * n_branches), 1.0 / N, 1.0 / N, 1 if include_value else 0, _ptr(out8), _ptr(d_logits),
-                                  _ptr(d_value), _ptr(ws), nbytes, N, A, _stream())
+        rc = lib.etm_ppo_loss(_ptr(logits), actions.data_ptr() + 8 * branch, B, old_logp.data_ptr() + 4 * branch, B, _ptr(adv),
+                              _ptr(old_value), _ptr(value), _ptr(stats3), float(clip), float(vf_coef), float(beta),
+                              1.0 / (N * n_branches), 1.0 / N, 1.0 / N, 1 if include_value else 0, _ptr(out8), _ptr(d_logits),
+                              _ptr(d_value), _ptr(ws), nbytes, N, A, _stream())
         _lib.check(rc, "etm_ppo_loss")
         ctx.save_for_backward(d_logits, d_value)
         ctx.include_value = include_value
