@@ -620,3 +620,28 @@ def test_fused_gru_gate_vs_module_ops():
             z = torch.sigmoid(gate.Wz(y) + gate.Uz(x) - gate.bg)
             h = torch.tanh(gate.Wg(y) + gate.Ug(r * x))
             close(got2, ((1 - z) * x + z * h).cpu().numpy(), atol=2e-6, rtol=1e-5, what=f"gate updated D={D}")
+
+
+def test_poc_memory_env_learns():
+    """BASELINE config (1) end to end on the MI355X path: PocMemoryEnv (goal cue visible only in the first two steps)
+    through subprocess workers; the policy must learn to use its episodic memory (success >= 0.9 within 30 updates)."""
+    from collections import deque
+    from yaml_parser import YamlParser
+    from trainer import PPOTrainer
+    dev = _dev()
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = YamlParser(os.path.join(here, "..", "episodic-transformer-memory-ppo_amd", "configs", "poc_memory_env.yaml")).get_config()
+    torch.manual_seed(0)
+    tr = PPOTrainer(cfg, run_id="poc", device=dev, tensorboard=False)
+    recent = deque(maxlen=100)
+    success = 0.0
+    for update in range(30):
+        lr, beta, clip = tr.schedules(update)
+        recent.extend(tr._sample_training_data())
+        tr.buffer.prepare_batch_dict()
+        tr._train_epochs(lr, clip, beta)
+        success = float(np.mean([i["success"] for i in recent]))
+        if update >= 10 and success >= 0.95:
+            break
+    tr.close()
+    assert success >= 0.9, success
