@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
         const long long o = ((long long)n_w * L + l) * D + head * HD + col;
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-          p.k_save[o + t * 32] = acc[t][r];
-          p.v_save[o + t * 32] = acc[HT + t][r];
+          // streamed out, not re-read before the backward pass: keep them from displacing window rows / weights in L2
+          __builtin_nontemporal_store(acc[t][r], p.k_save + o + t * 32);
+          __builtin_nontemporal_store(acc[HT + t][r], p.v_save + o + t * 32);
         }
       }
     }
