@@ -184,6 +184,10 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
       float4 bt[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) bt[t] = *reinterpret_cast<const float4 *>(&Ws[(t * 32 + col) * LDP + kk * 8 + half * 4]);
+#if defined(ETM_DIAG_SKIP_MFMA)   // diagnostic build only: everything but the matrix instructions (fragments kept alive)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][0] += a.x * bt[t].x + a.y * bt[t].y + a.z * bt[t].z + a.w * bt[t].w;
+#else
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bt[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bt[t].z, acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bt[t].w, acc[t], 0, 0, 0);
+#endif
     }
     __syncthreads();
   }
