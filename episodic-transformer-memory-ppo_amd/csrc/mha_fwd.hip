@@ -8,9 +8,10 @@
 //
 // Decomposition: one workgroup (4 waves, 256 threads) owns 128 window rows (= 128/Lp whole samples, Lp = L rounded
 // up to 32) and ONE head.  Wave w owns rows [32w, 32w+32) and all 2*hd output columns (K_h | V_h): 2*HT 32x32
-// accumulator tiles (HT = hd/32).  The reduction dimension D is streamed in chunks of BK = 32 through LDS (register
-// prefetch of the next chunk overlaps the MFMAs of the current one).  K and V never leave registers unless the
-// caller asks for them (training saves them for the backward pass).
+// accumulator tiles (HT = hd/32).  The reduction dimension D is walked in chunks of BK = 32 (register prefetch of the
+// next chunk overlaps the MFMAs of the current one): window rows go straight from global memory into the owning lane's
+// registers (they are never shared between lanes), the head's weight rows are shared by the four waves through LDS.
+// K and V never leave registers unless the caller asks for them (training saves them for the backward pass).
 //
 // Blocks of the same row tile (different heads) are placed on the same XCD (block b runs on XCD b % 8) so that the
 // window rows are fetched from HBM once and re-read from that XCD's L2.
@@ -84,9 +85,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
   constexpr int NT = 2 * HT;     // accumulator tiles per wave: K tiles [0,HT), V tiles [HT,2HT)
   constexpr int HD = 32 * HT;    // head dim
   constexpr int WROWS = 64 * HT; // weight rows staged per chunk (K_h rows then V_h rows)
-  __shared__ __attribute__((aligned(16))) float smem[(ROWS + WROWS) * LDP + 2 * ROWS + 4 * HD];
-  float *Xs = smem;
-  float *Ws = Xs + ROWS * LDP;
+  __shared__ __attribute__((aligned(16))) float smem[WROWS * LDP + 2 * ROWS + 4 * HD];
+  float *Ws = smem;
   float *e_s = Ws + WROWS * LDP;
   float *a_s = e_s + ROWS;
   float *c_s = a_s + ROWS;
@@ -102,50 +102,54 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
   const int wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int L = p.L, Lp = p.Lp, D = p.D, N = p.N;
 
-  // ---- per-thread staging descriptors: thread stages rows r0 + 32 i (i < 4), float4 column c4 of every chunk.
-  // Rows that do not exist (padding up to Lp, samples past N) read a valid dummy address and are zeroed when stored, so
-  // every load is unconditional: the compiler can keep the whole next chunk in flight under the MFMAs.
-  const int c4 = tid & 7, r0 = tid >> 3;
-  const float *xptr[4];
-  const float *pptr[4];
-  bool valid[4];
-  float mu[4], rs[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 32 * i;
-    const int s = r / Lp, l = r - s * Lp;
-    const int n = tile * p.spw + s;
-    valid[i] = (s < p.spw) && (n < N) && (l < L);
-    const long long row = valid[i] ? (long long)n * L + l : 0;
-    const long long e = p.ep ? p.ep[valid[i] ? n : 0] : (valid[i] ? n : 0);
-    xptr[i] = p.bank + e * p.ep_stride + p.win[row] * p.row_stride + c4 * 4;
-    pptr[i] = HAS_POS ? p.pos + p.pidx[row] * D + c4 * 4 : nullptr;
-    mu[i] = HAS_LN ? p.ln_stats[row * 2] : 0.f;
-    rs[i] = HAS_LN ? p.ln_stats[row * 2 + 1] : 0.f;
+  // ---- operands.  A (window rows): a window row is only ever used by ONE lane pair (lane l and l+32 of the wave that owns
+  // the row), so it is loaded straight from global memory into that lane's registers in fragment order -- an LDS round trip
+  // would be pure overhead.  B (the head's Wk / Wv rows) is shared by the four waves and goes through LDS.
+  // Rows that do not exist (padding up to Lp, samples past N) read a valid dummy address and are zeroed at first use, so
+  // every load is unconditional and the whole next chunk stays in flight under the MFMAs.
+  const int c4 = tid & 7, r0 = tid >> 3;          // weight staging role: float4 column c4 of weight rows r0 + 32 j
+  const int arow = wave * 32 + col;                 // this lane's window row inside the tile
+  const float *xptr;
+  const float *pptr = nullptr;
+  bool avalid;
+  float amu = 0.f, ars = 0.f;
+  {
+    const int s_ = arow / Lp, l_ = arow - s_ * Lp;
+    const int n_ = tile * p.spw + s_;
+    avalid = (s_ < p.spw) && (n_ < N) && (l_ < L);
+    const long long row = avalid ? (long long)n_ * L + l_ : 0;
+    const long long e = p.ep ? p.ep[avalid ? n_ : 0] : (avalid ? n_ : 0);
+    xptr = p.bank + e * p.ep_stride + p.win[row] * p.row_stride + half * 4;
+    if (HAS_POS) pptr = p.pos + p.pidx[row] * D + half * 4;
+    if (HAS_LN) {
+      amu = p.ln_stats[row * 2];
+      ars = p.ln_stats[row * 2 + 1];
+    }
   }
+  const float *lgp = HAS_LN ? p.ln_g + half * 4 : nullptr;
+  const float *lbp = HAS_LN ? p.ln_b + half * 4 : nullptr;
   // weight rows r0 + 32 j: [0, HD) are K_h rows of Wk, [HD, 2HD) V_h rows of Wv
   const float *wk_row = p.wk + (long long)(head * HD + r0) * D + c4 * 4;
   const float *wv_row = p.wv + (long long)(head * HD + r0) * D + c4 * 4;
   const long long wstep = (long long)32 * D;
 
-  float4 xr[4], pr[4], lg, lb;
+  f32x4 xa[4], pa[4], ga[4], ba[4];   // next chunk's A fragments (k = 8 kk + 4 half + 0..3), raw
   f32x4 wr[NT];
-  lg = lb = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #define ETM_ISSUE_LOADS(kb_)                                                                        \
   {                                                                                                 \
     const int k0_ = (kb_) * BK;                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
-      xr[i] = *reinterpret_cast<const float4 *>(xptr[i] + k0_);                                     \
-      if (HAS_POS) pr[i] = *reinterpret_cast<const float4 *>(pptr[i] + k0_);                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                              \
+      xa[kk] = *reinterpret_cast<const f32x4 *>(xptr + k0_ + kk * 8);                               \
+      if (HAS_POS) pa[kk] = *reinterpret_cast<const f32x4 *>(pptr + k0_ + kk * 8);                  \
+      if (HAS_LN) {                                                                                 \
+        ga[kk] = *reinterpret_cast<const f32x4 *>(lgp + k0_ + kk * 8);                              \
+        ba[kk] = *reinterpret_cast<const f32x4 *>(lbp + k0_ + kk * 8);                              \
+      }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int j = 0; j < HT; ++j) {                                                \
       wr[j] = *reinterpret_cast<const f32x4 *>(wk_row + j * wstep + k0_);                           \
       wr[HT + j] = *reinterpret_cast<const f32x4 *>(wv_row + j * wstep + k0_);                      \
-    }                                                                                               \
-    if (HAS_LN) {                                                                                   \
-      lg = *reinterpret_cast<const float4 *>(p.ln_g + k0_ + c4 * 4);                                \
-      lb = *reinterpret_cast<const float4 *>(p.ln_b + k0_ + c4 * 4);                                \
     }                                                                                               \
   }
 
@@ -158,44 +162,41 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
   const int nk = D / BK;
   ETM_ISSUE_LOADS(0)
   for (int kb = 0; kb < nk; ++kb) {
-    // registers -> LDS: positional add / LayerNorm / zeroing of non-existent rows happen here, at the first use
+    // finish this chunk's A fragments in registers (positional add / LayerNorm / zeroing of non-existent rows)
+    f32x4 af[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = xr[i];
-      if (HAS_POS) { v.x += pr[i].x; v.y += pr[i].y; v.z += pr[i].z; v.w += pr[i].w; }
-      if (HAS_LN) {
-        v.x = (v.x - mu[i]) * rs[i] * lg.x + lb.x;
-        v.y = (v.y - mu[i]) * rs[i] * lg.y + lb.y;
-        v.z = (v.z - mu[i]) * rs[i] * lg.z + lb.z;
-        v.w = (v.w - mu[i]) * rs[i] * lg.w + lb.w;
-      }
-      if (!valid[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4 *>(&Xs[(r0 + 32 * i) * LDP + c4 * 4]) = v;
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 v = xa[kk];
+      if (HAS_POS) v += pa[kk];
+      if (HAS_LN) v = (v - amu) * ars * ga[kk] + ba[kk];
+      if (!avalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      af[kk] = v;
     }
+    // weight chunk: registers -> LDS
 #pragma unroll
     for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4 *>(&Ws[(r0 + 32 * j) * LDP + c4 * 4]) = wr[j];
     __syncthreads();
-    if (kb + 1 < nk) ETM_ISSUE_LOADS(kb + 1)  // global loads stay in flight under the MFMAs below
+    ETM_ISSUE_LOADS(min(kb + 1, nk - 1))  // global loads stay in flight under the MFMAs below (last chunk re-fetched: harmless)
 
-    // lane supplies A[row = 32 wave + col][k] and B[k][col'] with k = 8 kk + 4 half + j (same pairing on both sides)
+    // lane supplies A[row][k] from its registers and B[k][col'] from LDS with k = 8 kk + 4 half + j (same pairing)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const float4 a = *reinterpret_cast<const float4 *>(&Xs[(wave * 32 + col) * LDP + kk * 8 + half * 4]);
+      const f32x4 a = af[kk];
       float4 bt[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) bt[t] = *reinterpret_cast<const float4 *>(&Ws[(t * 32 + col) * LDP + kk * 8 + half * 4]);
 #if defined(ETM_DIAG_SKIP_MFMA)   // diagnostic build only: everything but the matrix instructions (fragments kept alive)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][0] += a.x * bt[t].x + a.y * bt[t].y + a.z * bt[t].z + a.w * bt[t].w;
+      for (int t = 0; t < NT; ++t) acc[t][0] += a[0] * bt[t].x + a[1] * bt[t].y + a[2] * bt[t].z + a[3] * bt[t].w;
 #else
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bt[t].x, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bt[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bt[t].y, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bt[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bt[t].z, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bt[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bt[t].w, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bt[t].w, acc[t], 0, 0, 0);
 #endif
     }
     __syncthreads();
