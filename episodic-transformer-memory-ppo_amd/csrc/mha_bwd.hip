@@ -271,10 +271,14 @@ __global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
         nb1 = bp[(2 * s + 2) * TN + 32];
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the next fragments' LDS reads ahead of this step's MFMAs
+#if defined(ETM_DIAG_SKIP_MFMA)   // diagnostic build only: everything but the matrix instructions (fragments kept alive)
+      acc[0][0][0] += a0 * b0; acc[0][1][0] += a0 * b1; acc[1][0][0] += a1 * b0; acc[1][1][0] += a1 * b1;
+#else
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#endif
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     __syncthreads();
