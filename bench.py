@@ -12,7 +12,8 @@ environments; gradients are all-reduced with RCCL.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline     the dominant kernel's achieved rate from HIP events recorded around its launches inside the timed
-               region (libetm_hip.so's etm_profile_* facility), against the fp32 MFMA peak of gfx950;
+               region (libetm_hip.so's etm_profile_* facility): the folded window-attention pass against the HBM peak
+               (or, with --attention dense, the fp32-MFMA contraction against the fp32 MFMA peak of gfx950);
   cpu_baseline the CPU oracle (oracle/ref_algo.OracleTrainer, a validated restatement of the reference trainer)
                timed on this host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
 """
@@ -40,12 +41,17 @@ def load_config():
     return YamlParser(os.path.join(PKG, "configs", "synthetic_minigrid.yaml")).get_config()
 
 
-def kernel_flops(name, N, L, D, H):
-    """Algorithmic flops one launch of a kernel performs at the training shape (DESIGN.md section 'Kernels')."""
-    if name == "mha_fwd_kernel":      # K and V projections of the window + QK^T + att.V
-        return N * 2.0 * (2 * L * D * D + 2 * L * D)
-    if name == "bwd_dw_kernel":       # dWk and dWv: [2D, N*L] x [N*L, D]
-        return N * 2.0 * (2 * L * D * D)
+def kernel_work(name, N, L, D, H):
+    """Algorithmic work of one launch at the training shape (DESIGN.md section 'Kernels'): ("hbm", bytes) or ("mfma", flops)."""
+    if name in ("window_fwd_kernel", "window_bwd_kernel"):
+        # folded attention pass: one read of the gathered window (L*D*4 B per sample and block, SURVEY.md 8d) + the H folded
+        # vectors in and out + the attention weights (backward also re-reads them)
+        per_sample = 4.0 * (L * D + 2 * H * D + H * L * (2 if name.endswith("bwd_kernel") else 1))
+        return "hbm", N * per_sample
+    if name == "mha_fwd_kernel":      # dense variant: K and V projections of the window + QK^T + att.V
+        return "mfma", N * 2.0 * (2 * L * D * D + 2 * L * D)
+    if name == "bwd_dw_kernel":       # dense variant: dWk and dWv: [2D, N*L] x [N*L, D]
+        return "mfma", N * 2.0 * (2 * L * D * D)
     return None
 
 
@@ -99,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
+                    help="kernel family of the window attention (etm.ops.set_attention_impl); folded is the product default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +126,8 @@ def main():
     from etm.dist import DataParallel
     from trainer import PPOTrainer
     lib = etm_lib.load()
+    from etm import ops as etm_ops
+    etm_ops.set_attention_impl(args.attention)
 
     cfg = load_config()
     dp = DataParallel(device) if world > 1 else None
@@ -176,19 +186,27 @@ def main():
             if tag != 1:
                 continue
             entry = {"launches": cnt, "avg_ms": ms / cnt, "total_ms": ms}
-            fl = kernel_flops(name, N, L, D, H)
-            if fl:
-                entry["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
+            work = kernel_work(name, N, L, D, H)
+            if work:
+                entry["bound"] = work[0]
+                if work[0] == "mfma":
+                    entry["tflops"] = work[1] / (ms / cnt * 1e-3) / 1e12
+                else:
+                    entry["gbs"] = work[1] / (ms / cnt * 1e-3) / 1e9
             kernels[name] = entry
         roofline = None
-        cand = [k for k in ("mha_fwd_kernel", "bwd_dw_kernel") if k in kernels]
+        cand = [k for k in kernels if "bound" in kernels[k]]
         if cand:
             dom = max(cand, key=lambda k: kernels[k]["total_ms"])
-            ach = kernels[dom]["tflops"]
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom), "avg_launch_ms": kernels[dom]["avg_ms"],
-                        "flops_per_launch": kernel_flops(dom, N, L, D, H), "launches": kernels[dom]["launches"],
-                        "shape": {"N": N, "L": L, "D": D, "H": H}, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+            kind, work = kernel_work(dom, N, L, D, H)
+            if kind == "mfma":
+                ach, peak, unit, extra = kernels[dom]["tflops"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", {"flops_per_launch": work, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+            else:
+                ach, peak, unit, extra = kernels[dom]["gbs"], HBM_PEAK_GBS, "GB/s", {"bytes_per_launch": work, "dtype": "f32"}
+            roofline = {"kernel": dom, "bound": kind, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                        "traffic": pmc_traffic(dom), "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
+                        "shape": {"N": N, "L": L, "D": D, "H": H}}
+            roofline.update(extra)
         rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
         out = {
             "metric": "env-steps/sec (whole node) MinigridMemory 3x84x84",
@@ -206,7 +224,8 @@ def main():
             "config": {"workload": "BASELINE config (3)/(4): configs/synthetic_minigrid.yaml -- per GPU n_workers=32 x worker_steps=512 "
                                    "= 16384 env steps per update, 5 epochs x 8 minibatches of 2048, TrXL 3 blocks D=384 H=4 L=64, "
                                    "synthetic U[0,1) 3x84x84 observations, random-init weights",
-                       "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}"},
+                       "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
+                       "attention": args.attention},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline,
             "kernels_train": kernels,

@@ -62,8 +62,12 @@ static inline int etm_launch_status() { return (int)hipGetLastError(); }
 enum EtmKernelId {
   ETM_K_LN_STATS = 0, ETM_K_MHA_FWD, ETM_K_BWD_SCORES, ETM_K_BWD_DW, ETM_K_BWD_REDUCE, ETM_K_BWD_UW, ETM_K_BWD_DX,
   ETM_K_GAE, ETM_K_ADV_STATS, ETM_K_PPO_LOSS, ETM_K_PPO_FINAL, ETM_K_ATTN_CACHED, ETM_K_RESET_ROWS,
-  ETM_K_ROLLOUT_WINDOW, ETM_K_ROLLOUT_SAMPLE, ETM_K_ADD_LN, ETM_K_CONV_RELU, ETM_K_ROLLOUT_HEADS, ETM_K_GRU_GATE, ETM_K_COUNT
+  ETM_K_ROLLOUT_WINDOW, ETM_K_ROLLOUT_SAMPLE, ETM_K_ADD_LN, ETM_K_CONV_RELU, ETM_K_ROLLOUT_HEADS, ETM_K_GRU_GATE, ETM_K_WINDOW_FWD, ETM_K_WINDOW_BWD,
+  ETM_K_COUNT
 };
+// LayerNorm statistics of the gathered window rows (defined in mha_fwd.hip; shared by the dense and the folded attention).
+int etm_launch_ln_stats(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                        const int64_t *pidx, const float *pos, float eps, float *stats, int N, int L, int D, hipStream_t st);
 void etm_prof_begin(int kid, hipStream_t st);
 void etm_prof_end(int kid, hipStream_t st);
 struct EtmProfScope {

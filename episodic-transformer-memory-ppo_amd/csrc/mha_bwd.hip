@@ -632,3 +632,42 @@ extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_str
   }
   return ETM_OK;
 }
+
+// LayerNorm-gain / bias and learned-positional-table gradients of the FOLDED attention (window_attn.hip): the same dX pass as
+// step B3b above, fed with the folded vectors the host already holds -- uw[0] = u (q_h . Wk_h), uw[1] = gz (dctx_h . Wv_h),
+// both [N,H,D] -- and the dE / attention of etm_window_bwd.
+extern "C" int etm_window_dx(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                             const int64_t *pidx, const float *pos, const float *ln_g, const float *ln_b, const float *ln_stats,
+                             const float *att, const float *d_e, const float *uw, float *d_ln_g, float *d_ln_b, float *d_pos,
+                             int N, int L, int D, int H, void *stream) {
+  (void)hipGetLastError();
+  if (!bank || !win || !att || !d_e || !uw) return ETM_EINVAL;
+  if (N <= 0 || L <= 0 || D <= 0 || H <= 0 || D % H != 0) return ETM_EINVAL;
+  if ((pos != nullptr) != (pidx != nullptr)) return ETM_EINVAL;
+  if ((ln_g != nullptr) != (ln_b != nullptr)) return ETM_EINVAL;
+  if (ln_g && !ln_stats) return ETM_EINVAL;
+  if ((d_ln_g != nullptr) != (d_ln_b != nullptr)) return ETM_EINVAL;
+  if (d_ln_g && !ln_g) return ETM_EINVAL;
+  if (d_pos && !pos) return ETM_EINVAL;
+  if (!d_ln_g && !d_pos) return ETM_OK;
+  if (D % 32 != 0 || L > 128 || D > 1024) return ETM_EUNSUPPORTED;
+  const size_t sm3 = (size_t)(2 * H * D + 8 * D + 2 * H * L) * sizeof(float);
+  if (sm3 > 160 * 1024) return ETM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  BwdParams p{};
+  p.bank = bank; p.ep_stride = ep_stride; p.row_stride = row_stride;
+  p.ep = (const long long *)ep; p.win = (const long long *)win; p.pidx = (const long long *)pidx;
+  p.pos = pos; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_stats = ln_stats; p.att = att; p.d_e = const_cast<float *>(d_e);
+  p.uw = const_cast<float *>(uw); p.d_ln_g = d_ln_g; p.d_ln_b = d_ln_b; p.d_pos = d_pos;
+  p.N = N; p.L = L; p.D = D; p.H = H; p.hd = D / H;
+  if (sm3 > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void *)bwd_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);
+    (void)hipFuncSetAttribute((const void *)bwd_dx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);
+  }
+  {
+    EtmProfScope prof(ETM_K_BWD_DX, st);
+    if (ln_g) hipLaunchKernelGGL((bwd_dx_kernel<true>), dim3(N), dim3(256), sm3, st, p);
+    else hipLaunchKernelGGL((bwd_dx_kernel<false>), dim3(N), dim3(256), sm3, st, p);
+  }
+  return etm_launch_status();
+}

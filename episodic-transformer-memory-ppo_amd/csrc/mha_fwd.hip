@@ -349,6 +349,16 @@ int launch_fwd(const FwdParams &p, bool has_ln, bool has_pos, hipStream_t st) {
 
 }  // namespace
 
+int etm_launch_ln_stats(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                        const int64_t *pidx, const float *pos, float eps, float *stats, int N, int L, int D, hipStream_t st) {
+  const long long rows = (long long)N * L;
+  EtmProfScope prof(ETM_K_LN_STATS, st);
+  hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, bank, (long long)ep_stride,
+                     (long long)row_stride, (const long long *)ep, (const long long *)win, (const long long *)pidx, pos, eps, stats,
+                     N, L, D);
+  return etm_launch_status();
+}
+
 #if defined(ETM_DIAG_TRACE)
 extern "C" int etm_diag_fw_trace_read(void *dst, long long bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fw_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost);
@@ -371,14 +381,7 @@ extern "C" int etm_mha_fwd(const float *bank, int64_t ep_stride, int64_t row_str
   hipStream_t st = (hipStream_t)stream;
 
   if (ln_g) {
-    const long long rows = (long long)N * L;
-    {
-      EtmProfScope prof(ETM_K_LN_STATS, st);
-      hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, bank, (long long)ep_stride,
-                         (long long)row_stride, (const long long *)ep, (const long long *)win, (const long long *)pidx, pos, ln_eps,
-                         ln_stats, N, L, D);
-    }
-    int rc = etm_launch_status();
+    int rc = etm_launch_ln_stats(bank, ep_stride, row_stride, ep, win, pidx, pos, ln_eps, ln_stats, N, L, D, st);
     if (rc) return rc;
   }
 

@@ -1,0 +1,352 @@
+// Folded single-query window attention (kernel #1, HBM-bound form; DESIGN.md "Folded attention").
+//
+// The query of the episodic attention is ONE row per sample (transformer.py:31-86 with queries [N,1,D]).  For a single
+// query the key / value projections of the L window rows never have to be formed:
+//
+//   energy[n,h,l] = sum_c q[n,h,c] K[n,l,h,c]          with K = x Wk^T   (transformer.py:43-62)
+//                 = x[n,l,:] . u[n,h,:]                 with u[n,h,:] = q[n,h,:] . Wk_h        (a [hd] x [hd,D] product)
+//   ctx[n,h,:]    = sum_l att[n,h,l] V[n,l,h,:]         with V = x Wv^T   (transformer.py:72-75)
+//                 = z[n,h,:] . Wv_h^T                   with z[n,h,:] = sum_l att[n,h,l] x[n,l,:]
+//
+// so the per-sample work is two passes over the gathered window rows -- a dot product of every row with H vectors and a
+// weighted sum of the rows with H weight vectors -- plus two small dense products per head that the host runs as library
+// GEMMs.  Executed flops drop from 2(2 L D^2) to 2(2 H L D + 2 D^2) per sample and the op becomes bound by the one read
+// of the window (L D 4 bytes per sample and block; SURVEY.md section 8d names this variant and its roofline).  The same
+// pass serves the backward: d att = x . gz (gz = dctx_h . Wv_h), softmax backward, du = sum_l dE x.  Only the summation
+// order differs from the reference (tolerances in tests/test_gpu_parity.py).
+//
+// One workgroup per sample.  Every wave owns RW window rows and keeps them in registers between the two passes (a row is
+// spread over the 64 lanes, float2 per lane per 128 columns), so the window is read from memory exactly once.
+#include "etm_common.h"
+
+#include <math.h>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinParams {
+  const float *bank;
+  long long ep_stride, row_stride;
+  const long long *ep, *win, *pidx;
+  const unsigned char *mask;
+  const float *pos, *ln_g, *ln_b, *ln_stats;
+  const float *vec;      // u (forward) or gz (backward): element (h, n, c) at vec[h * vec_hs + n * vec_ns + c]
+  const float *att_in;   // backward: attention saved by the forward [N,H,L]
+  float *att_out;        // forward: [N,H,L]
+  float *d_e;            // backward: [N,H,L]
+  float *out;            // z (forward) or du (backward), same addressing as vec
+  long long vec_hs, vec_ns, out_hs, out_ns;
+  int N, L, D, H, bwd;
+  float sqrt_d;
+};
+
+// Sums NV per-lane values across the 64 lanes of a wave with NV + log-many shuffles instead of 6 NV: at every step half
+// of the values travel to the partner lane.  On return v[0] of lane l holds the total of value  l >> (6 - log2 NV).
+template <int NV, int OFF>
+struct TransposeReduce {
+  static __device__ __forceinline__ void run(float *v, int lane) {
+    if constexpr (OFF >= 1) {
+      if constexpr (NV > 1) {
+        constexpr int HALF = NV / 2;
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) {
+          const float send = up ? v[k] : v[k + HALF];
+          const float keep = up ? v[k + HALF] : v[k];
+          v[k] = keep + __shfl_xor(send, OFF, 64);
+        }
+        TransposeReduce<HALF, OFF / 2>::run(v, lane);
+      } else {
+        v[0] += __shfl_xor(v[0], OFF, 64);
+        TransposeReduce<1, OFF / 2>::run(v, lane);
+      }
+    }
+  }
+};
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+constexpr int HG = 4;  // heads handled per pass over the register-resident rows
+
+template <int NJ, int RW, int NW, bool RESIDENT>
+__global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int LP = NW * RW;     // padded window length
+  constexpr int DP = NJ * 128;    // padded feature width
+  constexpr int NV = RW * HG;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L, D = p.D, H = p.H;
+  float *a_s = sm;              // [H][LP]   logits, then attention (forward) / dE (backward)
+  float *zs = sm + H * LP;      // [NW][HG][DP] per-wave partial weighted sums
+
+  const bool has_pos = p.pos != nullptr, has_ln = p.ln_g != nullptr;
+  const long long e = p.ep ? p.ep[n] : n;
+  const float *bank_e = p.bank + e * p.ep_stride;
+
+  // this lane's columns: c = 128 j + 2 lane (D is a multiple of 32, so c < D implies c + 1 < D)
+  int cc[NJ];
+  bool cv[NJ];
+  f32x2 lg[NJ], lb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = j * 128 + 2 * lane;
+    cv[j] = c < D;
+    cc[j] = cv[j] ? c : 0;
+    lg[j] = lb[j] = f32x2{0.f, 0.f};
+    if (has_ln) {
+      lg[j] = *reinterpret_cast<const f32x2 *>(p.ln_g + cc[j]);
+      lb[j] = *reinterpret_cast<const f32x2 *>(p.ln_b + cc[j]);
+    }
+  }
+
+  // Window row i of this wave (l = wave RW + i; rows past L read row L-1 and get zero weight), normalised as the
+  // reference does: (+ positional row, transformer.py:237-239) (LayerNorm of the block, transformer.py:137-141).
+#define ETM_LOAD_ROW(i_, dst_)                                                                        \
+  {                                                                                                   \
+    const int l_ = wave * RW + (i_);                                                                  \
+    const long long row_ = (long long)n * L + (l_ < L ? l_ : L - 1);                                  \
+    const float *xp_ = bank_e + p.win[row_] * p.row_stride;                                           \
+    const float *pp_ = has_pos ? p.pos + p.pidx[row_] * D : nullptr;                                  \
+    float mu_ = 0.f, rs_ = 1.f;                                                                       \
+    if (has_ln) { mu_ = p.ln_stats[row_ * 2]; rs_ = p.ln_stats[row_ * 2 + 1]; }                       \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                  \
+      f32x2 v_ = *reinterpret_cast<const f32x2 *>(xp_ + cc[j]);                                       \
+      if (has_pos) v_ += *reinterpret_cast<const f32x2 *>(pp_ + cc[j]);                               \
+      if (has_ln) v_ = (v_ - mu_) * rs_ * lg[j] + lb[j];                                              \
+      if (!cv[j]) v_ = f32x2{0.f, 0.f};                                                               \
+      dst_[j] = v_;                                                                                   \
+    }                                                                                                 \
+  }
+
+  f32x2 x[RESIDENT ? RW : 1][NJ];
+  if (RESIDENT) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
+  }
+
+  // ---- pass 1: logits[h][l] = x[l] . vec[h]
+  for (int h0 = 0; h0 < H; h0 += HG) {
+    f32x2 uv[HG][NJ];
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        uv[hh][j] = f32x2{0.f, 0.f};
+        if (h0 + hh < H && cv[j]) uv[hh][j] = *reinterpret_cast<const f32x2 *>(p.vec + (long long)(h0 + hh) * p.vec_hs + (long long)n * p.vec_ns + cc[j]);
+      }
+    float ev[NV];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      f32x2 xr[NJ];
+      if (!RESIDENT) ETM_LOAD_ROW(i, xr)
+#pragma unroll
+      for (int hh = 0; hh < HG; ++hh) {
+        f32x2 s = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s += (RESIDENT ? x[RESIDENT ? i : 0][j] : xr[j]) * uv[hh][j];
+        ev[i * HG + hh] = s[0] + s[1];
+      }
+    }
+    TransposeReduce<NV, 32>::run(ev, lane);
+    constexpr int SH = 6 - ilog2(NV);
+    const int vi = lane >> SH, i_ = vi / HG, hh_ = vi - i_ * HG;
+    if ((lane & ((1 << SH) - 1)) == 0 && h0 + hh_ < H) a_s[(h0 + hh_) * LP + wave * RW + i_] = ev[0];
+  }
+  __syncthreads();
+
+  // ---- per head: masked softmax (forward) or its backward (one wave per head; LP <= 128 = 2 values per lane)
+  for (int h = wave; h < H; h += NW) {
+    float t[2];
+    bool keep[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int l = lane + 64 * jj;
+      t[jj] = (l < L) ? a_s[h * LP + l] : 0.f;
+      keep[jj] = (l < L) && p.mask[(long long)n * L + l] != 0;
+    }
+    if (!p.bwd) {
+      float ev2[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int l = lane + 64 * jj;
+        float e_ = -INFINITY;
+        if (l < L) e_ = (keep[jj] ? t[jj] : -1e20f) / p.sqrt_d;  // fill BEFORE the scale (transformer.py:66,69)
+        ev2[jj] = e_;
+      }
+      const float m = wave_max(fmaxf(ev2[0], ev2[1]));
+      float xv[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) xv[jj] = (lane + 64 * jj < L) ? expf(ev2[jj] - m) : 0.f;
+      const float denom = wave_sum(xv[0] + xv[1]);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int l = lane + 64 * jj;
+        if (l < LP) {
+          const float a = xv[jj] / denom;
+          a_s[h * LP + l] = a;
+          if (l < L) p.att_out[((long long)n * H + h) * L + l] = a;
+        }
+      }
+    } else {
+      float a[2];
+      float dot = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int l = lane + 64 * jj;
+        a[jj] = (l < L) ? p.att_in[((long long)n * H + h) * L + l] : 0.f;
+        dot += a[jj] * t[jj];
+      }
+      dot = wave_sum(dot);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int l = lane + 64 * jj;
+        if (l < LP) {
+          float de = keep[jj] ? a[jj] * (t[jj] - dot) / p.sqrt_d : 0.f;  // masked_fill blocks the gradient
+          a_s[h * LP + l] = de;
+          if (l < L) p.d_e[((long long)n * H + h) * L + l] = de;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: out[h][:] = sum_l w[h][l] x[l][:]   (w = attention or dE)
+  for (int h0 = 0; h0 < H; h0 += HG) {
+    f32x2 zp[HG][NJ];
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) zp[hh][j] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      f32x2 xr[NJ];
+      if (!RESIDENT) ETM_LOAD_ROW(i, xr)
+#pragma unroll
+      for (int hh = 0; hh < HG; ++hh) {
+        if (h0 + hh < H) {
+          const float w = a_s[(h0 + hh) * LP + wave * RW + i];   // same address for the whole wave: LDS broadcast
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) zp[hh][j] += w * (RESIDENT ? x[RESIDENT ? i : 0][j] : xr[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zp[hh][j];
+    __syncthreads();
+    for (int idx = tid; idx < HG * (DP / 2); idx += NW * 64) {
+      const int hh = idx / (DP / 2), c = 2 * (idx - hh * (DP / 2));
+      if (h0 + hh < H && c < D) {
+        f32x2 s = {0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x2 *>(&zs[(w * HG + hh) * DP + c]);
+        *reinterpret_cast<f32x2 *>(p.out + (long long)(h0 + hh) * p.out_hs + (long long)n * p.out_ns + c) = s;
+      }
+    }
+    __syncthreads();
+  }
+#undef ETM_LOAD_ROW
+}
+
+template <int NJ, int RW, int NW, bool RESIDENT>
+int launch_pass(const WinParams &p, hipStream_t st) {
+  const size_t lds = (size_t)(p.H * NW * RW + NW * HG * NJ * 128) * sizeof(float);
+  if (lds > 160 * 1024) return ETM_EUNSUPPORTED;
+  auto kern = window_pass_kernel<NJ, RW, NW, RESIDENT>;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
+  hipLaunchKernelGGL(kern, dim3(p.N), dim3(NW * 64), lds, st, p);
+  return etm_launch_status();
+}
+
+// rows per wave x waves: (8,4) L <= 32; (16,4) L <= 64; (16,8) L <= 128, and (8,8) L <= 64 for D > 512 so that the rows
+// still fit in registers (RW * NJ <= 64).  D > 512 with L > 64 is left to the dense MFMA kernels (mha_fwd.hip / mha_bwd.hip).
+template <int NJ>
+int dispatch_rows(const WinParams &p, hipStream_t st) {
+  if constexpr (NJ <= 4) {
+    if (p.L <= 32) return launch_pass<NJ, 8, 4, true>(p, st);
+    if (p.L <= 64) return launch_pass<NJ, 16, 4, true>(p, st);
+    return launch_pass<NJ, 16, 8, true>(p, st);
+  } else {
+    if (p.L <= 32) return launch_pass<NJ, 8, 4, true>(p, st);
+    if (p.L <= 64) return launch_pass<NJ, 8, 8, true>(p, st);
+    return ETM_EUNSUPPORTED;
+  }
+}
+
+int dispatch(const WinParams &p, hipStream_t st) {
+  const int nj = (p.D + 127) / 128;
+  switch (nj) {
+    case 1: return dispatch_rows<1>(p, st);
+    case 2: return dispatch_rows<2>(p, st);
+    case 3: return dispatch_rows<3>(p, st);
+    case 4: return dispatch_rows<4>(p, st);
+    case 5: case 6: return dispatch_rows<6>(p, st);
+    case 7: case 8: return dispatch_rows<8>(p, st);
+  }
+  return ETM_EUNSUPPORTED;
+}
+
+int check_common(const void *bank, const void *win, const void *mask, const void *pos, const void *pidx, const void *ln_g,
+                 const void *ln_b, const void *ln_stats, int N, int L, int D, int H) {
+  if (!bank || !win || !mask) return ETM_EINVAL;
+  if (N <= 0 || L <= 0 || D <= 0 || H <= 0 || D % H != 0) return ETM_EINVAL;
+  if ((pos != nullptr) != (pidx != nullptr)) return ETM_EINVAL;
+  if ((ln_g != nullptr) != (ln_b != nullptr)) return ETM_EINVAL;
+  if (ln_g && !ln_stats) return ETM_EINVAL;
+  if (D % 32 != 0 || (D / H) % 2 != 0 || L > 128 || D > 1024) return ETM_EUNSUPPORTED;
+  return ETM_OK;
+}
+
+}  // namespace
+
+extern "C" int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                              const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,
+                              float ln_eps, const float *u, int64_t u_head_stride, int64_t u_sample_stride, float *att, float *z,
+                              int64_t z_head_stride, int64_t z_sample_stride, float *ln_stats, int N, int L, int D, int H,
+                              void *stream) {
+  (void)hipGetLastError();
+  int rc = check_common(bank, win, mask, pos, pidx, ln_g, ln_b, ln_stats, N, L, D, H);
+  if (rc) return rc;
+  if (!u || !att || !z) return ETM_EINVAL;
+  if (u_head_stride % 2 || u_sample_stride % 2 || z_head_stride % 2 || z_sample_stride % 2) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (ln_g) {
+    rc = etm_launch_ln_stats(bank, ep_stride, row_stride, ep, win, pidx, pos, ln_eps, ln_stats, N, L, D, st);
+    if (rc) return rc;
+  }
+  WinParams p{};
+  p.bank = bank; p.ep_stride = ep_stride; p.row_stride = row_stride;
+  p.ep = (const long long *)ep; p.win = (const long long *)win; p.pidx = (const long long *)pidx;
+  p.mask = mask; p.pos = pos; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_stats = ln_stats;
+  p.vec = u; p.vec_hs = u_head_stride; p.vec_ns = u_sample_stride;
+  p.out = z; p.out_hs = z_head_stride; p.out_ns = z_sample_stride;
+  p.att_out = att; p.att_in = nullptr; p.d_e = nullptr;
+  p.N = N; p.L = L; p.D = D; p.H = H; p.bwd = 0;
+  p.sqrt_d = (float)sqrt((double)D);
+  return dispatch(p, st);
+}
+
+extern "C" int etm_window_bwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                              const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,
+                              const float *ln_stats, const float *att, const float *gz, int64_t gz_head_stride,
+                              int64_t gz_sample_stride, float *d_e, float *du, int64_t du_head_stride, int64_t du_sample_stride,
+                              int N, int L, int D, int H, void *stream) {
+  (void)hipGetLastError();
+  int rc = check_common(bank, win, mask, pos, pidx, ln_g, ln_b, ln_stats, N, L, D, H);
+  if (rc) return rc;
+  if (!att || !gz || !d_e || !du) return ETM_EINVAL;
+  if (gz_head_stride % 2 || gz_sample_stride % 2 || du_head_stride % 2 || du_sample_stride % 2) return ETM_EINVAL;
+  WinParams p{};
+  p.bank = bank; p.ep_stride = ep_stride; p.row_stride = row_stride;
+  p.ep = (const long long *)ep; p.win = (const long long *)win; p.pidx = (const long long *)pidx;
+  p.mask = mask; p.pos = pos; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_stats = ln_stats;
+  p.vec = gz; p.vec_hs = gz_head_stride; p.vec_ns = gz_sample_stride;
+  p.out = du; p.out_hs = du_head_stride; p.out_ns = du_sample_stride;
+  p.att_out = nullptr; p.att_in = att; p.d_e = d_e;
+  p.N = N; p.L = L; p.D = D; p.H = H; p.bwd = 1;
+  p.sqrt_d = (float)sqrt((double)D);
+  return dispatch(p, (hipStream_t)stream);
+}

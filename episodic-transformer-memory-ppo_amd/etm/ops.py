@@ -165,9 +165,114 @@ class _MhaFn(torch.autograd.Function):
         return d_q, d_wk, d_wv, d_ln_g, d_ln_b, d_pos, None, None, None, None
 
 
-def mha(q, wk, wv, spec, block, num_heads, ln_g=None, ln_b=None, pos=None, ln_eps=1e-5):
-    """Fused window attention.  q [N,D] projected queries -> (ctx [N,D] before fc_out, attention [N,H,L])."""
-    return _MhaFn.apply(q, wk, wv, ln_g, ln_b, pos, spec, block, num_heads, ln_eps)
+class _WindowFn(torch.autograd.Function):
+    """Folded window attention pass: u [H,N,D] -> (z [H,N,D], att [N,H,L]); see csrc/window_attn.hip."""
+
+    @staticmethod
+    def forward(ctx, u, ln_g, ln_b, pos, spec, block, ln_eps):
+        lib = _lib.load()
+        _need_dev(u, ln_g, ln_b, pos)
+        u = _f32c(u, "u")
+        ln_g, ln_b, pos = _f32c(ln_g, "ln_g"), _f32c(ln_b, "ln_b"), _f32c(pos, "pos")
+        H, N, D = u.shape
+        L = spec.L
+        if N != spec.N:
+            raise ValueError("query batch and window batch differ")
+        dev = u.device
+        att = torch.empty((N, H, L), dtype=torch.float32, device=dev)
+        z = torch.empty((H, N, D), dtype=torch.float32, device=dev)
+        ln_stats = torch.empty((N, L, 2), dtype=torch.float32, device=dev) if ln_g is not None else None
+        pidx = spec.pidx if pos is not None else None
+        rc = lib.etm_window_fwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), float(ln_eps), _ptr(u), N * D, D, _ptr(att),
+                                _ptr(z), N * D, D, _ptr(ln_stats), N, L, D, H, _stream())
+        _lib.check(rc, "etm_window_fwd")
+        if any(ctx.needs_input_grad[:4]):
+            ctx.spec, ctx.block = spec, block
+            ctx.has_ln, ctx.has_pos = ln_g is not None, pos is not None
+            saved = [u, att]
+            if ln_g is not None:
+                saved += [ln_g, ln_b, ln_stats]
+            if pos is not None:
+                saved += [pos]
+            ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(att)
+        return z, att
+
+    @staticmethod
+    def backward(ctx, gz, _d_att):
+        lib = _lib.load()
+        spec, block = ctx.spec, ctx.block
+        saved = list(ctx.saved_tensors)
+        u, att = saved[:2]
+        rest = saved[2:]
+        ln_g = ln_b = ln_stats = pos = None
+        if ctx.has_ln:
+            ln_g, ln_b, ln_stats = rest[:3]
+            rest = rest[3:]
+        if ctx.has_pos:
+            pos = rest[0]
+        H, N, D = u.shape
+        L = spec.L
+        dev = u.device
+        gz = _f32c(gz, "d_z")
+        d_e = torch.empty((N, H, L), dtype=torch.float32, device=dev)
+        du = torch.empty((H, N, D), dtype=torch.float32, device=dev)
+        pidx = spec.pidx if pos is not None else None
+        rc = lib.etm_window_bwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), _ptr(ln_stats), _ptr(att), _ptr(gz), N * D, D,
+                                _ptr(d_e), _ptr(du), N * D, D, N, L, D, H, _stream())
+        _lib.check(rc, "etm_window_bwd")
+        want_ln = ctx.has_ln and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        want_pos = ctx.has_pos and ctx.needs_input_grad[3]
+        d_ln_g = d_ln_b = d_pos = None
+        if want_ln or want_pos:
+            d_ln_g = torch.zeros_like(ln_g) if want_ln else None
+            d_ln_b = torch.zeros_like(ln_b) if want_ln else None
+            d_pos = torch.zeros_like(pos) if want_pos else None
+            uw = torch.empty((2, N, H, D), dtype=torch.float32, device=dev)
+            uw[0].copy_(u.transpose(0, 1))
+            uw[1].copy_(gz.transpose(0, 1))
+            rc = lib.etm_window_dx(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                   _ptr(pos), _ptr(ln_g), _ptr(ln_b), _ptr(ln_stats), _ptr(att), _ptr(d_e), _ptr(uw), _ptr(d_ln_g),
+                                   _ptr(d_ln_b), _ptr(d_pos), N, L, D, H, _stream())
+            _lib.check(rc, "etm_window_dx")
+        return du, d_ln_g, d_ln_b, d_pos, None, None, None
+
+
+ATTENTION_IMPLS = ("folded", "dense")
+_default_impl = "folded"
+
+
+def set_attention_impl(impl):
+    """Select the kernel family behind ``mha``: 'folded' (one HBM-bound pass over the window, default) or 'dense' (the
+    K/V projections of the window as fp32-MFMA contractions).  Both compute transformer.py:31-86 for a single query."""
+    global _default_impl
+    if impl not in ATTENTION_IMPLS:
+        raise ValueError(f"attention impl must be one of {ATTENTION_IMPLS}, got {impl!r}")
+    _default_impl = impl
+
+
+def folded_supported(D, L, num_heads):
+    hd = D // num_heads
+    return D % 32 == 0 and hd % 2 == 0 and ((D <= 512 and L <= 128) or (D <= 1024 and L <= 64))
+
+
+def mha(q, wk, wv, spec, block, num_heads, ln_g=None, ln_b=None, pos=None, ln_eps=1e-5, impl=None):
+    """Window attention of one block.  q [N,D] projected queries -> (ctx [N,D] before fc_out, attention [N,H,L])."""
+    impl = _default_impl if impl is None else impl
+    if impl not in ATTENTION_IMPLS:
+        raise ValueError(f"attention impl must be one of {ATTENTION_IMPLS}, got {impl!r}")
+    N, D = q.shape
+    H = int(num_heads)
+    if impl == "dense" or not folded_supported(D, spec.L, H):
+        return _MhaFn.apply(q, wk, wv, ln_g, ln_b, pos, spec, block, num_heads, ln_eps)
+    hd = D // H
+    # u[h] = q_h Wk_h and ctx_h = z_h Wv_h^T: [N,hd] x [hd,D] per head (library GEMMs; autograd supplies d q, d Wk, d Wv)
+    u = torch.bmm(q.view(N, H, hd).transpose(0, 1), wk.view(H, hd, D))
+    z, att = _WindowFn.apply(u, ln_g, ln_b, pos, spec, block, ln_eps)
+    ctx = torch.bmm(z, wv.view(H, hd, D).transpose(1, 2)).transpose(0, 1).reshape(N, D)
+    return ctx, att
 
 
 def attn_cached(q, kv_spec, block, num_heads, want_att=False):

@@ -103,6 +103,46 @@ int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_stride,
                 int N, int L, int D, int H, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Kernel #1, folded form (default training path): the same reference sequence as etm_mha_fwd / etm_mha_bwd
+ * (utils.py:52-75, transformer.py:237-242, :131, :50-51, :59-75) for a SINGLE query per sample, without ever forming the
+ * key / value projections of the window.  With u[n,h,:] = q[n,h,:] . Wk_h and z[n,h,:] = sum_l att[n,h,l] X[n,l,:]
+ *     energy[n,h,l] = X[n,l,:] . u[n,h,:]          (== Q_h . K_h of transformer.py:59-62)
+ *     ctx[n,h,:]    = z[n,h,:] . Wv_h^T            (== att . V_h of transformer.py:72-75)
+ * so one pass over the gathered window rows (L*D*4 bytes per sample and block: HBM-bound) replaces the
+ * two [N*L, D] x [D, D] contractions; the [hd, D] products per head (u, ctx and their gradients) are library GEMMs on the
+ * caller side (etm/ops.py).  Results differ from the dense form only by fp32 summation order.
+ *
+ *   bank/ep/win/pidx/mask/pos/ln_g/ln_b/ln_eps/ln_stats: exactly as for etm_mha_fwd
+ *   u, z, gz, du: element (h, n, c) at base[h * head_stride + n * sample_stride + c]   (strides in floats, even)
+ * etm_window_fwd:  u -> att [N,H,L] (softmax(masked_fill(energy, -1e20) / sqrt(D))), z
+ * etm_window_bwd:  gz = d loss / d z, att (saved) -> d_e [N,H,L] (gradient of the pre-scale logits; 0 where masked),
+ *                  du[h,n,:] = sum_l d_e[n,h,l] X[n,l,:]
+ * etm_window_dx:   LayerNorm gain / bias and learned positional table gradients (accumulated; caller zero-fills):
+ *                  dX[n,l,:] = sum_h d_e[n,h,l] u[n,h,:] + att[n,h,l] gz[n,h,:] pushed through the LayerNorm;
+ *                  uw = [2, N, H, D] contiguous (u, then gz).  No-op when d_ln_g and d_pos are both NULL.
+ * Shape support: D % 32 == 0, head_dim even, L <= 128 for D <= 512, L <= 64 for D <= 1024 (ETM_EUNSUPPORTED otherwise:
+ * use the dense pair above).
+ */
+int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_stride,
+                   const int64_t *ep, const int64_t *win, const int64_t *pidx, const uint8_t *mask,
+                   const float *pos, const float *ln_g, const float *ln_b, float ln_eps,
+                   const float *u, int64_t u_head_stride, int64_t u_sample_stride,
+                   float *att, float *z, int64_t z_head_stride, int64_t z_sample_stride,
+                   float *ln_stats, int N, int L, int D, int H, void *stream);
+int etm_window_bwd(const float *bank, int64_t ep_stride, int64_t row_stride,
+                   const int64_t *ep, const int64_t *win, const int64_t *pidx, const uint8_t *mask,
+                   const float *pos, const float *ln_g, const float *ln_b, const float *ln_stats,
+                   const float *att, const float *gz, int64_t gz_head_stride, int64_t gz_sample_stride,
+                   float *d_e, float *du, int64_t du_head_stride, int64_t du_sample_stride,
+                   int N, int L, int D, int H, void *stream);
+int etm_window_dx(const float *bank, int64_t ep_stride, int64_t row_stride,
+                  const int64_t *ep, const int64_t *win, const int64_t *pidx,
+                  const float *pos, const float *ln_g, const float *ln_b, const float *ln_stats,
+                  const float *att, const float *d_e, const float *uw,
+                  float *d_ln_g, float *d_ln_b, float *d_pos,
+                  int N, int L, int D, int H, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Rollout-time variant of kernel #1 over CACHED key/value projections (inference only, no backward).
  * During sampling the weights are frozen and an item's positional row is fixed by its absolute episode index
  * (transformer.py:237-239), so the trainer projects each new memory item once (library GEMM) into a cache

@@ -53,6 +53,15 @@ def grad_close(g, z, tag, key, n_sample, rel=2e-4):
     close(dg.sample(g, n_sample), z[tag + "grad_sample/" + key], atol=tol, rtol=1e-3, what=key)
 
 
+@pytest.fixture(params=["folded", "dense"])
+def attn_impl(request):
+    """Both kernel families behind ops.mha: the folded HBM-bound pass (default) and the dense fp32-MFMA contractions."""
+    from etm import ops
+    ops.set_attention_impl(request.param)
+    yield request.param
+    ops.set_attention_impl("folded")
+
+
 def test_library_loaded_and_no_fallback():
     from etm import lib, ops
     h = lib.load()
@@ -62,7 +71,7 @@ def test_library_loaded_and_no_fallback():
 
 
 # ------------------------------------------------------------------ kernel #1 vs reference golden
-def test_mha_module_vs_reference(golden_dir):
+def test_mha_module_vs_reference(golden_dir, attn_impl):
     from transformer import MultiHeadAttention
     dev = _dev()
     z = load(golden_dir, "mha.npz")
@@ -87,7 +96,7 @@ def test_mha_module_vs_reference(golden_dir):
             grad_close(p.grad, z, tag, k, 384)
 
 
-def test_transformer_variants_vs_reference(golden_dir):
+def test_transformer_variants_vs_reference(golden_dir, attn_impl):
     from transformer import Transformer
     dev = _dev()
     z = load(golden_dir, "transformer.npz")
@@ -161,7 +170,7 @@ def test_actor_critic_vs_reference(golden_dir):
                                             (64, 1, 32, 7, True, True), (256, 4, 96, 6, False, False), (384, 4, 118, 5, True, True),
                                             (96, 3, 5, 11, False, True), (1024, 8, 16, 3, True, True), (32, 1, 1, 1, False, False),
                                             (128, 1, 128, 2, True, True), (64, 2, 33, 130, False, True), (512, 4, 64, 1, True, False)])
-def test_mha_banked_vs_oracle(D, H, L, N, ln, pos):
+def test_mha_banked_vs_oracle(D, H, L, N, ln, pos, attn_impl):
     from etm import ops
     from oracle import ref_model as rm
     dev = _dev()
@@ -221,7 +230,7 @@ def test_mha_banked_vs_oracle(D, H, L, N, ln, pos):
         gclose(ptd.grad, ref["pt"], "dpos", 5e-4)
 
 
-def test_mha_full_size_vs_torch_on_device():
+def test_mha_full_size_vs_torch_on_device(attn_impl):
     """BASELINE config (3) training shape (N=2048, L=64, D=384, H=4, 3 blocks in the bank) against plain torch ops
     on the same device, plus size-independent properties (rows of the attention sum to 1, masked slots are 0)."""
     from etm import ops

@@ -1,0 +1,44 @@
+"""Forward+backward time of ops.mha at the training shape for both kernel families (folded / dense), with the library's
+per-kernel HIP-event breakdown.  python tools/window_time.py [L] [D] [H]"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
+import torch
+from etm import ops, lib as etm_lib
+dev = torch.device("cuda"); torch.manual_seed(0)
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 384
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+N, T, nb, E = 2048, L + 32, 3, 416
+bank = torch.randn((E, T, nb, D), device=dev)
+ep = torch.randint(0, E, (N,), device=dev)
+win = torch.randint(0, T - L + 1, (N, 1), device=dev) + torch.arange(L, device=dev)[None, :]
+mask = torch.arange(L, device=dev)[None, :] < torch.randint(0, L, (N,), device=dev)[:, None]
+wk = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True); wv = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
+q = torch.randn((N, D), device=dev).requires_grad_(True); g = torch.randn((N, D), device=dev)
+spec = ops.WindowSpec.from_bank(bank, ep, win, None, mask)
+l = etm_lib.load()
+res = {}
+for impl in ("folded", "dense"):
+    ops.set_attention_impl(impl)
+    for it in range(3):
+        out, att = ops.mha(q, wk, wv, spec, 1, H); (out * g).sum().backward()
+    res[impl] = (out.detach().clone(), q.grad.clone(), wk.grad.clone(), wv.grad.clone())
+    q.grad = wk.grad = wv.grad = None
+    torch.cuda.synchronize()
+    t0, t1, t2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    fw = bw = 0.0
+    for it in range(10):
+        t0.record(); out, att = ops.mha(q, wk, wv, spec, 1, H); t1.record(); (out * g).sum().backward(); t2.record()
+        torch.cuda.synchronize(); fw += t0.elapsed_time(t1); bw += t1.elapsed_time(t2)
+    l.etm_profile_enable(1)
+    for it in range(5):
+        out, att = ops.mha(q, wk, wv, spec, 1, H); (out * g).sum().backward()
+    torch.cuda.synchronize(); l.etm_profile_enable(0)
+    ks = "  ".join(f"{k}={ms / c * 1e3:.1f}us" for (tag, k), (ms, c) in sorted(etm_lib.profile_collect().items()))
+    print(f"{impl:7s} N={N} L={L} D={D} H={H}: forward {fw / 10 * 1e3:7.1f} us  backward(+loss) {bw / 10 * 1e3:7.1f} us | {ks}", flush=True)
+a, b = res["folded"], res["dense"]
+for name, x, y in zip(("ctx", "dq", "dwk", "dwv"), a, b):
+    print(f"  folded vs dense {name}: max abs diff {(x - y).abs().max().item():.3e}  rel-to-norm {((x - y).norm() / y.norm()).item():.3e}")
+gb = N * L * D * 4 / 1e9
+print(f"  window bytes per pass (un-deduplicated) {gb * 1e3:.1f} MB")
