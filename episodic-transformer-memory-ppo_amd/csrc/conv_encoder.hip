@@ -10,8 +10,8 @@
 //   NHWC input (layers 2, 3):                          segment = ky,      length KW * C      -> weights pre-permuted to
 //                                                                                               [Cout][KH][KW][C]
 // so every lane fetches its A fragment with 16-byte loads straight from global memory/L2 (no LDS staging, no barrier in
-// the main loop).  One workgroup = one tile of 32 output pixels x all Cout (NT = Cout/32 accumulator tiles); its four
-// waves split K (interleaved 8-wide k-groups) and are reduced through LDS, then bias + ReLU + store (NHWC for the next
+// the main loop).  One workgroup = one tile of 32 output pixels x all Cout (NT = Cout/32 accumulator tiles); its eight
+// waves split K (interleaved 8-wide k-groups, operands of the next batch prefetched) and are reduced through LDS, then bias + ReLU + store (NHWC for the next
 // layer, NCHW for the last one so that the flatten order of model.py:94 is unchanged).
 #include "etm_common.h"
 
@@ -24,27 +24,28 @@ struct ConvParams {
   int seg_len, n_seg, groups;  // K = n_seg * seg_len, groups = K / 8
 };
 
+constexpr int CONV_NW = 8;   // waves per workgroup = K slices
+constexpr int CONV_GB = 4;   // 8-wide k-groups per wave and batch (one batch of operands in flight under the MFMAs of the last)
+
 template <int NT>
-__global__ __launch_bounds__(256) void conv_relu_kernel(const ConvParams p) {
-  __shared__ float red[4 * NT * 16 * 64];
+__global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParams p) {
+  constexpr int NW = CONV_NW, GB = CONV_GB;
+  __shared__ float red[NW * NT * 16 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int M = p.N * p.Ho * p.Wo;
   const int m = min((int)blockIdx.x * 32 + col, M - 1);
   const int n = m / (p.Ho * p.Wo);
   const int rem = m - n * p.Ho * p.Wo;
   const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-  const int K = p.n_seg * p.seg_len;
-
-  // base offset of this lane's pixel; a segment s adds seg_stride_a * (its row) ... computed per group below
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const float *wrow[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) wrow[t] = p.w + (long long)(t * 32 + col) * K + half * 4;
+  // weights arrive packed in fragment order (etm_hip.h): the B fragment of (k-group g, tile t) is 64 lanes x 4 floats,
+  // contiguous -- one fully coalesced 1 KB load per wave instead of 64 different cache lines
+  const float *wlane = p.w + lane * 4;
 
   auto a_ptr = [&](int k0) -> const float * {
     const int seg = k0 / p.seg_len, off = k0 - seg * p.seg_len;
@@ -58,48 +59,50 @@ __global__ __launch_bounds__(256) void conv_relu_kernel(const ConvParams p) {
     return p.in + base + off + half * 4;
   };
 
-  // wave w takes k-groups w, w+4, ...; two groups in flight
-  int g = wave;
-  for (; g + 4 < p.groups; g += 8) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a_ptr(g * 8));
-    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a_ptr((g + 4) * 8));
-    f32x4 b0[NT], b1[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      b0[t] = *reinterpret_cast<const f32x4 *>(wrow[t] + g * 8);
-      b1[t] = *reinterpret_cast<const f32x4 *>(wrow[t] + (g + 4) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[t][j], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[t][j], acc[t], 0, 0, 0);
+  // Wave w takes k-groups w, w + NW, ...  in batches of GB; the loads of batch i+1 are issued before the MFMAs of batch i
+  // (the loop used to expose one global-memory round trip per iteration: ~1 us each at 32 images).  Groups past the end
+  // are clamped to the last one (unconditional loads) and their A fragment is zeroed.
+  f32x4 a_cur[GB], b_cur[GB][NT], a_nxt[GB], b_nxt[GB][NT];
+  const int last = p.groups - 1;
+#define ETM_CONV_LOAD(dst_a, dst_b, g0_)                                                          \
+  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                                \
+    const int g_ = (g0_) + u * NW;                                                                \
+    const int gc_ = g_ < p.groups ? g_ : last;                                                    \
+    f32x4 av_ = *reinterpret_cast<const f32x4 *>(a_ptr(gc_ * 8));                                 \
+    if (g_ >= p.groups) av_ = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+    dst_a[u] = av_;                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) dst_b[u][t] = *reinterpret_cast<const f32x4 *>(wlane + ((long long)gc_ * NT + t) * 256); \
   }
-  for (; g < p.groups; g += 4) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a_ptr(g * 8));
+  ETM_CONV_LOAD(a_cur, b_cur, wave)
+  for (int g0 = wave; g0 < p.groups; g0 += GB * NW) {
+    ETM_CONV_LOAD(a_nxt, b_nxt, g0 + GB * NW)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(wrow[t] + g * 8);
+    for (int u = 0; u < GB; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[t], 0, 0, 0);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][j], b_cur[u][t][j], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      a_cur[u] = a_nxt[u];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b_cur[u][t] = b_nxt[u][t];
     }
   }
+#undef ETM_CONV_LOAD
 
-  // reduce the four K-slices through LDS (lane-contiguous: conflict-free)
+  // reduce the K-slices of the waves through LDS (lane-contiguous: conflict-free)
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[((wave * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
-  // each thread finishes (t, r) pairs for its lane: NT*16 pairs over 4 waves
-  for (int pr = wave; pr < NT * 16; pr += 4) {
+  // each thread finishes (t, r) pairs for its lane: NT*16 pairs over the waves
+  for (int pr = wave; pr < NT * 16; pr += NW) {
     const int t = pr / 16, r = pr - t * 16;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += red[((w * NT + t) * 16 + r) * 64 + lane];
+    for (int w = 0; w < NW; ++w) v += red[((w * NT + t) * 16 + r) * 64 + lane];
     const int row = mfma32_row(r, lane);
     const int mm = (int)blockIdx.x * 32 + row;
     if (mm < M) {
@@ -135,7 +138,7 @@ extern "C" int etm_conv_relu(const float *in, const float *w, const float *bias,
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_CONV_RELU, st);
   const dim3 grid((unsigned)((M + 31) / 32));
-  if (Cout == 32) hipLaunchKernelGGL((conv_relu_kernel<1>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((conv_relu_kernel<2>), grid, dim3(256), 0, st, p);
+  if (Cout == 32) hipLaunchKernelGGL((conv_relu_kernel<1>), grid, dim3(CONV_NW * 64), 0, st, p);
+  else hipLaunchKernelGGL((conv_relu_kernel<2>), grid, dim3(CONV_NW * 64), 0, st, p);
   return etm_launch_status();
 }

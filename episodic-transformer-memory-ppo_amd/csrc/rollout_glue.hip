@@ -7,19 +7,37 @@
 namespace {
 
 // mask_t[w,:] = mask_table[clip(step[w],0,L-1),:], win_t[w,:] = index_table[step[w],:]   (trainer.py:165-166),
-// also written to row t of the time-major staging arrays.
+// also written to row t of the time-major staging arrays.  The same launch carries two more pieces of per-step glue that
+// used to be launches of their own on the critical path of a rollout step: t_row = t (the staging row the tail of the step
+// writes to) and, in extra workgroups, the K/V-cache reset of workers that start an episode (cache[w] = init when
+// step[w] == 0; a new episode starts from the projection of an all-zero memory).
+constexpr int RESET_CHUNKS = 64;
 __global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__restrict__ step, const unsigned char *__restrict__ mask_table,
                                                              const long long *__restrict__ index_table, const long long *__restrict__ t_dev,
                                                              unsigned char *__restrict__ mask_t, long long *__restrict__ win_t,
-                                                             unsigned char *__restrict__ st_mask, long long *__restrict__ st_idx, int W, int L) {
+                                                             unsigned char *__restrict__ st_mask, long long *__restrict__ st_idx,
+                                                             long long *__restrict__ t_row, float *__restrict__ reset_dst,
+                                                             const float *__restrict__ reset_init, long long reset_row_elems, int nb_window,
+                                                             int W, int L) {
+  if ((int)blockIdx.x >= nb_window) {     // reset role: (worker, chunk)
+    const int e = (int)blockIdx.x - nb_window;
+    const int w = e / RESET_CHUNKS, chunk = e - w * RESET_CHUNKS;
+    if (step[w] != 0) return;
+    const long long n4 = reset_row_elems / 4;
+    float4 *d = reinterpret_cast<float4 *>(reset_dst + (long long)w * reset_row_elems);
+    const float4 *s = reinterpret_cast<const float4 *>(reset_init);
+    for (long long i = (long long)chunk * 256 + threadIdx.x; i < n4; i += (long long)RESET_CHUNKS * 256) d[i] = s[i];
+    return;
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const long long t = *t_dev;
+  if (i == 0 && t_row) *t_row = t;
   if (i >= W * L) return;
   const int w = i / L, l = i - w * L;
   const long long s = step[w];
   const long long r = s < 0 ? 0 : (s > L - 1 ? L - 1 : s);
   const unsigned char m = mask_table[r * L + l];
   const long long idx = index_table[s * L + l];
-  const long long t = *t_dev;
   mask_t[i] = m;
   win_t[i] = idx;
   st_mask[t * W * L + i] = m;
@@ -115,13 +133,19 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 }  // namespace
 
 extern "C" int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
-                                  uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int W, int L, void *stream) {
+                                  uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int64_t *t_row, float *reset_dst,
+                                  const float *reset_init, int64_t reset_row_elems, int W, int L, void *stream) {
   (void)hipGetLastError();
   if (!step || !mask_table || !index_table || !t_dev || !mask_t || !win_t || !st_mask || !st_idx || W <= 0 || L <= 0) return ETM_EINVAL;
+  if ((reset_dst != nullptr) != (reset_init != nullptr)) return ETM_EINVAL;
+  if (reset_dst && (reset_row_elems <= 0 || reset_row_elems % 4 != 0)) return ETM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_ROLLOUT_WINDOW, st);
-  hipLaunchKernelGGL(rollout_window_kernel, dim3((unsigned)((W * L + 255) / 256)), dim3(256), 0, st, (const long long *)step, mask_table,
-                     (const long long *)index_table, (const long long *)t_dev, mask_t, (long long *)win_t, st_mask, (long long *)st_idx, W, L);
+  const int nbw = (W * L + 255) / 256;
+  const int nbr = reset_dst ? W * RESET_CHUNKS : 0;
+  hipLaunchKernelGGL(rollout_window_kernel, dim3((unsigned)(nbw + nbr)), dim3(256), 0, st, (const long long *)step, mask_table,
+                     (const long long *)index_table, (const long long *)t_dev, mask_t, (long long *)win_t, st_mask, (long long *)st_idx,
+                     (long long *)t_row, reset_dst, reset_init, (long long)reset_row_elems, nbw, W, L);
   return etm_launch_status();
 }
 

@@ -64,11 +64,25 @@ struct TransposeReduce {
     }
   }
 };
+__device__ __forceinline__ long long readlane64(long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, l);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((long long)hi << 32) | lo;
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
 constexpr int HG = 4;  // heads handled per pass over the register-resident rows
 
-template <int NJ, int RW, int NW, bool RESIDENT>
+#if defined(ETM_DIAG_TRACE)
+constexpr int WIN_TRACE_WGS = 2048, WIN_TRACE_SLOTS = 16;
+__device__ unsigned long long g_win_trace[WIN_TRACE_WGS * 8 * WIN_TRACE_SLOTS];
+#define WIN_T(i_) { if (lane == 0) tb[i_] = __builtin_amdgcn_s_memtime(); }
+#else
+#define WIN_T(i_)
+#endif
+
+template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS>
 __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int LP = NW * RW;     // padded window length
@@ -77,10 +91,15 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L, D = p.D, H = p.H;
+#if defined(ETM_DIAG_TRACE)
+  unsigned long long *tb = g_win_trace + ((long long)min((int)blockIdx.x, WIN_TRACE_WGS - 1) * 8 + (wave & 7)) * WIN_TRACE_SLOTS;
+  if (lane == 0) tb[0] = etm_hw_ids();
+#endif
+  WIN_T(1)
   float *a_s = sm;              // [H][LP]   logits, then attention (forward) / dE (backward)
   float *zs = sm + H * LP;      // [NW][HG][DP] per-wave partial weighted sums
 
-  const bool has_pos = p.pos != nullptr, has_ln = p.ln_g != nullptr;
+  constexpr bool has_pos = HAS_POS, has_ln = HAS_LN;   // compile-time: the row loads below must be straight-line code
   const long long e = p.ep ? p.ep[n] : n;
   const float *bank_e = p.bank + e * p.ep_stride;
 
@@ -100,16 +119,24 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     }
   }
 
-  // Window row i of this wave (l = wave RW + i; rows past L read row L-1 and get zero weight), normalised as the
-  // reference does: (+ positional row, transformer.py:237-239) (LayerNorm of the block, transformer.py:137-141).
+  // Row bookkeeping is fetched ONCE per wave, lane i holding what row i needs (window offset, positional offset,
+  // LayerNorm statistics), and handed to the row loads through v_readlane: one memory round trip instead of one per row.
+  const int l_me = wave * RW + (lane & (RW - 1));
+  const long long row_me = (long long)n * L + (l_me < L ? l_me : L - 1);   // rows past L read row L-1 and get zero weight
+  const long long xoff_me = p.win[row_me] * p.row_stride;
+  const long long poff_me = has_pos ? p.pidx[row_me] * D : 0;
+  float mu_me = 0.f, rs_me = 1.f;
+  if (has_ln) { mu_me = p.ln_stats[row_me * 2]; rs_me = p.ln_stats[row_me * 2 + 1]; }
+
+  // Window row i of this wave (l = wave RW + i), normalised as the reference does: (+ positional row,
+  // transformer.py:237-239) (LayerNorm of the block, transformer.py:137-141).  Straight-line code: all loads of all rows
+  // are in flight together.
 #define ETM_LOAD_ROW(i_, dst_)                                                                        \
   {                                                                                                   \
-    const int l_ = wave * RW + (i_);                                                                  \
-    const long long row_ = (long long)n * L + (l_ < L ? l_ : L - 1);                                  \
-    const float *xp_ = bank_e + p.win[row_] * p.row_stride;                                           \
-    const float *pp_ = has_pos ? p.pos + p.pidx[row_] * D : nullptr;                                  \
+    const float *xp_ = bank_e + readlane64(xoff_me, (i_));                                            \
+    const float *pp_ = has_pos ? p.pos + readlane64(poff_me, (i_)) : nullptr;                         \
     float mu_ = 0.f, rs_ = 1.f;                                                                       \
-    if (has_ln) { mu_ = p.ln_stats[row_ * 2]; rs_ = p.ln_stats[row_ * 2 + 1]; }                       \
+    if (has_ln) { mu_ = readlane_f(mu_me, (i_)); rs_ = readlane_f(rs_me, (i_)); }                     \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                  \
       f32x2 v_ = *reinterpret_cast<const f32x2 *>(xp_ + cc[j]);                                       \
       if (has_pos) v_ += *reinterpret_cast<const f32x2 *>(pp_ + cc[j]);                               \
@@ -119,12 +146,29 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     }                                                                                                 \
   }
 
-  f32x2 x[RESIDENT ? RW : 1][NJ];
-  if (RESIDENT) {
+  f32x2 x[RW][NJ];
+#if defined(ETM_DIAG_TRACE)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WIN_T(2)   // row bookkeeping arrived
+#endif
 #pragma unroll
-    for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
-  }
+  for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
+#if defined(ETM_DIAG_TRACE)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WIN_T(3)   // window rows arrived
+#endif
 
+#if defined(ETM_DIAG_LOAD_ONLY)   // diagnostic build only: the gather alone (ceiling of the access pattern)
+  {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc += x[i][j];
+    if (acc[0] + acc[1] == 123.456f) p.out[0] = acc[0];
+    return;
+  }
+#endif
   // ---- pass 1: logits[h][l] = x[l] . vec[h]
   for (int h0 = 0; h0 < H; h0 += HG) {
     f32x2 uv[HG][NJ];
@@ -132,19 +176,18 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     for (int hh = 0; hh < HG; ++hh)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        uv[hh][j] = f32x2{0.f, 0.f};
-        if (h0 + hh < H && cv[j]) uv[hh][j] = *reinterpret_cast<const f32x2 *>(p.vec + (long long)(h0 + hh) * p.vec_hs + (long long)n * p.vec_ns + cc[j]);
+        const int hc = h0 + hh < H ? h0 + hh : H - 1;   // heads past H: a valid address, result never stored
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(p.vec + (long long)hc * p.vec_hs + (long long)n * p.vec_ns + cc[j]);
+        uv[hh][j] = cv[j] ? t : f32x2{0.f, 0.f};
       }
     float ev[NV];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      f32x2 xr[NJ];
-      if (!RESIDENT) ETM_LOAD_ROW(i, xr)
 #pragma unroll
       for (int hh = 0; hh < HG; ++hh) {
         f32x2 s = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) s += (RESIDENT ? x[RESIDENT ? i : 0][j] : xr[j]) * uv[hh][j];
+        for (int j = 0; j < NJ; ++j) s += x[i][j] * uv[hh][j];
         ev[i * HG + hh] = s[0] + s[1];
       }
     }
@@ -153,7 +196,9 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     const int vi = lane >> SH, i_ = vi / HG, hh_ = vi - i_ * HG;
     if ((lane & ((1 << SH) - 1)) == 0 && h0 + hh_ < H) a_s[(h0 + hh_) * LP + wave * RW + i_] = ev[0];
   }
+  WIN_T(4)   // pass 1 + reduction done
   __syncthreads();
+  WIN_T(5)
 
   // ---- per head: masked softmax (forward) or its backward (one wave per head; LP <= 128 = 2 values per lane)
   for (int h = wave; h < H; h += NW) {
@@ -209,7 +254,9 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
       }
     }
   }
+  WIN_T(6)   // softmax done
   __syncthreads();
+  WIN_T(7)
 
   // ---- pass 2: out[h][:] = sum_l w[h][l] x[l][:]   (w = attention or dE)
   for (int h0 = 0; h0 < H; h0 += HG) {
@@ -220,22 +267,21 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
       for (int j = 0; j < NJ; ++j) zp[hh][j] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      f32x2 xr[NJ];
-      if (!RESIDENT) ETM_LOAD_ROW(i, xr)
 #pragma unroll
       for (int hh = 0; hh < HG; ++hh) {
-        if (h0 + hh < H) {
-          const float w = a_s[(h0 + hh) * LP + wave * RW + i];   // same address for the whole wave: LDS broadcast
+        const int hc = h0 + hh < H ? h0 + hh : H - 1;
+        const float w = a_s[hc * LP + wave * RW + i];   // same address for the whole wave: LDS broadcast
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) zp[hh][j] += w * (RESIDENT ? x[RESIDENT ? i : 0][j] : xr[j]);
-        }
+        for (int j = 0; j < NJ; ++j) zp[hh][j] += w * x[i][j];
       }
     }
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zp[hh][j];
+    WIN_T(8)   // pass 2 done
     __syncthreads();
+    WIN_T(9)
     for (int idx = tid; idx < HG * (DP / 2); idx += NW * 64) {
       const int hh = idx / (DP / 2), c = 2 * (idx - hh * (DP / 2));
       if (h0 + hh < H && c < D) {
@@ -245,20 +291,31 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
         *reinterpret_cast<f32x2 *>(p.out + (long long)(h0 + hh) * p.out_hs + (long long)n * p.out_ns + c) = s;
       }
     }
+    WIN_T(10)  // cross-wave sum + store done
     __syncthreads();
   }
+  WIN_T(11)
 #undef ETM_LOAD_ROW
 }
 
-template <int NJ, int RW, int NW, bool RESIDENT>
-int launch_pass(const WinParams &p, hipStream_t st) {
+template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS>
+int launch_pass2(const WinParams &p, hipStream_t st) {
   const size_t lds = (size_t)(p.H * NW * RW + NW * HG * NJ * 128) * sizeof(float);
   if (lds > 160 * 1024) return ETM_EUNSUPPORTED;
-  auto kern = window_pass_kernel<NJ, RW, NW, RESIDENT>;
+  auto kern = window_pass_kernel<NJ, RW, NW, HAS_LN, HAS_POS>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
   hipLaunchKernelGGL(kern, dim3(p.N), dim3(NW * 64), lds, st, p);
   return etm_launch_status();
+}
+
+template <int NJ, int RW, int NW>
+int launch_pass(const WinParams &p, hipStream_t st) {
+  const bool ln = p.ln_g != nullptr, pos = p.pos != nullptr;
+  if (ln && pos) return launch_pass2<NJ, RW, NW, true, true>(p, st);
+  if (ln) return launch_pass2<NJ, RW, NW, true, false>(p, st);
+  if (pos) return launch_pass2<NJ, RW, NW, false, true>(p, st);
+  return launch_pass2<NJ, RW, NW, false, false>(p, st);
 }
 
 // rows per wave x waves: (8,4) L <= 32; (16,4) L <= 64; (16,8) L <= 128, and (8,8) L <= 64 for D > 512 so that the rows
@@ -266,12 +323,16 @@ int launch_pass(const WinParams &p, hipStream_t st) {
 template <int NJ>
 int dispatch_rows(const WinParams &p, hipStream_t st) {
   if constexpr (NJ <= 4) {
-    if (p.L <= 32) return launch_pass<NJ, 8, 4, true>(p, st);
-    if (p.L <= 64) return launch_pass<NJ, 16, 4, true>(p, st);
-    return launch_pass<NJ, 16, 8, true>(p, st);
+    if (p.L <= 32) return launch_pass<NJ, 8, 4>(p, st);
+#if defined(ETM_DIAG_ROWS16)
+    if (p.L <= 64) return launch_pass<NJ, 16, 4>(p, st);
+#else
+    if (p.L <= 64) return launch_pass<NJ, 8, 8>(p, st);
+#endif
+    return launch_pass<NJ, 16, 8>(p, st);
   } else {
-    if (p.L <= 32) return launch_pass<NJ, 8, 4, true>(p, st);
-    if (p.L <= 64) return launch_pass<NJ, 8, 8, true>(p, st);
+    if (p.L <= 32) return launch_pass<NJ, 8, 4>(p, st);
+    if (p.L <= 64) return launch_pass<NJ, 8, 8>(p, st);
     return ETM_EUNSUPPORTED;
   }
 }
@@ -301,6 +362,12 @@ int check_common(const void *bank, const void *win, const void *mask, const void
 }
 
 }  // namespace
+
+#if defined(ETM_DIAG_TRACE)
+extern "C" int etm_diag_win_trace_read(void *dst, long long bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_win_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
                               const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,

@@ -303,12 +303,22 @@ def reset_rows(dst, init, step):
     return dst
 
 
-def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx):
-    """Window-table lookup of one rollout step + staging (all outputs preallocated, in place)."""
+def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx, t_row=None, reset=None):
+    """Window-table lookup of one rollout step + staging (all outputs preallocated, in place).  Optional riders of the same
+    launch: ``t_row`` (int64 scalar tensor) receives the staging row t, ``reset = (cache [W, ...], init [...])`` performs
+    ``reset_rows(cache, init, step)``."""
     lib = _lib.load()
     W, L = win_t.shape
+    rdst = rinit = None
+    relems = 0
+    if reset is not None:
+        rdst, rinit = reset
+        if not rdst.is_contiguous() or not rinit.is_contiguous() or rdst.shape[0] != W:
+            raise TypeError("reset needs a contiguous cache [W, ...] and a contiguous initial row")
+        relems = rinit.numel()
     _lib.check(lib.etm_rollout_window(_ptr(step), _ptr(mask_table), _ptr(index_table), _ptr(t_dev), _ptr(mask_t), _ptr(win_t),
-                                      _ptr(st_mask), _ptr(st_idx), W, L, _stream()), "etm_rollout_window")
+                                      _ptr(st_mask), _ptr(st_idx), _ptr(t_row), _ptr(rdst), _ptr(rinit), relems, W, L, _stream()),
+               "etm_rollout_window")
 
 
 def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values):
@@ -350,21 +360,34 @@ def gru_gate(x, y, wy, ux, ug, bg):
     return out
 
 
-def add_layernorm(a, b, norm):
+def add_layernorm(a, b, norm, out=None):
     """LayerNorm(a + b) with ``norm``'s affine parameters; forward only (rollout path)."""
     lib = _lib.load()
     _need_dev(a, b)
     a, b = _f32c(a, "a"), _f32c(b, "b")
     N, D = a.shape
-    out = torch.empty_like(a)
+    if out is None:
+        out = torch.empty_like(a)
+    elif out.shape != a.shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise TypeError("add_layernorm: out must be a contiguous float32 tensor of the input shape")
     _lib.check(lib.etm_add_layernorm(_ptr(a), _ptr(b), _ptr(norm.weight), _ptr(norm.bias), float(norm.eps), _ptr(out), N, D, _stream()),
                "etm_add_layernorm")
     return out
 
 
+def conv_pack_weights(weight2d):
+    """[Cout, K] (K in the order that matches the input layout) -> the MFMA-fragment order etm_conv_relu reads
+    (include/etm_hip.h): packed[g, t, half, col, j] = w[t * 32 + col, g * 8 + half * 4 + j]; returned as [Cout, K]."""
+    Cout, K = weight2d.shape
+    if Cout % 32 or K % 8:
+        raise ValueError("conv_pack_weights needs Cout % 32 == 0 and K % 8 == 0")
+    w = weight2d.reshape(Cout // 32, 32, K // 8, 2, 4)          # [t, col, g, half, j]
+    return w.permute(2, 0, 3, 1, 4).contiguous().view(Cout, K)   # [g, t, half, col, j]
+
+
 def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw):
-    """relu(conv2d(x) + bias) on the no-grad path (see etm_conv_relu).  ``weight2d`` [Cout, K] in the K order that matches
-    the input layout.  Returns NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
+    """relu(conv2d(x) + bias) on the no-grad path (see etm_conv_relu).  ``weight2d``: ``conv_pack_weights`` of the [Cout, K]
+    weights in the K order that matches the input layout.  Returns NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
     lib = _lib.load()
     _need_dev(x, weight2d, bias)
     x = _f32c(x, "x")
@@ -381,22 +404,30 @@ def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw):
 _fused_linear_relu = None  # None: untested, True/False after the first call
 
 
-def linear_relu(lin, x):
+def linear_relu(lin, x, out=None):
     """relu(lin(x)).  In the no-grad rollout path the ReLU rides in the GEMM epilogue (hipBLASLt through
-    ``torch._addmm_activation``), saving one launch per layer; with autograd enabled it is the plain two-op form."""
+    ``torch._addmm_activation``), saving one launch per layer; with autograd enabled it is the plain two-op form.
+    ``out`` (no-grad only): contiguous destination."""
     global _fused_linear_relu
+
+    def plain():
+        y = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+        return y if out is None else out.copy_(y)
+
     if torch.is_grad_enabled() or _fused_linear_relu is False or x.dim() != 2:
-        return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+        return plain()
     if _fused_linear_relu is None:
         if torch.cuda.is_current_stream_capturing():
-            return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+            return plain()
         try:
             y = torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
             ref = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
             _fused_linear_relu = bool(torch.allclose(y, ref, atol=1e-5, rtol=1e-5))
         except Exception:
             _fused_linear_relu = False
-        return torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+        return plain()
+    if out is not None:
+        return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False, out=out)
     return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
 
 

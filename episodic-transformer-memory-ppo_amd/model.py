@@ -82,21 +82,25 @@ class ActorCriticModel(nn.Module):
         if not self.visual:
             return
         with torch.no_grad():
-            for name, conv in (("_w2p", self.conv2), ("_w3p", self.conv3)):
-                perm = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, -1)
+            # encoder weights in the K order of each layer's input layout (layer 1 reads NCHW: native order; layers 2, 3 read
+            # NHWC: (ky, kx, c)), packed in MFMA fragment order (ops.conv_pack_weights)
+            for name, conv, nhwc in (("_w1p", self.conv1, False), ("_w2p", self.conv2, True), ("_w3p", self.conv3, True)):
+                w4 = conv.weight.permute(0, 2, 3, 1) if nhwc else conv.weight
+                perm = ops.conv_pack_weights(w4.reshape(conv.out_channels, -1))
                 buf = getattr(self, name, None)
                 if buf is None or buf.shape != perm.shape or buf.device != perm.device:
                     setattr(self, name, perm.contiguous())
                 else:
                     buf.copy_(perm)
-            self._wver = (self.conv2.weight._version, self.conv3.weight._version)
+            self._wver = (self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
 
     def _encode_fused(self, obs):
         if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()
-                                                     and self._wver != (self.conv2.weight._version, self.conv3.weight._version)):
+                                                     and self._wver != (self.conv1.weight._version, self.conv2.weight._version,
+                                                                        self.conv3.weight._version)):
             self.refresh_rollout_weights()
         n, c, hh, ww = obs.shape
-        x = ops.conv_relu(obs, self.conv1.weight.reshape(32, -1), self.conv1.bias, c, hh, ww, 8, 8, 4, False, False)   # -> NHWC
+        x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False)                               # -> NHWC
         h1, w1 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)
         h2, w2 = x.shape[1], x.shape[2]
@@ -126,9 +130,10 @@ class ActorCriticModel(nn.Module):
         value = self.value(h_value).reshape(-1)
         return [branch(h_policy) for branch in self.policy_branches], value, memory
 
-    def forward_logits_cached(self, obs, kv_spec: WindowSpec):
-        """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache."""
-        h, memory = self.transformer.forward_cached(self._encode(obs), kv_spec)
+    def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None):
+        """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache.  With ``items_out``
+        [blocks, N, D] the new memory items are written there (block-major) and returned in that layout."""
+        h, memory = self.transformer.forward_cached(self._encode(obs), kv_spec, items_out)
         if len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled():
             # [lin_policy ; lin_value] as ONE GEMM (+ReLU epilogue), then both output heads in one small kernel
             h2 = ops.linear_relu(self._heads_lin, h)

@@ -137,13 +137,15 @@ class PPOTrainer:
         self._obs_pin = torch.zeros((W,) + obs_shape, dtype=torch.float32).pin_memory()
         self.obs = self._obs_pin.numpy()
         self._act_pin = torch.zeros((W, len(self.action_space_shape)), dtype=torch.int64).pin_memory()
-        self._step_pin = torch.zeros((W,), dtype=torch.int64).pin_memory()
-        self._slot_pin = torch.zeros((W,), dtype=torch.int64).pin_memory()
+        # (episode step, episode slot) of every worker: one pinned [2, W] block, uploaded with ONE copy per rollout step
+        self._ss_pin = torch.zeros((2, W), dtype=torch.int64).pin_memory()
+        self._step_pin, self._slot_pin = self._ss_pin[0], self._ss_pin[1]
         self.worker_current_episode_step = self._step_pin.numpy()   # host truth, mirrored on device each step
         self.worker_episode_slot = self._slot_pin.numpy()
         self.worker_episode_slot[:] = np.arange(W)
-        self._step_dev = torch.zeros((W,), dtype=torch.int64, device=device)
-        self._slot_dev = torch.arange(W, dtype=torch.int64, device=device)
+        self._ss_dev = torch.zeros((2, W), dtype=torch.int64, device=device)
+        self._ss_dev[1] = torch.arange(W, dtype=torch.int64, device=device)
+        self._step_dev, self._slot_dev = self._ss_dev[0], self._ss_dev[1]
         self.env.reset(out=self.obs)
 
         # fixed-address operands of the rollout step (HIP-graph friendly) and time-major staging of the step outputs
@@ -165,7 +167,7 @@ class PPOTrainer:
         self._step_graph = None
         self._act_ready = torch.cuda.Event()
         self._t_row = torch.zeros((), dtype=torch.int64, device=device)
-        self._item = torch.zeros((W, self.num_blocks, self.embed_dim), dtype=torch.float32, device=device)
+        self._item = torch.zeros((self.num_blocks, W, self.embed_dim), dtype=torch.float32, device=device)   # block-major
         # rollout K/V cache (weights are frozen while sampling): per worker [T, blocks, 2D] projections of its episode
         self._use_kv_cache = bool(config.get("kv_cache_rollout", True))
         T, nb, D = self.max_episode_length, self.num_blocks, self.embed_dim
@@ -294,22 +296,23 @@ class PPOTrainer:
         Returns what the tail needs (the new memory item)."""
         buf = self.buffer
         self._obs_dev.copy_(self._obs_pin, non_blocking=True)
-        self._step_dev.copy_(self._step_pin, non_blocking=True)
-        self._slot_dev.copy_(self._slot_pin, non_blocking=True)
+        self._ss_dev.copy_(self._ss_pin, non_blocking=True)
         st = self._stage
         single = len(self.action_space_shape) == 1
         mask_t, win_t = self._mask_t, self._win_t
+        # window lookup + staging; the same launch records the staging row of this step for the tail (t_dev is incremented by
+        # the sampling kernel) and resets the K/V cache of workers at episode step 0 (they start from the projection of an
+        # empty memory)
         ops.rollout_window(self._step_dev, self._mask_table, self._index_table, self._t_dev, mask_t, win_t,
-                           st["memory_mask"], st["memory_indices"])
+                           st["memory_mask"], st["memory_indices"], t_row=self._t_row,
+                           reset=(self._kv_cache, self._kv_init) if self._use_kv_cache else None)
         if self._use_kv_cache:
-            # a worker at episode step 0 starts from the projection of an empty memory
-            ops.reset_rows(self._kv_cache, self._kv_init, self._step_dev)
             kv_spec = WindowSpec.from_bank(self._kv_cache, None, win_t, None, mask_t)
-            logits, value, item = self.model.forward_logits_cached(self._obs_dev, kv_spec)
+            logits, value, item = self.model.forward_logits_cached(self._obs_dev, kv_spec, items_out=self._item)
         else:
             spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
             logits, value, item = self.model.forward_logits(self._obs_dev, spec)
-        self._t_row.copy_(self._t_dev)               # row index of this step for the tail (t_dev is incremented below)
+            item = item.transpose(0, 1)
         if single:
             # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
             ops.rollout_sample(logits[0], value, self._uniforms, forced_t, self._t_dev, self._act_dev,
@@ -328,13 +331,15 @@ class PPOTrainer:
             st["values"].index_copy_(0, row, value.unsqueeze(0))
             self._t_dev.add_(1)
         self._act_pin.copy_(self._act_dev, non_blocking=True)
-        self._item.copy_(item)
+        if item.data_ptr() != self._item.data_ptr():
+            self._item.copy_(item)
         return self._item
 
     def _rollout_step_tail(self, item):
         """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
         K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
         buf, st = self.buffer, self._stage
+        item = item.transpose(0, 1)                  # block-major staging -> [W, blocks, D]
         buf.bank[self._slot_dev, self._step_dev] = item
         if self._use_kv_cache:
             tr = self.model.transformer

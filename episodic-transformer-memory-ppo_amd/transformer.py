@@ -118,26 +118,26 @@ class TransformerBlock(Module):
         att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
         return self._after_attention(h, att_out), att_w
 
-    def forward_cached(self, h, kv_spec: WindowSpec, block=0):
-        """Rollout path: attention over cached K/V projections (no grad)."""
+    def forward_cached(self, h, kv_spec: WindowSpec, block=0, out=None):
+        """Rollout path: attention over cached K/V projections (no grad).  ``out``: contiguous destination of the result."""
         q_in = self.norm1(h) if self.layer_norm == "pre" else h
         ctx, _ = ops.attn_cached(self.attention.queries(q_in), kv_spec, block, self.attention.num_heads)
-        return self._after_attention(h, self.attention.fc_out(ctx))
+        return self._after_attention(h, self.attention.fc_out(ctx), out)
 
-    def _after_attention(self, h, att_out):
+    def _after_attention(self, h, att_out, out=None):
         pre, post = self.layer_norm == "pre", self.layer_norm == "post"
         if post and not self.use_gtrxl and not torch.is_grad_enabled():
             # rollout: residual + LayerNorm and Linear + ReLU are one launch each
             x = ops.add_layernorm(att_out, h, self.norm1)
-            return ops.add_layernorm(ops.linear_relu(self.fc[0], x), x, self.norm2)
+            return ops.add_layernorm(ops.linear_relu(self.fc[0], x), x, self.norm2, out=out)
         x = self.gate1(h, att_out) if self.use_gtrxl else att_out + h
         if post:
             x = self.norm1(x)
         f = ops.linear_relu(self.fc[0], self.norm2(x) if pre else x)
-        out = self.gate2(x, f) if self.use_gtrxl else f + x
+        res = self.gate2(x, f) if self.use_gtrxl else f + x
         if post:
-            out = self.norm2(out)
-        return out
+            res = self.norm2(res)
+        return res if out is None else out.copy_(res)
 
     def forward(self, value, key, query, mask):
         """Upstream signature: value/key [N, L, D] (same tensor), query [N, 1, D], mask [N, L]."""
@@ -227,8 +227,16 @@ class Transformer(nn.Module):
             x = torch.nn.functional.layer_norm(x, (x.shape[-1],), None, None, eps) * g + bb
         return torch.bmm(x.transpose(0, 1), w).transpose(0, 1)
 
-    def forward_cached(self, h, kv_spec: WindowSpec):
-        """Rollout path of ``forward_window``: attention reads the K/V cache addressed by ``kv_spec``."""
+    def forward_cached(self, h, kv_spec: WindowSpec, items_out=None):
+        """Rollout path of ``forward_window``: attention reads the K/V cache addressed by ``kv_spec``.
+        ``items_out`` [blocks, N, D] (block-major, preallocated): every block's input -- the new memory items -- is produced
+        directly in it (no stack / copy launches); it is then returned instead of the [N, blocks, D] stack."""
+        nb = len(self.transformer_blocks)
+        if items_out is not None:
+            h = ops.linear_relu(self.linear_embedding, h, out=items_out[0])
+            for i, blk in enumerate(self.transformer_blocks):
+                h = blk.forward_cached(h, kv_spec, i, out=items_out[i + 1] if i + 1 < nb else None)
+            return h, items_out
         h = ops.linear_relu(self.linear_embedding, h)
         items = []
         for i, blk in enumerate(self.transformer_blocks):

@@ -161,14 +161,17 @@ int etm_reset_rows(float *dst, const float *init, const int64_t *step, int W, in
  * what would be ~8 / ~17 / 2 framework launches into one each.  All operands have fixed addresses (HIP-graph friendly);
  * `t_dev` is a device-resident step counter, staging arrays are time-major [S, W, ...].
  *   etm_rollout_window: mask_t[w] = mask_table[clip(step[w], 0, L-1)], win_t[w] = index_table[step[w]] (trainer.py:165-166),
- *                       also stored to row *t_dev of st_mask / st_idx.
+ *                       also stored to row *t_dev of st_mask / st_idx.  Optional riders of the same launch: *t_row = *t_dev
+ *                       (t_row non-NULL) and etm_reset_rows(reset_dst, reset_init, step, W, reset_row_elems) (reset_dst non-NULL).
  *   etm_rollout_sample: per worker log-softmax of logits [W,A], categorical sample by inverse CDF with the pre-drawn
  *                       uniform uniforms[*t_dev, w] (or forced[w] if non-NULL), log-prob; writes actions [W] and row *t_dev
  *                       of st_actions / st_logp / st_values, then *t_dev += 1 (trainer.py:179-186).
  *   etm_add_layernorm:  out = LayerNorm(a + b) (residual + post-LN, transformer.py:145-149 / :166-170), forward only, D <= 1024.
  */
 int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
-                       uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int W, int L, void *stream);
+                       uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx,
+                       int64_t *t_row, float *reset_dst, const float *reset_init, int64_t reset_row_elems,
+                       int W, int L, void *stream);
 int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
                        int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
 int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
@@ -186,7 +189,10 @@ int etm_rollout_heads(const float *h, const float *wp, const float *bp, const fl
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
  * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C];
- * w: [Cout, K] with K ordered (c, ky, kx) for NCHW input (= the native torch layout) or (ky, kx, c) for NHWC input;
+ * w: the [Cout, K] weight matrix, K ordered (c, ky, kx) for NCHW input (= the native torch layout) or (ky, kx, c) for NHWC
+ *    input, PACKED in MFMA fragment order: packed[((g * Cout/32 + t) * 64 + half * 32 + col) * 4 + j]
+ *    = w2d[t * 32 + col][g * 8 + half * 4 + j]   (g < K/8, t < Cout/32, half < 2, col < 32, j < 4), so that a wave reads the
+ *    B fragment of one 8-wide k-group with one contiguous 1 KB load (etm.ops.conv_pack_weights does the packing);
  * out: NHWC [N,Ho,Wo,Cout] or NCHW (out_nchw = 1).  Shape support: Cout in {32, 64}; NCHW input: KW % 8 == 0, W % 4 == 0,
  * S % 4 == 0; NHWC input: (KW * C) % 8 == 0, C % 4 == 0.  (Covers the three layers of the Atari-style encoder.) */
 int etm_conv_relu(const float *in, const float *w, const float *bias, float *out, int N, int C, int H, int W, int Cout,

@@ -17,6 +17,15 @@ build() {  # name, flags...
   rm -f $OUT/fwd_$name.o $OUT/bwd_$name.o
   echo built $name
 }
+if [ "$1" = "window" ]; then
+  for v in base loadonly trace; do
+    fl=""; [ $v = loadonly ] && fl="-DETM_DIAG_LOAD_ONLY"; [ $v = trace ] && fl="-DETM_DIAG_TRACE"
+    /opt/rocm/bin/hipcc $FLAGS $fl -c $SRC/window_attn.hip -o $OUT/win_$v.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/win_$v.o $(ls $SRC/build/*.o | grep -v window_attn.o) -o $OUT/libetm_win_$v.so
+    rm -f $OUT/win_$v.o; echo built win_$v
+  done
+  exit 0
+fi
 if [ "$1" = "prio" ]; then
   build base &
   build stage3 -DETM_PRIO_OTHER=3 -DETM_PRIO_MFMA=0 &

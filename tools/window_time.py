@@ -4,7 +4,10 @@ import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
 import torch
-from etm import ops, lib as etm_lib
+from etm import lib as etm_lib
+if os.environ.get("ETM_DIAG_LIB"):
+    etm_lib.LIB_PATH = os.environ["ETM_DIAG_LIB"]   # diagnostic variants (tools/diag_variants.sh)
+from etm import ops
 dev = torch.device("cuda"); torch.manual_seed(0)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 384
@@ -42,3 +45,19 @@ for name, x, y in zip(("ctx", "dq", "dwk", "dwv"), a, b):
     print(f"  folded vs dense {name}: max abs diff {(x - y).abs().max().item():.3e}  rel-to-norm {((x - y).norm() / y.norm()).item():.3e}")
 gb = N * L * D * 4 / 1e9
 print(f"  window bytes per pass (un-deduplicated) {gb * 1e3:.1f} MB")
+
+if os.environ.get("ETM_DIAG_LIB", "").endswith("trace.so"):
+    import ctypes, numpy as np
+    ops.set_attention_impl("folded")
+    out, att = ops.mha(q, wk, wv, spec, 1, H); torch.cuda.synchronize()      # last launch = one forward pass
+    buf = np.zeros(2048 * 8 * 16, dtype=np.uint64)
+    f = l.etm_diag_win_trace_read; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    assert f(buf.ctypes.data, buf.nbytes) == 0
+    t = buf.reshape(2048, 8, 16).astype(np.int64)
+    names = ["", "start", "bookkeeping loaded", "rows loaded", "pass1+reduce", "barrier", "softmax", "barrier", "pass2", "barrier", "sum+store", "end"]
+    print("  per-wave phase durations (s_memtime ticks, mean / p90):")
+    for i in range(2, 12):
+        d = t[:, :, i] - t[:, :, i - 1]
+        print(f"    {names[i]:20s} {d.mean():8.0f} {np.percentile(d, 90):8.0f}")
+    life = t[:, :, 11] - t[:, :, 1]
+    print(f"    lifetime {life.mean():.0f}; kernel span {t[:, :, 11].max() - t[:, :, 1].min()} ticks")
