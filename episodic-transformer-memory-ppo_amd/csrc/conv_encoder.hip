@@ -17,6 +17,8 @@
 
 namespace {
 struct ConvParams {
+  const long long *in_index;   // optional: input = in + *in_index * in_index_stride (row of a time-major staging array)
+  long long in_index_stride;
   const float *in, *w, *bias;
   float *out;
   int N, C, H, W, Cout, KH, KW, S, Ho, Wo;
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
   const int n = m / (p.Ho * p.Wo);
   const int rem = m - n * p.Ho * p.Wo;
   const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const float *in_base = p.in + (p.in_index ? *p.in_index * p.in_index_stride : 0);
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
       const int c = seg / p.KH, ky = seg - c * p.KH;
       base = (((long long)n * p.C + c) * p.H + oy * p.S + ky) * p.W + ox * p.S;
     }
-    return p.in + base + off + half * 4;
+    return in_base + base + off + half * 4;
   };
 
   // Wave w takes k-groups w, w + NW, ...  in batches of GB; the loads of batch i+1 are issued before the MFMAs of batch i
@@ -120,11 +123,13 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
 }
 }  // namespace
 
-extern "C" int etm_conv_relu(const float *in, const float *w, const float *bias, float *out, int N, int C, int H, int W, int Cout,
-                             int KH, int KW, int S, int in_nhwc, int out_nchw, void *stream) {
+extern "C" int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_stride, const float *w, const float *bias,
+                             float *out, int N, int C, int H, int W, int Cout, int KH, int KW, int S, int in_nhwc, int out_nchw,
+                             void *stream) {
   (void)hipGetLastError();
   if (!in || !w || !bias || !out || N <= 0 || C <= 0 || H < KH || W < KW || Cout <= 0 || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   ConvParams p;
+  p.in_index = (const long long *)in_index; p.in_index_stride = in_index_stride;
   p.in = in; p.w = w; p.bias = bias; p.out = out; p.N = N; p.C = C; p.H = H; p.W = W; p.Cout = Cout; p.KH = KH; p.KW = KW; p.S = S;
   p.Ho = (H - KH) / S + 1; p.Wo = (W - KW) / S + 1; p.in_nhwc = in_nhwc; p.out_nchw = out_nchw;
   p.seg_len = in_nhwc ? KW * C : KW;

@@ -79,3 +79,11 @@ extern "C" int etm_profile_collect(double *total_ms, int64_t *count) {
   g_recs.clear();
   return rc;
 }
+
+// Asynchronous pinned-host -> device copy on `stream` (the trainer streams observation rows to the device while the
+// environments are still producing the rest; a bare runtime call keeps the per-chunk host cost at a few microseconds).
+extern "C" int etm_upload(void *dst, const void *src, int64_t bytes, void *stream) {
+  (void)hipGetLastError();
+  if (!dst || !src || bytes <= 0) return ETM_EINVAL;
+  return (int)hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+}

@@ -118,12 +118,21 @@ class SyntheticVecEnv:
         self._t = np.zeros(self.num_envs, dtype=np.int64)
         self._ret = np.zeros(self.num_envs, dtype=np.float64)
 
-    def _emit(self, out):
+    ROW_CHUNKS = 4   # on_rows granularity (vec_env protocol)
+
+    def _emit(self, out, on_rows=None):
         frame = self._frames[:, self._cursor % self._pool]
         self._cursor += 1
         if out is None:
-            return frame.copy()
-        np.copyto(out, frame)
+            out = np.empty_like(frame)
+        if on_rows is None:
+            np.copyto(out, frame)
+            return out
+        step = max(1, -(-self.num_envs // self.ROW_CHUNKS))
+        for lo in range(0, self.num_envs, step):       # rows are handed over as soon as they are written
+            hi = min(lo + step, self.num_envs)
+            np.copyto(out[lo:hi], frame[lo:hi])
+            on_rows(lo, hi)
         return out
 
     def reset(self, out=None):
@@ -131,7 +140,7 @@ class SyntheticVecEnv:
         self._ret[:] = 0.0
         return self._emit(out)
 
-    def step(self, actions, out=None):
+    def step(self, actions, out=None, on_rows=None):
         if self._upos >= _CHUNK:
             for w, rng in enumerate(self._rngs):
                 self._u[w] = rng.random((_CHUNK, 2))
@@ -148,7 +157,7 @@ class SyntheticVecEnv:
                 infos[w] = {"reward": float(self._ret[w]), "length": int(self._t[w])}
             self._t[dones] = 0
             self._ret[dones] = 0.0
-        obs = self._emit(out)  # for finished workers this frame *is* the reset observation
+        obs = self._emit(out, on_rows)  # for finished workers this frame *is* the reset observation
         return obs, rewards, dones, infos
 
     def close(self):

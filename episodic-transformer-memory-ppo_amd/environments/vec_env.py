@@ -3,7 +3,9 @@
 ``VecEnv`` protocol (what ``PPOTrainer`` steps):
     num_envs, observation_space_shape, num_actions, max_episode_steps
     reset(out=None) -> obs [W, *obs_shape] float32
-    step(actions [W] or [W, B], out=None) -> (obs, rewards [W] f32, dones [W] bool, infos [W] (dict or None))
+    step(actions [W] or [W, B], out=None, on_rows=None) -> (obs, rewards [W] f32, dones [W] bool, infos [W] (dict or None))
+        on_rows(lo, hi), optional: called as soon as observation rows [lo, hi) of ``out`` are final, in increasing order and
+        covering [0, W) -- the trainer starts their upload while the remaining environments still step
 with auto-reset: for a finished worker the returned observation is already the first one of the next episode, which
 is exactly what upstream's loop does by hand (trainer.py:195-201).
 
@@ -15,8 +17,21 @@ import numpy as np
 
 
 class _VecBase:
+    ROW_CHUNKS = 4   # on_rows granularity: W / ROW_CHUNKS workers per notification
+
     def _alloc(self, out):
         return out if out is not None else np.zeros((self.num_envs,) + self.observation_space_shape, dtype=np.float32)
+
+    def _notify(self, on_rows, done_upto, sent_upto):
+        """Call on_rows for the complete chunks in [sent_upto, done_upto); returns the new sent_upto."""
+        if on_rows is None:
+            return sent_upto
+        step = max(1, -(-self.num_envs // self.ROW_CHUNKS))
+        while sent_upto + step <= done_upto or (done_upto == self.num_envs and sent_upto < done_upto):
+            hi = min(sent_upto + step, self.num_envs)
+            on_rows(sent_upto, hi)
+            sent_upto = hi
+        return sent_upto
 
 
 class SerialVecEnv(_VecBase):
@@ -34,18 +49,20 @@ class SerialVecEnv(_VecBase):
             out[w] = e.reset()
         return out
 
-    def step(self, actions, out=None):
+    def step(self, actions, out=None, on_rows=None):
         out = self._alloc(out)
         actions = np.asarray(actions).reshape(self.num_envs, -1)
         rewards = np.zeros(self.num_envs, dtype=np.float32)
         dones = np.zeros(self.num_envs, dtype=bool)
         infos = [None] * self.num_envs
+        sent = 0
         for w, e in enumerate(self.envs):
             obs, rewards[w], dones[w], info = e.step(actions[w])
             if info:
                 infos[w] = info
                 obs = e.reset()
             out[w] = obs
+            sent = self._notify(on_rows, w + 1, sent)
         return out, rewards, dones, infos
 
     def close(self):
@@ -76,7 +93,7 @@ class PipeVecEnv(_VecBase):
             out[w] = self._recv(wk)
         return out
 
-    def step(self, actions, out=None):
+    def step(self, actions, out=None, on_rows=None):
         out = self._alloc(out)
         actions = np.asarray(actions).reshape(self.num_envs, -1)
         for w, wk in enumerate(self.workers):
@@ -84,6 +101,7 @@ class PipeVecEnv(_VecBase):
         rewards = np.zeros(self.num_envs, dtype=np.float32)
         dones = np.zeros(self.num_envs, dtype=bool)
         infos = [None] * self.num_envs
+        sent = 0
         for w, wk in enumerate(self.workers):
             obs, rewards[w], dones[w], info = self._recv(wk)
             if info:
@@ -91,6 +109,7 @@ class PipeVecEnv(_VecBase):
                 wk.child.send(("reset", None))
                 obs = self._recv(wk)
             out[w] = obs
+            sent = self._notify(on_rows, w + 1, sent)
         return out, rewards, dones, infos
 
     @staticmethod

@@ -385,20 +385,39 @@ def conv_pack_weights(weight2d):
     return w.permute(2, 0, 3, 1, 4).contiguous().view(Cout, K)   # [g, t, half, col, j]
 
 
-def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw):
+def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw, index=None):
     """relu(conv2d(x) + bias) on the no-grad path (see etm_conv_relu).  ``weight2d``: ``conv_pack_weights`` of the [Cout, K]
-    weights in the K order that matches the input layout.  Returns NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
+    weights in the K order that matches the input layout.  With ``index`` (int64 device scalar) ``x`` is a stack [S, N, ...]
+    and the layer reads x[index] -- the row is chosen on the device, so a captured graph can walk a staging array.
+    Returns NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
     lib = _lib.load()
-    _need_dev(x, weight2d, bias)
+    _need_dev(x, weight2d, bias, index)
     x = _f32c(x, "x")
-    N, Cout = x.shape[0], weight2d.shape[0]
+    stride = 0
+    if index is not None:
+        if index.dtype != torch.int64 or index.numel() != 1:
+            raise TypeError("conv_relu: index must be an int64 device scalar")
+        stride = x[0].numel()
+        N = x.shape[1]
+    else:
+        N = x.shape[0]
+    Cout = weight2d.shape[0]
     Ho, Wo = (H - KH) // S + 1, (W - KW) // S + 1
     shape = (N, Cout, Ho, Wo) if out_nchw else (N, Ho, Wo, Cout)
     out = torch.empty(shape, dtype=torch.float32, device=x.device)
-    rc = lib.etm_conv_relu(_ptr(x), _ptr(weight2d), _ptr(bias), _ptr(out), N, C, H, W, Cout, KH, KW, S, 1 if in_nhwc else 0,
-                           1 if out_nchw else 0, _stream())
+    rc = lib.etm_conv_relu(_ptr(x), _ptr(index), stride, _ptr(weight2d), _ptr(bias), _ptr(out), N, C, H, W, Cout, KH, KW, S,
+                           1 if in_nhwc else 0, 1 if out_nchw else 0, _stream())
     _lib.check(rc, "etm_conv_relu")
     return out
+
+
+def upload(dst, src_pinned, stream):
+    """Asynchronous pinned-host -> device copy of a contiguous block on ``stream`` (a torch.cuda.Stream)."""
+    lib = _lib.load()
+    nbytes = src_pinned.numel() * src_pinned.element_size()
+    if not (dst.is_contiguous() and src_pinned.is_contiguous()) or dst.numel() * dst.element_size() != nbytes:
+        raise TypeError("upload needs contiguous blocks of equal size")
+    _lib.check(lib.etm_upload(dst.data_ptr(), src_pinned.data_ptr(), nbytes, stream.cuda_stream), "etm_upload")
 
 
 _fused_linear_relu = None  # None: untested, True/False after the first call

@@ -94,20 +94,26 @@ class ActorCriticModel(nn.Module):
                     buf.copy_(perm)
             self._wver = (self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
 
-    def _encode_fused(self, obs):
+    def _encode_fused(self, obs, obs_index=None):
         if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()
                                                      and self._wver != (self.conv1.weight._version, self.conv2.weight._version,
                                                                         self.conv3.weight._version)):
             self.refresh_rollout_weights()
-        n, c, hh, ww = obs.shape
-        x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False)                               # -> NHWC
+        n, c, hh, ww = obs.shape[-4:]      # with obs_index: obs is a stack [S, N, C, H, W] and the layer reads obs[obs_index]
+        x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False, index=obs_index)              # -> NHWC
         h1, w1 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)
         h2, w2 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w3p, self.conv3.bias, 64, h2, w2, 3, 3, 1, True, True)                                # -> NCHW
         return ops.linear_relu(self.lin_hidden, x.reshape(n, -1))
 
-    def _encode(self, obs):
+    def _encode(self, obs, obs_index=None):
+        """Observation encoder.  ``obs_index`` (int64 device scalar, fused rollout encoder only): ``obs`` is a time-major
+        stack [S, N, C, H, W] and row obs[obs_index] is encoded (the row is selected on the device)."""
+        if obs_index is not None:
+            if not self._fused_encoder_ok(obs[0]):
+                raise RuntimeError("obs_index needs the fused rollout encoder (visual observations, no grad)")
+            return self._encode_fused(obs, obs_index)
         h = obs
         if self._fused_encoder_ok(obs):
             return self._encode_fused(obs)
@@ -130,10 +136,10 @@ class ActorCriticModel(nn.Module):
         value = self.value(h_value).reshape(-1)
         return [branch(h_policy) for branch in self.policy_branches], value, memory
 
-    def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None):
+    def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None):
         """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache.  With ``items_out``
         [blocks, N, D] the new memory items are written there (block-major) and returned in that layout."""
-        h, memory = self.transformer.forward_cached(self._encode(obs), kv_spec, items_out)
+        h, memory = self.transformer.forward_cached(self._encode(obs, obs_index), kv_spec, items_out)
         if len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled():
             # [lin_policy ; lin_value] as ONE GEMM (+ReLU epilogue), then both output heads in one small kernel
             h2 = ops.linear_relu(self._heads_lin, h)

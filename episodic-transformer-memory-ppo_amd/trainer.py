@@ -166,6 +166,11 @@ class PPOTrainer:
         self._uniforms = torch.zeros((S, W), dtype=torch.float32, device=device)
         self._step_graph = None
         self._act_ready = torch.cuda.Event()
+        # observation streaming (graph rollout with the fused encoder): rows of the next observation go from pinned memory
+        # straight into their row of the time-major staging array on a second stream while the environments still step
+        self._up_stream = torch.cuda.Stream(device=device)
+        self._up_done = torch.cuda.Event()
+        self._stream_obs = False     # decided when the step graph is captured
         self._t_row = torch.zeros((), dtype=torch.int64, device=device)
         self._item = torch.zeros((self.num_blocks, W, self.embed_dim), dtype=torch.float32, device=device)   # block-major
         # rollout K/V cache (weights are frozen while sampling): per worker [T, blocks, 2D] projections of its episode
@@ -250,8 +255,19 @@ class PPOTrainer:
         self._t_dev.zero_()
         self._uniforms.uniform_()                # one draw per (step, worker) for the whole rollout
         t_env = 0.0
+        stream_obs = use_graph and self._stream_obs
+        if stream_obs:
+            lib = etm_lib.load()
+            up = self._up_stream.cuda_stream
+            row_bytes = self._obs_pin[0].numel() * 4
+            src_base, stage_base = self._obs_pin.data_ptr(), self._stage["obs"].data_ptr()
+            self._up_stream.wait_stream(stream)          # the staging array may still be read by the previous update
+            etm_lib.check(lib.etm_upload(stage_base, src_base, W * row_bytes, up), "etm_upload")
+            self._up_done.record(self._up_stream)
         for t in range(S):
             if use_graph:
+                if stream_obs:
+                    stream.wait_event(self._up_done)     # rows of observation t are in staging row t
                 self._step_graph[0].replay()
                 self._act_ready.record(stream)       # actions are in pinned memory once this event completes
                 self._step_graph[1].replay()         # tail runs while the host steps the environments
@@ -262,7 +278,16 @@ class PPOTrainer:
                     self._rollout_step_tail(carry)
             self._act_ready.synchronize()
             te = time.perf_counter()
-            _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
+            if stream_obs and t + 1 < S:
+                dst_base = stage_base + (t + 1) * W * row_bytes
+
+                def rows_ready(lo, hi):
+                    lib.etm_upload(dst_base + lo * row_bytes, src_base + lo * row_bytes, (hi - lo) * row_bytes, up)
+
+                _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs, on_rows=rows_ready)
+                self._up_done.record(self._up_stream)
+            else:
+                _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
             t_env += time.perf_counter() - te
             buf.rewards[:, t] = rewards
             buf.dones[:, t] = dones
@@ -285,19 +310,23 @@ class PPOTrainer:
         self.last_update_timing["env_s"] = t_env
         return episode_infos
 
-    def _rollout_step_device(self, forced_t=None):
+    def _rollout_step_device(self, forced_t=None, stream_obs=False):
         """Device side of one rollout step (upstream trainer.py:161-186) = head + tail."""
-        carry = self._rollout_step_head(forced_t)
-        self._rollout_step_tail(carry)
+        carry = self._rollout_step_head(forced_t, stream_obs)
+        self._rollout_step_tail(carry, stream_obs)
 
-    def _rollout_step_head(self, forced_t=None):
+    def _rollout_step_head(self, forced_t=None, stream_obs=False):
         """Everything the ACTIONS depend on: observation / step / slot upload, window lookup, model forward, sampling,
         staging of the step's rows, action download.  Every operand has a fixed address (HIP-graph capturable).
         Returns what the tail needs (the new memory item)."""
         buf = self.buffer
-        self._obs_dev.copy_(self._obs_pin, non_blocking=True)
-        self._ss_dev.copy_(self._ss_pin, non_blocking=True)
         st = self._stage
+        if stream_obs:      # the observation of this step is already in row t of the staging array (see _sample_training_data)
+            obs, obs_index = st["obs"], self._t_dev
+        else:
+            self._obs_dev.copy_(self._obs_pin, non_blocking=True)
+            obs, obs_index = self._obs_dev, None
+        self._ss_dev.copy_(self._ss_pin, non_blocking=True)
         single = len(self.action_space_shape) == 1
         mask_t, win_t = self._mask_t, self._win_t
         # window lookup + staging; the same launch records the staging row of this step for the tail (t_dev is incremented by
@@ -308,10 +337,10 @@ class PPOTrainer:
                            reset=(self._kv_cache, self._kv_init) if self._use_kv_cache else None)
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(self._kv_cache, None, win_t, None, mask_t)
-            logits, value, item = self.model.forward_logits_cached(self._obs_dev, kv_spec, items_out=self._item)
+            logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
         else:
             spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
-            logits, value, item = self.model.forward_logits(self._obs_dev, spec)
+            logits, value, item = self.model.forward_logits(obs, spec)
             item = item.transpose(0, 1)
         if single:
             # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
@@ -335,7 +364,7 @@ class PPOTrainer:
             self._item.copy_(item)
         return self._item
 
-    def _rollout_step_tail(self, item):
+    def _rollout_step_tail(self, item, stream_obs=False):
         """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
         K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
         buf, st = self.buffer, self._stage
@@ -346,7 +375,8 @@ class PPOTrainer:
             pos = tr._pos()
             pos_rows = pos.index_select(0, self._step_dev) if pos is not None else None
             self._kv_cache[self._worker_ids, self._step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
-        st["obs"].index_copy_(0, self._t_row.view(1), self._obs_dev.unsqueeze(0))
+        if not stream_obs:
+            st["obs"].index_copy_(0, self._t_row.view(1), self._obs_dev.unsqueeze(0))
 
     def _refresh_kv_cache(self):
         """Start of a rollout: re-project every live episode's memory with the CURRENT weights (they changed in the
@@ -373,20 +403,24 @@ class PPOTrainer:
         """Warm the step up on a side stream (library handles, MIOpen find, allocator), then capture it as TWO graphs:
         the head (ends with the action download) and the tail (bank / cache / staging writes)."""
         self._t_dev.zero_()
+        with torch.no_grad():
+            self._stream_obs = bool(self.config.get("stream_observations", True) and self._use_kv_cache
+                                    and self.model._fused_encoder_ok(self._obs_dev))
+        so = self._stream_obs
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(3):
-                self._rollout_step_device()
+                self._rollout_step_device(None, so)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
         head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
         with torch.no_grad(), torch.cuda.graph(head, pool=pool, capture_error_mode="thread_local"):
-            self._rollout_step_head()
+            self._rollout_step_head(None, so)
         with torch.no_grad(), torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
-            self._rollout_step_tail(self._item)
+            self._rollout_step_tail(self._item, so)
         self._step_graph = (head, tail)
         self._t_dev.zero_()
 

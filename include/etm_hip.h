@@ -188,15 +188,20 @@ int etm_rollout_heads(const float *h, const float *wp, const float *bp, const fl
                       int W, int A, int hid, void *stream);
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
- * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C];
+ * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C]; with
+ * in_index non-NULL the input is in + (*in_index) * in_index_stride floats (a row of a staging array chosen on the device);
  * w: the [Cout, K] weight matrix, K ordered (c, ky, kx) for NCHW input (= the native torch layout) or (ky, kx, c) for NHWC
  *    input, PACKED in MFMA fragment order: packed[((g * Cout/32 + t) * 64 + half * 32 + col) * 4 + j]
  *    = w2d[t * 32 + col][g * 8 + half * 4 + j]   (g < K/8, t < Cout/32, half < 2, col < 32, j < 4), so that a wave reads the
  *    B fragment of one 8-wide k-group with one contiguous 1 KB load (etm.ops.conv_pack_weights does the packing);
  * out: NHWC [N,Ho,Wo,Cout] or NCHW (out_nchw = 1).  Shape support: Cout in {32, 64}; NCHW input: KW % 8 == 0, W % 4 == 0,
  * S % 4 == 0; NHWC input: (KW * C) % 8 == 0, C % 4 == 0.  (Covers the three layers of the Atari-style encoder.) */
-int etm_conv_relu(const float *in, const float *w, const float *bias, float *out, int N, int C, int H, int W, int Cout,
-                  int KH, int KW, int S, int in_nhwc, int out_nchw, void *stream);
+int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_stride, const float *w, const float *bias, float *out,
+                  int N, int C, int H, int W, int Cout, int KH, int KW, int S, int in_nhwc, int out_nchw, void *stream);
+
+/* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
+ * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
+int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).
