@@ -330,6 +330,21 @@ def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, 
                                       _ptr(st_actions), _ptr(st_logp), _ptr(st_values), W, A, _stream()), "etm_rollout_sample")
 
 
+def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values,
+                   host_actions=None, host_flag=None):
+    """``rollout_heads`` + ``rollout_sample`` in one launch (single-branch policy); ``host_actions`` / ``host_flag``: pinned
+    int64 tensors that receive the actions and then the incremented step counter (the host spins on the flag)."""
+    lib = _lib.load()
+    W, A = h2.shape[0], policy_head.weight.shape[0]
+    hid = h2.shape[1] // 2
+    h2 = _f32c(h2, "h")
+    ha = 0 if host_actions is None else host_actions.data_ptr()
+    hf = 0 if host_flag is None else host_flag.data_ptr()
+    _lib.check(lib.etm_rollout_policy(_ptr(h2), _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight),
+                                      _ptr(value_head.bias), _ptr(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions), _ptr(st_actions),
+                                      _ptr(st_logp), _ptr(st_values), ha, hf, W, A, hid, _stream()), "etm_rollout_policy")
+
+
 def rollout_heads(h2, branch, value_head):
     """logits [W,A] and value [W] from h2 = [relu(lin_policy(h)) | relu(lin_value(h))] ([W, 2*hid]); no-grad path."""
     lib = _lib.load()

@@ -136,6 +136,16 @@ class ActorCriticModel(nn.Module):
         value = self.value(h_value).reshape(-1)
         return [branch(h_policy) for branch in self.policy_branches], value, memory
 
+    def rollout_heads_fusable(self):
+        """Single-branch policy with the concatenated hidden heads built: the trainer may run output heads + sampling as one
+        kernel on ``forward_hidden_cached``'s result."""
+        return len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled()
+
+    def forward_hidden_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None):
+        """Rollout path up to the hidden heads: -> (h2 [N, 2*hidden] = [relu(lin_policy(h)) | relu(lin_value(h))], memory)."""
+        h, memory = self.transformer.forward_cached(self._encode(obs, obs_index), kv_spec, items_out)
+        return ops.linear_relu(self._heads_lin, h), memory
+
     def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None):
         """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache.  With ``items_out``
         [blocks, N, D] the new memory items are written there (block-major) and returned in that layout."""

@@ -168,6 +168,9 @@ class PPOTrainer:
         self._act_ready = torch.cuda.Event()
         # observation streaming (graph rollout with the fused encoder): rows of the next observation go from pinned memory
         # straight into their row of the time-major staging array on a second stream while the environments still step
+        self._flag_pin = torch.zeros((1,), dtype=torch.int64).pin_memory()   # step counter written by the sampling kernel
+        self._flag_np = self._flag_pin.numpy()
+        self._host_flag = False      # decided when the step graph is captured
         self._up_stream = torch.cuda.Stream(device=device)
         self._up_done = torch.cuda.Event()
         self._stream_obs = False     # decided when the step graph is captured
@@ -253,6 +256,7 @@ class PPOTrainer:
         if use_graph and self._step_graph is None:
             self._capture_step_graph()
         self._t_dev.zero_()
+        self._flag_np[0] = 0
         self._uniforms.uniform_()                # one draw per (step, worker) for the whole rollout
         t_env = 0.0
         stream_obs = use_graph and self._stream_obs
@@ -265,18 +269,28 @@ class PPOTrainer:
             etm_lib.check(lib.etm_upload(stage_base, src_base, W * row_bytes, up), "etm_upload")
             self._up_done.record(self._up_stream)
         for t in range(S):
+            t_wait0 = time.perf_counter()
             if use_graph:
                 if stream_obs:
                     stream.wait_event(self._up_done)     # rows of observation t are in staging row t
                 self._step_graph[0].replay()
-                self._act_ready.record(stream)       # actions are in pinned memory once this event completes
+                if not self._host_flag:
+                    self._act_ready.record(stream)   # actions are in pinned memory once this event completes
                 self._step_graph[1].replay()         # tail runs while the host steps the environments
             else:
                 with torch.no_grad():
                     carry = self._rollout_step_head(forced[:, t].contiguous() if forced is not None else None)
                     self._act_ready.record(stream)
                     self._rollout_step_tail(carry)
-            self._act_ready.synchronize()
+            if use_graph and self._host_flag:
+                # the sampling kernel stored the actions and then step t + 1 into pinned memory: spin on the counter
+                flag, target, spins = self._flag_np, t + 1, 0
+                while flag[0] != target:
+                    spins += 1
+                    if spins % 4096 == 0 and time.perf_counter() - t_wait0 > 30.0:
+                        raise RuntimeError("rollout step did not complete within 30 s (device hang?)")
+            else:
+                self._act_ready.synchronize()
             te = time.perf_counter()
             if stream_obs and t + 1 < S:
                 dst_base = stage_base + (t + 1) * W * row_bytes
@@ -310,12 +324,12 @@ class PPOTrainer:
         self.last_update_timing["env_s"] = t_env
         return episode_infos
 
-    def _rollout_step_device(self, forced_t=None, stream_obs=False):
+    def _rollout_step_device(self, forced_t=None, stream_obs=False, host_flag=False):
         """Device side of one rollout step (upstream trainer.py:161-186) = head + tail."""
-        carry = self._rollout_step_head(forced_t, stream_obs)
+        carry = self._rollout_step_head(forced_t, stream_obs, host_flag)
         self._rollout_step_tail(carry, stream_obs)
 
-    def _rollout_step_head(self, forced_t=None, stream_obs=False):
+    def _rollout_step_head(self, forced_t=None, stream_obs=False, host_flag=False):
         """Everything the ACTIONS depend on: observation / step / slot upload, window lookup, model forward, sampling,
         staging of the step's rows, action download.  Every operand has a fixed address (HIP-graph capturable).
         Returns what the tail needs (the new memory item)."""
@@ -335,17 +349,33 @@ class PPOTrainer:
         ops.rollout_window(self._step_dev, self._mask_table, self._index_table, self._t_dev, mask_t, win_t,
                            st["memory_mask"], st["memory_indices"], t_row=self._t_row,
                            reset=(self._kv_cache, self._kv_init) if self._use_kv_cache else None)
+        fused_policy = False
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(self._kv_cache, None, win_t, None, mask_t)
-            logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
+            if single and self.model.rollout_heads_fusable():
+                # hidden heads -> ONE launch for output heads, sampling, staging, t += 1 and (graph mode) the hand-over of the
+                # actions to the host through pinned memory + a step-counter flag
+                h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
+                flag = host_flag and forced_t is None
+                ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, forced_t, self._t_dev,
+                                   self._act_dev, st["actions"], st["log_probs"], st["values"],
+                                   host_actions=self._act_pin if flag else None, host_flag=self._flag_pin if flag else None)
+                fused_policy = True
+                if not flag:
+                    self._act_pin.copy_(self._act_dev, non_blocking=True)
+            else:
+                logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
         else:
             spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
             logits, value, item = self.model.forward_logits(obs, spec)
             item = item.transpose(0, 1)
-        if single:
+        if fused_policy:
+            pass
+        elif single:
             # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
             ops.rollout_sample(logits[0], value, self._uniforms, forced_t, self._t_dev, self._act_dev,
                                st["actions"], st["log_probs"], st["values"])
+            self._act_pin.copy_(self._act_dev, non_blocking=True)
         else:
             row = self._t_row.view(1)
             acts, logps = [], []
@@ -359,7 +389,7 @@ class PPOTrainer:
             st["log_probs"].index_copy_(0, row, torch.stack(logps, dim=1).unsqueeze(0))
             st["values"].index_copy_(0, row, value.unsqueeze(0))
             self._t_dev.add_(1)
-        self._act_pin.copy_(self._act_dev, non_blocking=True)
+            self._act_pin.copy_(self._act_dev, non_blocking=True)
         if item.data_ptr() != self._item.data_ptr():
             self._item.copy_(item)
         return self._item
@@ -407,18 +437,21 @@ class PPOTrainer:
             self._stream_obs = bool(self.config.get("stream_observations", True) and self._use_kv_cache
                                     and self.model._fused_encoder_ok(self._obs_dev))
         so = self._stream_obs
+        with torch.no_grad():
+            hf = self._host_flag = bool(self.config.get("host_flag_actions", True) and self._use_kv_cache
+                                        and len(self.action_space_shape) == 1 and self.model.rollout_heads_fusable())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(3):
-                self._rollout_step_device(None, so)
+                self._rollout_step_device(None, so, hf)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
         head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
         with torch.no_grad(), torch.cuda.graph(head, pool=pool, capture_error_mode="thread_local"):
-            self._rollout_step_head(None, so)
+            self._rollout_step_head(None, so, hf)
         with torch.no_grad(), torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
             self._rollout_step_tail(self._item, so)
         self._step_graph = (head, tail)

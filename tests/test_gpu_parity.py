@@ -488,6 +488,109 @@ def test_rollout_cache_and_graph_paths_agree():
             assert torch.allclose(a[k], b[k], atol=2e-4, rtol=1e-3), (k, (a[k] - b[k]).abs().max())
 
 
+def test_rollout_fast_paths_agree():
+    """Graph rollout with observation streaming + host-flag action hand-over (defaults), the graph without them, and the eager
+    step must sample the same actions and fill the buffer identically (same torch seed => same device uniforms)."""
+    from trainer import PPOTrainer
+    dev = _dev()
+    base = dict(environment=dict(type="Synthetic", obs_shape=[3, 36, 36], num_actions=4, max_episode_steps=20, seed=5, p_done=0.08, pool=8),
+                gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=8, worker_steps=40, n_mini_batch=2, value_loss_coefficient=0.5,
+                hidden_layer_size=64, max_grad_norm=0.5,
+                transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8, positional_encoding="relative",
+                                 layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
+                learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
+                beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
+                clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
+    variants = [dict(), dict(stream_observations=False, host_flag_actions=False), dict(hip_graph_rollout=False)]
+    results = []
+    for over in variants:
+        cfg = json.loads(json.dumps(base))
+        cfg.update(over)
+        torch.manual_seed(3)
+        tr = PPOTrainer(cfg, run_id="paths", device=dev, tensorboard=False)
+        snap = []
+        for u in range(2):
+            tr._sample_training_data()
+            tr.buffer.prepare_batch_dict()
+            b = tr.buffer
+            snap.append({k: getattr(b, k).clone() for k in ("obs", "actions", "values", "log_probs", "advantages", "memory_mask",
+                                                            "memory_indices", "memory_index")})
+            snap[-1]["rewards"] = torch.from_numpy(np.asarray(b.rewards).copy())
+            tr._train_epochs(3e-4, 0.1, 1e-3, perms=[np.arange(8 * 40)])
+        if not over:
+            assert tr._stream_obs and tr._host_flag, "default config must take the streamed / host-flag graph path"
+        results.append(snap)
+        tr.close()
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            for k in ("obs", "actions", "memory_mask", "memory_indices", "memory_index", "rewards"):
+                assert torch.equal(a[k], b[k]), k
+            for k in ("values", "log_probs", "advantages"):
+                assert torch.allclose(a[k], b[k], atol=1e-5, rtol=1e-5), (k, (a[k] - b[k]).abs().max())
+
+
+def test_rollout_glue_riders_and_fused_policy():
+    """rollout_window's riders (t_row, cache reset) == the stand-alone ops; rollout_policy == rollout_heads + rollout_sample
+    (bit-exact), including the pinned-memory hand-over; conv_relu with a device-side row index == conv_relu on that row."""
+    from etm import ops
+    from trainer import build_window_tables
+    dev = _dev()
+    torch.manual_seed(0)
+    W, L, T, S, A, hid = 7, 8, 12, 5, 3, 64
+    mask_tab, idx_tab = build_window_tables(L, T)
+    mask_tab, idx_tab = mask_tab.to(dev).bool(), idx_tab.to(dev)
+    step = torch.tensor([0, 3, 11, 0, 7, 1, 0], device=dev)
+    t_dev = torch.tensor(2, dtype=torch.int64, device=dev)
+    outs = []
+    for riders in (False, True):
+        mask_t = torch.zeros((W, L), dtype=torch.bool, device=dev); win_t = torch.zeros((W, L), dtype=torch.int64, device=dev)
+        st_m = torch.zeros((S, W, L), dtype=torch.bool, device=dev); st_i = torch.zeros((S, W, L), dtype=torch.int64, device=dev)
+        cache = torch.randn((W, 4, 2, 16), device=dev); init = torch.randn((4, 2, 16), device=dev)
+        torch.manual_seed(1); cache.copy_(torch.randn_like(cache)); init.copy_(torch.randn_like(init))
+        t_row = torch.full((), -1, dtype=torch.int64, device=dev)
+        if riders:
+            ops.rollout_window(step, mask_tab, idx_tab, t_dev, mask_t, win_t, st_m, st_i, t_row=t_row, reset=(cache, init))
+        else:
+            ops.rollout_window(step, mask_tab, idx_tab, t_dev, mask_t, win_t, st_m, st_i)
+            ops.reset_rows(cache, init, step)
+            t_row.copy_(t_dev)
+        outs.append((mask_t, win_t, st_m, st_i, cache, t_row))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[1][5]) == 2 and torch.equal(outs[1][4][0], outs[1][4][3])
+
+    lin_p, lin_v = torch.nn.Linear(hid, A).to(dev), torch.nn.Linear(hid, 1).to(dev)
+    h2 = torch.randn((W, 2 * hid), device=dev)
+    uni = torch.rand((S, W), device=dev)
+    res = []
+    for fused in (False, True):
+        t = torch.tensor(1, dtype=torch.int64, device=dev)
+        act = torch.zeros((W, 1), dtype=torch.int64, device=dev)
+        sa = torch.zeros((S, W, 1), dtype=torch.int64, device=dev); sl = torch.zeros((S, W, 1), device=dev); sv = torch.zeros((S, W), device=dev)
+        hp = torch.full((W, 1), -1, dtype=torch.int64).pin_memory(); hf = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        if fused:
+            ops.rollout_policy(h2, lin_p, lin_v, uni, None, t, act, sa, sl, sv, host_actions=hp, host_flag=hf)
+        else:
+            logits, value = ops.rollout_heads(h2, lin_p, lin_v)
+            ops.rollout_sample(logits, value, uni, None, t, act, sa, sl, sv)
+        torch.cuda.synchronize()
+        res.append((act, sa, sl, sv, t))
+        if fused:
+            assert int(hf[0]) == 2 and torch.equal(hp, act.cpu())
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+    stack = torch.rand((3, 5, 3, 36, 36), device=dev)
+    conv = torch.nn.Conv2d(3, 32, 8, 4).to(dev)
+    wp = ops.conv_pack_weights(conv.weight.detach().reshape(32, -1))
+    idx = torch.tensor(2, dtype=torch.int64, device=dev)
+    a = ops.conv_relu(stack, wp, conv.bias.detach(), 3, 36, 36, 8, 8, 4, False, False, index=idx)
+    b = ops.conv_relu(stack[2].contiguous(), wp, conv.bias.detach(), 3, 36, 36, 8, 8, 4, False, False)
+    assert torch.equal(a, b)
+    want = torch.relu(conv(stack[2])).permute(0, 2, 3, 1)
+    close(a, want.detach().cpu().numpy(), atol=2e-5, rtol=1e-4, what="conv_relu vs library")
+
+
 # ------------------------------------------------------------------ other BASELINE config shapes + RCCL plumbing on one device
 @pytest.mark.parametrize("cfg_name,over", [
     ("synthetic_cartpole", dict(n_workers=8, worker_steps=64, n_mini_batch=2, epochs=1)),              # config (2): GTrXL, pre-LN, D=128 H=1

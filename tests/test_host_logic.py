@@ -169,3 +169,34 @@ def test_pipe_worker_protocol_and_vec_env():
         ob, rb, db, ib = serial.step(np.zeros(3, dtype=np.int64))
         assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db) and ia == ib
     pipe_env.close()
+
+
+def test_vec_env_on_rows_protocol():
+    """step(..., on_rows=cb): cb(lo, hi) covers [0, W) in increasing order, the rows are final when it is called, and the
+    results equal a step without the callback (synthetic vectorised env and the serial front-end over single envs)."""
+    from environments.synthetic import SyntheticEnv, SyntheticVecEnv
+    from environments.vec_env import SerialVecEnv
+    W = 6
+
+    def make(kind):
+        if kind == "vec":
+            return SyntheticVecEnv(W, obs_shape=(2, 5), num_actions=3, max_episode_steps=7, seed=4, pool=4)
+        return SerialVecEnv([SyntheticEnv(obs_shape=(2, 5), num_actions=3, max_episode_steps=7, seed=4, worker_id=w, pool=4) for w in range(W)])
+
+    for kind in ("vec", "serial"):
+        a, b = make(kind), make(kind)
+        oa, ob = np.zeros((W, 2, 5), np.float32), np.zeros((W, 2, 5), np.float32)
+        a.reset(out=oa); b.reset(out=ob)
+        for t in range(20):
+            seen = []
+
+            def cb(lo, hi):
+                seen.append((lo, hi, ob[lo:hi].copy()))
+
+            ra = a.step(np.zeros(W, dtype=np.int64), out=oa)
+            rb = b.step(np.zeros(W, dtype=np.int64), out=ob, on_rows=cb)
+            assert [s[0] for s in seen] == sorted(s[0] for s in seen) and seen[0][0] == 0 and seen[-1][1] == W
+            assert all(seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
+            for lo, hi, rows in seen:
+                assert np.array_equal(rows, ob[lo:hi])          # rows did not change after the notification
+            assert np.array_equal(oa, ob) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
