@@ -122,6 +122,12 @@ class Buffer:
                 mini_batch["memories"] = self.memories
             yield mini_batch
 
+    def gather(self, idx: torch.Tensor, materialize: bool = False) -> dict:
+        """One minibatch dict (see ``mini_batch_generator``) for the flat sample indices ``idx``."""
+        mini_batch = {k: v.index_select(0, idx) for k, v in self.samples_flat.items()}
+        mini_batch["memories"] = self.memories[mini_batch.pop("memory_index")] if materialize else self.memories
+        return mini_batch
+
     def calc_advantages(self, last_value: torch.Tensor, gamma: float, lamda: float) -> None:
         """GAE over the [W, S] buffer on device (upstream buffer.py:95-113)."""
         self.rewards_dev.copy_(self._rewards_host, non_blocking=True)

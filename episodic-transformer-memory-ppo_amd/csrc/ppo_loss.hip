@@ -51,12 +51,19 @@ struct LossParams {
   long long logp_stride;
   const float *adv, *old_value, *value, *adv_stats3;
   float clip, clip_lo, clip_hi, vf_coef, beta, pol_scale, ent_scale, val_scale;
+  const double *dyn;   // optional device-resident (clip, beta): same arithmetic as the host-side scalars, read at run time
   int include_value;
   float *d_logits, *d_value, *partials;
   int N, A;
 };
 
-__global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p) {
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p0) {
+  LossParams p = p0;
+  if (p.dyn) {   // schedules that change between replays of a captured training step
+    const double c = p.dyn[0];
+    p.clip = (float)c; p.clip_lo = (float)(1.0 - c); p.clip_hi = (float)(1.0 + c);
+    p.beta = (float)p.dyn[1];
+  }
   __shared__ float red[4][5];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x * 256 + tid;
@@ -131,8 +138,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p) {
 }
 
 __global__ __launch_bounds__(64) void ppo_finalize_kernel(const float *__restrict__ partials, int n_blocks, float vf_coef, float beta,
-                                                          float pol_scale, float ent_scale, float val_scale, float *__restrict__ out8) {
+                                                          float pol_scale, float ent_scale, float val_scale, float *__restrict__ out8,
+                                                          const double *__restrict__ dyn) {
   const int lane = threadIdx.x;
+  if (dyn) beta = (float)dyn[1];
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int b = lane; b < n_blocks; b += 64)
 #pragma unroll
@@ -167,7 +176,7 @@ extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t
                             int64_t logp_stride, const float *adv, const float *old_value, const float *value,
                             const float *adv_stats3, double clip, float vf_coef, float beta, float pol_scale, float ent_scale,
                             float val_scale, int include_value, float *out8, float *d_logits, float *d_value, void *partials,
-                            int64_t partials_bytes, int N, int A, void *stream) {
+                            int64_t partials_bytes, const double *dyn_clip_beta, int N, int A, void *stream) {
   (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated runtime calls
   if (!logits || !actions || !old_logp || !adv || !adv_stats3 || !out8 || !d_logits || !partials) return ETM_EINVAL;
   if (include_value && (!old_value || !value || !d_value)) return ETM_EINVAL;
@@ -179,6 +188,7 @@ extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t
   p.adv_stats3 = adv_stats3;
   p.clip = (float)clip; p.clip_lo = (float)(1.0 - clip); p.clip_hi = (float)(1.0 + clip);
   p.vf_coef = vf_coef; p.beta = beta; p.pol_scale = pol_scale; p.ent_scale = ent_scale; p.val_scale = val_scale;
+  p.dyn = dyn_clip_beta;
   p.include_value = include_value; p.d_logits = d_logits; p.d_value = d_value; p.partials = (float *)partials;
   p.N = N; p.A = A;
   const int nb = (N + 255) / 256;
@@ -192,7 +202,7 @@ extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t
   {
     EtmProfScope prof(ETM_K_PPO_FINAL, st);
     hipLaunchKernelGGL(ppo_finalize_kernel, dim3(1), dim3(64), 0, st, (const float *)partials, nb, vf_coef, beta, pol_scale, ent_scale,
-                       val_scale, out8);
+                       val_scale, out8, dyn_clip_beta);
   }
   return etm_launch_status();
 }

@@ -47,7 +47,7 @@ SIGNATURES = {
     "etm_profile_kernel_count": (_I, []),
     "etm_profile_kernel_name": (ctypes.c_char_p, [_I]),
     "etm_profile_collect": (_I, [_P, _P]),
-    "etm_ppo_loss": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P, _D, _F, _F, _F, _F, _F, _I, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "etm_ppo_loss": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P, _D, _F, _F, _F, _F, _F, _I, _P, _P, _P, _P, _L, _P, _I, _I, _P]),
 }
 
 

@@ -497,7 +497,7 @@ def adv_stats(adv):
 class _PpoLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, value, actions, old_logp, adv, old_value, stats3, branch, n_branches, clip, vf_coef, beta,
-                include_value):
+                include_value, dyn=None):
         lib = _lib.load()
         _need_dev(logits, value, actions, old_logp, adv, old_value, stats3)
         logits = _f32c(logits, "logits")
@@ -517,7 +517,7 @@ class _PpoLossFn(torch.autograd.Function):
         rc = lib.etm_ppo_loss(_ptr(logits), actions.data_ptr() + 8 * branch, B, old_logp.data_ptr() + 4 * branch, B, _ptr(adv),
                               _ptr(old_value), _ptr(value), _ptr(stats3), float(clip), float(vf_coef), float(beta),
                               1.0 / (N * n_branches), 1.0 / N, 1.0 / N, 1 if include_value else 0, _ptr(out8), _ptr(d_logits),
-                              _ptr(d_value), _ptr(ws), nbytes, N, A, _stream())
+                              _ptr(d_value), _ptr(ws), nbytes, _ptr(dyn), N, A, _stream())
         _lib.check(rc, "etm_ppo_loss")
         ctx.save_for_backward(d_logits, d_value)
         ctx.include_value = include_value
@@ -528,21 +528,24 @@ class _PpoLossFn(torch.autograd.Function):
     def backward(ctx, g_loss, _g_stats):
         d_logits, d_value = ctx.saved_tensors
         gv = d_value * g_loss if ctx.include_value else None
-        return d_logits * g_loss, gv, None, None, None, None, None, None, None, None, None, None, None
+        return d_logits * g_loss, gv, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def ppo_loss(logits_list, value, actions, old_logp, adv, old_value, clip, vf_coef, beta, stats3=None):
-    """PPO loss over all action branches.  Returns (loss scalar with grad, stats[6] device tensor in trainer.py:318-323 order)."""
+def ppo_loss(logits_list, value, actions, old_logp, adv, old_value, clip, vf_coef, beta, stats3=None, dyn=None):
+    """PPO loss over all action branches.  Returns (loss scalar with grad, stats[6] device tensor in trainer.py:318-323 order).
+    ``dyn``: optional float64 device tensor (clip, beta) read by the kernels at run time instead of the two scalars."""
     if stats3 is None:
         stats3 = adv_stats(adv)
+    if dyn is not None and (dyn.dtype != torch.float64 or dyn.numel() != 2 or not dyn.is_cuda):
+        raise TypeError("ppo_loss: dyn must be a float64 device tensor (clip, beta)")
     nb = len(logits_list)
-    loss, st = _PpoLossFn.apply(logits_list[0], value, actions, old_logp, adv, old_value, stats3, 0, nb, clip, vf_coef, beta, True)
+    loss, st = _PpoLossFn.apply(logits_list[0], value, actions, old_logp, adv, old_value, stats3, 0, nb, clip, vf_coef, beta, True, dyn)
     if nb == 1:
         return loss, st[:6]
     pol, ent, kl, cf = st[0], st[3], st[4], st[5]
     total = loss
     for b in range(1, nb):
-        l_b, s_b = _PpoLossFn.apply(logits_list[b], value, actions, old_logp, adv, old_value, stats3, b, nb, clip, vf_coef, beta, False)
+        l_b, s_b = _PpoLossFn.apply(logits_list[b], value, actions, old_logp, adv, old_value, stats3, b, nb, clip, vf_coef, beta, False, dyn)
         total = total + l_b
         pol, ent, kl, cf = pol + s_b[0], ent + s_b[3], kl + s_b[4], cf + s_b[5]
     return total, torch.stack([pol, st[1], total.detach(), ent, kl, cf])

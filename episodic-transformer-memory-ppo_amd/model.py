@@ -128,9 +128,9 @@ class ActorCriticModel(nn.Module):
             h = h.reshape(h.shape[0], -1)
         return ops.linear_relu(self.lin_hidden, h)
 
-    def forward_logits(self, obs, spec: WindowSpec):
-        """-> (list of raw logits per branch, value [N], new memory items [N, blocks, D])."""
-        h, memory = self.transformer.forward_window(self._encode(obs), spec)
+    def forward_logits(self, obs, spec: WindowSpec, want_items=True):
+        """-> (list of raw logits per branch, value [N], new memory items [N, blocks, D] or None)."""
+        h, memory = self.transformer.forward_window(self._encode(obs), spec, want_items)
         h_policy = ops.linear_relu(self.lin_policy, h)
         h_value = ops.linear_relu(self.lin_value, h)
         value = self.value(h_value).reshape(-1)

@@ -121,7 +121,23 @@ class PPOTrainer:
         if self.dp is not None:
             self.dp.broadcast_parameters(self.model)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
-        self.optimizer = optim.AdamW(self.params, lr=self.lr_schedule["initial"], fused=True)
+        # The optimisation step of one minibatch (gather, forward, loss, backward, clipping, AdamW) is captured in a HIP graph
+        # after two eager warm-up steps and replayed for every other minibatch of the run: the host then issues one launch
+        # per minibatch instead of ~280.  lr / clip range / entropy coefficient live on the device so that their schedules
+        # keep working under replay.  (Data-parallel runs keep the eager step: the all-reduce sits between backward and
+        # clipping.)
+        self._use_train_graph = bool(config.get("hip_graph_train", True)) and self.dp is None
+        self._train_graph = None
+        self._train_warm = 0
+        if self._use_train_graph:
+            self._lr_dev = torch.tensor(float(self.lr_schedule["initial"]), dtype=torch.float32, device=device)
+            self._dyn = torch.zeros(2, dtype=torch.float64, device=device)      # (clip range, entropy coefficient)
+            self._sched_host = [None, None, None]   # (lr, clip, beta) currently on the device
+            self.profile_sample_every = 0     # bench.py: run every k-th minibatch eagerly so that per-kernel events exist
+            self._mb_counter = 0
+            self.optimizer = optim.AdamW(self.params, lr=self._lr_dev, fused=True, capturable=True)
+        else:
+            self.optimizer = optim.AdamW(self.params, lr=self.lr_schedule["initial"], fused=True)
         # one flat gradient bucket aliased by every p.grad (the all-reduce message; also makes clipping 3 launches)
         total = sum(p.numel() for p in self.params)
         self.flat_grads = torch.zeros(total, dtype=torch.float32, device=device)
@@ -479,10 +495,22 @@ class PPOTrainer:
         # sinusoidal positions: add them to the (read-only) episode bank once per update instead of once per window row,
         # block, minibatch and epoch inside the kernels (bit-identical sums; halves the kernels' window-row loads)
         with torch.no_grad():
-            self._bank_pos = self.model.transformer.bank_with_positions(self.buffer.memories)
+            self._bank_pos = self._bank_with_positions()
+        mbs = self.buffer.batch_size // self.buffer.n_mini_batches
         for epoch in range(self.config["epochs"]):
-            indices = None if perms is None else perms[epoch]
-            for mini_batch in self.buffer.mini_batch_generator(indices):
+            if perms is None:
+                perm = torch.randperm(self.buffer.batch_size, device=self.device)
+            else:
+                perm = torch.as_tensor(perms[epoch], device=self.device, dtype=torch.long)
+            for start in range(0, self.buffer.batch_size, mbs):
+                idx = perm[start: start + mbs]
+                if self._use_train_graph and idx.numel() == mbs:
+                    st_row, norm_row = self._train_step_graph(idx, learning_rate, clip_range, beta, monitor)
+                    stats.append(st_row)
+                    if monitor:
+                        norms.append(norm_row)
+                    continue
+                mini_batch = self.buffer.gather(idx)
                 stats.append(self._train_mini_batch(mini_batch, learning_rate, clip_range, beta))
                 if monitor:
                     norms.append(self._grad_group_norms())
@@ -510,8 +538,7 @@ class PPOTrainer:
             stats3 = self.dp.merge_adv_stats(stats3)
         loss, stats = ops.ppo_loss(logits, value, samples["actions"], samples["log_probs"], samples["advantages"],
                                    samples["values"], clip_range, self.config["value_loss_coefficient"], beta, stats3)
-        for pg in self.optimizer.param_groups:
-            pg["lr"] = learning_rate
+        self._set_lr(learning_rate)
         self.flat_grads.zero_()
         loss.backward()
         if self.dp is not None:
@@ -521,6 +548,74 @@ class PPOTrainer:
         self.flat_grads.mul_(torch.clamp(self.config["max_grad_norm"] / (total_norm + 1e-6), max=1.0))
         self.optimizer.step()
         return stats
+
+    def _set_lr(self, learning_rate: float):
+        if self._use_train_graph:
+            if self._sched_host[0] != learning_rate:
+                self._lr_dev.fill_(float(learning_rate))
+                self._sched_host[0] = learning_rate
+        else:
+            for pg in self.optimizer.param_groups:
+                pg["lr"] = learning_rate
+
+    def _bank_with_positions(self):
+        """Episode bank with the sinusoidal positional rows pre-added, in a buffer that keeps its address (the captured
+        training step reads it); None when the positional encoding is not the fixed sinusoid."""
+        tr = self.model.transformer
+        if tr.pos_kind != "relative":
+            return None
+        mem = self.buffer.memories
+        if getattr(self, "_bank_pos_buf", None) is None or self._bank_pos_buf.shape != self.buffer.bank.shape:
+            self._bank_pos_buf = torch.empty_like(self.buffer.bank)
+        out = self._bank_pos_buf[: mem.shape[0]]
+        torch.add(mem, tr._pos_table[None, : mem.shape[1], None, :], out=out)
+        return self._bank_pos_buf
+
+    def _train_body(self, idx, clip_range, beta, monitor):
+        """One optimiser step on the minibatch ``idx`` (device int64 [mbs], fixed address) with device-resident schedules:
+        what the training graph captures (and what the warm-up steps run eagerly)."""
+        buf = self.buffer
+        mb = {k: v.index_select(0, idx) for k, v in buf.samples_flat.items()}
+        if self._bank_pos is not None:
+            spec = WindowSpec.from_bank(self._bank_pos_buf, mb["memory_index"], mb["memory_indices"], None, mb["memory_mask"])
+            spec.pos_included = True
+        else:
+            spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
+        logits, value, _ = self.model.forward_logits(mb["obs"], spec, want_items=False)
+        stats3 = ops.adv_stats(mb["advantages"])
+        loss, stats = ops.ppo_loss(logits, value, mb["actions"], mb["log_probs"], mb["advantages"], mb["values"], clip_range,
+                                   self.config["value_loss_coefficient"], beta, stats3, dyn=self._dyn)
+        self.flat_grads.zero_()
+        loss.backward()
+        total_norm = torch.linalg.vector_norm(self.flat_grads)
+        self.flat_grads.mul_(torch.clamp(self.config["max_grad_norm"] / (total_norm + 1e-6), max=1.0))
+        self.optimizer.step()
+        return stats, (self._grad_group_norms() if monitor else None)
+
+    def _train_step_graph(self, idx, learning_rate, clip_range, beta, monitor):
+        """Minibatch step through the captured graph (two eager warm-up steps first).  Returns (stats[6], norms or None)."""
+        if getattr(self, "_tg_idx", None) is None:
+            self._tg_idx = torch.empty_like(idx)
+        self._tg_idx.copy_(idx)
+        self._set_lr(learning_rate)
+        if self._sched_host[1] != clip_range or self._sched_host[2] != beta:
+            self._dyn.copy_(torch.tensor([clip_range, beta], dtype=torch.float64))
+            self._sched_host[1:] = [clip_range, beta]
+        self._mb_counter += 1
+        sample_eager = self.profile_sample_every and self._mb_counter % self.profile_sample_every == 0
+        key = (monitor, self._bank_pos is not None)
+        if (self._train_graph is None and self._train_warm < 2) or sample_eager:
+            self._train_warm += 1
+            st, nm = self._train_body(self._tg_idx, clip_range, beta, monitor)
+            return st.clone(), (nm.clone() if nm is not None else None)
+        if self._train_graph is None or self._tg_key != key:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._tg_stats, self._tg_norms = self._train_body(self._tg_idx, clip_range, beta, monitor)
+            self._train_graph, self._tg_key = g, key
+        self._train_graph.replay()
+        return self._tg_stats.clone(), (self._tg_norms.clone() if monitor else None)
 
     def _build_grad_groups(self):
         """Group-membership matrix so all monitored gradient norms come from one pass over per-parameter norms."""

@@ -190,15 +190,17 @@ class Transformer(nn.Module):
             return self.pos_embedding
         return None
 
-    def forward_window(self, h, spec: WindowSpec):
-        """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D])."""
+    def forward_window(self, h, spec: WindowSpec, want_items=True):
+        """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D]) -- the items
+        are None with ``want_items=False`` (the optimisation phase never stores them)."""
         h = ops.linear_relu(self.linear_embedding, h)
         pos = None if spec.pos_included else self._pos()
         items = []
         for i, blk in enumerate(self.transformer_blocks):
-            items.append(h.detach())
+            if want_items:
+                items.append(h.detach())
             h, _ = blk.forward_window(h, spec, i, pos)
-        return h, torch.stack(items, dim=1)
+        return h, (torch.stack(items, dim=1) if want_items else None)
 
     def bank_with_positions(self, bank):
         """[E, T, blocks, D] episode bank with every row's positional row already added (same fp32 add the kernel would

@@ -237,6 +237,8 @@ int etm_gae(const float *rewards, const uint8_t *dones, const float *values, con
  *                     hyper-parameters of trainer.py:289-304
  *   pol_scale = 1 / (N * branches), ent_scale = val_scale = 1 / N  (the `.mean()`s of the reference)
  *   include_value: 0 to skip the value term (2nd.. branch of a multi-discrete policy)
+ *   dyn_clip_beta: NULL, or device doubles (clip, beta) that override the two scalars at run time with the same arithmetic
+ *                  (a captured training step is replayed across updates while the schedules of trainer.py:117-119 decay)
  * outputs
  *   out[8]   : policy, value_loss, loss, entropy, kl, clip_fraction, 0, 0   (trainer.py:318-323 order)
  *   d_logits [N,A], d_value [N] : gradient of `loss` (d_value untouched when include_value == 0)
@@ -253,7 +255,7 @@ int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t action_str
                  double clip, float vf_coef, float beta,
                  float pol_scale, float ent_scale, float val_scale, int include_value,
                  float *out8, float *d_logits, float *d_value,
-                 void *partials, int64_t partials_bytes,
+                 void *partials, int64_t partials_bytes, const double *dyn_clip_beta,
                  int N, int A, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

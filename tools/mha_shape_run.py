@@ -1,6 +1,6 @@
 """Run kernel #1 forward + backward a few times at the BASELINE config (3) training shape (for rocprofv3 passes).
 
-    python tools/mha_shape_run.py [iters] [N] [L] [D] [H]
+    python tools/mha_shape_run.py [iters] [N] [L] [D] [H]        (env ETM_ATTENTION=folded|dense, ETM_POS=1 for in-kernel positions)
 Prints the average wall time per fwd / bwd call measured with torch events."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,12 +22,14 @@ wk = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
 wv = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
 q = torch.randn((N, D), device=dev).requires_grad_(True)
 gout = torch.randn((N, D), device=dev)
-spec = ops.WindowSpec.from_bank(bank, ep, win, win, mask)
+ops.set_attention_impl(os.environ.get("ETM_ATTENTION", "folded"))
+use_pos = os.environ.get("ETM_POS", "0") == "1"      # the trainer pre-adds the positional rows to the bank (no in-kernel positions)
+spec = ops.WindowSpec.from_bank(bank, ep, win, win if use_pos else None, mask)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 tf = tb = 0.0
 for it in range(iters + 2):
     ev[0].record()
-    out, att = ops.mha(q, wk, wv, spec, 1, H, pos=pos)
+    out, att = ops.mha(q, wk, wv, spec, 1, H, pos=pos if use_pos else None)
     ev[1].record()
     (out * gout).sum().backward()
     ev[2].record()

@@ -4,13 +4,15 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/pmc
+IMPL=${ETM_ATTENTION:-folded}
+export ETM_ATTENTION=$IMPL
+OUT=$ROOT/gpurun_out/pmc_$IMPL
 mkdir -p $OUT
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$tag -o pmc -- python $ROOT/tools/mha_shape_run.py 3 > /tmp/pmc_$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_${IMPL}_$tag -o pmc -- python $ROOT/tools/mha_shape_run.py 3 > /tmp/pmc_${IMPL}_$tag.log 2>&1
   mkdir -p $OUT/$tag
-  for f in $(find /tmp/pmc_$tag -name "*counter_collection.csv"); do cp $f $OUT/$tag/; done
-  tail -1 /tmp/pmc_$tag.log
+  for f in $(find /tmp/pmc_${IMPL}_$tag -name "*counter_collection.csv"); do cp $f $OUT/$tag/; done
+  tail -1 /tmp/pmc_${IMPL}_$tag.log
 done
 ls -R $OUT | head -30
