@@ -139,9 +139,8 @@ class PPOTrainer:
         # The optimisation step of one minibatch (gather, forward, loss, backward, clipping, AdamW) is captured in a HIP graph
         # after two eager warm-up steps and replayed for every other minibatch of the run: the host then issues one launch
         # per minibatch instead of ~280.  lr / clip range / entropy coefficient live on the device so that their schedules
-        # keep working under replay.  (Data-parallel runs keep the eager step: the all-reduce sits between backward and
-        # clipping.)
-        self._use_train_graph = bool(config.get("hip_graph_train", True)) and self.dp is None
+        # keep working under replay.  (Data-parallel runs replay two graphs around the eager RCCL all-reduce of the bucket.)
+        self._use_train_graph = bool(config.get("hip_graph_train", True))
         self._train_graph = None
         self._train_warm = 0
         if self._use_train_graph:
@@ -588,9 +587,10 @@ class PPOTrainer:
         torch.add(mem, tr._pos_table[None, : mem.shape[1], None, :], out=out)
         return self._bank_pos_buf
 
-    def _train_body(self, idx, clip_range, beta, monitor):
-        """One optimiser step on the minibatch ``idx`` (device int64 [mbs], fixed address) with device-resident schedules:
-        what the training graph captures (and what the warm-up steps run eagerly)."""
+    def _train_body_a(self, idx, clip_range, beta, stats3=None):
+        """First half of one optimiser step on the minibatch ``idx`` (device int64 [mbs], fixed address): gather, forward,
+        loss, backward, gradients packed into the flat bucket.  ``stats3``: (count, mean, M2) of the GLOBAL minibatch's
+        advantages (data-parallel runs merge them over ranks before this graph); None: computed here.  Returns stats[6]."""
         buf = self.buffer
         mb = {k: v.index_select(0, idx) for k, v in buf.samples_flat.items()}
         if self._bank_pos is not None:
@@ -599,12 +599,13 @@ class PPOTrainer:
         else:
             spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
         logits, value, _ = self.model.forward_logits(mb["obs"], spec, want_items=False)
-        stats3 = ops.adv_stats(mb["advantages"])
+        if stats3 is None:
+            stats3 = ops.adv_stats(mb["advantages"])
         loss, stats = ops.ppo_loss(logits, value, mb["actions"], mb["log_probs"], mb["advantages"], mb["values"], clip_range,
                                    self.config["value_loss_coefficient"], beta, stats3, dyn=self._dyn)
         # backward() hands every parameter its gradient tensor (no accumulate launch while .grad is None); ONE multi-tensor copy
-        # packs them into the flat bucket that clipping and the fused AdamW read -- ~50 launches fewer per step than
-        # accumulating into the zeroed bucket (the python-side re-aliasing below costs nothing under graph replay)
+        # packs them into the flat bucket that the all-reduce, clipping and the fused AdamW read -- ~50 launches fewer per step
+        # than accumulating into the zeroed bucket (the python-side re-aliasing below costs nothing under graph replay)
         for p in self.params:
             p.grad = None
         loss.backward()
@@ -614,34 +615,60 @@ class PPOTrainer:
         torch._foreach_copy_(self._grad_views, grads)
         for p, v in zip(self.params, self._grad_views):
             p.grad = v
+        return stats
+
+    def _train_body_b(self, monitor):
+        """Second half: global-norm clipping (same rule as torch.nn.utils.clip_grad_norm_, upstream :311) on the flat bucket,
+        fused AdamW, monitored gradient norms."""
         total_norm = torch.linalg.vector_norm(self.flat_grads)
         self.flat_grads.mul_(torch.clamp(self.config["max_grad_norm"] / (total_norm + 1e-6), max=1.0))
         self.optimizer.step()
-        return stats, (self._grad_group_norms() if monitor else None)
+        return self._grad_group_norms() if monitor else None
 
     def _train_step_graph(self, idx, learning_rate, clip_range, beta, monitor):
-        """Minibatch step through the captured graph (two eager warm-up steps first).  Returns (stats[6], norms or None)."""
+        """Minibatch step through captured graphs (two eager warm-up steps first).  Single GPU: one graph.  Data parallel: the
+        merged advantage statistics are computed eagerly first, then graph A (through the packed gradients), the RCCL
+        all-reduce of the flat bucket, graph B (clip + AdamW).  Returns (stats[6], norms or None)."""
+        dp = self.dp
         if getattr(self, "_tg_idx", None) is None:
             self._tg_idx = torch.empty_like(idx)
+            self._tg_stats3 = torch.zeros(3, dtype=torch.float32, device=self.device) if dp is not None else None
         self._tg_idx.copy_(idx)
         self._set_lr(learning_rate)
         if self._sched_host[1] != clip_range or self._sched_host[2] != beta:
             self._dyn.copy_(torch.tensor([clip_range, beta], dtype=torch.float64))
             self._sched_host[1:] = [clip_range, beta]
+        if dp is not None:
+            adv = self.buffer.samples_flat["advantages"].index_select(0, self._tg_idx)
+            self._tg_stats3.copy_(dp.merge_adv_stats(ops.adv_stats(adv)))
         self._mb_counter += 1
         sample_eager = self.profile_sample_every and self._mb_counter % self.profile_sample_every == 0
         key = (monitor, self._bank_pos is not None)
         if (self._train_graph is None and self._train_warm < 2) or sample_eager:
             self._train_warm += 1
-            st, nm = self._train_body(self._tg_idx, clip_range, beta, monitor)
+            st = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
+            if dp is not None:
+                dp.all_reduce_grads()
+            nm = self._train_body_b(monitor)
             return st.clone(), (nm.clone() if nm is not None else None)
         if self._train_graph is None or self._tg_key != key:
             torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._tg_stats, self._tg_norms = self._train_body(self._tg_idx, clip_range, beta, monitor)
-            self._train_graph, self._tg_key = g, key
-        self._train_graph.replay()
+            ga = torch.cuda.CUDAGraph()
+            gb = None
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                self._tg_stats = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
+                if dp is None:
+                    self._tg_norms = self._train_body_b(monitor)
+            if dp is not None:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                    self._tg_norms = self._train_body_b(monitor)
+            self._train_graph, self._tg_key = (ga, gb), key
+        ga, gb = self._train_graph
+        ga.replay()
+        if gb is not None:
+            dp.all_reduce_grads()
+            gb.replay()
         return self._tg_stats.clone(), (self._tg_norms.clone() if monitor else None)
 
     def _build_grad_groups(self):
