@@ -14,15 +14,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)          (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Wave-wide reductions on the DPP path (no LDS round trips): xor-1 / xor-2 inside a quad, the other quad of the 8-group
+// (row_half_mirror), the other half of the 16-lane row (row_mirror) -- after these every lane of a row holds the row total --
+// then the row totals are accumulated into the last row (row_bcast:15 / :31, gfx9) and lane 63 is broadcast through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float etm_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += etm_dpp<0xB1, 0xF>(0.f, v);    // quad_perm [1,0,3,2]
+  v += etm_dpp<0x4E, 0xF>(0.f, v);    // quad_perm [2,3,0,1]
+  v += etm_dpp<0x141, 0xF>(0.f, v);   // row_half_mirror
+  v += etm_dpp<0x140, 0xF>(0.f, v);   // row_mirror
+  v += etm_dpp<0x142, 0xA>(0.f, v);   // row_bcast:15 into rows 1, 3
+  v += etm_dpp<0x143, 0xC>(0.f, v);   // row_bcast:31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmaxf(v, etm_dpp<0xB1, 0xF>(v, v));
+  v = fmaxf(v, etm_dpp<0x4E, 0xF>(v, v));
+  v = fmaxf(v, etm_dpp<0x141, 0xF>(v, v));
+  v = fmaxf(v, etm_dpp<0x140, 0xF>(v, v));
+  v = fmaxf(v, etm_dpp<0x142, 0xA>(v, v));   // rows not written keep their own value (old = v)
+  v = fmaxf(v, etm_dpp<0x143, 0xC>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // sum over the 32 lanes that share (lane >> 5)
 __device__ __forceinline__ float half_sum(float v) {

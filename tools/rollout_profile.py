@@ -9,7 +9,11 @@ from trainer import PPOTrainer
 cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", "synthetic_minigrid.yaml")).get_config()
 for k in sys.argv[1:]:
     name, val = k.split("=")
-    cfg[name] = (val == "1")
+    tgt = cfg
+    *path, leaf = name.split(".")
+    for part in path:
+        tgt = tgt[part]
+    tgt[leaf] = (val == "1")
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="prof", device=dev, tensorboard=False)
@@ -26,3 +30,18 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     print(f"rollout: {dt * 1e3:.1f} ms = {dt / S * 1e6:.0f} us per step (host env.step {tr.last_update_timing['env_s'] / S * 1e6:.0f} us per step)"
           f"  stream_observations={tr._stream_obs}")
+
+# device time of the step graphs alone (no host work in between): head = critical path of a step, tail = under env.step
+if tr._step_graph is not None:
+    tr._t_dev.zero_(); torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    n = 200
+    e0.record()
+    for _ in range(n):
+        tr._step_graph[0].replay()
+    e1.record()
+    for _ in range(n):
+        tr._step_graph[1].replay()
+    e2.record(); torch.cuda.synchronize()
+    print(f"step graphs back-to-back: head {e0.elapsed_time(e1) / n * 1e3:.1f} us, tail {e1.elapsed_time(e2) / n * 1e3:.1f} us  "
+          f"(rollout_chain={tr.model.transformer.rollout_chain})")
