@@ -115,7 +115,7 @@ class PPOTrainer:
         self.action_space_shape = (self.env.num_actions,)  # one branch, like upstream (trainer.py:47)
         self.max_episode_length = self.env.max_episode_steps
 
-        if config.get("tunable_gemm", True):
+        if config.get("tunable_gemm", os.environ.get("ETM_TUNABLE_GEMM", "1") != "0"):
             # let PyTorch pick the fastest hipBLASLt / rocBLAS solution per GEMM shape (the small [N, D] x [D, D] products around
             # the kernels are far from the libraries' default heuristics: -5 % optimisation time, -14 us per rollout step);
             # every shape is met in the eager warm-up steps, i.e. before any graph capture.  fp32 in, fp32 out: only the
