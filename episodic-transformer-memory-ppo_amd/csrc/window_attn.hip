@@ -41,12 +41,28 @@ struct WinParams {
   float sqrt_d;
 };
 
-// Sums NV per-lane values across the 64 lanes of a wave with NV + log-many shuffles instead of 6 NV: at every step half
-// of the values travel to the partner lane.  On return v[0] of lane l holds the total of value  l >> (6 - log2 NV).
+// Value of `v` in lane (lane ^ OFF).  xor 1 / 2 / 8 are single DPP controls (quad_perm, row_ror:8), xor 4 is a row_shl:4
+// for the lanes whose bit 2 is clear (banks 0 and 2 of the 16-lane row) merged with a row_shr:4 for the others; only the
+// cross-row offsets 16 and 32 go through the LDS crossbar (ds_bpermute).
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int i = __float_as_int(v);
+  if constexpr (OFF == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, false));
+  else if constexpr (OFF == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, false));
+  else if constexpr (OFF == 4) {
+    const int lo = __builtin_amdgcn_update_dpp(0, i, 0x104, 0xF, 0x5, false);     // lanes with bit 2 clear read lane + 4
+    return __int_as_float(__builtin_amdgcn_update_dpp(lo, i, 0x114, 0xF, 0xA, false));   // the others read lane - 4
+  } else if constexpr (OFF == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x128, 0xF, 0xF, false));
+  else return __shfl_xor(v, OFF, 64);
+}
+
+// Sums NV per-lane values across the 64 lanes of a wave with NV + log-many exchanges instead of 6 NV: at every step half of
+// the values travel to the partner lane.  Offsets ascend (1, 2, 4, ...) so that the steps with many exchanges are the DPP
+// ones.  On return v[0] of lane l holds the total of value  bit_reverse(l mod NV)  (over log2 NV bits).
 template <int NV, int OFF>
 struct TransposeReduce {
   static __device__ __forceinline__ void run(float *v, int lane) {
-    if constexpr (OFF >= 1) {
+    if constexpr (OFF <= 32) {
       if constexpr (NV > 1) {
         constexpr int HALF = NV / 2;
         const bool up = (lane & OFF) != 0;
@@ -54,12 +70,12 @@ struct TransposeReduce {
         for (int k = 0; k < HALF; ++k) {
           const float send = up ? v[k] : v[k + HALF];
           const float keep = up ? v[k + HALF] : v[k];
-          v[k] = keep + __shfl_xor(send, OFF, 64);
+          v[k] = keep + lane_xor<OFF>(send);
         }
-        TransposeReduce<HALF, OFF / 2>::run(v, lane);
+        TransposeReduce<HALF, OFF * 2>::run(v, lane);
       } else {
-        v[0] += __shfl_xor(v[0], OFF, 64);
-        TransposeReduce<1, OFF / 2>::run(v, lane);
+        v[0] += lane_xor<OFF>(v[0]);
+        TransposeReduce<1, OFF * 2>::run(v, lane);
       }
     }
   }
@@ -82,7 +98,7 @@ __device__ unsigned long long g_win_trace[WIN_TRACE_WGS * 8 * WIN_TRACE_SLOTS];
 #define WIN_T(i_)
 #endif
 
-template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS>
+template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS, bool FULLD>
 __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int LP = NW * RW;     // padded window length
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = j * 128 + 2 * lane;
-    cv[j] = c < D;
+    cv[j] = FULLD || c < D;     // FULLD (D == 128 NJ): compile-time true, the validity selects below disappear
     cc[j] = cv[j] ? c : 0;
     lg[j] = lb[j] = f32x2{0.f, 0.f};
     if (has_ln) {
@@ -191,10 +207,10 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
         ev[i * HG + hh] = s[0] + s[1];
       }
     }
-    TransposeReduce<NV, 32>::run(ev, lane);
-    constexpr int SH = 6 - ilog2(NV);
-    const int vi = lane >> SH, i_ = vi / HG, hh_ = vi - i_ * HG;
-    if ((lane & ((1 << SH) - 1)) == 0 && h0 + hh_ < H) a_s[(h0 + hh_) * LP + wave * RW + i_] = ev[0];
+    TransposeReduce<NV, 1>::run(ev, lane);
+    constexpr int LG = ilog2(NV);
+    const int vi = (int)(__brev((unsigned)(lane & (NV - 1))) >> (32 - LG)), i_ = vi / HG, hh_ = vi - i_ * HG;
+    if (lane < NV && h0 + hh_ < H) a_s[(h0 + hh_) * LP + wave * RW + i_] = ev[0];
   }
   WIN_T(4)   // pass 1 + reduction done
   __syncthreads();
@@ -298,15 +314,21 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
 #undef ETM_LOAD_ROW
 }
 
-template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS>
-int launch_pass2(const WinParams &p, hipStream_t st) {
+template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS, bool FULLD>
+int launch_pass3(const WinParams &p, hipStream_t st) {
   const size_t lds = (size_t)(p.H * NW * RW + NW * HG * NJ * 128) * sizeof(float);
   if (lds > 160 * 1024) return ETM_EUNSUPPORTED;
-  auto kern = window_pass_kernel<NJ, RW, NW, HAS_LN, HAS_POS>;
+  auto kern = window_pass_kernel<NJ, RW, NW, HAS_LN, HAS_POS, FULLD>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
   hipLaunchKernelGGL(kern, dim3(p.N), dim3(NW * 64), lds, st, p);
   return etm_launch_status();
+}
+
+template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS>
+int launch_pass2(const WinParams &p, hipStream_t st) {
+  if (p.D == NJ * 128) return launch_pass3<NJ, RW, NW, HAS_LN, HAS_POS, true>(p, st);
+  return launch_pass3<NJ, RW, NW, HAS_LN, HAS_POS, false>(p, st);
 }
 
 template <int NJ, int RW, int NW>
