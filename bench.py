@@ -60,11 +60,13 @@ def pmc_traffic(kernel):
     (profiles/r01_pmc_summary.json, produced by tools/run_pmc.sh in separate --pmc passes): FETCH_SIZE KiB x 2 (gfx950 reports
     half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KiB.  None if no profile is present."""
     path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    symbol = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel"}.get(kernel, kernel)
     try:
         with open(path) as f:
-            k = json.load(f)[kernel]
+            k = json.load(f)[symbol]
         return {"bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"]["mean"] + 1024 * k["WRITE_SIZE"]["mean"],
-                "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, N=2048 L=64 D=384 H=4)",
+                "source": f"profiles/r01_pmc_summary.json, kernel symbol {symbol} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                          "N=2048 L=64 D=384 H=4; forward and backward launches of the window pass averaged)",
                 "mfma_busy_fraction_pmc": k.get("derived", {}).get("mfma_busy_fraction")}
     except Exception:
         return None

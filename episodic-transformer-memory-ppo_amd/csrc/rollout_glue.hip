@@ -148,7 +148,8 @@ __global__ __launch_bounds__(1024) void rollout_policy_kernel(const float *__res
     st_logp[t * W + w] = lg[a] - lse;
     st_values[t * W + w] = lg[A];
   }
-  __threadfence_system();
+  // One system-scope release, by one thread: the barrier orders the workgroup's stores before it (a fence in every wave
+  // made each of the 16 waves write back the L2: 22 us for this kernel instead of 6).
   __syncthreads();
   if (threadIdx.x == 0) {
     *t_dev = t + 1;

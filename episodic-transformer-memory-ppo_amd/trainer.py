@@ -470,7 +470,7 @@ class PPOTrainer:
                                     and self.model._fused_encoder_ok(self._obs_dev))
         so = self._stream_obs
         with torch.no_grad():
-            hf = self._host_flag = bool(self.config.get("host_flag_actions", True) and self._use_kv_cache
+            hf = self._host_flag = bool(self.config.get("host_flag_actions", False) and self._use_kv_cache
                                         and len(self.action_space_shape) == 1 and self.model.rollout_heads_fusable())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))

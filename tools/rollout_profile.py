@@ -44,4 +44,4 @@ if tr._step_graph is not None:
         tr._step_graph[1].replay()
     e2.record(); torch.cuda.synchronize()
     print(f"step graphs back-to-back: head {e0.elapsed_time(e1) / n * 1e3:.1f} us, tail {e1.elapsed_time(e2) / n * 1e3:.1f} us  "
-          f"(rollout_chain={tr.model.transformer.rollout_chain})")
+          f"(host_flag={tr._host_flag})")
