@@ -118,7 +118,7 @@ class SyntheticVecEnv:
         self._t = np.zeros(self.num_envs, dtype=np.int64)
         self._ret = np.zeros(self.num_envs, dtype=np.float64)
 
-    ROW_CHUNKS = 4   # on_rows granularity (vec_env protocol)
+    ROW_CHUNKS = 2   # on_rows granularity (vec_env protocol); 2 measured best: every upload call costs ~9 us of host time
 
     def _emit(self, out, on_rows=None):
         frame = self._frames[:, self._cursor % self._pool]

@@ -17,7 +17,7 @@ import numpy as np
 
 
 class _VecBase:
-    ROW_CHUNKS = 4   # on_rows granularity: W / ROW_CHUNKS workers per notification
+    ROW_CHUNKS = 2   # on_rows granularity: W / ROW_CHUNKS workers per notification (each notification costs the trainer ~9 us)
 
     def _alloc(self, out):
         return out if out is not None else np.zeros((self.num_envs,) + self.observation_space_shape, dtype=np.float32)
