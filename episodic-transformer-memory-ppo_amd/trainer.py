@@ -143,6 +143,7 @@ class PPOTrainer:
         self._use_train_graph = bool(config.get("hip_graph_train", True))
         self._train_graph = None
         self._train_warm = 0
+        self._obs_train = None
         if self._use_train_graph:
             self._lr_dev = torch.tensor(float(self.lr_schedule["initial"]), dtype=torch.float32, device=device)
             self._dyn = torch.zeros(2, dtype=torch.float64, device=device)      # (clip range, entropy coefficient)
@@ -512,6 +513,7 @@ class PPOTrainer:
         # block, minibatch and epoch inside the kernels (bit-identical sums; halves the kernels' window-row loads)
         with torch.no_grad():
             self._bank_pos = self._bank_with_positions()
+            self._obs_train = self._observations_channels_last()
         mbs = self.buffer.batch_size // self.buffer.n_mini_batches
         for epoch in range(self.config["epochs"]):
             if perms is None:
@@ -587,18 +589,35 @@ class PPOTrainer:
         torch.add(mem, tr._pos_table[None, : mem.shape[1], None, :], out=out)
         return self._bank_pos_buf
 
+    def _observations_channels_last(self):
+        """Visual observations of the whole buffer in NHWC memory order, converted ONCE per update into a fixed-address buffer
+        (the library convolutions of the optimisation phase run on channels_last activations; converting every gathered
+        minibatch costs a 173 MB copy per minibatch at config 3).  Returns the flat [W*S, H, W, C] buffer or None."""
+        obs = self.buffer.samples_flat["obs"]
+        if obs.dim() != 4 or not getattr(self.model, "channels_last", False):
+            return None
+        n, c, h, w = obs.shape
+        if getattr(self, "_obs_nhwc_buf", None) is None or self._obs_nhwc_buf.shape != (n, h, w, c):
+            self._obs_nhwc_buf = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
+        self._obs_nhwc_buf.copy_(obs.permute(0, 2, 3, 1))
+        return self._obs_nhwc_buf
+
     def _train_body_a(self, idx, clip_range, beta, stats3=None):
         """First half of one optimiser step on the minibatch ``idx`` (device int64 [mbs], fixed address): gather, forward,
         loss, backward, gradients packed into the flat bucket.  ``stats3``: (count, mean, M2) of the GLOBAL minibatch's
         advantages (data-parallel runs merge them over ranks before this graph); None: computed here.  Returns stats[6]."""
         buf = self.buffer
-        mb = {k: v.index_select(0, idx) for k, v in buf.samples_flat.items()}
+        skip = ("obs",) if self._obs_train is not None else ()
+        mb = {k: v.index_select(0, idx) for k, v in buf.samples_flat.items() if k not in skip}
         if self._bank_pos is not None:
             spec = WindowSpec.from_bank(self._bank_pos_buf, mb["memory_index"], mb["memory_indices"], None, mb["memory_mask"])
             spec.pos_included = True
         else:
             spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
-        logits, value, _ = self.model.forward_logits(mb["obs"], spec, want_items=False)
+        obs = mb.get("obs")
+        if self._obs_train is not None:     # gather NHWC rows; the NCHW view of them is already channels_last
+            obs = self._obs_train.index_select(0, idx).permute(0, 3, 1, 2)
+        logits, value, _ = self.model.forward_logits(obs, spec, want_items=False)
         if stats3 is None:
             stats3 = ops.adv_stats(mb["advantages"])
         loss, stats = ops.ppo_loss(logits, value, mb["actions"], mb["log_probs"], mb["advantages"], mb["values"], clip_range,
