@@ -660,6 +660,50 @@ print("rccl-ok")
     assert "rccl-ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_graph_and_eager_optimisation_steps_agree():
+    """The captured minibatch step (device-resident lr / clip / beta under changing schedules) trains exactly like the eager
+    `_train_mini_batch` path that mirrors upstream's method (hip_graph_train: false), and the upstream-style generator API
+    still yields usable minibatches."""
+    from trainer import PPOTrainer
+    dev = _dev()
+    cfg = dict(environment=dict(type="Synthetic", obs_shape=[3, 36, 36], num_actions=3, max_episode_steps=20, seed=7, p_done=0.07, pool=8),
+               gamma=0.99, lamda=0.95, updates=1, epochs=2, n_workers=6, worker_steps=32, n_mini_batch=4, value_loss_coefficient=0.5,
+               hidden_layer_size=64, max_grad_norm=0.5,
+               transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8, positional_encoding="relative",
+                                layer_norm="pre", gtrxl=True, gtrxl_bias=0.0),
+               learning_rate_schedule=dict(initial=3e-4, final=1e-4, power=1.0, max_decay_steps=3),
+               beta_schedule=dict(initial=1e-3, final=1e-4, power=1.0, max_decay_steps=3),
+               clip_range_schedule=dict(initial=0.2, final=0.1, power=1.0, max_decay_steps=3))
+    rng = np.random.default_rng(1)
+    acts = rng.integers(0, 3, size=(3, 6, 32))
+    perms = [[rng.permutation(6 * 32) for _ in range(2)] for _ in range(3)]
+    params, stats = [], []
+    for graph in (True, False):
+        c = json.loads(json.dumps(cfg))
+        c["hip_graph_train"] = graph
+        torch.manual_seed(9)
+        tr = PPOTrainer(c, run_id="ge", device=dev, tensorboard=False)
+        rows = []
+        for u in range(3):
+            lr, beta, clip = tr.schedules(u)
+            tr._sample_training_data(forced_actions=acts[u])
+            tr.buffer.prepare_batch_dict()
+            info, _ = tr._train_epochs(lr, clip, beta, perms=perms[u])
+            rows.append(np.asarray(info))
+        assert (tr._train_graph is not None) == graph
+        params.append([p.detach().clone() for p in tr.model.parameters()])
+        stats.append(np.concatenate(rows))
+        if not graph:     # upstream-style API: generator + one more eager step
+            mb = next(iter(tr.buffer.mini_batch_generator(perms[0][0])))
+            assert set(mb) >= {"actions", "values", "log_probs", "advantages", "obs", "memory_mask", "memory_indices", "memories"}
+            st = tr._train_mini_batch(mb, 1e-4, 0.1, 1e-4)
+            assert st.shape == (6,) and bool(torch.isfinite(st).all())
+        tr.close()
+    assert np.allclose(stats[0], stats[1], atol=1e-5, rtol=1e-4), np.abs(stats[0] - stats[1]).max()
+    for a, b in zip(*params):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), float((a - b).abs().max())
+
+
 def test_dp_graph_step_single_rank(tmp_path):
     """Data-parallel optimisation step (graph A -> RCCL all-reduce of the flat bucket -> graph B, advantage statistics merged
     with an all-gather) on one device with the collectives really issued (world size 1, `active` forced): must train exactly
