@@ -292,6 +292,8 @@ class PPOTrainer:
         self._flag_np[0] = 0
         self._uniforms.uniform_()                # one draw per (step, worker) for the whole rollout
         t_env = 0.0
+        acts_host = self._act_pin.numpy()
+        acts_host = acts_host[:, 0] if acts_host.shape[1] == 1 else acts_host      # [W] for one branch, [W, B] for multi-discrete
         stream_obs = use_graph and self._stream_obs
         if stream_obs:
             lib = etm_lib.load()
@@ -331,10 +333,10 @@ class PPOTrainer:
                 def rows_ready(lo, hi):
                     lib.etm_upload(dst_base + lo * row_bytes, src_base + lo * row_bytes, (hi - lo) * row_bytes, up)
 
-                _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs, on_rows=rows_ready)
+                _, rewards, dones, infos = self.env.step(acts_host, out=self.obs, on_rows=rows_ready)
                 self._up_done.record(self._up_stream)
             else:
-                _, rewards, dones, infos = self.env.step(self._act_pin.numpy()[:, 0], out=self.obs)
+                _, rewards, dones, infos = self.env.step(acts_host, out=self.obs)
             t_env += time.perf_counter() - te
             buf.rewards[:, t] = rewards
             buf.dones[:, t] = dones
