@@ -11,7 +11,7 @@
 //                                                                                               [Cout][KH][KW][C]
 // so every lane fetches its A fragment with 16-byte loads straight from global memory/L2 (no LDS staging, no barrier in
 // the main loop).  One workgroup = one tile of 32 output pixels x all Cout (NT = Cout/32 accumulator tiles); its eight
-// waves split K (interleaved 8-wide k-groups, operands of the next batch prefetched) and are reduced through LDS, then bias + ReLU + store (NHWC for the next
+// waves split K (interleaved 8-wide k-groups, all operands of a batch requested up front) and are reduced through LDS, then bias + ReLU + store (NHWC for the next
 // layer, NCHW for the last one so that the flatten order of model.py:94 is unchanged).
 #include "etm_common.h"
 
@@ -27,11 +27,12 @@ struct ConvParams {
 };
 
 constexpr int CONV_NW = 8;   // waves per workgroup = K slices
-constexpr int CONV_GB = 4;   // 8-wide k-groups per wave and batch (one batch of operands in flight under the MFMAs of the last)
+// GB (template parameter) = 8-wide k-groups per wave and batch: all operands of a batch are requested before its first MFMA;
+// the launcher picks the smallest instantiated GB that covers a wave's share of K in one batch.
 
-template <int NT>
+template <int NT, int GB>
 __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParams p) {
-  constexpr int NW = CONV_NW, GB = CONV_GB;
+  constexpr int NW = CONV_NW;
   __shared__ float red[NW * NT * 16 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int M = p.N * p.Ho * p.Wo;
@@ -62,34 +63,29 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
     return in_base + base + off + half * 4;
   };
 
-  // Wave w takes k-groups w, w + NW, ...  in batches of GB; the loads of batch i+1 are issued before the MFMAs of batch i
-  // (the loop used to expose one global-memory round trip per iteration: ~1 us each at 32 images).  Groups past the end
-  // are clamped to the last one (unconditional loads) and their A fragment is zeroed.
-  f32x4 a_cur[GB], b_cur[GB][NT], a_nxt[GB], b_nxt[GB][NT];
+  // Wave w takes k-groups w, w + NW, ... in batches of GB.  Every operand of a batch is requested up front (unconditional
+  // loads, groups past the end clamped to the last one), so a batch exposes ONE global-memory round trip; the three encoder
+  // layers (3 / 8 / 9 groups per wave) are a single batch.  (The first version exposed a round trip per pair of groups, the
+  // second one per four: at 32 images the kernel is pure latency.)
+  f32x4 a_cur[GB], b_cur[GB][NT];
   const int last = p.groups - 1;
 #define ETM_CONV_LOAD(dst_a, dst_b, g0_)                                                          \
   _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                                \
     const int g_ = (g0_) + u * NW;                                                                \
     const int gc_ = g_ < p.groups ? g_ : last;                                                    \
-    f32x4 av_ = *reinterpret_cast<const f32x4 *>(a_ptr(gc_ * 8));                                 \
-    if (g_ >= p.groups) av_ = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
-    dst_a[u] = av_;                                                                               \
+    dst_a[u] = *reinterpret_cast<const f32x4 *>(a_ptr(gc_ * 8));                                  \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) dst_b[u][t] = *reinterpret_cast<const f32x4 *>(wlane + ((long long)gc_ * NT + t) * 256); \
   }
-  ETM_CONV_LOAD(a_cur, b_cur, wave)
   for (int g0 = wave; g0 < p.groups; g0 += GB * NW) {
-    ETM_CONV_LOAD(a_nxt, b_nxt, g0 + GB * NW)
-#pragma unroll
-    for (int u = 0; u < GB; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][j], b_cur[u][t][j], acc[t], 0, 0, 0);
+    ETM_CONV_LOAD(a_cur, b_cur, g0)
 #pragma unroll
     for (int u = 0; u < GB; ++u) {
-      a_cur[u] = a_nxt[u];
+      if (g0 + u * NW < p.groups) {     // wave-uniform: groups past the end are skipped
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b_cur[u][t] = b_nxt[u][t];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][j], b_cur[u][t][j], acc[t], 0, 0, 0);
+      }
     }
   }
 #undef ETM_CONV_LOAD
@@ -143,7 +139,16 @@ extern "C" int etm_conv_relu(const float *in, const int64_t *in_index, int64_t i
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_CONV_RELU, st);
   const dim3 grid((unsigned)((M + 31) / 32));
-  if (Cout == 32) hipLaunchKernelGGL((conv_relu_kernel<1>), grid, dim3(CONV_NW * 64), 0, st, p);
-  else hipLaunchKernelGGL((conv_relu_kernel<2>), grid, dim3(CONV_NW * 64), 0, st, p);
+  const int gpw = (p.groups + CONV_NW - 1) / CONV_NW;     // k-groups per wave
+  const dim3 block(CONV_NW * 64);
+  if (Cout == 32) {
+    if (gpw <= 4) hipLaunchKernelGGL((conv_relu_kernel<1, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_relu_kernel<1, 12>), grid, block, 0, st, p);
+  } else {
+    if (gpw <= 4) hipLaunchKernelGGL((conv_relu_kernel<2, 4>), grid, block, 0, st, p);
+    else if (gpw <= 8) hipLaunchKernelGGL((conv_relu_kernel<2, 8>), grid, block, 0, st, p);
+    else if (gpw <= 10) hipLaunchKernelGGL((conv_relu_kernel<2, 10>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_relu_kernel<2, 12>), grid, block, 0, st, p);
+  }
   return etm_launch_status();
 }

@@ -3,6 +3,9 @@ import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
 import numpy as np, torch
+from etm import lib as _etm_lib
+if os.environ.get("ETM_DIAG_LIB"):
+    _etm_lib.LIB_PATH = os.environ["ETM_DIAG_LIB"]      # A/B against another build of the library
 from yaml_parser import YamlParser
 from trainer import PPOTrainer
 
@@ -13,7 +16,7 @@ for k in sys.argv[1:]:
     *path, leaf = name.split(".")
     for part in path:
         tgt = tgt[part]
-    tgt[leaf] = (val == "1")
+    tgt[leaf] = (val == "1") if val in ("0", "1") else int(val)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="prof", device=dev, tensorboard=False)
