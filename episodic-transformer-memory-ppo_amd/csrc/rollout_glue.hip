@@ -100,31 +100,34 @@ __global__ __launch_bounds__(1024) void rollout_sample_kernel(const float *__res
   if (threadIdx.x == 0) *t_dev = t + 1;
 }
 
-// Output heads + sampling of a single-branch policy in ONE launch (rollout_heads_kernel + rollout_sample_kernel), and the
-// action hand-over to the host without a copy launch and without an event: the actions are also stored straight into pinned
-// host memory, followed (after a system-scope fence) by the step counter the host spins on.
-__global__ __launch_bounds__(1024) void rollout_policy_kernel(const float *__restrict__ h, const float *__restrict__ wp,
-                                                              const float *__restrict__ bp, const float *__restrict__ wv,
-                                                              const float *__restrict__ bv, const float *__restrict__ uniforms,
-                                                              const long long *__restrict__ forced, long long *__restrict__ t_dev,
-                                                              long long *__restrict__ actions, long long *__restrict__ st_actions,
-                                                              float *__restrict__ st_logp, float *__restrict__ st_values,
-                                                              long long *host_actions, long long *host_flag, int W, int A, int hid) {
-  extern __shared__ float out_s[];   // [W][A + 1]: logits, then the value
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int job = wave; job < W * (A + 1); job += 16) {
-    const int w = job / (A + 1), o = job - w * (A + 1);
+// Output heads + sampling of a single-branch policy in ONE launch (rollout_heads_kernel + rollout_sample_kernel): one
+// workgroup per worker, one wave per output (A logits + the value; a single workgroup looping over all W (A + 1) dot products
+// took 19 us, each pass being one global-memory round trip), then lane 0 samples.  The step counter is advanced by the LAST
+// workgroup to finish (every workgroup has read it by then).  Optional hand-over to the host without a copy launch and
+// without an event: the actions are also stored straight into pinned host memory, followed (after ONE system-scope release)
+// by the step counter the host spins on.
+__global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__restrict__ h, const float *__restrict__ wp,
+                                                             const float *__restrict__ bp, const float *__restrict__ wv,
+                                                             const float *__restrict__ bv, const float *__restrict__ uniforms,
+                                                             const long long *__restrict__ forced, long long *__restrict__ t_dev,
+                                                             long long *__restrict__ actions, long long *__restrict__ st_actions,
+                                                             float *__restrict__ st_logp, float *__restrict__ st_values,
+                                                             long long *host_actions, long long *host_flag, int *sync_counter,
+                                                             int W, int A, int hid) {
+  extern __shared__ float out_s[];   // [A + 1]: logits, then the value
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w = blockIdx.x;
+  const long long t = *t_dev;
+  for (int o = wave; o < A + 1; o += 4) {
     const float *x = h + (long long)w * 2 * hid + (o < A ? 0 : hid);
     const float *wt = (o < A) ? wp + (long long)o * hid : wv;
     float s = 0.f;
     for (int c = lane; c < hid; c += 64) s += x[c] * wt[c];
     s = wave_sum(s);
-    if (lane == 0) out_s[job] = s + (o < A ? bp[o] : bv[0]);
+    if (lane == 0) out_s[o] = s + (o < A ? bp[o] : bv[0]);
   }
   __syncthreads();
-  const long long t = *t_dev;
-  for (int w = threadIdx.x; w < W; w += 1024) {
-    const float *lg = out_s + w * (A + 1);
+  if (threadIdx.x == 0) {
+    const float *lg = out_s;
     float mx = -INFINITY;
     for (int j = 0; j < A; ++j) mx = fmaxf(mx, lg[j]);
     float se = 0.f;
@@ -147,15 +150,14 @@ __global__ __launch_bounds__(1024) void rollout_policy_kernel(const float *__res
     st_actions[t * W + w] = a;
     st_logp[t * W + w] = lg[a] - lse;
     st_values[t * W + w] = lg[A];
-  }
-  // One system-scope release, by one thread: the barrier orders the workgroup's stores before it (a fence in every wave
-  // made each of the 16 waves write back the L2: 22 us for this kernel instead of 6).
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    *t_dev = t + 1;
-    if (host_flag) {
-      __threadfence_system();
-      __hip_atomic_store(host_flag, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence();                                     // this worker's rows are visible before the arrival below
+    if (atomicAdd(sync_counter, 1) == W - 1) {           // last workgroup of the step
+      *sync_counter = 0;
+      *t_dev = t + 1;
+      if (host_flag) {
+        __threadfence_system();
+        __hip_atomic_store(host_flag, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -223,20 +225,20 @@ extern "C" int etm_rollout_sample(const float *logits, const float *value, const
 
 extern "C" int etm_rollout_policy(const float *h, const float *wp, const float *bp, const float *wv, const float *bv,
                                   const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
-                                  float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int W, int A, int hid,
-                                  void *stream) {
+                                  float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
+                                  int W, int A, int hid, void *stream) {
   (void)hipGetLastError();
   if (!h || !wp || !bp || !wv || !bv || (!uniforms && !forced) || !t_dev || !actions || !st_actions || !st_logp || !st_values ||
-      W <= 0 || A <= 0 || hid <= 0)
+      !sync_counter || W <= 0 || A <= 0 || hid <= 0)
     return ETM_EINVAL;
   if ((host_actions != nullptr) != (host_flag != nullptr)) return ETM_EINVAL;
-  const size_t lds = (size_t)W * (A + 1) * sizeof(float);
+  const size_t lds = (size_t)(A + 1) * sizeof(float);
   if (lds > 64 * 1024) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_ROLLOUT_SAMPLE, st);
-  hipLaunchKernelGGL(rollout_policy_kernel, dim3(1), dim3(1024), lds, st, h, wp, bp, wv, bv, uniforms, (const long long *)forced,
+  hipLaunchKernelGGL(rollout_policy_kernel, dim3((unsigned)W), dim3(256), lds, st, h, wp, bp, wv, bv, uniforms, (const long long *)forced,
                      (long long *)t_dev, (long long *)actions, (long long *)st_actions, st_logp, st_values, (long long *)host_actions,
-                     (long long *)host_flag, W, A, hid);
+                     (long long *)host_flag, (int *)sync_counter, W, A, hid);
   return etm_launch_status();
 }
 

@@ -330,6 +330,9 @@ def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, 
                                       _ptr(st_actions), _ptr(st_logp), _ptr(st_values), W, A, _stream()), "etm_rollout_sample")
 
 
+_policy_sync = {}
+
+
 def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values,
                    host_actions=None, host_flag=None):
     """``rollout_heads`` + ``rollout_sample`` in one launch (single-branch policy); ``host_actions`` / ``host_flag``: pinned
@@ -340,9 +343,12 @@ def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions
     h2 = _f32c(h2, "h")
     ha = 0 if host_actions is None else host_actions.data_ptr()
     hf = 0 if host_flag is None else host_flag.data_ptr()
+    sync = _policy_sync.get(t_dev.data_ptr())       # arrival counter of the launch's workgroups, one per step counter
+    if sync is None:
+        sync = _policy_sync[t_dev.data_ptr()] = torch.zeros(1, dtype=torch.int32, device=h2.device)
     _lib.check(lib.etm_rollout_policy(_ptr(h2), _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight),
                                       _ptr(value_head.bias), _ptr(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions), _ptr(st_actions),
-                                      _ptr(st_logp), _ptr(st_values), ha, hf, W, A, hid, _stream()), "etm_rollout_policy")
+                                      _ptr(st_logp), _ptr(st_values), ha, hf, _ptr(sync), W, A, hid, _stream()), "etm_rollout_policy")
 
 
 def rollout_heads(h2, branch, value_head):

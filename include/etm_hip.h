@@ -189,11 +189,12 @@ int etm_rollout_heads(const float *h, const float *wp, const float *bp, const fl
 /* etm_rollout_heads + etm_rollout_sample of a single-branch policy in one launch.  With host_actions / host_flag (both or
  * neither; PINNED host memory) the sampled actions are also stored to host_actions[W] and then, after a system-scope fence,
  * the new step counter (*t_dev after the increment) to *host_flag: the host spins on the flag instead of paying a copy launch
- * and an event wait per environment step. */
+ * and an event wait per environment step.  sync_counter: one device int32, zero before the first call (the workgroups of a
+ * launch count themselves in; the last one advances *t_dev and resets the counter). */
 int etm_rollout_policy(const float *h, const float *wp, const float *bp, const float *wv, const float *bv,
                        const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
-                       float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int W, int A, int hid,
-                       void *stream);
+                       float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
+                       int W, int A, int hid, void *stream);
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
  * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C]; with
