@@ -169,12 +169,16 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
   const float *pa = a + (long long)row * D, *pb = b + (long long)row * D;
-  float v[16];
+  float v[16], g[16], be[16];
   float s = 0.f;
+  // gain / bias are requested together with the row (not after the statistics): the kernel is one memory round trip long
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int c = lane + 64 * j;
-    v[j] = (c < D) ? pa[c] + pb[c] : 0.f;
+    const int cc = c < D ? c : 0;
+    g[j] = gamma[cc];
+    be[j] = beta[cc];
+    v[j] = (c < D) ? pa[cc] + pb[cc] : 0.f;
     s += v[j];
   }
   const float mean = wave_sum(s) / (float)D;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int c = lane + 64 * j;
-    if (c < D) out[(long long)row * D + c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+    if (c < D) out[(long long)row * D + c] = (v[j] - mean) * rstd * g[j] + be[j];
   }
 }
 }  // namespace
