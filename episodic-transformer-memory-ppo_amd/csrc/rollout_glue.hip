@@ -235,7 +235,7 @@ extern "C" int etm_rollout_policy(const float *h, const float *wp, const float *
   if (!h || !wp || !bp || !wv || !bv || (!uniforms && !forced) || !t_dev || !actions || !st_actions || !st_logp || !st_values ||
       !sync_counter || W <= 0 || A <= 0 || hid <= 0)
     return ETM_EINVAL;
-  if ((host_actions != nullptr) != (host_flag != nullptr)) return ETM_EINVAL;
+  if (host_flag && !host_actions) return ETM_EINVAL;
   const size_t lds = (size_t)(A + 1) * sizeof(float);
   if (lds > 64 * 1024) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;

@@ -300,8 +300,10 @@ class PPOTrainer:
             up = self._up_stream.cuda_stream
             row_bytes = self._obs_pin[0].numel() * 4
             src_base, stage_base = self._obs_pin.data_ptr(), self._stage["obs"].data_ptr()
+            ss_src, ss_dst, ss_bytes = self._ss_pin.data_ptr(), self._ss_dev.data_ptr(), self._ss_pin.numel() * 8
             self._up_stream.wait_stream(stream)          # the staging array may still be read by the previous update
             etm_lib.check(lib.etm_upload(stage_base, src_base, W * row_bytes, up), "etm_upload")
+            etm_lib.check(lib.etm_upload(ss_dst, ss_src, ss_bytes, up), "etm_upload")     # (episode step, slot) of every worker
             self._up_done.record(self._up_stream)
         for t in range(S):
             t_wait0 = time.perf_counter()
@@ -334,7 +336,6 @@ class PPOTrainer:
                     lib.etm_upload(dst_base + lo * row_bytes, src_base + lo * row_bytes, (hi - lo) * row_bytes, up)
 
                 _, rewards, dones, infos = self.env.step(acts_host, out=self.obs, on_rows=rows_ready)
-                self._up_done.record(self._up_stream)
             else:
                 _, rewards, dones, infos = self.env.step(acts_host, out=self.obs)
             t_env += time.perf_counter() - te
@@ -349,6 +350,10 @@ class PPOTrainer:
                     self.worker_episode_slot[w] = slot
                     if t < S - 1:
                         buf.memory_index_host[w, t + 1:] = slot
+            if stream_obs and t + 1 < S:
+                # bookkeeping of this step is final: the workers' (episode step, slot) follow the observation rows
+                lib.etm_upload(ss_dst, ss_src, ss_bytes, up)
+                self._up_done.record(self._up_stream)
         # time-major staging -> the buffer's [W, S, ...] fields (one strided copy per field)
         self._step_dev.copy_(self._step_pin, non_blocking=True)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
@@ -375,7 +380,7 @@ class PPOTrainer:
         else:
             self._obs_dev.copy_(self._obs_pin, non_blocking=True)
             obs, obs_index = self._obs_dev, None
-        self._ss_dev.copy_(self._ss_pin, non_blocking=True)
+            self._ss_dev.copy_(self._ss_pin, non_blocking=True)      # (streamed mode: uploaded with the observation rows)
         single = len(self.action_space_shape) == 1
         mask_t, win_t = self._mask_t, self._win_t
         # window lookup + staging; the same launch records the staging row of this step for the tail (t_dev is incremented by
@@ -392,12 +397,12 @@ class PPOTrainer:
                 # actions to the host through pinned memory + a step-counter flag
                 h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
                 flag = host_flag and forced_t is None
+                # the kernel stores the actions straight into the pinned host buffer (no copy launch); they are visible to
+                # the host when the step's event (or, with host_flag_actions, the flag) says the launch is done
                 ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, forced_t, self._t_dev,
                                    self._act_dev, st["actions"], st["log_probs"], st["values"],
-                                   host_actions=self._act_pin if flag else None, host_flag=self._flag_pin if flag else None)
+                                   host_actions=self._act_pin, host_flag=self._flag_pin if flag else None)
                 fused_policy = True
-                if not flag:
-                    self._act_pin.copy_(self._act_dev, non_blocking=True)
             else:
                 logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
         else:

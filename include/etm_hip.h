@@ -186,10 +186,11 @@ int etm_gru_gate_out(const float *a, const float *c, const float *z, const float
  * logits [W,A] = h_pol Wp^T + bp, value [W] = h_val . wv + bv.  One launch instead of two small library GEMMs. */
 int etm_rollout_heads(const float *h, const float *wp, const float *bp, const float *wv, const float *bv, float *logits, float *value,
                       int W, int A, int hid, void *stream);
-/* etm_rollout_heads + etm_rollout_sample of a single-branch policy in one launch.  With host_actions / host_flag (both or
- * neither; PINNED host memory) the sampled actions are also stored to host_actions[W] and then, after a system-scope fence,
- * the new step counter (*t_dev after the increment) to *host_flag: the host spins on the flag instead of paying a copy launch
- * and an event wait per environment step.  sync_counter: one device int32, zero before the first call (the workgroups of a
+/* etm_rollout_heads + etm_rollout_sample of a single-branch policy in one launch.  host_actions (PINNED host memory, optional):
+ * the sampled actions are also stored to host_actions[W] -- visible to the host once the launch has completed (event), which
+ * saves the device-to-host copy launch of every environment step.  host_flag (optional, needs host_actions): after a
+ * system-scope fence the new step counter (*t_dev after the increment) is stored to *host_flag, so the host can spin on
+ * the flag instead of waiting for an event.  sync_counter: one device int32, zero before the first call (the workgroups of a
  * launch count themselves in; the last one advances *t_dev and resets the counter). */
 int etm_rollout_policy(const float *h, const float *wp, const float *bp, const float *wv, const float *bv,
                        const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
