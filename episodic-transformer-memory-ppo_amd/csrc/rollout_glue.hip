@@ -108,7 +108,8 @@ __global__ __launch_bounds__(1024) void rollout_sample_kernel(const float *__res
 // by the step counter the host spins on.
 __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__restrict__ h, const float *__restrict__ wp,
                                                              const float *__restrict__ bp, const float *__restrict__ wv,
-                                                             const float *__restrict__ bv, const float *__restrict__ uniforms,
+                                                             const float *__restrict__ bv, const float *__restrict__ h_bias,
+                                                             const float *__restrict__ uniforms,
                                                              const long long *__restrict__ forced, long long *__restrict__ t_dev,
                                                              long long *__restrict__ actions, long long *__restrict__ st_actions,
                                                              float *__restrict__ st_logp, float *__restrict__ st_values,
@@ -118,10 +119,15 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w = blockIdx.x;
   const long long t = *t_dev;
   for (int o = wave; o < A + 1; o += 4) {
-    const float *x = h + (long long)w * 2 * hid + (o < A ? 0 : hid);
+    const int xo = (o < A ? 0 : hid);
+    const float *x = h + (long long)w * 2 * hid + xo;
     const float *wt = (o < A) ? wp + (long long)o * hid : wv;
     float s = 0.f;
-    for (int c = lane; c < hid; c += 64) s += x[c] * wt[c];
+    if (h_bias) {     // h holds the pre-activations of the hidden heads: relu(h + h_bias) on the fly (model.py:106-107)
+      for (int c = lane; c < hid; c += 64) s += fmaxf(x[c] + h_bias[xo + c], 0.f) * wt[c];
+    } else {
+      for (int c = lane; c < hid; c += 64) s += x[c] * wt[c];
+    }
     s = wave_sum(s);
     if (lane == 0) out_s[o] = s + (o < A ? bp[o] : bv[0]);
   }
@@ -162,8 +168,12 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
   }
 }
 
-// out = LayerNorm(a + b) * gamma + beta, one wave per row (post-LN blocks, transformer.py:143-149 / :164-170), forward only.
-__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ gamma,
+// out = LayerNorm(act(a + a_bias) + b) * gamma + beta, one wave per row (post-LN blocks, transformer.py:143-149 / :164-170),
+// forward only.  a_bias / relu (optional) are the bias and ReLU of the linear layer that produced `a`: with them folded in
+// here that layer runs as a plain library GEMM (which torch.cuda.tunable tunes per shape; its bias / activation epilogue
+// variants are not tuned and cost ~2.7 us more per launch at 32 rows).
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ a, const float *__restrict__ a_bias, int relu,
+                                                            const float *__restrict__ b, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps, float *__restrict__ out, int N, int D) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -178,7 +188,10 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
     const int cc = c < D ? c : 0;
     g[j] = gamma[cc];
     be[j] = beta[cc];
-    v[j] = (c < D) ? pa[cc] + pb[cc] : 0.f;
+    float av = pa[cc];
+    if (a_bias) av += a_bias[cc];
+    if (relu) av = fmaxf(av, 0.f);
+    v[j] = (c < D) ? av + pb[cc] : 0.f;
     s += v[j];
   }
   const float mean = wave_sum(s) / (float)D;
@@ -227,7 +240,7 @@ extern "C" int etm_rollout_sample(const float *logits, const float *value, const
   return etm_launch_status();
 }
 
-extern "C" int etm_rollout_policy(const float *h, const float *wp, const float *bp, const float *wv, const float *bv,
+extern "C" int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, const float *bp, const float *wv, const float *bv,
                                   const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                                   float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                                   int W, int A, int hid, void *stream) {
@@ -240,7 +253,7 @@ extern "C" int etm_rollout_policy(const float *h, const float *wp, const float *
   if (lds > 64 * 1024) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_ROLLOUT_SAMPLE, st);
-  hipLaunchKernelGGL(rollout_policy_kernel, dim3((unsigned)W), dim3(256), lds, st, h, wp, bp, wv, bv, uniforms, (const long long *)forced,
+  hipLaunchKernelGGL(rollout_policy_kernel, dim3((unsigned)W), dim3(256), lds, st, h, wp, bp, wv, bv, h_bias, uniforms, (const long long *)forced,
                      (long long *)t_dev, (long long *)actions, (long long *)st_actions, st_logp, st_values, (long long *)host_actions,
                      (long long *)host_flag, (int *)sync_counter, W, A, hid);
   return etm_launch_status();
@@ -256,14 +269,14 @@ extern "C" int etm_rollout_heads(const float *h, const float *wp, const float *b
   return etm_launch_status();
 }
 
-extern "C" int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
-                                 void *stream) {
+extern "C" int etm_add_layernorm(const float *a, const float *a_bias, int relu, const float *b, const float *gamma, const float *beta,
+                                 float eps, float *out, int N, int D, void *stream) {
   (void)hipGetLastError();
   if (!a || !b || !gamma || !beta || !out || N <= 0 || D <= 0) return ETM_EINVAL;
   if (D > 1024) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_ADD_LN, st);
-  hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, a, b, gamma, beta, eps, out, N, D);
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, a, a_bias, relu, b, gamma, beta, eps, out, N, D);
   return etm_launch_status();
 }
 

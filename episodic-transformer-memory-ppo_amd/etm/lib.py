@@ -29,10 +29,10 @@ SIGNATURES = {
     "etm_reset_rows": (_I, [_P, _P, _P, _I, _L, _P]),
     "etm_rollout_window": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_rollout_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "etm_add_layernorm": (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P]),
+    "etm_add_layernorm": (_I, [_P, _P, _I, _P, _P, _P, _F, _P, _I, _I, _P]),
     "etm_conv_relu": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_upload": (_I, [_P, _P, _L, _P]),
-    "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "etm_gru_gate_rz": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_gru_gate_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

@@ -334,7 +334,7 @@ _policy_sync = {}
 
 
 def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values,
-                   host_actions=None, host_flag=None):
+                   host_actions=None, host_flag=None, h_bias=None):
     """``rollout_heads`` + ``rollout_sample`` in one launch (single-branch policy); ``host_actions`` / ``host_flag``: pinned
     int64 tensors that receive the actions and then the incremented step counter (the host spins on the flag)."""
     lib = _lib.load()
@@ -346,7 +346,7 @@ def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions
     sync = _policy_sync.get(t_dev.data_ptr())       # arrival counter of the launch's workgroups, one per step counter
     if sync is None:
         sync = _policy_sync[t_dev.data_ptr()] = torch.zeros(1, dtype=torch.int32, device=h2.device)
-    _lib.check(lib.etm_rollout_policy(_ptr(h2), _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight),
+    _lib.check(lib.etm_rollout_policy(_ptr(h2), _ptr(h_bias), _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight),
                                       _ptr(value_head.bias), _ptr(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions), _ptr(st_actions),
                                       _ptr(st_logp), _ptr(st_values), ha, hf, _ptr(sync), W, A, hid, _stream()), "etm_rollout_policy")
 
@@ -381,8 +381,9 @@ def gru_gate(x, y, wy, ux, ug, bg):
     return out
 
 
-def add_layernorm(a, b, norm, out=None):
-    """LayerNorm(a + b) with ``norm``'s affine parameters; forward only (rollout path)."""
+def add_layernorm(a, b, norm, out=None, bias=None, relu=False):
+    """LayerNorm(act(a + bias) + b) with ``norm``'s affine parameters; forward only (rollout path).  ``bias`` / ``relu`` fold
+    the epilogue of the linear layer that produced ``a`` (which then runs as a plain, per-shape tuned library GEMM)."""
     lib = _lib.load()
     _need_dev(a, b)
     a, b = _f32c(a, "a"), _f32c(b, "b")
@@ -391,8 +392,8 @@ def add_layernorm(a, b, norm, out=None):
         out = torch.empty_like(a)
     elif out.shape != a.shape or out.dtype != torch.float32 or not out.is_contiguous():
         raise TypeError("add_layernorm: out must be a contiguous float32 tensor of the input shape")
-    _lib.check(lib.etm_add_layernorm(_ptr(a), _ptr(b), _ptr(norm.weight), _ptr(norm.bias), float(norm.eps), _ptr(out), N, D, _stream()),
-               "etm_add_layernorm")
+    _lib.check(lib.etm_add_layernorm(_ptr(a), _ptr(bias), 1 if relu else 0, _ptr(b), _ptr(norm.weight), _ptr(norm.bias), float(norm.eps),
+                                     _ptr(out), N, D, _stream()), "etm_add_layernorm")
     return out
 
 

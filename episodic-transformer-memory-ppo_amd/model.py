@@ -141,9 +141,13 @@ class ActorCriticModel(nn.Module):
         kernel on ``forward_hidden_cached``'s result."""
         return len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled()
 
-    def forward_hidden_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None):
-        """Rollout path up to the hidden heads: -> (h2 [N, 2*hidden] = [relu(lin_policy(h)) | relu(lin_value(h))], memory)."""
+    def forward_hidden_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None, raw=False):
+        """Rollout path up to the hidden heads: -> (h2 [N, 2*hidden] = [relu(lin_policy(h)) | relu(lin_value(h))], memory).
+        ``raw=True``: h2 are the PRE-activations (plain GEMM without epilogue); the caller applies relu(h2 + self._b_heads)
+        (``ops.rollout_policy(h_bias=...)`` does it on the fly)."""
         h, memory = self.transformer.forward_cached(self._encode(obs, obs_index), kv_spec, items_out)
+        if raw:
+            return F.linear(h, self._w_heads), memory
         return ops.linear_relu(self._heads_lin, h), memory
 
     def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None):

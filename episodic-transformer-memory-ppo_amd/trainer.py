@@ -395,13 +395,14 @@ class PPOTrainer:
             if single and self.model.rollout_heads_fusable():
                 # hidden heads -> ONE launch for output heads, sampling, staging, t += 1 and (graph mode) the hand-over of the
                 # actions to the host through pinned memory + a step-counter flag
-                h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
+                h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index, raw=True)
                 flag = host_flag and forced_t is None
                 # the kernel stores the actions straight into the pinned host buffer (no copy launch); they are visible to
                 # the host when the step's event (or, with host_flag_actions, the flag) says the launch is done
                 ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, forced_t, self._t_dev,
                                    self._act_dev, st["actions"], st["log_probs"], st["values"],
-                                   host_actions=self._act_pin, host_flag=self._flag_pin if flag else None)
+                                   host_actions=self._act_pin, host_flag=self._flag_pin if flag else None,
+                                   h_bias=self.model._b_heads)
                 fused_policy = True
             else:
                 logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)

@@ -122,12 +122,18 @@ class TransformerBlock(Module):
         """Rollout path: attention over cached K/V projections (no grad).  ``out``: contiguous destination of the result."""
         q_in = self.norm1(h) if self.layer_norm == "pre" else h
         ctx, _ = ops.attn_cached(self.attention.queries(q_in), kv_spec, block, self.attention.num_heads)
+        if self.layer_norm == "post" and not self.use_gtrxl and not torch.is_grad_enabled():
+            # rollout, post-LN without gates: the two linear layers run WITHOUT their bias / ReLU epilogue (plain library GEMMs,
+            # tuned per shape) and the epilogues ride in the residual + LayerNorm kernels that follow them
+            fc_out, fc = self.attention.fc_out, self.fc[0]
+            x = ops.add_layernorm(torch.nn.functional.linear(ctx, fc_out.weight), h, self.norm1, bias=fc_out.bias)
+            return ops.add_layernorm(torch.nn.functional.linear(x, fc.weight), x, self.norm2, out=out, bias=fc.bias, relu=True)
         return self._after_attention(h, self.attention.fc_out(ctx), out)
 
     def _after_attention(self, h, att_out, out=None):
         pre, post = self.layer_norm == "pre", self.layer_norm == "post"
         if post and not self.use_gtrxl and not torch.is_grad_enabled():
-            # rollout: residual + LayerNorm and Linear + ReLU are one launch each
+            # no-grad path with materialised att_out: residual + LayerNorm and Linear + ReLU are one launch each
             x = ops.add_layernorm(att_out, h, self.norm1)
             return ops.add_layernorm(ops.linear_relu(self.fc[0], x), x, self.norm2, out=out)
         x = self.gate1(h, att_out) if self.use_gtrxl else att_out + h

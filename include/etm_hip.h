@@ -166,7 +166,8 @@ int etm_reset_rows(float *dst, const float *init, const int64_t *step, int W, in
  *   etm_rollout_sample: per worker log-softmax of logits [W,A], categorical sample by inverse CDF with the pre-drawn
  *                       uniform uniforms[*t_dev, w] (or forced[w] if non-NULL), log-prob; writes actions [W] and row *t_dev
  *                       of st_actions / st_logp / st_values, then *t_dev += 1 (trainer.py:179-186).
- *   etm_add_layernorm:  out = LayerNorm(a + b) (residual + post-LN, transformer.py:145-149 / :166-170), forward only, D <= 1024.
+ *   etm_add_layernorm:  out = LayerNorm(act(a + a_bias) + b) (residual + post-LN, transformer.py:145-149 / :166-170), forward only,
+ *                       D <= 1024; a_bias [D] (or NULL) and relu fold the bias / ReLU of the linear layer that produced `a`.
  */
 int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
                        uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx,
@@ -174,8 +175,8 @@ int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int
                        int W, int L, void *stream);
 int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
                        int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
-int etm_add_layernorm(const float *a, const float *b, const float *gamma, const float *beta, float eps, float *out, int N, int D,
-                      void *stream);
+int etm_add_layernorm(const float *a, const float *a_bias, int relu, const float *b, const float *gamma, const float *beta, float eps,
+                      float *out, int N, int D, void *stream);
 /* Elementwise parts of the GTrXL GRU gate on the rollout path (transformer.py:287-298), around concatenated library GEMMs
  * a = y [Wr;Wz;Wg]^T [N,3D], b = x [Ur;Uz]^T [N,2D], c = rx Ug^T [N,D]:
  *   etm_gru_gate_rz : r = sigmoid(a_r + b_r); z = sigmoid(a_z + b_z - bg); rx = r * x        (writes rx, z)
@@ -188,11 +189,12 @@ int etm_rollout_heads(const float *h, const float *wp, const float *bp, const fl
                       int W, int A, int hid, void *stream);
 /* etm_rollout_heads + etm_rollout_sample of a single-branch policy in one launch.  host_actions (PINNED host memory, optional):
  * the sampled actions are also stored to host_actions[W] -- visible to the host once the launch has completed (event), which
- * saves the device-to-host copy launch of every environment step.  host_flag (optional, needs host_actions): after a
+ * saves the device-to-host copy launch of every environment step.  h_bias [2*hid] (optional): h holds the PRE-activations of the
+ * hidden heads and relu(h + h_bias) is applied on the fly (the concatenated hidden-head GEMM then runs without an epilogue).  host_flag (optional, needs host_actions): after a
  * system-scope fence the new step counter (*t_dev after the increment) is stored to *host_flag, so the host can spin on
  * the flag instead of waiting for an event.  sync_counter: one device int32, zero before the first call (the workgroups of a
  * launch count themselves in; the last one advances *t_dev and resets the counter). */
-int etm_rollout_policy(const float *h, const float *wp, const float *bp, const float *wv, const float *bv,
+int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, const float *bp, const float *wv, const float *bv,
                        const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                        float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                        int W, int A, int hid, void *stream);

@@ -582,6 +582,28 @@ def test_rollout_glue_riders_and_fused_policy():
     for a, b in zip(*res):
         assert torch.equal(a, b)
 
+    # folded epilogues: add_layernorm(act(a + bias) + b) and rollout_policy on pre-activations
+    with torch.no_grad():
+        a_, b_ = torch.randn((W, 96), device=dev), torch.randn((W, 96), device=dev)
+        norm, bias = torch.nn.LayerNorm(96).to(dev), torch.randn(96, device=dev)
+        norm.weight.add_(0.1 * torch.randn_like(norm.weight))
+        got = ops.add_layernorm(a_, b_, norm, bias=bias, relu=True)
+        close(got, norm(torch.relu(a_ + bias) + b_).cpu().numpy(), atol=2e-5, rtol=1e-4, what="add_layernorm with folded bias + relu")
+        hb = torch.randn(2 * hid, device=dev)
+        raw = torch.randn((W, 2 * hid), device=dev)
+        outs2 = []
+        for folded in (False, True):
+            t = torch.tensor(1, dtype=torch.int64, device=dev)
+            act = torch.zeros((W, 1), dtype=torch.int64, device=dev)
+            sa = torch.zeros((S, W, 1), dtype=torch.int64, device=dev); sl = torch.zeros((S, W, 1), device=dev); sv = torch.zeros((S, W), device=dev)
+            if folded:
+                ops.rollout_policy(raw, lin_p, lin_v, uni, None, t, act, sa, sl, sv, h_bias=hb)
+            else:
+                ops.rollout_policy(torch.relu(raw + hb), lin_p, lin_v, uni, None, t, act, sa, sl, sv)
+            outs2.append((act, sa, sl, sv))
+        for x_, y_ in zip(*outs2):
+            assert torch.equal(x_, y_)
+
     stack = torch.rand((3, 5, 3, 36, 36), device=dev)
     conv = torch.nn.Conv2d(3, 32, 8, 4).to(dev)
     wp = ops.conv_pack_weights(conv.weight.detach().reshape(32, -1))
