@@ -124,12 +124,12 @@ class PPOTrainer:
                 import torch.cuda.tunable as tunable
                 tunable.enable(True)
                 tunable.tuning_enable(True)
-                tunable.write_file_on_exit(False)
-                tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "etm_tunableop_results.csv"))
+                # results file (written by the library at exit) goes to the temp directory, not the working directory
+                tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "etm_tunableop_results.csv"), True)
                 tunable.set_max_tuning_duration(30)
                 tunable.set_max_tuning_iterations(20)
-            except Exception:
-                pass
+            except Exception as exc:        # an older / newer torch without this API: run with the default heuristics
+                print(f"[trainer] per-shape GEMM tuning not available ({exc})")
         self.buffer = Buffer(config, self.observation_space, self.action_space_shape, self.max_episode_length, device)
         self.model = ActorCriticModel(config, self.observation_space, self.action_space_shape, self.max_episode_length).to(device)
         self.model.train()
