@@ -200,3 +200,22 @@ def test_vec_env_on_rows_protocol():
             for lo, hi, rows in seen:
                 assert np.array_equal(rows, ob[lo:hi])          # rows did not change after the notification
             assert np.array_equal(oa, ob) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+
+
+def test_conv_pack_weights_layout_and_attention_dispatch_rules():
+    """conv_pack_weights implements the fragment order documented in include/etm_hip.h; folded_supported matches the shape
+    rules of etm_window_fwd; set_attention_impl validates its argument (pure host logic, no kernel call)."""
+    from etm import ops
+    cout, k = 64, 40
+    w = torch.arange(cout * k, dtype=torch.float32).reshape(cout, k)
+    packed = ops.conv_pack_weights(w).reshape(-1)
+    T = cout // 32
+    for g, t, half, col, j in ((0, 0, 0, 0, 0), (1, 1, 1, 5, 3), (4, 0, 1, 31, 2), (2, 1, 0, 17, 1)):
+        assert packed[((g * T + t) * 64 + half * 32 + col) * 4 + j] == w[t * 32 + col, g * 8 + half * 4 + j]
+    with pytest.raises(ValueError):
+        ops.conv_pack_weights(torch.zeros(48, 40))
+    assert ops.folded_supported(384, 64, 4) and ops.folded_supported(384, 128, 4) and ops.folded_supported(1024, 64, 8)
+    assert not ops.folded_supported(1024, 128, 8) and not ops.folded_supported(48, 8, 1) and not ops.folded_supported(96, 8, 32)
+    with pytest.raises(ValueError):
+        ops.set_attention_impl("fast")
+    ops.set_attention_impl("dense"); ops.set_attention_impl("folded")
