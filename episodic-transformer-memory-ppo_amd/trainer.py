@@ -6,11 +6,13 @@ mask / window-index tables (bit-exact, :78, :88-90), per-step window rule (:165-
 ``get_last_value`` (:230-236, quirk Q5), episode hand-over on ``done`` (:195-213) -- while the data path is redesigned
 for the GPU:
 
-* rollout state (episode bank, tables, buffer) is HBM-resident; per step there is ONE pinned host->device
-  observation upload and ONE device->host action download (upstream: one ``.cpu()`` per worker, :190);
+* rollout state (episode bank, tables, buffer) is HBM-resident; per step the observation rows are streamed from pinned
+  memory into the staging array while the environments still step and the actions are stored into pinned memory by the
+  sampling kernel (upstream: one ``.cpu()`` per worker, :190); the step itself is two captured HIP graphs;
 * memory windows are never gathered: the attention kernel reads the bank through (slot, row) indices;
 * GAE and the PPO loss (+ its backward) are single fused kernels; loss statistics stay on the device and are
-  fetched once per update (upstream: 6 host syncs per minibatch, :318-323);
+  fetched once per update (upstream: 6 host syncs per minibatch, :318-323); the whole minibatch step (gather, forward,
+  loss, backward, clip, AdamW) is one captured HIP graph with device-resident schedules;
 * data parallelism (absent upstream): ``dp`` all-reduces one flat gradient bucket with RCCL between ``backward()``
   and gradient clipping (:310-311) and merges advantage statistics so normalisation is over the global minibatch.
 
@@ -268,9 +270,12 @@ class PPOTrainer:
     def _sample_training_data(self, forced_actions=None) -> list:
         """Runs all workers for ``worker_steps`` steps; fills the buffer; returns finished-episode infos.
 
-        The device work of one step (observation upload, window lookup, model forward, memory write, action sampling,
-        staging of the step's buffer rows, action download) is captured ONCE in a HIP graph and replayed per step, so
-        the host issues one launch instead of ~75 (``hip_graph_rollout: false`` in the config selects the eager path).
+        The device work of one step (window lookup, model forward, action sampling, staging of the step's buffer rows,
+        action hand-over; then memory write and K/V projection of the new items) is captured ONCE in two HIP graphs -- head
+        and tail -- and replayed per step (``hip_graph_rollout: false`` in the config selects the eager path).  With the
+        fused encoder the observation rows of step t+1 are streamed from pinned memory into row t+1 of the staging array
+        on a second stream while the environments still step (``stream_observations``), together with the workers'
+        (episode step, slot) vector; the actions arrive in pinned host memory straight from the sampling kernel.
         ``forced_actions`` [W, S] (optional) replays recorded actions instead of sampling (teacher forcing for parity
         tests -- CPU and GPU RNG streams differ); it always uses the eager path."""
         buf, W, S = self.buffer, self.num_workers, self.config["worker_steps"]
