@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--dist-backend", default=None, help="testing only: torch.distributed backend instead of nccl (= RCCL), e.g. gloo")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="testing only: every rank uses this device index (exercises the multi-process path on a 1-GPU box)")
     ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
                     help="kernel family of the window attention (etm.ops.set_attention_impl); folded is the product default")
     args = ap.parse_args()
@@ -120,7 +123,7 @@ def main():
                              f"--nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the MI355X path; no HIP device is visible (there is no CPU fallback)")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device)
     torch.cuda.set_device(device)
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))  # host side is a single python loop per rank
 
@@ -132,7 +135,7 @@ def main():
     etm_ops.set_attention_impl(args.attention)
 
     cfg = load_config()
-    dp = DataParallel(device) if world > 1 else None
+    dp = DataParallel(device, backend=args.dist_backend) if world > 1 else None
     torch.manual_seed(0)
     np.random.seed(0)
     trainer = PPOTrainer(cfg, run_id="bench", device=device, dp=dp, first_worker_id=rank * cfg["n_workers"], tensorboard=False)
