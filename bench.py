@@ -212,9 +212,14 @@ def main():
                 ach, peak, unit, extra = kernels[dom]["tflops"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", {"flops_per_launch": work, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
             else:
                 ach, peak, unit, extra = kernels[dom]["gbs"], HBM_PEAK_GBS, "GB/s", {"bytes_per_launch": work, "dtype": "f32"}
+            tr_pmc = pmc_traffic(dom)
             roofline = {"kernel": dom, "bound": kind, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                        "traffic": pmc_traffic(dom), "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
+                        "traffic": tr_pmc["bytes_per_launch"] if tr_pmc else None,       # HBM-side bytes per launch (PMC)
+                        "traffic_unit": "bytes per launch", "traffic_source": tr_pmc["source"] if tr_pmc else None,
+                        "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
                         "shape": {"N": N, "L": L, "D": D, "H": H}}
+            if tr_pmc and kind == "mfma":
+                roofline["mfma_busy_fraction_pmc"] = tr_pmc.get("mfma_busy_fraction_pmc")
             roofline.update(extra)
         rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
         out = {
