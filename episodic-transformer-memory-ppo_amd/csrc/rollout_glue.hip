@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__
                                                              unsigned char *__restrict__ st_mask, long long *__restrict__ st_idx,
                                                              long long *__restrict__ t_row, float *__restrict__ reset_dst,
                                                              const float *__restrict__ reset_init, long long reset_row_elems, int nb_window,
-                                                             int W, int L) {
+                                                             int W, int L, int stage_W) {
   if ((int)blockIdx.x >= nb_window) {     // reset role: (worker, chunk)
     const int e = (int)blockIdx.x - nb_window;
     const int w = e / RESET_CHUNKS, chunk = e - w * RESET_CHUNKS;
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__
   const long long idx = index_table[s * L + l];
   mask_t[i] = m;
   win_t[i] = idx;
-  st_mask[t * W * L + i] = m;
-  st_idx[t * W * L + i] = idx;
+  st_mask[t * stage_W * L + i] = m;      // staging rows are stage_W workers wide; the caller's pointers are at this group's first worker
+  st_idx[t * stage_W * L + i] = idx;
 }
 
 // One thread per worker: log-softmax, inverse-CDF sample with the pre-drawn uniform of (t, w) (or a forced action),
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
                                                              long long *__restrict__ actions, long long *__restrict__ st_actions,
                                                              float *__restrict__ st_logp, float *__restrict__ st_values,
                                                              long long *host_actions, long long *host_flag, int *sync_counter,
-                                                             int W, int A, int hid) {
+                                                             int W, int A, int hid, int stage_W) {
   extern __shared__ float out_s[];   // [A + 1]: logits, then the value
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w = blockIdx.x;
   const long long t = *t_dev;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
     if (forced) {
       a = (int)forced[w];
     } else {
-      const float u = uniforms[t * W + w];
+      const float u = uniforms[t * stage_W + w];
       float c = 0.f;
       a = A - 1;
       for (int j = 0; j < A; ++j) {
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
     }
     actions[w] = a;
     if (host_actions) host_actions[w] = a;
-    st_actions[t * W + w] = a;
-    st_logp[t * W + w] = lg[a] - lse;
-    st_values[t * W + w] = lg[A];
+    st_actions[t * stage_W + w] = a;
+    st_logp[t * stage_W + w] = lg[a] - lse;
+    st_values[t * stage_W + w] = lg[A];
     __threadfence();                                     // this worker's rows are visible before the arrival below
     if (atomicAdd(sync_counter, 1) == W - 1) {           // last workgroup of the step
       *sync_counter = 0;
@@ -213,9 +213,10 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 
 extern "C" int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
                                   uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int64_t *t_row, float *reset_dst,
-                                  const float *reset_init, int64_t reset_row_elems, int W, int L, void *stream) {
+                                  const float *reset_init, int64_t reset_row_elems, int W, int L, int stage_W, void *stream) {
   (void)hipGetLastError();
-  if (!step || !mask_table || !index_table || !t_dev || !mask_t || !win_t || !st_mask || !st_idx || W <= 0 || L <= 0) return ETM_EINVAL;
+  if (!step || !mask_table || !index_table || !t_dev || !mask_t || !win_t || !st_mask || !st_idx || W <= 0 || L <= 0 || stage_W < W)
+    return ETM_EINVAL;
   if ((reset_dst != nullptr) != (reset_init != nullptr)) return ETM_EINVAL;
   if (reset_dst && (reset_row_elems <= 0 || reset_row_elems % 4 != 0)) return ETM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -224,7 +225,7 @@ extern "C" int etm_rollout_window(const int64_t *step, const uint8_t *mask_table
   const int nbr = reset_dst ? W * RESET_CHUNKS : 0;
   hipLaunchKernelGGL(rollout_window_kernel, dim3((unsigned)(nbw + nbr)), dim3(256), 0, st, (const long long *)step, mask_table,
                      (const long long *)index_table, (const long long *)t_dev, mask_t, (long long *)win_t, st_mask, (long long *)st_idx,
-                     (long long *)t_row, reset_dst, reset_init, (long long)reset_row_elems, nbw, W, L);
+                     (long long *)t_row, reset_dst, reset_init, (long long)reset_row_elems, nbw, W, L, stage_W);
   return etm_launch_status();
 }
 
@@ -243,10 +244,10 @@ extern "C" int etm_rollout_sample(const float *logits, const float *value, const
 extern "C" int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, const float *bp, const float *wv, const float *bv,
                                   const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                                   float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
-                                  int W, int A, int hid, void *stream) {
+                                  int W, int A, int hid, int stage_W, void *stream) {
   (void)hipGetLastError();
   if (!h || !wp || !bp || !wv || !bv || (!uniforms && !forced) || !t_dev || !actions || !st_actions || !st_logp || !st_values ||
-      !sync_counter || W <= 0 || A <= 0 || hid <= 0)
+      !sync_counter || W <= 0 || A <= 0 || hid <= 0 || stage_W < W)
     return ETM_EINVAL;
   if (host_flag && !host_actions) return ETM_EINVAL;
   const size_t lds = (size_t)(A + 1) * sizeof(float);
@@ -255,7 +256,7 @@ extern "C" int etm_rollout_policy(const float *h, const float *h_bias, const flo
   EtmProfScope prof(ETM_K_ROLLOUT_SAMPLE, st);
   hipLaunchKernelGGL(rollout_policy_kernel, dim3((unsigned)W), dim3(256), lds, st, h, wp, bp, wv, bv, h_bias, uniforms, (const long long *)forced,
                      (long long *)t_dev, (long long *)actions, (long long *)st_actions, st_logp, st_values, (long long *)host_actions,
-                     (long long *)host_flag, (int *)sync_counter, W, A, hid);
+                     (long long *)host_flag, (int *)sync_counter, W, A, hid, stage_W);
   return etm_launch_status();
 }
 

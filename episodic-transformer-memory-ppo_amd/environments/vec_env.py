@@ -127,8 +127,53 @@ class PipeVecEnv(_VecBase):
                 pass
 
 
-def make_vec_env(env_config: dict, num_envs: int, first_worker_id: int = 0):
-    """Pick the front-end for ``env_config["type"]``."""
+class CompositeVecEnv(_VecBase):
+    """Several vectorised environments side by side (workers of part p are rows [lo_p, hi_p) of every array).  ``step`` /
+    ``reset`` behave like one environment over all workers; the trainer's pipelined rollout steps the ``parts`` one at a time
+    (while one part is being stepped on the host the device runs the other part's forward pass).  All state lives in the
+    parts, so both ways of stepping can be mixed."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.bounds, lo = [], 0
+        for p in self.parts:
+            self.bounds.append((lo, lo + p.num_envs))
+            lo += p.num_envs
+        self.num_envs = lo
+        e = self.parts[0]
+        self.observation_space_shape = tuple(e.observation_space_shape)
+        self.num_actions = int(e.num_actions)
+        self.max_episode_steps = int(e.max_episode_steps)
+
+    def reset(self, out=None):
+        out = self._alloc(out)
+        for p, (lo, hi) in zip(self.parts, self.bounds):
+            p.reset(out=out[lo:hi])
+        return out
+
+    def step(self, actions, out=None, on_rows=None):
+        out = self._alloc(out)
+        actions = np.asarray(actions)
+        rewards = np.zeros(self.num_envs, dtype=np.float32)
+        dones = np.zeros(self.num_envs, dtype=bool)
+        infos = []
+        for p, (lo, hi) in zip(self.parts, self.bounds):
+            cb = None if on_rows is None else (lambda a, b, lo=lo: on_rows(lo + a, lo + b))
+            _, rewards[lo:hi], dones[lo:hi], inf = p.step(actions[lo:hi], out=out[lo:hi], on_rows=cb)
+            infos.extend(inf)
+        return out, rewards, dones, infos
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+
+
+def make_vec_env(env_config: dict, num_envs: int, first_worker_id: int = 0, groups: int = 1):
+    """Pick the front-end for ``env_config["type"]``.  ``groups`` > 1: a ``CompositeVecEnv`` of that many equal parts (worker
+    ids stay consecutive, so every worker sees the same stream as in a single front-end)."""
+    if groups > 1 and num_envs % groups == 0:
+        per = num_envs // groups
+        return CompositeVecEnv([make_vec_env(env_config, per, first_worker_id + g * per) for g in range(groups)])
     if env_config["type"] == "Synthetic":
         from environments.synthetic import SyntheticVecEnv
         keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool")

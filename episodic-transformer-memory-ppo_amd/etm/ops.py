@@ -303,12 +303,14 @@ def reset_rows(dst, init, step):
     return dst
 
 
-def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx, t_row=None, reset=None):
+def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx, t_row=None, reset=None, w_off=0):
     """Window-table lookup of one rollout step + staging (all outputs preallocated, in place).  Optional riders of the same
     launch: ``t_row`` (int64 scalar tensor) receives the staging row t, ``reset = (cache [W, ...], init [...])`` performs
-    ``reset_rows(cache, init, step)``."""
+    ``reset_rows(cache, init, step)``.  Worker groups: ``mask_t`` / ``win_t`` / ``step`` (and the cache) cover the W workers of
+    the group, the staging arrays ``st_mask`` / ``st_idx`` [S, W_total, L] all of them; ``w_off`` is the group's first worker."""
     lib = _lib.load()
     W, L = win_t.shape
+    stage_w = st_idx.shape[1]
     rdst = rinit = None
     relems = 0
     if reset is not None:
@@ -317,8 +319,9 @@ def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask,
             raise TypeError("reset needs a contiguous cache [W, ...] and a contiguous initial row")
         relems = rinit.numel()
     _lib.check(lib.etm_rollout_window(_ptr(step), _ptr(mask_table), _ptr(index_table), _ptr(t_dev), _ptr(mask_t), _ptr(win_t),
-                                      _ptr(st_mask), _ptr(st_idx), _ptr(t_row), _ptr(rdst), _ptr(rinit), relems, W, L, _stream()),
-               "etm_rollout_window")
+                                      st_mask.data_ptr() + w_off * L * st_mask.element_size(),
+                                      st_idx.data_ptr() + w_off * L * st_idx.element_size(), _ptr(t_row), _ptr(rdst), _ptr(rinit),
+                                      relems, W, L, stage_w, _stream()), "etm_rollout_window")
 
 
 def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values):
@@ -334,7 +337,7 @@ _policy_sync = {}
 
 
 def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values,
-                   host_actions=None, host_flag=None, h_bias=None):
+                   host_actions=None, host_flag=None, h_bias=None, w_off=0):
     """``rollout_heads`` + ``rollout_sample`` in one launch (single-branch policy); ``host_actions`` / ``host_flag``: pinned
     int64 tensors that receive the actions and then the incremented step counter (the host spins on the flag)."""
     lib = _lib.load()
@@ -346,9 +349,14 @@ def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions
     sync = _policy_sync.get(t_dev.data_ptr())       # arrival counter of the launch's workgroups, one per step counter
     if sync is None:
         sync = _policy_sync[t_dev.data_ptr()] = torch.zeros(1, dtype=torch.int32, device=h2.device)
+    # worker groups: h2 / actions / forced / host_actions cover this group's W workers; uniforms and the staging arrays are
+    # [S, W_total(, 1)] and are addressed from the group's first worker ``w_off``
+    stage_w = st_values.shape[1]
+    off = lambda t: None if t is None else t.data_ptr() + w_off * t.element_size()
     _lib.check(lib.etm_rollout_policy(_ptr(h2), _ptr(h_bias), _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight),
-                                      _ptr(value_head.bias), _ptr(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions), _ptr(st_actions),
-                                      _ptr(st_logp), _ptr(st_values), ha, hf, _ptr(sync), W, A, hid, _stream()), "etm_rollout_policy")
+                                      _ptr(value_head.bias), off(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions), off(st_actions),
+                                      off(st_logp), off(st_values), ha, hf, _ptr(sync), W, A, hid, stage_w, _stream()),
+               "etm_rollout_policy")
 
 
 def rollout_heads(h2, branch, value_head):
@@ -407,10 +415,11 @@ def conv_pack_weights(weight2d):
     return w.permute(2, 0, 3, 1, 4).contiguous().view(Cout, K)   # [g, t, half, col, j]
 
 
-def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw, index=None):
+def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw, index=None, rows=None):
     """relu(conv2d(x) + bias) on the no-grad path (see etm_conv_relu).  ``weight2d``: ``conv_pack_weights`` of the [Cout, K]
     weights in the K order that matches the input layout.  With ``index`` (int64 device scalar) ``x`` is a stack [S, N, ...]
-    and the layer reads x[index] -- the row is chosen on the device, so a captured graph can walk a staging array.
+    and the layer reads x[index] -- the row is chosen on the device, so a captured graph can walk a staging array; ``rows =
+    (lo, hi)`` restricts it to images lo..hi-1 of that row (a worker group).
     Returns NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
     lib = _lib.load()
     _need_dev(x, weight2d, bias, index)
@@ -423,11 +432,18 @@ def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw, index=No
         N = x.shape[1]
     else:
         N = x.shape[0]
+    base = x.data_ptr()
+    if rows is not None:          # only images [lo, hi) of every row of the stack (a worker group)
+        if index is None:
+            raise TypeError("conv_relu: rows needs index (stacked input)")
+        lo, hi = rows
+        base += lo * x[0, 0].numel() * 4
+        N = hi - lo
     Cout = weight2d.shape[0]
     Ho, Wo = (H - KH) // S + 1, (W - KW) // S + 1
     shape = (N, Cout, Ho, Wo) if out_nchw else (N, Ho, Wo, Cout)
     out = torch.empty(shape, dtype=torch.float32, device=x.device)
-    rc = lib.etm_conv_relu(_ptr(x), _ptr(index), stride, _ptr(weight2d), _ptr(bias), _ptr(out), N, C, H, W, Cout, KH, KW, S,
+    rc = lib.etm_conv_relu(base, _ptr(index), stride, _ptr(weight2d), _ptr(bias), _ptr(out), N, C, H, W, Cout, KH, KW, S,
                            1 if in_nhwc else 0, 1 if out_nchw else 0, _stream())
     _lib.check(rc, "etm_conv_relu")
     return out

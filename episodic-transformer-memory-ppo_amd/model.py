@@ -94,26 +94,28 @@ class ActorCriticModel(nn.Module):
                     buf.copy_(perm)
             self._wver = (self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
 
-    def _encode_fused(self, obs, obs_index=None):
+    def _encode_fused(self, obs, obs_index=None, obs_rows=None):
         if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()
                                                      and self._wver != (self.conv1.weight._version, self.conv2.weight._version,
                                                                         self.conv3.weight._version)):
             self.refresh_rollout_weights()
         n, c, hh, ww = obs.shape[-4:]      # with obs_index: obs is a stack [S, N, C, H, W] and the layer reads obs[obs_index]
-        x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False, index=obs_index)              # -> NHWC
+        if obs_rows is not None:
+            n = obs_rows[1] - obs_rows[0]
+        x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False, index=obs_index, rows=obs_rows)  # -> NHWC
         h1, w1 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)
         h2, w2 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w3p, self.conv3.bias, 64, h2, w2, 3, 3, 1, True, True)                                # -> NCHW
         return ops.linear_relu(self.lin_hidden, x.reshape(n, -1))
 
-    def _encode(self, obs, obs_index=None):
+    def _encode(self, obs, obs_index=None, obs_rows=None):
         """Observation encoder.  ``obs_index`` (int64 device scalar, fused rollout encoder only): ``obs`` is a time-major
         stack [S, N, C, H, W] and row obs[obs_index] is encoded (the row is selected on the device)."""
         if obs_index is not None:
             if not self._fused_encoder_ok(obs[0]):
                 raise RuntimeError("obs_index needs the fused rollout encoder (visual observations, no grad)")
-            return self._encode_fused(obs, obs_index)
+            return self._encode_fused(obs, obs_index, obs_rows)
         h = obs
         if self._fused_encoder_ok(obs):
             return self._encode_fused(obs)
@@ -141,19 +143,19 @@ class ActorCriticModel(nn.Module):
         kernel on ``forward_hidden_cached``'s result."""
         return len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled()
 
-    def forward_hidden_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None, raw=False):
+    def forward_hidden_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None, raw=False, obs_rows=None):
         """Rollout path up to the hidden heads: -> (h2 [N, 2*hidden] = [relu(lin_policy(h)) | relu(lin_value(h))], memory).
         ``raw=True``: h2 are the PRE-activations (plain GEMM without epilogue); the caller applies relu(h2 + self._b_heads)
         (``ops.rollout_policy(h_bias=...)`` does it on the fly)."""
-        h, memory = self.transformer.forward_cached(self._encode(obs, obs_index), kv_spec, items_out)
+        h, memory = self.transformer.forward_cached(self._encode(obs, obs_index, obs_rows), kv_spec, items_out)
         if raw:
             return F.linear(h, self._w_heads), memory
         return ops.linear_relu(self._heads_lin, h), memory
 
-    def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None):
+    def forward_logits_cached(self, obs, kv_spec: WindowSpec, items_out=None, obs_index=None, obs_rows=None):
         """Rollout path (no grad): like ``forward_logits`` but attention reads the per-worker K/V cache.  With ``items_out``
         [blocks, N, D] the new memory items are written there (block-major) and returned in that layout."""
-        h, memory = self.transformer.forward_cached(self._encode(obs, obs_index), kv_spec, items_out)
+        h, memory = self.transformer.forward_cached(self._encode(obs, obs_index, obs_rows), kv_spec, items_out)
         if len(self.policy_branches) == 1 and getattr(self, "_w_heads", None) is not None and not torch.is_grad_enabled():
             # [lin_policy ; lin_value] as ONE GEMM (+ReLU epilogue), then both output heads in one small kernel
             h2 = ops.linear_relu(self._heads_lin, h)

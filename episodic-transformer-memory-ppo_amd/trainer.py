@@ -110,7 +110,14 @@ class PPOTrainer:
         self.writer = _make_writer(run_id) if tensorboard else _NullWriter()
 
         # environments (batched front-end over the upstream per-worker protocol)
-        self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id)
+        # rollout_groups (default 2): the workers are stepped as that many groups in a software pipeline -- while the host steps
+        # one group's environments the device runs the other group's forward pass (two small head graphs overlap almost
+        # perfectly on the GPU: 163 us per pair vs 150 us each, tools/two_group_probe.py).  Needs an environment front-end made
+        # of parts (make_vec_env(groups=...)); an externally supplied environment is stepped as one group.
+        n_groups = int(config.get("rollout_groups", 2))
+        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < 2:
+            n_groups = 1
+        self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers
         obs_shape = tuple(self.env.observation_space_shape)
         self.observation_space = type("Space", (), {"shape": obs_shape})()
@@ -219,6 +226,14 @@ class PPOTrainer:
         self._kv_weights = None
         self._worker_ids = torch.arange(W, dtype=torch.int64, device=device)
 
+        # worker groups: the full-width group (eager path, single-group graph path) aliases the buffers above; the pipelined
+        # groups own what cannot be a contiguous slice of them
+        self._group_all = self._make_group(0, W, self.env, full=True)
+        parts = getattr(self.env, "parts", None)
+        self._groups = [self._group_all]
+        if parts is not None and len(parts) > 1:
+            self._groups = [self._make_group(lo, hi, part, full=False) for part, (lo, hi) in zip(parts, self.env.bounds)]
+
         mask, indices = build_window_tables(self.memory_length, self.max_episode_length)
         self.memory_mask, self.memory_indices = mask, indices                       # host copies (upstream names)
         self._mask_table = mask.bool().contiguous().to(device)
@@ -267,19 +282,50 @@ class PPOTrainer:
         return s(self.lr_schedule), s(self.beta_schedule), s(self.cr_schedule)
 
     # ------------------------------------------------------------------ rollout
+    def _make_group(self, lo, hi, env, full):
+        """Device / pinned state of the workers [lo, hi) for one rollout step (see ``rollout_groups``)."""
+        from types import SimpleNamespace
+        dev, Wg, B = self.device, hi - lo, len(self.action_space_shape)
+        g = SimpleNamespace(lo=lo, hi=hi, W=Wg, env=env, full=full, graphs=None)
+        g.obs_pin, g.act_pin = self._obs_pin[lo:hi], self._act_pin[lo:hi]
+        g.obs_np = self.obs[lo:hi]
+        acts = g.act_pin.numpy()
+        g.acts_host = acts[:, 0] if B == 1 else acts            # [Wg] for one branch, [Wg, B] for multi-discrete
+        g.obs_dev, g.mask_t, g.win_t, g.act_dev = self._obs_dev[lo:hi], self._mask_t[lo:hi], self._win_t[lo:hi], self._act_dev[lo:hi]
+        g.kv = self._kv_cache[lo:hi]
+        if full:
+            g.ss_pin, g.ss_dev, g.item, g.t_dev, g.t_row = self._ss_pin, self._ss_dev, self._item, self._t_dev, self._t_row
+            g.ids, g.flag_pin, g.act_ready, g.up_done, g.stream = self._worker_ids, self._flag_pin, self._act_ready, self._up_done, None
+        else:
+            g.ss_pin = torch.zeros((2, Wg), dtype=torch.int64).pin_memory()
+            g.ss_dev = torch.zeros((2, Wg), dtype=torch.int64, device=dev)
+            g.item = torch.zeros((self.num_blocks, Wg, self.embed_dim), dtype=torch.float32, device=dev)
+            g.t_dev = torch.zeros((), dtype=torch.int64, device=dev)
+            g.t_row = torch.zeros((), dtype=torch.int64, device=dev)
+            g.ids = torch.arange(Wg, dtype=torch.int64, device=dev)
+            g.flag_pin = torch.zeros((1,), dtype=torch.int64).pin_memory()
+            g.act_ready, g.up_done = torch.cuda.Event(), torch.cuda.Event()
+            g.stream = torch.cuda.Stream(device=dev)
+        g.ss_np = g.ss_pin.numpy()
+        g.flag_np = g.flag_pin.numpy()
+        g.step_dev, g.slot_dev = g.ss_dev[0], g.ss_dev[1]
+        return g
+
     def _sample_training_data(self, forced_actions=None) -> list:
         """Runs all workers for ``worker_steps`` steps; fills the buffer; returns finished-episode infos.
 
         The device work of one step (window lookup, model forward, action sampling, staging of the step's buffer rows,
         action hand-over; then memory write and K/V projection of the new items) is captured ONCE in two HIP graphs -- head
-        and tail -- and replayed per step (``hip_graph_rollout: false`` in the config selects the eager path).  With the
-        fused encoder the observation rows of step t+1 are streamed from pinned memory into row t+1 of the staging array
-        on a second stream while the environments still step (``stream_observations``), together with the workers'
-        (episode step, slot) vector; the actions arrive in pinned host memory straight from the sampling kernel.
+        and tail -- per worker group and replayed per step (``hip_graph_rollout: false`` in the config selects the eager
+        path).  With ``rollout_groups`` = 2 the groups form a software pipeline: the host steps one group's environments
+        while the device runs the other group's head graph.  With the fused encoder the observation rows of step t+1 are
+        streamed from pinned memory into row t+1 of the staging array on a second stream while the environments still step
+        (``stream_observations``), together with the workers' (episode step, slot) vector; the actions arrive in pinned host
+        memory straight from the sampling kernel.
         ``forced_actions`` [W, S] (optional) replays recorded actions instead of sampling (teacher forcing for parity
         tests -- CPU and GPU RNG streams differ); it always uses the eager path."""
         buf, W, S = self.buffer, self.num_workers, self.config["worker_steps"]
-        stream = torch.cuda.current_stream(self.device)
+        main = torch.cuda.current_stream(self.device)
         use_graph = forced_actions is None and self.config.get("hip_graph_rollout", True)
         episode_infos = []
         buf.begin_rollout(self._slot_dev)
@@ -291,74 +337,108 @@ class PPOTrainer:
         forced = None
         if forced_actions is not None:
             forced = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).to(self.device)
-        if use_graph and self._step_graph is None:
-            self._capture_step_graph()
-        self._t_dev.zero_()
-        self._flag_np[0] = 0
+        groups = self._groups if use_graph else [self._group_all]
+        if use_graph and groups[0].graphs is None:
+            self._capture_step_graph(groups)
         self._uniforms.uniform_()                # one draw per (step, worker) for the whole rollout
-        t_env = 0.0
-        acts_host = self._act_pin.numpy()
-        acts_host = acts_host[:, 0] if acts_host.shape[1] == 1 else acts_host      # [W] for one branch, [W, B] for multi-discrete
+        for g in groups:
+            g.t_dev.zero_()
+            g.flag_np[0] = 0
         stream_obs = use_graph and self._stream_obs
+        host_flag = use_graph and self._host_flag
+        lib = etm_lib.load()
+        up = self._up_stream.cuda_stream
+        row_bytes = self._obs_pin[0].numel() * 4
+        src_base, stage_base = self._obs_pin.data_ptr(), self._stage["obs"].data_ptr()
+        ss_global = self._ss_pin.numpy()
+        side_streams = [g.stream for g in groups if g.stream is not None]
+        for st_ in side_streams:
+            st_.wait_stream(main)                  # buffers prepared above on the main stream
         if stream_obs:
-            lib = etm_lib.load()
-            up = self._up_stream.cuda_stream
-            row_bytes = self._obs_pin[0].numel() * 4
-            src_base, stage_base = self._obs_pin.data_ptr(), self._stage["obs"].data_ptr()
-            ss_src, ss_dst, ss_bytes = self._ss_pin.data_ptr(), self._ss_dev.data_ptr(), self._ss_pin.numel() * 8
-            self._up_stream.wait_stream(stream)          # the staging array may still be read by the previous update
-            etm_lib.check(lib.etm_upload(stage_base, src_base, W * row_bytes, up), "etm_upload")
-            etm_lib.check(lib.etm_upload(ss_dst, ss_src, ss_bytes, up), "etm_upload")     # (episode step, slot) of every worker
-            self._up_done.record(self._up_stream)
-        for t in range(S):
-            t_wait0 = time.perf_counter()
+            self._up_stream.wait_stream(main)      # the staging array may still be read by the previous update
+
+        def upload_state(g):
+            """(episode step, slot) of the group's workers -> device, after the host bookkeeping of the step."""
+            if not g.full:
+                g.ss_np[:] = ss_global[:, g.lo:g.hi]
+            lib.etm_upload(g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8, up)
+            g.up_done.record(self._up_stream)
+
+        def launch(g, t):
+            """Device work of step t of group g (graph mode: two replays on the group's stream)."""
             if use_graph:
+                if g.stream is not None:
+                    torch.cuda.set_stream(g.stream)
+                cur = g.stream if g.stream is not None else main
                 if stream_obs:
-                    stream.wait_event(self._up_done)     # rows of observation t are in staging row t
-                self._step_graph[0].replay()
-                if not self._host_flag:
-                    self._act_ready.record(stream)   # actions are in pinned memory once this event completes
-                self._step_graph[1].replay()         # tail runs while the host steps the environments
+                    cur.wait_event(g.up_done)        # observation rows and (step, slot) of step t are on the device
+                elif not g.full:
+                    g.ss_np[:] = ss_global[:, g.lo:g.hi]
+                g.graphs[0].replay()
+                if not host_flag:
+                    g.act_ready.record(cur)          # actions are in pinned memory once this event completes
+                g.graphs[1].replay()                 # tail runs while the host steps the environments
+                if g.stream is not None:
+                    torch.cuda.set_stream(main)
             else:
                 with torch.no_grad():
-                    carry = self._rollout_step_head(forced[:, t].contiguous() if forced is not None else None)
-                    self._act_ready.record(stream)
-                    self._rollout_step_tail(carry)
-            if use_graph and self._host_flag:
-                # the sampling kernel stored the actions and then step t + 1 into pinned memory: spin on the counter
-                flag, target, spins = self._flag_np, t + 1, 0
-                while flag[0] != target:
-                    spins += 1
-                    if spins % 4096 == 0 and time.perf_counter() - t_wait0 > 30.0:
-                        raise RuntimeError("rollout step did not complete within 30 s (device hang?)")
-            else:
-                self._act_ready.synchronize()
-            te = time.perf_counter()
-            if stream_obs and t + 1 < S:
-                dst_base = stage_base + (t + 1) * W * row_bytes
+                    carry = self._rollout_step_head(g, forced[:, t].contiguous() if forced is not None else None)
+                    g.act_ready.record(main)
+                    self._rollout_step_tail(g, carry)
 
-                def rows_ready(lo, hi):
-                    lib.etm_upload(dst_base + lo * row_bytes, src_base + lo * row_bytes, (hi - lo) * row_bytes, up)
+        if stream_obs:
+            for g in groups:                       # observation 0 -> staging row 0
+                lib.etm_upload(stage_base + g.lo * row_bytes, src_base + g.lo * row_bytes, g.W * row_bytes, up)
+                upload_state(g)
+        for g in groups:
+            launch(g, 0)
+        t_env = t_wait = t_launch = 0.0
+        for t in range(S):
+            for g in groups:
+                lo, hi = g.lo, g.hi
+                tw = time.perf_counter()
+                if host_flag:
+                    # the sampling kernel stored the actions and then step t + 1 into pinned memory: spin on the counter
+                    flag, target, spins, t_wait0 = g.flag_np, t + 1, 0, time.perf_counter()
+                    while flag[0] != target:
+                        spins += 1
+                        if spins % 4096 == 0 and time.perf_counter() - t_wait0 > 30.0:
+                            raise RuntimeError("rollout step did not complete within 30 s (device hang?)")
+                else:
+                    g.act_ready.synchronize()
+                te = time.perf_counter()
+                t_wait += te - tw
+                if stream_obs and t + 1 < S:
+                    dst_base = stage_base + ((t + 1) * W + lo) * row_bytes
+                    src_g = src_base + lo * row_bytes
 
-                _, rewards, dones, infos = self.env.step(acts_host, out=self.obs, on_rows=rows_ready)
-            else:
-                _, rewards, dones, infos = self.env.step(acts_host, out=self.obs)
-            t_env += time.perf_counter() - te
-            buf.rewards[:, t] = rewards
-            buf.dones[:, t] = dones
-            self.worker_current_episode_step += 1
-            if dones.any():
-                for w in np.flatnonzero(dones):
-                    self.worker_current_episode_step[w] = 0
-                    episode_infos.append(infos[w])
-                    slot = buf.open_episode()                  # fresh zero memory for the next episode (upstream :208-213)
-                    self.worker_episode_slot[w] = slot
-                    if t < S - 1:
-                        buf.memory_index_host[w, t + 1:] = slot
-            if stream_obs and t + 1 < S:
-                # bookkeeping of this step is final: the workers' (episode step, slot) follow the observation rows
-                lib.etm_upload(ss_dst, ss_src, ss_bytes, up)
-                self._up_done.record(self._up_stream)
+                    def rows_ready(a, b):
+                        lib.etm_upload(dst_base + a * row_bytes, src_g + a * row_bytes, (b - a) * row_bytes, up)
+
+                    _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np, on_rows=rows_ready)
+                else:
+                    _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np)
+                t_env += time.perf_counter() - te
+                buf.rewards[lo:hi, t] = rewards
+                buf.dones[lo:hi, t] = dones
+                self.worker_current_episode_step[lo:hi] += 1
+                if dones.any():
+                    for wl in np.flatnonzero(dones):
+                        w = lo + int(wl)
+                        self.worker_current_episode_step[w] = 0
+                        episode_infos.append(infos[wl])
+                        slot = buf.open_episode()                  # fresh zero memory for the next episode (upstream :208-213)
+                        self.worker_episode_slot[w] = slot
+                        if t < S - 1:
+                            buf.memory_index_host[w, t + 1:] = slot
+                if t + 1 < S:
+                    tl = time.perf_counter()
+                    if stream_obs:
+                        upload_state(g)              # bookkeeping of this step is final: (step, slot) follow the observation rows
+                    launch(g, t + 1)
+                    t_launch += time.perf_counter() - tl
+        for st_ in side_streams:
+            main.wait_stream(st_)
         # time-major staging -> the buffer's [W, S, ...] fields (one strided copy per field)
         self._step_dev.copy_(self._step_pin, non_blocking=True)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
@@ -366,93 +446,98 @@ class PPOTrainer:
             getattr(buf, name).copy_(stage.transpose(0, 1))
         last_value = self.get_last_value()
         buf.calc_advantages(last_value, self.config["gamma"], self.config["lamda"])
-        self.last_update_timing["env_s"] = t_env
+        self.last_update_timing.update(env_s=t_env, wait_s=t_wait, launch_s=t_launch)
         return episode_infos
 
-    def _rollout_step_device(self, forced_t=None, stream_obs=False, host_flag=False):
-        """Device side of one rollout step (upstream trainer.py:161-186) = head + tail."""
-        carry = self._rollout_step_head(forced_t, stream_obs, host_flag)
-        self._rollout_step_tail(carry, stream_obs)
+    def _rollout_step_device(self, g, forced_t=None, stream_obs=False, host_flag=False):
+        """Device side of one rollout step of group ``g`` (upstream trainer.py:161-186) = head + tail."""
+        carry = self._rollout_step_head(g, forced_t, stream_obs, host_flag)
+        self._rollout_step_tail(g, carry, stream_obs)
 
-    def _rollout_step_head(self, forced_t=None, stream_obs=False, host_flag=False):
-        """Everything the ACTIONS depend on: observation / step / slot upload, window lookup, model forward, sampling,
-        staging of the step's rows, action download.  Every operand has a fixed address (HIP-graph capturable).
-        Returns what the tail needs (the new memory item)."""
+    def _rollout_step_head(self, g, forced_t=None, stream_obs=False, host_flag=False):
+        """Everything the ACTIONS of group ``g`` depend on: (observation / step / slot upload,) window lookup, model forward,
+        sampling, staging of the step's rows, action hand-over.  Every operand has a fixed address (HIP-graph capturable).
+        Returns what the tail needs (the new memory items, block-major)."""
         buf = self.buffer
         st = self._stage
+        rows = None if g.full else (g.lo, g.hi)
         if stream_obs:      # the observation of this step is already in row t of the staging array (see _sample_training_data)
-            obs, obs_index = st["obs"], self._t_dev
+            obs, obs_index = st["obs"], g.t_dev
         else:
-            self._obs_dev.copy_(self._obs_pin, non_blocking=True)
-            obs, obs_index = self._obs_dev, None
-            self._ss_dev.copy_(self._ss_pin, non_blocking=True)      # (streamed mode: uploaded with the observation rows)
+            g.obs_dev.copy_(g.obs_pin, non_blocking=True)
+            obs, obs_index, rows = g.obs_dev, None, None
+            g.ss_dev.copy_(g.ss_pin, non_blocking=True)      # (streamed mode: uploaded with the observation rows)
         single = len(self.action_space_shape) == 1
-        mask_t, win_t = self._mask_t, self._win_t
+        mask_t, win_t = g.mask_t, g.win_t
         # window lookup + staging; the same launch records the staging row of this step for the tail (t_dev is incremented by
         # the sampling kernel) and resets the K/V cache of workers at episode step 0 (they start from the projection of an
         # empty memory)
-        ops.rollout_window(self._step_dev, self._mask_table, self._index_table, self._t_dev, mask_t, win_t,
-                           st["memory_mask"], st["memory_indices"], t_row=self._t_row,
-                           reset=(self._kv_cache, self._kv_init) if self._use_kv_cache else None)
+        ops.rollout_window(g.step_dev, self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
+                           st["memory_mask"], st["memory_indices"], t_row=g.t_row,
+                           reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo)
         fused_policy = False
         if self._use_kv_cache:
-            kv_spec = WindowSpec.from_bank(self._kv_cache, None, win_t, None, mask_t)
+            kv_spec = WindowSpec.from_bank(g.kv, None, win_t, None, mask_t)
             if single and self.model.rollout_heads_fusable():
-                # hidden heads -> ONE launch for output heads, sampling, staging, t += 1 and (graph mode) the hand-over of the
-                # actions to the host through pinned memory + a step-counter flag
-                h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index, raw=True)
+                # hidden heads -> ONE launch for output heads, sampling, staging, t += 1; the kernel stores the actions straight
+                # into the pinned host buffer (no copy launch): they are visible to the host when the step's event (or, with
+                # host_flag_actions, the flag) says the launch is done
+                h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=g.item, obs_index=obs_index, raw=True,
+                                                            obs_rows=rows)
                 flag = host_flag and forced_t is None
-                # the kernel stores the actions straight into the pinned host buffer (no copy launch); they are visible to
-                # the host when the step's event (or, with host_flag_actions, the flag) says the launch is done
-                ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, forced_t, self._t_dev,
-                                   self._act_dev, st["actions"], st["log_probs"], st["values"],
-                                   host_actions=self._act_pin, host_flag=self._flag_pin if flag else None,
-                                   h_bias=self.model._b_heads)
+                ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, forced_t, g.t_dev,
+                                   g.act_dev, st["actions"], st["log_probs"], st["values"],
+                                   host_actions=g.act_pin, host_flag=g.flag_pin if flag else None,
+                                   h_bias=self.model._b_heads, w_off=g.lo)
                 fused_policy = True
             else:
-                logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=self._item, obs_index=obs_index)
+                logits, value, item = self.model.forward_logits_cached(obs, kv_spec, items_out=g.item, obs_index=obs_index,
+                                                                        obs_rows=rows)
         else:
-            spec = WindowSpec.from_bank(buf.bank, self._slot_dev, win_t, win_t, mask_t)
+            spec = WindowSpec.from_bank(buf.bank, g.slot_dev, win_t, win_t, mask_t)
             logits, value, item = self.model.forward_logits(obs, spec)
             item = item.transpose(0, 1)
         if fused_policy:
             pass
-        elif single:
-            # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
-            ops.rollout_sample(logits[0], value, self._uniforms, forced_t, self._t_dev, self._act_dev,
-                               st["actions"], st["log_probs"], st["values"])
-            self._act_pin.copy_(self._act_dev, non_blocking=True)
         else:
-            row = self._t_row.view(1)
-            acts, logps = [], []
-            for lg in logits:
-                lsm = torch.log_softmax(lg, dim=-1)
-                a = forced_t if forced_t is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
-                acts.append(a)
-                logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
-            self._act_dev.copy_(torch.stack(acts, dim=1))
-            st["actions"].index_copy_(0, row, self._act_dev.unsqueeze(0))
-            st["log_probs"].index_copy_(0, row, torch.stack(logps, dim=1).unsqueeze(0))
-            st["values"].index_copy_(0, row, value.unsqueeze(0))
-            self._t_dev.add_(1)
-            self._act_pin.copy_(self._act_dev, non_blocking=True)
-        if item.data_ptr() != self._item.data_ptr():
-            self._item.copy_(item)
-        return self._item
+            if not g.full:
+                raise RuntimeError("worker groups need the fused policy path (single-branch policy, K/V cache)")
+            if single:
+                # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
+                ops.rollout_sample(logits[0], value, self._uniforms, forced_t, g.t_dev, g.act_dev,
+                                   st["actions"], st["log_probs"], st["values"])
+                g.act_pin.copy_(g.act_dev, non_blocking=True)
+            else:
+                row = g.t_row.view(1)
+                acts, logps = [], []
+                for lg in logits:
+                    lsm = torch.log_softmax(lg, dim=-1)
+                    a = forced_t if forced_t is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
+                    acts.append(a)
+                    logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
+                g.act_dev.copy_(torch.stack(acts, dim=1))
+                st["actions"].index_copy_(0, row, g.act_dev.unsqueeze(0))
+                st["log_probs"].index_copy_(0, row, torch.stack(logps, dim=1).unsqueeze(0))
+                st["values"].index_copy_(0, row, value.unsqueeze(0))
+                g.t_dev.add_(1)
+                g.act_pin.copy_(g.act_dev, non_blocking=True)
+        if item.data_ptr() != g.item.data_ptr():
+            g.item.copy_(item)
+        return g.item
 
-    def _rollout_step_tail(self, item, stream_obs=False):
+    def _rollout_step_tail(self, g, item, stream_obs=False):
         """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
         K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
         buf, st = self.buffer, self._stage
-        item = item.transpose(0, 1)                  # block-major staging -> [W, blocks, D]
-        buf.bank[self._slot_dev, self._step_dev] = item
+        item = item.transpose(0, 1)                  # block-major staging -> [Wg, blocks, D]
+        buf.bank[g.slot_dev, g.step_dev] = item
         if self._use_kv_cache:
             tr = self.model.transformer
             pos = tr._pos()
-            pos_rows = pos.index_select(0, self._step_dev) if pos is not None else None
-            self._kv_cache[self._worker_ids, self._step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
+            pos_rows = pos.index_select(0, g.step_dev) if pos is not None else None
+            g.kv[g.ids, g.step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
         if not stream_obs:
-            st["obs"].index_copy_(0, self._t_row.view(1), self._obs_dev.unsqueeze(0))
+            st["obs"][:, g.lo:g.hi].index_copy_(0, g.t_row.view(1), g.obs_dev.unsqueeze(0))
 
     def _refresh_kv_cache(self):
         """Start of a rollout: re-project every live episode's memory with the CURRENT weights (they changed in the
@@ -475,33 +560,37 @@ class PPOTrainer:
             zeros = torch.zeros((T, self.num_blocks, self.embed_dim), dtype=torch.float32, device=self.device)
             self._kv_init.copy_(tr.project_memory(zeros, pos, self._kv_weights))
 
-    def _capture_step_graph(self):
-        """Warm the step up on a side stream (library handles, MIOpen find, allocator), then capture it as TWO graphs:
-        the head (ends with the action download) and the tail (bank / cache / staging writes)."""
-        self._t_dev.zero_()
+    def _capture_step_graph(self, groups):
+        """Warm the step of every worker group up on a side stream (library handles, MIOpen find, GEMM tuning, allocator),
+        then capture it as TWO graphs per group: the head (ends with the action hand-over) and the tail (bank / cache /
+        staging writes)."""
         with torch.no_grad():
             self._stream_obs = bool(self.config.get("stream_observations", True) and self._use_kv_cache
                                     and self.model._fused_encoder_ok(self._obs_dev))
-        so = self._stream_obs
-        with torch.no_grad():
-            hf = self._host_flag = bool(self.config.get("host_flag_actions", False) and self._use_kv_cache
-                                        and len(self.action_space_shape) == 1 and self.model.rollout_heads_fusable())
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(3):
-                self._rollout_step_device(None, so, hf)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        pool = torch.cuda.graph_pool_handle()
-        head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
-        with torch.no_grad(), torch.cuda.graph(head, pool=pool, capture_error_mode="thread_local"):
-            self._rollout_step_head(None, so, hf)
-        with torch.no_grad(), torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
-            self._rollout_step_tail(self._item, so)
-        self._step_graph = (head, tail)
-        self._t_dev.zero_()
+            fusable = self._use_kv_cache and len(self.action_space_shape) == 1 and self.model.rollout_heads_fusable()
+            self._host_flag = bool(self.config.get("host_flag_actions", False) and fusable)
+        if len(groups) > 1 and not fusable:
+            raise RuntimeError("rollout_groups > 1 needs a single-branch policy and the K/V cache (set rollout_groups: 1)")
+        so, hf = self._stream_obs, self._host_flag
+        for g in groups:
+            g.t_dev.zero_()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    self._rollout_step_device(g, None, so, hf)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            pool = torch.cuda.graph_pool_handle()
+            head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
+            with torch.no_grad(), torch.cuda.graph(head, pool=pool, capture_error_mode="thread_local"):
+                self._rollout_step_head(g, None, so, hf)
+            with torch.no_grad(), torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
+                self._rollout_step_tail(g, g.item, so)
+            g.graphs = (head, tail)
+            g.t_dev.zero_()
+        self._step_graph = groups[0].graphs
 
     def get_last_value(self):
         """Value of the observation after the last step (bootstrap for GAE), with upstream's window rule:

@@ -160,6 +160,9 @@ int etm_reset_rows(float *dst, const float *init, const int64_t *step, int W, in
  * Rollout-step glue (trainer.py:161-186).  At n_workers = 32 a step is bound by the number of launches, so these fuse
  * what would be ~8 / ~17 / 2 framework launches into one each.  All operands have fixed addresses (HIP-graph friendly);
  * `t_dev` is a device-resident step counter, staging arrays are time-major [S, W, ...].
+ * Worker GROUPS: the staging arrays and `uniforms` are stage_W workers wide per time row; a call handles W <= stage_W
+ * consecutive workers and receives those pointers already offset to its first worker (the trainer steps two groups of
+ * workers as a software pipeline: one group's head graph runs while the host steps the other group's environments).
  *   etm_rollout_window: mask_t[w] = mask_table[clip(step[w], 0, L-1)], win_t[w] = index_table[step[w]] (trainer.py:165-166),
  *                       also stored to row *t_dev of st_mask / st_idx.  Optional riders of the same launch: *t_row = *t_dev
  *                       (t_row non-NULL) and etm_reset_rows(reset_dst, reset_init, step, W, reset_row_elems) (reset_dst non-NULL).
@@ -172,7 +175,7 @@ int etm_reset_rows(float *dst, const float *init, const int64_t *step, int W, in
 int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
                        uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx,
                        int64_t *t_row, float *reset_dst, const float *reset_init, int64_t reset_row_elems,
-                       int W, int L, void *stream);
+                       int W, int L, int stage_W, void *stream);
 int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
                        int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
 int etm_add_layernorm(const float *a, const float *a_bias, int relu, const float *b, const float *gamma, const float *beta, float eps,
@@ -197,7 +200,7 @@ int etm_rollout_heads(const float *h, const float *wp, const float *bp, const fl
 int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, const float *bp, const float *wv, const float *bv,
                        const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                        float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
-                       int W, int A, int hid, void *stream);
+                       int W, int A, int hid, int stage_W, void *stream);
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
  * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C]; with

@@ -501,7 +501,8 @@ def test_rollout_fast_paths_agree():
                 learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
                 beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
                 clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
-    variants = [dict(host_flag_actions=True), dict(), dict(stream_observations=False), dict(hip_graph_rollout=False)]
+    variants = [dict(host_flag_actions=True), dict(), dict(rollout_groups=1), dict(stream_observations=False),
+                dict(stream_observations=False, rollout_groups=1), dict(hip_graph_rollout=False)]
     results = []
     for over in variants:
         cfg = json.loads(json.dumps(base))
@@ -518,7 +519,9 @@ def test_rollout_fast_paths_agree():
             snap[-1]["rewards"] = torch.from_numpy(np.asarray(b.rewards).copy())
             tr._train_epochs(3e-4, 0.1, 1e-3, perms=[np.arange(8 * 40)])
         if not over:
-            assert tr._stream_obs and not tr._host_flag, "default config must take the streamed graph path"
+            assert tr._stream_obs and not tr._host_flag and len(tr._groups) == 2, "default config: streamed, two worker groups"
+        if over.get("rollout_groups") == 1:
+            assert len(tr._groups) == 1
         if over.get("host_flag_actions"):
             assert tr._host_flag
         results.append(snap)

@@ -219,3 +219,26 @@ def test_conv_pack_weights_layout_and_attention_dispatch_rules():
     with pytest.raises(ValueError):
         ops.set_attention_impl("fast")
     ops.set_attention_impl("dense"); ops.set_attention_impl("folded")
+
+
+def test_composite_vec_env_equals_single_front_end():
+    """make_vec_env(groups=2) == one front-end over all workers (same per-worker streams), whether it is stepped as a whole or
+    part by part (what the pipelined rollout does)."""
+    from environments.vec_env import make_vec_env
+    cfg = dict(type="Synthetic", obs_shape=[2, 5], num_actions=3, max_episode_steps=9, seed=3, p_done=0.1, pool=4)
+    W = 8
+    one, whole, parts = make_vec_env(cfg, W), make_vec_env(cfg, W, groups=2), make_vec_env(cfg, W, groups=2)
+    assert hasattr(whole, "parts") and len(whole.parts) == 2 and not hasattr(one, "parts")
+    o1, o2, o3 = (np.zeros((W, 2, 5), np.float32) for _ in range(3))
+    one.reset(out=o1); whole.reset(out=o2); parts.reset(out=o3)
+    assert np.array_equal(o1, o2) and np.array_equal(o1, o3)
+    acts = np.zeros(W, dtype=np.int64)
+    for t in range(40):
+        r1 = one.step(acts, out=o1)
+        r2 = whole.step(acts, out=o2)
+        rew, don, inf = np.zeros(W, np.float32), np.zeros(W, bool), []
+        for p, (lo, hi) in zip(parts.parts, parts.bounds):
+            _, rew[lo:hi], don[lo:hi], i_ = p.step(acts[lo:hi], out=o3[lo:hi])
+            inf.extend(i_)
+        for o, r in ((o2, r2), (o3, (o3, rew, don, inf))):
+            assert np.array_equal(o1, o) and np.array_equal(r1[1], r[1]) and np.array_equal(r1[2], r[2]) and r1[3] == r[3]

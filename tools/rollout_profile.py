@@ -31,8 +31,10 @@ for rep in range(2):
     tr._sample_training_data()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"rollout: {dt * 1e3:.1f} ms = {dt / S * 1e6:.0f} us per step (host env.step {tr.last_update_timing['env_s'] / S * 1e6:.0f} us per step)"
-          f"  stream_observations={tr._stream_obs}")
+    lt = tr.last_update_timing
+    print(f"rollout: {dt * 1e3:.1f} ms = {dt / S * 1e6:.0f} us per step (host: env.step {lt['env_s'] / S * 1e6:.0f}, waiting for actions "
+          f"{lt['wait_s'] / S * 1e6:.0f}, upload + launch {lt['launch_s'] / S * 1e6:.0f} us per step)  stream_observations={tr._stream_obs} "
+          f"groups={len(tr._groups)}")
 
 # device time of the step graphs alone (no host work in between): head = critical path of a step, tail = under env.step
 if tr._step_graph is not None:
