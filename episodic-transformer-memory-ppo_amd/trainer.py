@@ -114,8 +114,11 @@ class PPOTrainer:
         # one group's environments the device runs the other group's forward pass (two small head graphs overlap almost
         # perfectly on the GPU: 163 us per pair vs 150 us each, tools/two_group_probe.py).  Needs an environment front-end made
         # of parts (make_vec_env(groups=...)); an externally supplied environment is stepped as one group.
+        # Groups of fewer than 8 workers are not formed: they do not pay off, and at a handful of rows per GEMM the BLAS
+        # library may pick kernels with handle-owned scratch buffers that two streams must not share (one intermittent
+        # mismatch was seen with groups of 2 workers; never with 4 or more).
         n_groups = int(config.get("rollout_groups", 2))
-        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < 2:
+        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < 8:
             n_groups = 1
         self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers

@@ -494,7 +494,7 @@ def test_rollout_fast_paths_agree():
     from trainer import PPOTrainer
     dev = _dev()
     base = dict(environment=dict(type="Synthetic", obs_shape=[3, 36, 36], num_actions=4, max_episode_steps=20, seed=5, p_done=0.08, pool=8),
-                gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=8, worker_steps=40, n_mini_batch=2, value_loss_coefficient=0.5,
+                gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=16, worker_steps=40, n_mini_batch=2, value_loss_coefficient=0.5,
                 hidden_layer_size=64, max_grad_norm=0.5,
                 transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8, positional_encoding="relative",
                                  layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
@@ -517,7 +517,7 @@ def test_rollout_fast_paths_agree():
             snap.append({k: getattr(b, k).clone() for k in ("obs", "actions", "values", "log_probs", "advantages", "memory_mask",
                                                             "memory_indices", "memory_index")})
             snap[-1]["rewards"] = torch.from_numpy(np.asarray(b.rewards).copy())
-            tr._train_epochs(3e-4, 0.1, 1e-3, perms=[np.arange(8 * 40)])
+            tr._train_epochs(3e-4, 0.1, 1e-3, perms=[np.arange(16 * 40)])
         if not over:
             assert tr._stream_obs and not tr._host_flag and len(tr._groups) == 2, "default config: streamed, two worker groups"
         if over.get("rollout_groups") == 1:
