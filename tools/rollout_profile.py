@@ -38,7 +38,8 @@ for rep in range(2):
 
 # device time of the step graphs alone (no host work in between): head = critical path of a step, tail = under env.step
 if tr._step_graph is not None:
-    tr._t_dev.zero_(); torch.cuda.synchronize()
+    g0 = tr._groups[0]                       # the first worker group's graphs (all workers when rollout_groups = 1)
+    g0.t_dev.zero_(); torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     n = 200
     e0.record()
@@ -48,5 +49,5 @@ if tr._step_graph is not None:
     for _ in range(n):
         tr._step_graph[1].replay()
     e2.record(); torch.cuda.synchronize()
-    print(f"step graphs back-to-back: head {e0.elapsed_time(e1) / n * 1e3:.1f} us, tail {e1.elapsed_time(e2) / n * 1e3:.1f} us  "
-          f"(host_flag={tr._host_flag})")
+    print(f"step graphs of one group ({g0.W} workers) back-to-back: head {e0.elapsed_time(e1) / n * 1e3:.1f} us, "
+          f"tail {e1.elapsed_time(e2) / n * 1e3:.1f} us  (host_flag={tr._host_flag})")

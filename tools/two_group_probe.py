@@ -9,6 +9,7 @@ from trainer import PPOTrainer
 cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", "synthetic_minigrid.yaml")).get_config()
 cfg["n_workers"] = 16
 cfg["worker_steps"] = 64
+cfg["rollout_groups"] = 1      # each trainer of this probe IS one group
 dev = torch.device("cuda", 0)
 streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
 trs = []
@@ -19,7 +20,7 @@ for g in range(2):
         trs.append(tr)
 torch.cuda.synchronize()
 def run(which, n=60):
-    for tr in trs: tr._t_dev.zero_()
+    for tr in trs: tr._groups[0].t_dev.zero_()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n):
         for g in which:
