@@ -41,7 +41,7 @@ if tr._step_graph is not None:
     g0 = tr._groups[0]                       # the first worker group's graphs (all workers when rollout_groups = 1)
     g0.t_dev.zero_(); torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    n = 200
+    n = max(1, min(200, S - 8))          # the step counter must stay inside the staging arrays
     e0.record()
     for _ in range(n):
         tr._step_graph[0].replay()
