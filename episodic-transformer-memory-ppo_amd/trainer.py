@@ -577,7 +577,10 @@ class PPOTrainer:
         so, hf = self._stream_obs, self._host_flag
         for g in groups:
             g.t_dev.zero_()
-            side = torch.cuda.Stream(device=self.device)
+            # warm-up and capture run on the stream the group's graphs are replayed on: the BLAS workspace of the library
+            # GEMMs is keyed by (handle, stream), so two groups whose graphs replay concurrently must not have been captured on
+            # one shared capture stream (torch's default) -- split-K solutions would accumulate in the same scratch
+            side = g.stream if g.stream is not None else torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(3):
@@ -587,9 +590,9 @@ class PPOTrainer:
             pool = torch.cuda.graph_pool_handle()
             head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
-            with torch.no_grad(), torch.cuda.graph(head, pool=pool, capture_error_mode="thread_local"):
+            with torch.no_grad(), torch.cuda.graph(head, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
                 self._rollout_step_head(g, None, so, hf)
-            with torch.no_grad(), torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
+            with torch.no_grad(), torch.cuda.graph(tail, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
                 self._rollout_step_tail(g, g.item, so)
             g.graphs = (head, tail)
             g.t_dev.zero_()
