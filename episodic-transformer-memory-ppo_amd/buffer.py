@@ -62,6 +62,7 @@ class Buffer:
         cap = config.get("episode_bank_capacity", W + self.batch_size)
         self.bank = torch.zeros((cap, max_episode_length, self.num_blocks, self.embed_dim), dtype=torch.float32, device=dev)
         self.num_episodes = W
+        self.address_captured = False      # set by the trainer once a captured graph reads / writes the bank
         self.samples_flat = None
 
     # ------------------------------------------------------------------ episode bank
@@ -83,6 +84,10 @@ class Buffer:
     def open_episode(self) -> int:
         """Reserve the next (zero-filled) slot and return its index; grows the bank if it is full."""
         if self.num_episodes == self.bank.shape[0]:
+            if self.address_captured:
+                raise RuntimeError(f"episode bank is full ({self.bank.shape[0]} slots) and captured HIP graphs hold its address: raise "
+                                   "episode_bank_capacity (default n_workers * (worker_steps + 1) never fills) or disable "
+                                   "hip_graph_rollout / hip_graph_train")
             grown = torch.zeros((2 * self.bank.shape[0],) + tuple(self.bank.shape[1:]), dtype=torch.float32, device=self.device)
             grown[: self.bank.shape[0]].copy_(self.bank)
             self.bank = grown

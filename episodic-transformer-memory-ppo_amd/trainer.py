@@ -114,9 +114,10 @@ class PPOTrainer:
         # one group's environments the device runs the other group's forward pass (two small head graphs overlap almost
         # perfectly on the GPU: 163 us per pair vs 150 us each, tools/two_group_probe.py).  Needs an environment front-end made
         # of parts (make_vec_env(groups=...)); an externally supplied environment is stepped as one group.
-        # Groups of fewer than 8 workers are not formed: they do not pay off, and at a handful of rows per GEMM the BLAS
-        # library may pick kernels with handle-owned scratch buffers that two streams must not share (one intermittent
-        # mismatch was seen with groups of 2 workers; never with 4 or more).
+        # Groups of fewer than 8 workers are not formed: they do not pay off, and one intermittent mismatch was seen with
+        # groups of 2 workers while both groups' graphs had been captured on torch's shared capture stream, i.e. with ONE
+        # BLAS scratch buffer between them (split-K solutions at a handful of rows per GEMM); the graphs are captured per
+        # group stream now (_capture_step_graph), the threshold stays until that has been re-measured.
         n_groups = int(config.get("rollout_groups", 2))
         if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < 8:
             n_groups = 1
@@ -596,6 +597,7 @@ class PPOTrainer:
                 self._rollout_step_tail(g, g.item, so)
             g.graphs = (head, tail)
             g.t_dev.zero_()
+        self.buffer.address_captured = True
         self._step_graph = groups[0].graphs
 
     def get_last_value(self):
@@ -791,6 +793,7 @@ class PPOTrainer:
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     self._tg_norms = self._train_body_b(monitor)
             self._train_graph, self._tg_key = (ga, gb), key
+            self.buffer.address_captured = True
         ga, gb = self._train_graph
         ga.replay()
         if gb is not None:
