@@ -242,3 +242,34 @@ def test_composite_vec_env_equals_single_front_end():
             inf.extend(i_)
         for o, r in ((o2, r2), (o3, (o3, rew, don, inf))):
             assert np.array_equal(o1, o) and np.array_equal(r1[1], r[1]) and np.array_equal(r1[2], r[2]) and r1[3] == r[3]
+
+
+def test_enjoy_episode_loop_window_rule(golden_dir):
+    """enjoy.py: tables equal the reference's, and the episode loop hands the model upstream's per-step window (rows
+    memory_indices[t] of the episode memory with the items of the earlier steps in place, mask row clip(t, 0, L-1))."""
+    import enjoy
+    from torch.distributions import Categorical
+    from environments.poc_memory_env import PocMemoryEnv
+    z = np.load(os.path.join(golden_dir, "tables.npz"))
+    L, T, nb, D = 4, 7, 2, 32
+    cfg = {"transformer": {"memory_length": L, "num_blocks": nb, "embed_dim": D}}
+    memory, mask, idx = enjoy.init_transformer_memory(cfg["transformer"], T, torch.device("cpu"))
+    assert memory.shape == (1, T, nb, D) and not memory.any()
+    assert np.array_equal(mask.numpy(), z["mask_L4_T7"]) and np.array_equal(idx.numpy(), z["index_L4_T7"])
+
+    seen = []
+
+    def model(obs, in_memory, m, indices):
+        t = len(seen)
+        assert obs.shape[0] == 1 and in_memory.shape == (1, L, nb, D) and m.shape == (1, L) and indices.shape == (1, L)
+        assert np.array_equal(indices[0].numpy(), z["index_L4_T7"][t]) and np.array_equal(m[0].numpy(), z["mask_L4_T7"][min(t, L - 1)])
+        # row j of the window is episode step indices[j]: written steps carry their step number + 1, the others are zero
+        expect = torch.tensor([float(s + 1) if s < t else 0.0 for s in indices[0].tolist()])
+        assert torch.equal(in_memory[0, :, 0, 0], expect) and torch.equal(in_memory[0, :, nb - 1, D - 1], expect)
+        seen.append(t)
+        return [Categorical(logits=torch.zeros(1, 3))], torch.zeros(1), torch.full((1, nb, D), float(t + 1))
+
+    env = PocMemoryEnv(glob=False, freeze=True, max_episode_steps=T)
+    rewards, info = enjoy.run_episode(model, env, cfg, torch.device("cpu"))
+    assert 1 <= len(rewards) <= T and len(seen) == len(rewards)
+    assert info is not None and info["length"] == len(rewards)
