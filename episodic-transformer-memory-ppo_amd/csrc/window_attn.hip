@@ -59,10 +59,33 @@ __device__ __forceinline__ float lane_xor(float v) {
 // Sums NV per-lane values across the 64 lanes of a wave with NV + log-many exchanges instead of 6 NV: at every step half of
 // the values travel to the partner lane.  Offsets ascend (1, 2, 4, ...) so that the steps with many exchanges are the DPP
 // ones.  On return v[0] of lane l holds the total of value  bit_reverse(l mod NV)  (over log2 NV bits).
-template <int NV, int OFF>
+// SWAP (gfx950 v_permlane16_swap / v_permlane32_swap, used by the V2 code path): the cross-row steps need neither the LDS
+// crossbar nor the send / keep selects -- swapping a = v[k], b = v[k + HALF] between the partner rows leaves (own, partner's)
+// copies of the value this lane keeps in (a, b) or (b, a), so the step is swap + add (same operands as the select form).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ float row_swap_sum(float a, float b) {
+  static_assert(OFF == 16 || OFF == 32, "cross-row offsets only");
+  u32x2 r;
+  if constexpr (OFF == 16) r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  else r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int NV, int OFF, bool SWAP = false>
 struct TransposeReduce {
   static __device__ __forceinline__ void run(float *v, int lane) {
-    if constexpr (OFF <= 32) {
+    if constexpr (OFF <= 32 && SWAP && OFF >= 16) {
+      if constexpr (NV > 1) {
+        constexpr int HALF = NV / 2;
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) v[k] = row_swap_sum<OFF>(v[k], v[k + HALF]);
+        TransposeReduce<HALF, OFF * 2, SWAP>::run(v, lane);
+      } else {
+        v[0] = row_swap_sum<OFF>(v[0], v[0]);
+        TransposeReduce<1, OFF * 2, SWAP>::run(v, lane);
+      }
+    } else if constexpr (OFF <= 32) {
       if constexpr (NV > 1) {
         constexpr int HALF = NV / 2;
         const bool up = (lane & OFF) != 0;
@@ -72,10 +95,10 @@ struct TransposeReduce {
           const float keep = up ? v[k + HALF] : v[k];
           v[k] = keep + lane_xor<OFF>(send);
         }
-        TransposeReduce<HALF, OFF * 2>::run(v, lane);
+        TransposeReduce<HALF, OFF * 2, SWAP>::run(v, lane);
       } else {
         v[0] += lane_xor<OFF>(v[0]);
-        TransposeReduce<1, OFF * 2>::run(v, lane);
+        TransposeReduce<1, OFF * 2, SWAP>::run(v, lane);
       }
     }
   }
@@ -88,7 +111,25 @@ __device__ __forceinline__ long long readlane64(long long v, int l) {
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
+#if defined(ETM_DIAG_WIN_HG)         // diagnostic builds only (tools/diag_variants.sh occ): register pressure experiments
+constexpr int HG = ETM_DIAG_WIN_HG;
+#else
 constexpr int HG = 4;  // heads handled per pass over the register-resident rows
+#endif
+// ETM_DIAG_WIN_V2 (diagnostic builds only until measured, tools/diag_variants.sh occ): one head at a time in registers -- the
+// vec rows come from LDS (loaded once per workgroup instead of once per wave) and the passes keep NJ + RW instead of
+// HG (NJ + RW) live values next to the rows: <= 80 VGPRs at (NJ, RW) = (3, 8), i.e. three workgroups per CU instead of two,
+// <= 128 at (3, 16).  Same summation trees as the default code path (bit-identical results).
+#if defined(ETM_DIAG_WIN_V2)
+constexpr bool V2 = true;
+#else
+constexpr bool V2 = false;
+#endif
+#if defined(ETM_DIAG_WIN_WAVES_PER_EU)
+#define ETM_WIN_OCC __attribute__((amdgpu_waves_per_eu(ETM_DIAG_WIN_WAVES_PER_EU, ETM_DIAG_WIN_WAVES_PER_EU)))
+#else
+#define ETM_WIN_OCC
+#endif
 
 #if defined(ETM_DIAG_TRACE)
 constexpr int WIN_TRACE_WGS = 2048, WIN_TRACE_SLOTS = 16;
@@ -99,7 +140,7 @@ __device__ unsigned long long g_win_trace[WIN_TRACE_WGS * 8 * WIN_TRACE_SLOTS];
 #endif
 
 template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS, bool FULLD>
-__global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p) {
+__global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int LP = NW * RW;     // padded window length
   constexpr int DP = NJ * 128;    // padded feature width
@@ -135,6 +176,43 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     }
   }
 
+  // V2: this thread's share of vec[h0 .. h0 + HG) (f32x2 granules of the [HG][DP] staging block in LDS, which aliases the
+  // start of zs: zs is not written before pass 2).  The loads of the first chunk are issued before the row loads.
+  constexpr int UI = (HG * NJ + NW - 1) / NW;
+  f32x2 ustage[UI];
+  auto load_vec = [&](int h0, int tid_) {
+#pragma unroll
+    for (int k = 0; k < UI; ++k) {
+      const int idx = tid_ + k * NW * 64, hh = idx / (NJ * 64), c = 2 * (idx - hh * (NJ * 64));
+      const bool ok = idx < HG * NJ * 64 && h0 + hh < H && (FULLD || c < D);
+      const int hc = ok ? h0 + hh : 0, cq = ok ? c : 0;
+      const f32x2 t = *reinterpret_cast<const f32x2 *>(p.vec + (long long)hc * p.vec_hs + (long long)n * p.vec_ns + cq);
+      ustage[k] = ok ? t : f32x2{0.f, 0.f};
+    }
+  };
+  auto store_vec = [&]() {
+#pragma unroll
+    for (int k = 0; k < UI; ++k) {
+      const int idx = tid + k * NW * 64;
+      if (idx < HG * NJ * 64) *reinterpret_cast<f32x2 *>(&zs[2 * idx]) = ustage[k];
+    }
+  };
+  if constexpr (V2) load_vec(0, tid);
+  // V2: what the softmax phase reads from memory (the sample's mask bytes; backward: the saved attention of this wave's first
+  // head) is requested here, together with the row bookkeeping, instead of as exposed round trips between the two passes
+  unsigned mask_pre = 0;
+  float att_pre[2] = {0.f, 0.f};
+  if constexpr (V2) {
+    unsigned char mb[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int l = lane + 64 * jj;
+      mb[jj] = p.mask[(long long)n * L + (l < L ? l : L - 1)];
+      if (p.bwd) att_pre[jj] = p.att_in[((long long)n * H + (wave < H ? wave : H - 1)) * L + (l < L ? l : L - 1)];
+    }
+    mask_pre = (mb[0] != 0 ? 1u : 0u) | (mb[1] != 0 ? 2u : 0u);
+  }
+
   // Row bookkeeping is fetched ONCE per wave, lane i holding what row i needs (window offset, positional offset,
   // LayerNorm statistics), and handed to the row loads through v_readlane: one memory round trip instead of one per row.
   const int l_me = wave * RW + (lane & (RW - 1));
@@ -167,6 +245,9 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WIN_T(2)   // row bookkeeping arrived
 #endif
+  // V2: the vec rows of the first chunk arrived with the row bookkeeping (same round trip); they go to LDS before the row
+  // loads are issued, so the barrier in front of pass 1 is reached while the rows are still in flight
+  if constexpr (V2) store_vec();
 #pragma unroll
   for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
 #if defined(ETM_DIAG_TRACE)
@@ -186,6 +267,51 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   }
 #endif
   // ---- pass 1: logits[h][l] = x[l] . vec[h]
+  if constexpr (V2) {
+    for (int h0 = 0; h0 < H; h0 += HG) {
+      if (h0 > 0) {
+        __syncthreads();          // every wave is done with the previous chunk's vec rows
+        int tid_c = tid;          // opaque: nothing of this (rare, H > HG) path is precomputed and kept live across pass 1
+        asm volatile("" : "+v"(tid_c));
+        load_vec(h0, tid_c);
+        store_vec();
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int hh = 0; hh < HG; ++hh) {
+        if (h0 + hh >= H) break;
+        f32x2 uvj[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) uvj[j] = *reinterpret_cast<const f32x2 *>(&zs[hh * DP + j * 128 + 2 * lane]);
+        // rows in groups of RG (one transposing reduction each), two rows at a time: the scheduler would otherwise
+        // interleave all rows' partial sums and bring the register count back up
+        constexpr int RG = 8, LGR = ilog2(RG);
+        static_assert(RW % RG == 0, "rows per wave");
+        const int i_ = (int)(__brev((unsigned)(lane & (RG - 1))) >> (32 - LGR));
+#pragma unroll
+        for (int g = 0; g < RW / RG; ++g) {
+          // rows k and k + RG/2 are the pair that the first step (offset 1) of TransposeReduce<RG, 1> merges: computed
+          // together and merged at once, so only RG/2 sums stay live
+          float ev[RG / 2];
+          const bool up = (lane & 1) != 0;
+#pragma unroll
+          for (int k = 0; k < RG / 2; ++k) {
+            f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              s0 += x[g * RG + k][j] * uvj[j];
+              s1 += x[g * RG + k + RG / 2][j] * uvj[j];
+            }
+            const float e0 = s0[0] + s0[1], e1 = s1[0] + s1[1];
+            ev[k] = (up ? e1 : e0) + lane_xor<1>(up ? e0 : e1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          TransposeReduce<RG / 2, 2, true>::run(ev, lane);
+          if (lane < RG) a_s[(h0 + hh) * LP + wave * RW + g * RG + i_] = ev[0];
+        }
+      }
+    }
+  } else
   for (int h0 = 0; h0 < H; h0 += HG) {
     f32x2 uv[HG][NJ];
 #pragma unroll
@@ -217,20 +343,29 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   WIN_T(5)
 
   // ---- per head: masked softmax (forward) or its backward (one wave per head; LP <= 128 = 2 values per lane)
+  // V2: later phases see sample index / lane through opaque copies -- their (loop-invariant, 64-bit) address arithmetic would
+  // otherwise be hoisted above pass 1 and stay live next to the rows.
+  int n_l = n, lane_l = lane, tid_l = tid;
+  if constexpr (V2) {
+    asm volatile("" : "+s"(n_l));
+    asm volatile("" : "+v"(lane_l));
+    asm volatile("" : "+v"(tid_l));
+  }
   for (int h = wave; h < H; h += NW) {
     float t[2];
     bool keep[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      const int l = lane + 64 * jj;
+      const int l = lane_l + 64 * jj;
       t[jj] = (l < L) ? a_s[h * LP + l] : 0.f;
-      keep[jj] = (l < L) && p.mask[(long long)n * L + l] != 0;
+      if constexpr (V2) keep[jj] = (l < L) && ((mask_pre >> jj) & 1u) != 0;
+      else keep[jj] = (l < L) && p.mask[(long long)n_l * L + l] != 0;
     }
     if (!p.bwd) {
       float ev2[2];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int l = lane + 64 * jj;
+        const int l = lane_l + 64 * jj;
         float e_ = -INFINITY;
         if (l < L) e_ = (keep[jj] ? t[jj] : -1e20f) / p.sqrt_d;  // fill BEFORE the scale (transformer.py:66,69)
         ev2[jj] = e_;
@@ -238,15 +373,15 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
       const float m = wave_max(fmaxf(ev2[0], ev2[1]));
       float xv[2];
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) xv[jj] = (lane + 64 * jj < L) ? expf(ev2[jj] - m) : 0.f;
+      for (int jj = 0; jj < 2; ++jj) xv[jj] = (lane_l + 64 * jj < L) ? expf(ev2[jj] - m) : 0.f;
       const float denom = wave_sum(xv[0] + xv[1]);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int l = lane + 64 * jj;
+        const int l = lane_l + 64 * jj;
         if (l < LP) {
           const float a = xv[jj] / denom;
           a_s[h * LP + l] = a;
-          if (l < L) p.att_out[((long long)n * H + h) * L + l] = a;
+          if (l < L) p.att_out[((long long)n_l * H + h) * L + l] = a;
         }
       }
     } else {
@@ -254,18 +389,19 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
       float dot = 0.f;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int l = lane + 64 * jj;
-        a[jj] = (l < L) ? p.att_in[((long long)n * H + h) * L + l] : 0.f;
+        const int l = lane_l + 64 * jj;
+        if (V2 && h == wave) a[jj] = (l < L) ? att_pre[jj] : 0.f;
+        else a[jj] = (l < L) ? p.att_in[((long long)n_l * H + h) * L + l] : 0.f;
         dot += a[jj] * t[jj];
       }
       dot = wave_sum(dot);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int l = lane + 64 * jj;
+        const int l = lane_l + 64 * jj;
         if (l < LP) {
           float de = keep[jj] ? a[jj] * (t[jj] - dot) / p.sqrt_d : 0.f;  // masked_fill blocks the gradient
           a_s[h * LP + l] = de;
-          if (l < L) p.d_e[((long long)n * H + h) * L + l] = de;
+          if (l < L) p.d_e[((long long)n_l * H + h) * L + l] = de;
         }
       }
     }
@@ -276,6 +412,23 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
 
   // ---- pass 2: out[h][:] = sum_l w[h][l] x[l][:]   (w = attention or dE)
   for (int h0 = 0; h0 < H; h0 += HG) {
+    if constexpr (V2) {
+#pragma unroll 1
+      for (int hh = 0; hh < HG; ++hh) {
+        if (h0 + hh >= H) break;
+        f32x2 zq[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) zq[j] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const float w = a_s[(h0 + hh) * LP + wave * RW + i];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) zq[j] += w * x[i][j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zq[j];
+      }
+    } else {
     f32x2 zp[HG][NJ];
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh)
@@ -295,16 +448,17 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     for (int hh = 0; hh < HG; ++hh)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zp[hh][j];
+    }
     WIN_T(8)   // pass 2 done
     __syncthreads();
     WIN_T(9)
-    for (int idx = tid; idx < HG * (DP / 2); idx += NW * 64) {
+    for (int idx = tid_l; idx < HG * (DP / 2); idx += NW * 64) {
       const int hh = idx / (DP / 2), c = 2 * (idx - hh * (DP / 2));
       if (h0 + hh < H && c < D) {
         f32x2 s = {0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x2 *>(&zs[(w * HG + hh) * DP + c]);
-        *reinterpret_cast<f32x2 *>(p.out + (long long)(h0 + hh) * p.out_hs + (long long)n * p.out_ns + c) = s;
+        *reinterpret_cast<f32x2 *>(p.out + (long long)(h0 + hh) * p.out_hs + (long long)n_l * p.out_ns + c) = s;
       }
     }
     WIN_T(10)  // cross-wave sum + store done

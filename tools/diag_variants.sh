@@ -18,8 +18,10 @@ build() {  # name, flags...
   echo built $name
 }
 if [ "$1" = "window" ]; then
-  for v in base loadonly trace; do
+  # v2: the lower-register form of the pass (three workgroups per CU at config 3, two at L = 128; see window_attn.hip)
+  for v in base loadonly trace v2 v2trace; do
     fl=""; [ $v = loadonly ] && fl="-DETM_DIAG_LOAD_ONLY"; [ $v = trace ] && fl="-DETM_DIAG_TRACE"
+    [ $v = v2 ] && fl="-DETM_DIAG_WIN_V2"; [ $v = v2trace ] && fl="-DETM_DIAG_WIN_V2 -DETM_DIAG_TRACE"
     /opt/rocm/bin/hipcc $FLAGS $fl -c $SRC/window_attn.hip -o $OUT/win_$v.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/win_$v.o $(ls $SRC/build/*.o | grep -v window_attn.o) -o $OUT/libetm_win_$v.so
     rm -f $OUT/win_$v.o; echo built win_$v

@@ -40,6 +40,9 @@ for impl in ("folded", "dense"):
     torch.cuda.synchronize(); l.etm_profile_enable(0)
     ks = "  ".join(f"{k}={ms / c * 1e3:.1f}us" for (tag, k), (ms, c) in sorted(etm_lib.profile_collect().items()))
     print(f"{impl:7s} N={N} L={L} D={D} H={H}: forward {fw / 10 * 1e3:7.1f} us  backward(+loss) {bw / 10 * 1e3:7.1f} us | {ks}", flush=True)
+import zlib
+print("  folded result checksums (crc32 of the fp32 bytes; equal across library variants = bit-identical): " +
+      "  ".join(f"{name}={zlib.crc32(x.cpu().numpy().tobytes()):08x}" for name, x in zip(("ctx", "dq", "dwk", "dwv"), res["folded"])))
 a, b = res["folded"], res["dense"]
 for name, x, y in zip(("ctx", "dq", "dwk", "dwv"), a, b):
     print(f"  folded vs dense {name}: max abs diff {(x - y).abs().max().item():.3e}  rel-to-norm {((x - y).norm() / y.norm()).item():.3e}")
