@@ -20,6 +20,7 @@
 #include "etm_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -39,6 +40,9 @@ struct WinParams {
   long long vec_hs, vec_ns, out_hs, out_ns;
   int N, L, D, H, bwd;
   float sqrt_d;
+#if defined(ETM_DIAG_WIN_V2)
+  int xcd_chunk;         // > 0: workgroup b handles sample (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk), see launch_pass3
+#endif
 };
 
 // Value of `v` in lane (lane ^ OFF).  xor 1 / 2 / 8 are single DPP controls (quad_perm, row_ror:8), xor 4 is a row_shl:4
@@ -145,7 +149,16 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
   constexpr int LP = NW * RW;     // padded window length
   constexpr int DP = NJ * 128;    // padded feature width
   constexpr int NV = RW * HG;
+#if defined(ETM_DIAG_WIN_V2)
+  // Workgroup b is observed to run on XCD b % 8 (each XCD has its own L2).  With a minibatch sorted by bank address,
+  // neighbouring samples share most of their window rows: giving every XCD a CONTIGUOUS chunk of the samples turns those
+  // re-reads into hits of that XCD's L2.  Placement is a speed matter only; every sample is handled exactly once either way.
+  const int n = p.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (n >= p.N) return;          // whole workgroup, before any barrier
+  const int tid = threadIdx.x, lane = tid & 63;
+#else
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L, D = p.D, H = p.H;
 #if defined(ETM_DIAG_TRACE)
@@ -475,7 +488,14 @@ int launch_pass3(const WinParams &p, hipStream_t st) {
   auto kern = window_pass_kernel<NJ, RW, NW, HAS_LN, HAS_POS, FULLD>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
+#if defined(ETM_DIAG_WIN_V2)
+  static const bool xcd_map = getenv("ETM_WIN_XCD_MAP") != nullptr && atoi(getenv("ETM_WIN_XCD_MAP")) != 0;
+  WinParams q = p;
+  q.xcd_chunk = xcd_map ? (p.N + 7) / 8 : 0;
+  hipLaunchKernelGGL(kern, dim3(xcd_map ? 8 * q.xcd_chunk : p.N), dim3(NW * 64), lds, st, q);
+#else
   hipLaunchKernelGGL(kern, dim3(p.N), dim3(NW * 64), lds, st, p);
+#endif
   return etm_launch_status();
 }
 

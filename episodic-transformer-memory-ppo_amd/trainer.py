@@ -625,6 +625,10 @@ class PPOTrainer:
             self._bank_pos = self._bank_with_positions()
             self._obs_train = self._observations_channels_last()
         mbs = self.buffer.batch_size // self.buffer.n_mini_batches
+        # sort_minibatch (default off until measured): the samples of a minibatch in ascending flat (worker, step) order.  The
+        # minibatch is the same SET (every loss term is a mean over it; only summation order changes), but neighbouring samples
+        # then share most of their window rows, which a cache-aware sample -> workgroup mapping can turn into L2 hits.
+        sort_mb = bool(self.config.get("sort_minibatch", False))
         for epoch in range(self.config["epochs"]):
             if perms is None:
                 perm = torch.randperm(self.buffer.batch_size, device=self.device)
@@ -632,6 +636,8 @@ class PPOTrainer:
                 perm = torch.as_tensor(perms[epoch], device=self.device, dtype=torch.long)
             for start in range(0, self.buffer.batch_size, mbs):
                 idx = perm[start: start + mbs]
+                if sort_mb:
+                    idx = idx.sort().values
                 if self._use_train_graph and idx.numel() == mbs:
                     st_row, norm_row = self._train_step_graph(idx, learning_rate, clip_range, beta, monitor)
                     stats.append(st_row)

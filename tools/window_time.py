@@ -14,9 +14,19 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 N, T, nb, E = 2048, L + 32, 3, 416
 bank = torch.randn((E, T, nb, D), device=dev)
-ep = torch.randint(0, E, (N,), device=dev)
-win = torch.randint(0, T - L + 1, (N, 1), device=dev) + torch.arange(L, device=dev)[None, :]
-mask = torch.arange(L, device=dev)[None, :] < torch.randint(0, L, (N,), device=dev)[:, None]
+mode = os.environ.get("ETM_WIN_SAMPLES", "random")
+if mode == "random":          # unrelated windows: no two samples share a row (the un-deduplicated roofline case)
+    ep = torch.randint(0, E, (N,), device=dev)
+    win = torch.randint(0, T - L + 1, (N, 1), device=dev) + torch.arange(L, device=dev)[None, :]
+    mask = torch.arange(L, device=dev)[None, :] < torch.randint(0, L, (N,), device=dev)[:, None]
+else:                         # training-like: N of the E * T (episode, step) pairs, sliding windows of trainer.py:88-90;
+    pairs = torch.randperm(E * T, device=dev)[:N]      # "sorted": minibatch ordered by bank address, "shuffled": as drawn
+    if mode == "sorted":
+        pairs = pairs.sort().values
+    ep, step = pairs // T, pairs % T
+    win = torch.clamp(step - (L - 1), min=0)[:, None] + torch.arange(L, device=dev)[None, :]
+    mask = torch.arange(L, device=dev)[None, :] < torch.clamp(step, max=L - 1)[:, None]
+print(f"samples: {mode}  (ETM_WIN_SAMPLES=random|shuffled|sorted; ETM_WIN_XCD_MAP=1 with a v2 library: contiguous sample chunk per XCD)")
 wk = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True); wv = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
 q = torch.randn((N, D), device=dev).requires_grad_(True); g = torch.randn((N, D), device=dev)
 spec = ops.WindowSpec.from_bank(bank, ep, win, None, mask)
