@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -32,6 +32,8 @@ SIGNATURES = {
     "etm_add_layernorm": (_I, [_P, _P, _I, _P, _P, _P, _F, _P, _I, _I, _P]),
     "etm_conv_relu": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_upload": (_I, [_P, _P, _L, _P]),
+    "etm_upload_record": (_I, [_P, _P, _L, _P, _P]),
+    "etm_step_launch": (_I, [_P, _P, _P, _P, _P]),
     "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "etm_gru_gate_rz": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

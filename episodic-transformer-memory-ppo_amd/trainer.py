@@ -361,16 +361,41 @@ class PPOTrainer:
         if stream_obs:
             self._up_stream.wait_stream(main)      # the staging array may still be read by the previous update
 
+        # native_step_launch (default off until measured): the per-step runtime calls of a group go through two entry points of
+        # the library (etm_upload_record, etm_step_launch) instead of ~7 framework calls (stream switch, event wait / record,
+        # two graph replays); same calls, same order, same streams
+        native = use_graph and bool(self.config.get("native_step_launch", False))
+        if native:
+            for g in groups:
+                if getattr(g, "raw", None) is None:
+                    st_g = g.stream if g.stream is not None else main
+                    g.up_done.record(self._up_stream)          # torch creates its events lazily: make the handles exist
+                    g.act_ready.record(st_g)
+                    g.raw = (st_g.cuda_stream, g.up_done.cuda_event, g.graphs[0].raw_cuda_graph_exec(), g.act_ready.cuda_event,
+                             g.graphs[1].raw_cuda_graph_exec(), g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8)
+
         def upload_state(g):
             """(episode step, slot) of the group's workers -> device, after the host bookkeeping of the step."""
             if not g.full:
                 g.ss_np[:] = ss_global[:, g.lo:g.hi]
+            if native:
+                rc = lib.etm_upload_record(g.raw[5], g.raw[6], g.raw[7], up, g.raw[1])
+                if rc:
+                    etm_lib.check(rc, "etm_upload_record")
+                return
             lib.etm_upload(g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8, up)
             g.up_done.record(self._up_stream)
 
         def launch(g, t):
             """Device work of step t of group g (graph mode: two replays on the group's stream)."""
-            if use_graph:
+            if native:
+                if not stream_obs and not g.full:
+                    g.ss_np[:] = ss_global[:, g.lo:g.hi]
+                r = g.raw
+                rc = lib.etm_step_launch(r[0], r[1] if stream_obs else None, r[2], None if host_flag else r[3], r[4])
+                if rc:
+                    etm_lib.check(rc, "etm_step_launch")
+            elif use_graph:
                 if g.stream is not None:
                     torch.cuda.set_stream(g.stream)
                 cur = g.stream if g.stream is not None else main

@@ -218,6 +218,14 @@ int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_str
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
 int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
 
+/* Host-loop helpers of the sampling loop (trainer.py:161-218 of the reference has no counterpart: it issues framework calls).
+ * etm_upload_record: etm_upload, then hipEventRecord(done_event, stream).
+ * etm_step_launch:   one rollout step of one worker group on `stream`:
+ *                    [hipStreamWaitEvent(wait_event)]  hipGraphLaunch(graph_head)  [hipEventRecord(record_event)]
+ *                    [hipGraphLaunch(graph_tail)] -- graph_* are instantiated graphs (hipGraphExec_t), events may be NULL. */
+int etm_upload_record(void *dst, const void *src, int64_t bytes, void *stream, void *done_event);
+int etm_step_launch(void *stream, void *wait_event, void *graph_head, void *record_event, void *graph_tail);
+
 /* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).
  *   rewards, values, advantages [W,S] fp32 row-major (time contiguous, the reference layout)
