@@ -1,13 +1,22 @@
-"""Time full PPO updates for any config of configs/ (whole-path env-steps/s, phases).  python tools/config_bench.py NAME [updates]"""
+"""Time full PPO updates for any config of configs/ (whole-path env-steps/s, phases).
+python tools/config_bench.py NAME [updates] [key=value ...]   (config keys: 0/1 -> bool, other integers as they are; ETM_DIAG_LIB=... selects
+another build of the library)"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
 import torch
 from yaml_parser import YamlParser
 from trainer import PPOTrainer
+from etm import lib as _etm_lib
+if os.environ.get("ETM_DIAG_LIB"):
+    _etm_lib.LIB_PATH = os.environ["ETM_DIAG_LIB"]
 name = sys.argv[1]
-n_upd = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+rest = [a for a in sys.argv[2:] if "=" not in a]
+n_upd = int(rest[0]) if rest else 3
 cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", name + ".yaml")).get_config()
+for kv in (a for a in sys.argv[2:] if "=" in a):
+    key, val = kv.split("=")
+    cfg[key] = (val == "1") if val in ("0", "1") else int(val)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="cfgbench", device=dev, tensorboard=False)
