@@ -182,6 +182,31 @@ def main():
     if dp is not None:
         elapsed = dp.max_over_ranks(elapsed)
 
+    # gradient all-reduce on its own (message = 4 * params bytes, bus bandwidth against the xGMI link rate);
+    # measured AFTER the timed region, on every rank, with the trainer's own flat bucket and collective call
+    allreduce = None
+    if dp is not None:
+        try:
+            bucket = trainer.flat_grads
+            for _ in range(3):
+                dp.all_reduce_grads()
+            torch.cuda.synchronize(device)
+            dp.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_ar = 20
+            e0.record()
+            for _ in range(n_ar):
+                dp.all_reduce_grads()
+            e1.record()
+            torch.cuda.synchronize(device)
+            ar_ms = dp.max_over_ranks(e0.elapsed_time(e1) / n_ar)
+            nbytes = bucket.numel() * 4
+            allreduce = {"bytes": nbytes, "avg_ms": ar_ms, "includes": "sum all-reduce + division by world size (one launch)",
+                         "bus_gbs": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9, "xgmi_link_peak_gbs": 153.0,
+                         "per_update": cfg["epochs"] * cfg["n_mini_batch"]}
+        except Exception as exc:       # reporting only: never lose the throughput line over it
+            allreduce = {"error": repr(exc)}
+
     W, S = cfg["n_workers"], cfg["worker_steps"]
     t = cfg["transformer"]
     L, D, H, nb = t["memory_length"], t["embed_dim"], t["num_heads"], t["num_blocks"]
@@ -242,6 +267,7 @@ def main():
                        "attention": args.attention},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline,
+            "allreduce": allreduce,
             "kernels_train": kernels,
             "kernels_rollout": rollout_k,
         }
