@@ -7,8 +7,6 @@
 // bit-identical to the reference loop.  HBM traffic: 13 bytes per (worker, step).
 #include "etm_common.h"
 
-#include <stdlib.h>
-
 namespace {
 constexpr int TT = 32;
 constexpr int LS = TT + 1;
@@ -63,7 +61,9 @@ __global__ __launch_bounds__(64) void gae_kernel(const float *__restrict__ rewar
     __syncthreads();
   }
 }
-// Candidate for large worker counts (selected with ETM_GAE_V2=1 until measured; tools/scan_roofline.py): same layout, same
+#if defined(ETM_DIAG_GAE_V2)
+// Candidate for large worker counts (diagnostic builds only until measured: tools/diag_variants.sh gae -> libetm_gae_v2.so,
+// ETM_DIAG_LIB=... python tools/scan_roofline.py): same layout, same
 // per-worker operation order (bit-identical), but the next time tile is requested into registers BEFORE the current one is
 // scanned (the loads fly during the recurrence instead of after it) and a full tile is scanned by straight-line code, so the
 // LDS reads of later steps are issued ahead of the dependent multiply / add chain.  With one wave per 64 workers a CU holds
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64) void gae_kernel_v2(const float *__restrict__ re
 #undef ETM_GAE_FETCH
 }
 #undef ETM_GAE_STEP
+#endif  // ETM_DIAG_GAE_V2
 }  // namespace
 
 extern "C" int etm_gae(const float *rewards, const uint8_t *dones, const float *values, const float *last_value, float gamma,
@@ -150,12 +151,12 @@ extern "C" int etm_gae(const float *rewards, const uint8_t *dones, const float *
   if (!rewards || !dones || !values || !last_value || !advantages) return ETM_EINVAL;
   if (W <= 0 || S <= 0) return ETM_EINVAL;
   EtmProfScope prof(ETM_K_GAE, (hipStream_t)stream);
-  static const bool v2 = getenv("ETM_GAE_V2") != nullptr && atoi(getenv("ETM_GAE_V2")) != 0;
-  if (v2)
-    hipLaunchKernelGGL(gae_kernel_v2, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rewards, dones, values,
-                       last_value, gamma, gamma_lambda, advantages, W, S);
-  else
+#if defined(ETM_DIAG_GAE_V2)
+  hipLaunchKernelGGL(gae_kernel_v2, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rewards, dones, values,
+                     last_value, gamma, gamma_lambda, advantages, W, S);
+#else
   hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rewards, dones, values,
                      last_value, gamma, gamma_lambda, advantages, W, S);
+#endif
   return etm_launch_status();
 }

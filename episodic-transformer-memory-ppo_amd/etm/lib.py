@@ -6,7 +6,9 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 #                             second HIP runtime in the process (kernels would then launch on a runtime with no device)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libetm_hip.so")
+# ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
+# tools and of the parity tests; announced on load, never the default
+LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
 ABI_VERSION = 10
 
 _lib = None
@@ -62,6 +64,8 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the MI355X kernels are not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C episodic-transformer-memory-ppo_amd/csrc`. There is no CPU fallback for this path.")
+    if os.path.basename(LIB_PATH) != "libetm_hip.so":
+        print(f"[etm] using the library build {LIB_PATH}", flush=True)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

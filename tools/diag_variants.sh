@@ -28,6 +28,12 @@ if [ "$1" = "window" ]; then
   done
   exit 0
 fi
+if [ "$1" = "gae" ]; then   # register-prefetch candidate of the GAE scan
+  /opt/rocm/bin/hipcc $FLAGS -DETM_DIAG_GAE_V2 -c $SRC/gae.hip -o $OUT/gae_v2.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/gae_v2.o $(ls $SRC/build/*.o | grep -v /gae.o) -o $OUT/libetm_gae_v2.so
+  rm -f $OUT/gae_v2.o; echo built gae_v2
+  exit 0
+fi
 if [ "$1" = "prio" ]; then
   build base &
   build stage3 -DETM_PRIO_OTHER=3 -DETM_PRIO_MFMA=0 &

@@ -40,8 +40,11 @@ run "window pass L=128, v2 candidate" 300 env ETM_DIAG_LIB=$V2 python tools/wind
 run "window pass v2 phase trace" 300 env ETM_DIAG_LIB=$ROOT/tools/diag_build/libetm_win_v2trace.so python tools/window_time.py
 
 run "scan / loss kernels vs HBM roofline" 600 python tools/scan_roofline.py
-run "scan / loss kernels vs HBM roofline, GAE candidate (register prefetch of the next time tile)" 600 env ETM_GAE_V2=1 python tools/scan_roofline.py
-run "GAE candidate: bit-exact parity tests" 300 env ETM_GAE_V2=1 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gae"
+run "build GAE candidate" 300 bash tools/diag_variants.sh gae
+GAE2=$ROOT/tools/diag_build/libetm_gae_v2.so
+run "scan / loss kernels vs HBM roofline, GAE candidate (register prefetch of the next time tile)" 600 env ETM_DIAG_LIB=$GAE2 python tools/scan_roofline.py
+run "GAE candidate: bit-exact parity tests" 300 env ETM_DIAG_LIB=$GAE2 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gae"
+run "window pass candidate: attention parity tests" 600 env ETM_DIAG_LIB=$V2 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "mha or transformer or actor_critic or teacher_forced"
 
 run "rollout step: defaults" 300 python -u tools/rollout_profile.py
 run "rollout step: native_step_launch" 300 python -u tools/rollout_profile.py native_step_launch=1
