@@ -358,7 +358,7 @@ class _InProcWorker:
         _InProcWorker.counter += 1
 
 
-def golden_rollout():
+def golden_rollout(only=None):
     cases = {
         "vec": dict(env=dict(obs_shape=(6,), num_actions=3, max_episode_steps=12, seed=3, p_done=0.08, p_reward=0.3, pool=16),
                     cfg=dict(gamma=0.99, lamda=0.95, updates=2, epochs=2, n_workers=4, worker_steps=40, n_mini_batch=2,
@@ -370,9 +370,17 @@ def golden_rollout():
                                value_loss_coefficient=0.2, hidden_layer_size=32, max_grad_norm=0.5,
                                transformer=dict(num_blocks=2, embed_dim=32, num_heads=1, memory_length=10,
                                                 positional_encoding="learned", layer_norm="pre", gtrxl=True, gtrxl_bias=0.0))),
+        # visual observations: the CNN encoder of model.py:40-56 / :90-94 inside the reference's own rollout and update
+        "img": dict(env=dict(obs_shape=(3, 36, 36), num_actions=3, max_episode_steps=12, seed=11, p_done=0.08, p_reward=0.3, pool=8),
+                    cfg=dict(gamma=0.99, lamda=0.95, updates=2, epochs=2, n_workers=4, worker_steps=24, n_mini_batch=2,
+                             value_loss_coefficient=0.25, hidden_layer_size=32, max_grad_norm=0.5,
+                             transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8,
+                                              positional_encoding="relative", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))),
     }
     sched = dict(initial=3e-4, final=1e-4, power=1.0, max_decay_steps=10)
     for name, case in cases.items():
+        if only is not None and name not in only:
+            continue
         cfg = dict(case["cfg"])
         cfg["environment"] = {"type": "Synthetic"}
         cfg["learning_rate_schedule"] = dict(sched)
@@ -403,7 +411,12 @@ def golden_rollout():
             tr._sample_training_data()
             b = tr.buffer
             tag = f"u{upd}/"
-            out.update({tag + "obs": b.obs.clone(), tag + "actions": b.actions.clone(), tag + "log_probs": b.log_probs.clone(),
+            if b.obs.numel() > 100_000:      # image observations: a deterministic subsample + the sum instead of 1.5 MB per update
+                out[tag + "obs_sample"] = dg.sample(b.obs.numpy(), 8192)
+                out[tag + "obs_sum"] = np.float64(b.obs.double().sum())
+            else:
+                out[tag + "obs"] = b.obs.clone()
+            out.update({tag + "actions": b.actions.clone(), tag + "log_probs": b.log_probs.clone(),
                         tag + "values": b.values.clone(), tag + "advantages": b.advantages.clone(), tag + "rewards": b.rewards.copy(),
                         tag + "dones": b.dones.copy(), tag + "memory_mask": b.memory_mask.clone(),
                         tag + "memory_index": b.memory_index.clone(), tag + "memory_indices": b.memory_indices.clone(),
@@ -446,4 +459,7 @@ def golden_decay():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tables", "mha", "transformer", "model", "gae", "loss", "rollout", "decay"]
     for w in which:
-        globals()["golden_" + w]()
+        if w.startswith("rollout:"):            # e.g. rollout:img -- only the named teacher-forced cases
+            golden_rollout(only=w.split(":", 1)[1].split(","))
+        else:
+            globals()["golden_" + w]()

@@ -334,7 +334,11 @@ def test_ppo_loss_multi_branch_vs_oracle():
 
 
 # ------------------------------------------------------------------ whole path: teacher-forced rollout + updates vs the reference
-@pytest.mark.parametrize("name", ["vec", "gtrxl"])
+_UNVERIFIED = pytest.mark.skipif(os.environ.get("ETM_TEST_CANDIDATES") != "1", reason="fixture added after round 1's GPU budget was "
+                                 "spent: run once with ETM_TEST_CANDIDATES=1, then drop the mark")
+
+
+@pytest.mark.parametrize("name", ["vec", "gtrxl", pytest.param("img", marks=_UNVERIFIED)])
 def test_trainer_teacher_forced_vs_reference(golden_dir, name):
     from environments.synthetic import SyntheticVecEnv
     from trainer import PPOTrainer
@@ -358,7 +362,11 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name):
         assert np.array_equal(b.memory_index.cpu().numpy(), z[tag + "memory_index"])
         assert np.array_equal(b.dones, z[tag + "dones"]) and np.array_equal(b.rewards, z[tag + "rewards"])
         assert np.array_equal(tr.worker_current_episode_step, z[tag + "ep_step_after"])
-        assert np.array_equal(b.obs.cpu().numpy(), z[tag + "obs"])
+        if tag + "obs" in z:
+            assert np.array_equal(b.obs.cpu().numpy(), z[tag + "obs"])
+        else:      # image observations: the fixture holds a subsample and the sum
+            ob = b.obs.cpu().numpy()
+            assert np.array_equal(dg.sample(ob, 8192), z[tag + "obs_sample"]) and np.float64(ob.astype(np.float64).sum()) == z[tag + "obs_sum"]
         close(b.values, z[tag + "values"], atol=1e-4, what="values")
         close(b.log_probs, z[tag + "log_probs"], atol=1e-4, what="log_probs")
         close(b.advantages, z[tag + "advantages"], atol=5e-4, what="advantages")
