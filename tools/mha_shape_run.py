@@ -1,6 +1,7 @@
 """Run kernel #1 forward + backward a few times at the BASELINE config (3) training shape (for rocprofv3 passes).
 
-    python tools/mha_shape_run.py [iters] [N] [L] [D] [H]        (env ETM_ATTENTION=folded|dense, ETM_POS=1 for in-kernel positions)
+    python tools/mha_shape_run.py [iters] [N] [L] [D] [H]        (env ETM_ATTENTION=folded|dense, ETM_POS=1 for in-kernel positions,
+    ETM_WIN_SAMPLES=random|shuffled|sorted, ETM_DIAG_LIB / ETM_WIN_XCD_MAP for the candidate build)
 Prints the average wall time per fwd / bwd call measured with torch events."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +15,18 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 T, nb, E = max(96, L), 3, 416
 bank = torch.randn((E, T, nb, D), device=dev)
-ep = torch.randint(0, E, (N,), device=dev)
-win = torch.randint(0, T - L + 1, (N, 1), device=dev) + torch.arange(L, device=dev)[None, :]
-mask = torch.arange(L, device=dev)[None, :] < torch.randint(0, L, (N,), device=dev)[:, None]
+mode = os.environ.get("ETM_WIN_SAMPLES", "random")      # same access patterns as tools/window_time.py
+if mode == "random":
+    ep = torch.randint(0, E, (N,), device=dev)
+    win = torch.randint(0, T - L + 1, (N, 1), device=dev) + torch.arange(L, device=dev)[None, :]
+    mask = torch.arange(L, device=dev)[None, :] < torch.randint(0, L, (N,), device=dev)[:, None]
+else:                                                    # training-like: N of the E * T (episode, step) pairs, sliding windows
+    pairs = torch.randperm(E * T, device=dev)[:N]
+    if mode == "sorted":
+        pairs = pairs.sort().values
+    ep, step = pairs // T, pairs % T
+    win = torch.clamp(step - (L - 1), min=0)[:, None] + torch.arange(L, device=dev)[None, :]
+    mask = torch.arange(L, device=dev)[None, :] < torch.clamp(step, max=L - 1)[:, None]
 pos = torch.randn((T, D), device=dev) * 0.5
 wk = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
 wv = (torch.randn((D, D), device=dev) / D ** 0.5).requires_grad_(True)
