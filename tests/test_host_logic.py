@@ -273,3 +273,49 @@ def test_enjoy_episode_loop_window_rule(golden_dir):
     rewards, info = enjoy.run_episode(model, env, cfg, torch.device("cpu"))
     assert 1 <= len(rewards) <= T and len(seen) == len(rewards)
     assert info is not None and info["length"] == len(rewards)
+
+
+def test_transposing_reduction_lane_mapping_emulated():
+    """Lane-level emulation of csrc/window_attn.hip's TransposeReduce (select form and the v_permlane16/32_swap form of the
+    candidate build, with the documented swap semantics: odd rows of the first operand <-> even rows of the second): after the
+    butterfly, v[0] of lane l holds the 64-lane total of value bit_reverse(l mod NV); also the candidate's pass 1, which merges
+    rows k and k + RG/2 at offset 1 inside the row loop and continues with TransposeReduce<RG/2, 2>."""
+    rng = np.random.default_rng(0)
+    lanes = np.arange(64)
+
+    def xor(v, off):
+        return v[lanes ^ off]
+
+    def swap_sum(a, b, off):
+        a2, b2 = a.copy(), b.copy()
+        for l in range(64):
+            if (l // off) % 2 == 1:
+                a2[l], b2[l - off] = b[l - off], a[l]
+        return a2 + b2
+
+    def reduce(v, off, swap):
+        while off <= 32:
+            up = (lanes & off) != 0
+            if len(v) > 1:
+                half = len(v) // 2
+                v = [swap_sum(v[k], v[k + half], off) if (swap and off >= 16) else
+                     np.where(up, v[k + half], v[k]) + xor(np.where(up, v[k], v[k + half]), off) for k in range(half)]
+            else:
+                v = [swap_sum(v[0], v[0], off)] if (swap and off >= 16) else [v[0] + xor(v[0], off)]
+            off *= 2
+        return v[0]
+
+    def brev(x, bits):
+        return int(format(x, f"0{bits}b")[::-1], 2)
+
+    for nv in (8, 16, 32):
+        e = [rng.integers(-50, 50, 64).astype(np.float64) for _ in range(nv)]
+        for swap in (False, True):
+            r = reduce(list(e), 1, swap)
+            assert all(r[l] == e[brev(l % nv, nv.bit_length() - 1)].sum() for l in range(64)), (nv, swap)
+    rg = 8
+    e = [rng.integers(-50, 50, 64).astype(np.float64) for _ in range(rg)]
+    up = (lanes & 1) != 0
+    ev = [np.where(up, e[k + rg // 2], e[k]) + xor(np.where(up, e[k], e[k + rg // 2]), 1) for k in range(rg // 2)]
+    r = reduce(ev, 2, True)
+    assert all(r[l] == e[brev(l % rg, 3)].sum() for l in range(64))
