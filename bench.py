@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--dist-backend", default=None, help="testing only: torch.distributed backend instead of nccl (= RCCL), e.g. gloo")
+    ap.add_argument("--dp-collective", choices=("torch", "etm"), default="torch",
+                    help="gradient all-reduce through torch.distributed (RCCL backend) or through the library's own RCCL communicator")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="testing only: every rank uses this device index (exercises the multi-process path on a 1-GPU box)")
     ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
@@ -135,7 +137,7 @@ def main():
     etm_ops.set_attention_impl(args.attention)
 
     cfg = load_config()
-    dp = DataParallel(device, backend=args.dist_backend) if world > 1 else None
+    dp = DataParallel(device, backend=args.dist_backend, collective=args.dp_collective) if world > 1 else None
     torch.manual_seed(0)
     np.random.seed(0)
     trainer = PPOTrainer(cfg, run_id="bench", device=device, dp=dp, first_worker_id=rank * cfg["n_workers"], tensorboard=False)
@@ -264,7 +266,7 @@ def main():
                                    "= 16384 env steps per update, 5 epochs x 8 minibatches of 2048, TrXL 3 blocks D=384 H=4 L=64, "
                                    "synthetic U[0,1) 3x84x84 observations, random-init weights",
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
-                       "attention": args.attention},
+                       "attention": args.attention, "dp_collective": dp.collective if dp is not None else None},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline,
             "allreduce": allreduce,

@@ -14,7 +14,14 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, device=None, backend=None):
+    def __init__(self, device=None, backend=None, collective=None):
+        """``collective``: who issues the gradient all-reduce -- "torch" (default: torch.distributed, backend nccl = RCCL) or
+        "etm" (the library's own RCCL communicator, ``etm_comm_*`` / ``etm_allreduce_f32``, enqueued on the current stream;
+        HIP device tensors only; rendezvous id distributed through torch.distributed).  ETM_DP_COLLECTIVE overrides."""
+        self.collective = os.environ.get("ETM_DP_COLLECTIVE") or collective or "torch"
+        if self.collective not in ("torch", "etm"):
+            raise ValueError(f"collective must be 'torch' or 'etm', got {self.collective!r}")
+        self._comm = None
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -58,11 +65,42 @@ class DataParallel:
             off += p.numel()
         return self.flat
 
+    def _etm_comm(self):
+        """Library-owned RCCL communicator (created on first use): rank 0 draws the rendezvous id, torch.distributed carries
+        its 128 bytes to the other ranks, every rank joins with its current device."""
+        if self._comm is None:
+            import ctypes
+            from . import lib as _lib
+            lib = _lib.load()
+            dev = torch.device(self.device)
+            if dev.type != "cuda":
+                raise RuntimeError("collective='etm' needs HIP device tensors (RCCL); use the torch collective for CPU / gloo runs")
+            buf = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                _lib.check(lib.etm_comm_unique_id(buf), "etm_comm_unique_id")
+            on_dev = dist.get_backend() == "nccl"
+            t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            t = t.to(dev) if on_dev else t
+            dist.broadcast(t, src=0)
+            raw = bytes(t.cpu().numpy().tobytes())
+            comm = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.check(lib.etm_comm_init(raw, self.rank, self.world, ctypes.byref(comm)), "etm_comm_init")
+            self._comm = comm
+        return self._comm
+
     def all_reduce_grads(self):
         """Sum the flat gradient bucket over ranks and average (one RCCL all-reduce)."""
-        if self.active:
+        if not self.active:
+            return
+        if self.collective == "etm":
+            from . import lib as _lib
+            rc = _lib.load().etm_allreduce_f32(self._etm_comm(), self.flat.data_ptr(), self.flat.data_ptr(), self.flat.numel(),
+                                               torch.cuda.current_stream(self.flat.device).cuda_stream)
+            _lib.check(rc, "etm_allreduce_f32")
+        else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(self.world)
+        self.flat.div_(self.world)
 
     def merge_adv_stats(self, stats3: torch.Tensor) -> torch.Tensor:
         """Merge per-rank (count, mean, M2) into global statistics (Chan et al. pairwise update)."""
@@ -89,5 +127,9 @@ class DataParallel:
             dist.barrier()
 
     def close(self):
+        if self._comm is not None:
+            from . import lib as _lib
+            _lib.load().etm_comm_destroy(self._comm)
+            self._comm = None
         if self.active and dist.is_initialized():
             dist.destroy_process_group()

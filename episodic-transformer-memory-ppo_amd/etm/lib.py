@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 
@@ -36,6 +36,10 @@ SIGNATURES = {
     "etm_upload": (_I, [_P, _P, _L, _P]),
     "etm_upload_record": (_I, [_P, _P, _L, _P, _P]),
     "etm_step_launch": (_I, [_P, _P, _P, _P, _P]),
+    "etm_comm_unique_id": (_I, [_P]),
+    "etm_comm_init": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_void_p)]),
+    "etm_allreduce_f32": (_I, [_P, _P, _P, _L, _P]),
+    "etm_comm_destroy": (_I, [_P]),
     "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "etm_gru_gate_rz": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

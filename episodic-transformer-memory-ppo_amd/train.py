@@ -6,7 +6,8 @@ One process drives one MI355X.  For data-parallel training over the GPUs of a no
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config ...
 
-(``n_workers`` in the YAML is the number of environments PER PROCESS; gradients are all-reduced with RCCL.)
+(``n_workers`` in the YAML is the number of environments PER PROCESS; gradients are all-reduced with RCCL -- through
+torch.distributed by default, through the library's own communicator with ETM_DP_COLLECTIVE=etm.)
 """
 import argparse
 import os

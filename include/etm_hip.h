@@ -29,6 +29,8 @@ extern "C" {
 #define ETM_EINVAL (-1)      /* bad dimension / null pointer */
 #define ETM_EUNSUPPORTED (-2) /* shape outside what the gfx950 kernels are built for */
 #define ETM_EWORKSPACE (-3)  /* workspace too small */
+#define ETM_ENOCOMM (-4)     /* librccl could not be loaded / communicator entry used before etm_comm_init */
+#define ETM_ERCCL_BASE 100000 /* ETM_ERCCL_BASE + ncclResult_t: an RCCL call failed */
 
 /* ABI version of this header (bumped on any signature change). */
 int etm_abi_version(void);
@@ -272,6 +274,21 @@ int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t action_str
                  float *out8, float *d_logits, float *d_value,
                  void *partials, int64_t partials_bytes, const double *dyn_clip_beta,
                  int N, int A, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel optimiser step (absent upstream -- the call goes between
+ * loss.backward() and clip_grad_norm_, trainer.py:310-311): RCCL over xGMI, one communicator per process (= per GPU).
+ *   etm_comm_unique_id(id_out[ETM_COMM_ID_BYTES])   rank 0 creates the rendezvous id; the caller distributes the bytes to all ranks
+ *   etm_comm_init(id, rank, world, &comm)           collective over all ranks; binds to the caller's current HIP device
+ *   etm_allreduce_f32(comm, send, recv, count, stream)   sum over ranks, in place when send == recv, enqueued on `stream`
+ *   etm_comm_destroy(comm)
+ * RCCL is dlopen()ed at the first of these calls (no link-time dependency; single-GPU use never loads it).  Errors: ETM_ENOCOMM,
+ * or ETM_ERCCL_BASE + ncclResult_t. */
+#define ETM_COMM_ID_BYTES 128
+int etm_comm_unique_id(void *id_out);
+int etm_comm_init(const void *id, int rank, int world, void **comm_out);
+int etm_allreduce_f32(void *comm, const float *send, float *recv, int64_t count, void *stream);
+int etm_comm_destroy(void *comm);
 
 /* ---------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline numbers).

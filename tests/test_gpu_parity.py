@@ -707,6 +707,30 @@ print("rccl-ok")
     assert "rccl-ok" in out.stdout, out.stderr[-2000:]
 
 
+@_UNVERIFIED
+def test_candidate_library_collective_single_rank():
+    """etm_comm_* / etm_allreduce_f32 on one device (world size 1): the sum over one rank is the identity, enqueued on the
+    caller's stream, in place and out of place."""
+    import ctypes
+    from etm import lib as etm_lib
+    dev = _dev()
+    lib = etm_lib.load()
+    buf = ctypes.create_string_buffer(128)
+    etm_lib.check(lib.etm_comm_unique_id(buf), "etm_comm_unique_id")
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        etm_lib.check(lib.etm_comm_init(bytes(buf.raw), 0, 1, ctypes.byref(comm)), "etm_comm_init")
+    x = torch.randn(1 << 20, device=dev)
+    ref = x.clone()
+    y = torch.empty_like(x)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    etm_lib.check(lib.etm_allreduce_f32(comm, x.data_ptr(), y.data_ptr(), x.numel(), st), "etm_allreduce_f32")
+    etm_lib.check(lib.etm_allreduce_f32(comm, x.data_ptr(), x.data_ptr(), x.numel(), st), "etm_allreduce_f32")
+    torch.cuda.synchronize(dev)
+    assert torch.equal(y, ref) and torch.equal(x, ref)
+    etm_lib.check(lib.etm_comm_destroy(comm), "etm_comm_destroy")
+
+
 def test_graph_and_eager_optimisation_steps_agree():
     """The captured minibatch step (device-resident lr / clip / beta under changing schedules) trains exactly like the eager
     `_train_mini_batch` path that mirrors upstream's method (hip_graph_train: false), and the upstream-style generator API

@@ -319,3 +319,20 @@ def test_transposing_reduction_lane_mapping_emulated():
     ev = [np.where(up, e[k + rg // 2], e[k]) + xor(np.where(up, e[k], e[k + rg // 2]), 1) for k in range(rg // 2)]
     r = reduce(ev, 2, True)
     assert all(r[l] == e[brev(l % rg, 3)].sum() for l in range(64))
+
+
+def test_library_collective_plumbing_without_a_device():
+    """etm_comm_*: RCCL is resolved lazily (dlopen), the rendezvous id can be drawn anywhere, argument errors are reported as
+    ETM_EINVAL; joining a communicator needs a HIP device (on the CPU-only build container RCCL reports an error, which must
+    come back as ETM_ERCCL_BASE + ncclResult_t, not as a crash)."""
+    import ctypes
+    from etm import lib as etm_lib
+    lib = etm_lib.load()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.etm_comm_unique_id(buf) == 0 and any(buf.raw)
+    comm = ctypes.c_void_p()
+    assert lib.etm_comm_init(bytes(buf.raw), 2, 1, ctypes.byref(comm)) == -1          # rank outside the world
+    assert lib.etm_allreduce_f32(None, None, None, 0, None) == -1 and lib.etm_comm_destroy(None) == -1
+    if not torch.cuda.is_available():
+        rc = lib.etm_comm_init(bytes(buf.raw), 0, 1, ctypes.byref(comm))
+        assert rc >= 100000 and b"RCCL" in lib.etm_error_string(rc)

@@ -22,7 +22,7 @@ run() {  # label, timeout, command...
   echo "    exit code $?" | tee -a $LOG
 }
 export ETM_TUNABLE_GEMM=0
-run "candidate rollout paths (parity)" 600 env ETM_TEST_CANDIDATES=1 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "candidate or fast_paths or teacher_forced"
+run "candidate rollout paths (parity)" 600 env ETM_TEST_CANDIDATES=1 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "candidate or fast_paths or teacher_forced"   # includes the library collective at world size 1
 for rep in 1 2 3; do
   run "BASELINE config shapes (GTrXL included), repetition $rep" 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "baseline_config_shapes_train"
 done
