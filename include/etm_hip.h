@@ -8,10 +8,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (torch); the library borrows it for the
- *     duration of the enqueue and allocates nothing;
+ *     duration of the enqueue and allocates nothing (exceptions: the event pool of etm_profile_*, the RCCL communicator
+ *     of etm_comm_init);
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no synchronisation;
- *   - return value: 0 on success, a hipError_t (> 0) from the launch, or a negative ETM_E* code for
- *     argument errors; nothing throws across the ABI;
+ *   - return value: 0 on success, a hipError_t (> 0) from the launch (ETM_ERCCL_BASE + an ncclResult_t from the
+ *     communicator entries), or a negative ETM_E* code for argument errors; nothing throws across the ABI;
  *   - fp32 tensors are dense row-major unless strides are given; indices are int64 (torch.long);
  *     masks are one byte per element (0 = masked);
  *   - thread-safety: calls are re-entrant; ordering is the stream's.
