@@ -1,7 +1,7 @@
 // ABI version + error strings of libetm_hip.so.
 #include "etm_common.h"
 
-extern "C" int etm_abi_version(void) { return 11; }
+extern "C" int etm_abi_version(void) { return 12; }
 
 extern "C" const char *etm_error_string(int code) {
   switch (code) {
@@ -88,30 +88,4 @@ extern "C" int etm_upload(void *dst, const void *src, int64_t bytes, void *strea
   (void)hipGetLastError();
   if (!dst || !src || bytes <= 0) return ETM_EINVAL;
   return (int)hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
-}
-
-// etm_upload followed by hipEventRecord(done_event, stream): the per-step (episode step, slot) upload of a worker group and the
-// event its step graphs wait on, as one call from the host loop.
-extern "C" int etm_upload_record(void *dst, const void *src, int64_t bytes, void *stream, void *done_event) {
-  (void)hipGetLastError();
-  if (!dst || !src || bytes <= 0 || !done_event) return ETM_EINVAL;
-  hipError_t rc = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
-  if (rc != hipSuccess) return (int)rc;
-  return (int)hipEventRecord((hipEvent_t)done_event, (hipStream_t)stream);
-}
-
-// One rollout step of one worker group, enqueued on `stream` with a single call from the host loop (the python-level
-// sequence costs ~5 runtime calls through the framework per group and step):
-//   [wait for wait_event]  launch graph_head  [record record_event]  launch graph_tail
-// graph_head / graph_tail are instantiated graphs (hipGraphExec_t); events may be NULL.
-extern "C" int etm_step_launch(void *stream, void *wait_event, void *graph_head, void *record_event, void *graph_tail) {
-  (void)hipGetLastError();
-  if (!graph_head) return ETM_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t rc = hipSuccess;
-  if (wait_event) rc = hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0);
-  if (rc == hipSuccess) rc = hipGraphLaunch((hipGraphExec_t)graph_head, st);
-  if (rc == hipSuccess && record_event) rc = hipEventRecord((hipEvent_t)record_event, st);
-  if (rc == hipSuccess && graph_tail) rc = hipGraphLaunch((hipGraphExec_t)graph_tail, st);
-  return (int)rc;
 }

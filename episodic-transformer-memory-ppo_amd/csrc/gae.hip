@@ -1,148 +1,132 @@
 // Kernel #2: generalized advantage estimation (replaces /root/reference buffer.py:95-113).
 //
-// Layout is the reference's [W, S] row-major (time contiguous).  One wave owns 64 workers; it walks the time axis
-// backwards in tiles of TT steps: the tile is loaded with coalesced reads (consecutive lanes = consecutive steps of
-// one worker), transposed through LDS (row stride TT+1: conflict-free), then lane w runs worker w's recurrence with
-// the reference's exact operation order -- separate multiplies and adds, no FMA contraction -- so the advantages are
-// bit-identical to the reference loop.  HBM traffic: 13 bytes per (worker, step).
+// Layout is the reference's [W, S] row-major (time contiguous).  The recurrence
+//     last_value *= mask_t;  last_adv *= mask_t;  delta = r_t + gamma * last_value - v_t;  last_adv = delta + (gamma lambda) last_adv
+// is split into the part that does NOT depend on the running advantage -- delta_t, computed by all 64 lanes in the
+// memory layout (consecutive lanes = consecutive steps of one worker: 16-byte loads, 256-byte contiguous segments per
+// worker) -- and the dependent chain (two multiplies and one add per step), which lane w runs for worker w from a transposed
+// LDS image of the tile (row stride TT + 1: conflict-free).  Every operation keeps the reference's order and rounding
+// (separate multiplies and adds, no FMA contraction), so the advantages are bit-identical to the reference loop.
+//
+// One wave owns WPW = 16 workers and walks the time axis backwards in tiles of TT = 64 steps; the next tile is requested
+// into registers BEFORE the current one is scanned, so the loads fly under the chain (which issues S x 3 dependent VALU
+// instructions per wave regardless of the tile shape).  W = 65,536 gives 4,096 single-wave workgroups = 16 waves per CU with
+// ~9 KB in flight each; W = 32 is two waves of 8 tiles each (launch- and latency-bound: ~10 us).
+// HBM traffic: 13 bytes per (worker, step).
 #include "etm_common.h"
 
 namespace {
-constexpr int TT = 32;
-constexpr int LS = TT + 1;
-
+template <int WPW, bool VEC>
 __global__ __launch_bounds__(64) void gae_kernel(const float *__restrict__ rewards, const unsigned char *__restrict__ dones,
                                                  const float *__restrict__ values, const float *__restrict__ last_value,
                                                  float gamma, float gamma_lambda, float *__restrict__ adv, int W, int S) {
-  __shared__ float r_s[64 * LS];
-  __shared__ float v_s[64 * (LS + 1)];  // one extra column: value at the step after the tile
-  __shared__ float m_s[64 * LS];        // 1 - done
+  constexpr int TT = 1024 / WPW;     // steps per tile
+  constexpr int LPR = TT / 4;        // lanes per worker row of a tile (4 steps per lane)
+  constexpr int R = 64 / LPR;        // worker rows covered by one load instruction of the wave
+  constexpr int NI = WPW / R;        // load instructions per array and tile
+  constexpr int LS = TT + 1;
+  __shared__ float d_s[WPW * LS];    // delta_t, overwritten by the advantages
+  __shared__ float m_s[WPW * LS];    // 1 - done_t
   const int lane = threadIdx.x;
-  const int w0 = blockIdx.x * 64;
-  const int w_mine = w0 + lane;
-  float la = 0.f;                                               // last_advantage
-  float v_next = (w_mine < W) ? last_value[w_mine] : 0.f;       // value after the current tile
+  const int w0 = blockIdx.x * WPW;
+  const int rsub = lane / LPR, lsub = lane % LPR, tsub = lsub * 4;
   const int n_tiles = (S + TT - 1) / TT;
-  for (int tile = n_tiles - 1; tile >= 0; --tile) {
-    const int t0 = tile * TT;
-    for (int idx = lane; idx < 64 * TT; idx += 64) {
-      const int w = idx / TT, t = idx - w * TT;
-      float r = 0.f, v = 0.f, m = 0.f;
-      if (w0 + w < W && t0 + t < S) {
-        const long long g = (long long)(w0 + w) * S + t0 + t;
-        r = rewards[g];
-        v = values[g];
-        m = dones[g] ? 0.f : 1.f;
-      }
-      r_s[w * LS + t] = r;
-      v_s[w * (LS + 1) + t] = v;
-      m_s[w * LS + t] = m;
-    }
-    v_s[lane * (LS + 1) + TT] = v_next;
-    __syncthreads();
-    const int t_hi = min(TT, S - t0);
-    float nv = v_s[lane * (LS + 1) + TT];
-    for (int t = t_hi - 1; t >= 0; --t) {
-      const float m = m_s[lane * LS + t];
-      const float lv = __fmul_rn(nv, m);            // last_value = last_value * mask
-      la = __fmul_rn(la, m);                        // last_advantage = last_advantage * mask
-      const float vt = v_s[lane * (LS + 1) + t];
-      const float delta = __fsub_rn(__fadd_rn(r_s[lane * LS + t], __fmul_rn(gamma, lv)), vt);
-      la = __fadd_rn(delta, __fmul_rn(gamma_lambda, la));
-      r_s[lane * LS + t] = la;                      // reuse the reward tile for the result
-      nv = vt;
-    }
-    v_next = v_s[lane * (LS + 1) + 0];
-    __syncthreads();
-    for (int idx = lane; idx < 64 * TT; idx += 64) {
-      const int w = idx / TT, t = idx - w * TT;
-      if (w0 + w < W && t0 + t < S) adv[(long long)(w0 + w) * S + t0 + t] = r_s[w * LS + t];
-    }
-    __syncthreads();
-  }
-}
-#if defined(ETM_DIAG_GAE_V2)
-// Candidate for large worker counts (diagnostic builds only until measured: tools/diag_variants.sh gae -> libetm_gae_v2.so,
-// ETM_DIAG_LIB=... python tools/scan_roofline.py): same layout, same
-// per-worker operation order (bit-identical), but the next time tile is requested into registers BEFORE the current one is
-// scanned (the loads fly during the recurrence instead of after it) and a full tile is scanned by straight-line code, so the
-// LDS reads of later steps are issued ahead of the dependent multiply / add chain.  With one wave per 64 workers a CU holds
-// W / 64 / 256 waves (4 at W = 65,536): overlap inside the wave is the only latency hiding there is.
-#define ETM_GAE_STEP(t_)                                                                                    \
-  {                                                                                                          \
-    const float m_ = m_s[lane * LS + (t_)];                                                                  \
-    const float lv_ = __fmul_rn(nv, m_);                                                                     \
-    la = __fmul_rn(la, m_);                                                                                  \
-    const float vt_ = v_s[lane * (LS + 1) + (t_)];                                                           \
-    const float delta_ = __fsub_rn(__fadd_rn(r_s[lane * LS + (t_)], __fmul_rn(gamma, lv_)), vt_);            \
-    la = __fadd_rn(delta_, __fmul_rn(gamma_lambda, la));                                                     \
-    r_s[lane * LS + (t_)] = la;                                                                              \
-    nv = vt_;                                                                                                \
-  }
 
-__global__ __launch_bounds__(64) void gae_kernel_v2(const float *__restrict__ rewards, const unsigned char *__restrict__ dones,
-                                                    const float *__restrict__ values, const float *__restrict__ last_value,
-                                                    float gamma, float gamma_lambda, float *__restrict__ adv, int W, int S) {
-  __shared__ float r_s[64 * LS];
-  __shared__ float v_s[64 * (LS + 1)];
-  __shared__ float m_s[64 * LS];
-  const int lane = threadIdx.x;
-  const int w0 = blockIdx.x * 64;
-  const int w_mine = w0 + lane;
-  // element i of this lane in a tile: worker w0 + 2 i + (lane >> 5), step t0 + (lane & 31)  (idx = lane + 64 i = w TT + t)
-  const int wsub = lane >> 5, tsub = lane & 31;
-  float la = 0.f;
-  float v_next = (w_mine < W) ? last_value[w_mine] : 0.f;
-  const int n_tiles = (S + TT - 1) / TT;
-  float pr[TT], pv[TT], pm[TT];
-#define ETM_GAE_FETCH(tile_)                                                                                 \
-  {                                                                                                          \
-    const int t_ = (tile_) * TT + tsub;                                                                      \
-    _Pragma("unroll") for (int i = 0; i < TT; ++i) {                                                         \
-      const int w_ = w0 + 2 * i + wsub;                                                                      \
-      const bool ok_ = w_ < W && t_ < S;                                                                     \
-      const long long g_ = ok_ ? (long long)w_ * S + t_ : 0;                                                 \
-      const float r_ = rewards[g_], v_ = values[g_];                                                         \
-      const unsigned char d_ = dones[g_];                                                                    \
-      pr[i] = ok_ ? r_ : 0.f;                                                                                \
-      pv[i] = ok_ ? v_ : 0.f;                                                                                \
-      pm[i] = (ok_ && !d_) ? 1.f : 0.f;                                                                      \
-    }                                                                                                        \
+  float pr[NI][4], pv[NI][4], pm[NI][4];      // prefetched tile: rewards, values, 1 - done of this lane's 4 steps per row
+  float lastv[NI], carry[NI];                 // bootstrap value of the row; first value of the tile scanned before (= later in time)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int w = w0 + i * R + rsub;
+    lastv[i] = (w < W) ? last_value[w] : 0.f;
+    carry[i] = 0.f;
   }
-  ETM_GAE_FETCH(n_tiles - 1)
+  auto fetch = [&](int tile) {
+    const int t = tile * TT + tsub;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int w = w0 + i * R + rsub;
+      if constexpr (VEC) {                    // S % 4 == 0: a lane's 4 steps are inside or outside together, rows are 16-byte aligned
+        const bool ok = w < W && t < S;
+        const long long g = ok ? (long long)w * S + t : 0;
+        const float4 r4 = *reinterpret_cast<const float4 *>(rewards + g);
+        const float4 v4 = *reinterpret_cast<const float4 *>(values + g);
+        const uchar4 d4 = *reinterpret_cast<const uchar4 *>(dones + g);
+        pr[i][0] = r4.x; pr[i][1] = r4.y; pr[i][2] = r4.z; pr[i][3] = r4.w;
+        pv[i][0] = ok ? v4.x : 0.f; pv[i][1] = ok ? v4.y : 0.f; pv[i][2] = ok ? v4.z : 0.f; pv[i][3] = ok ? v4.w : 0.f;
+        pm[i][0] = d4.x ? 0.f : 1.f; pm[i][1] = d4.y ? 0.f : 1.f; pm[i][2] = d4.z ? 0.f : 1.f; pm[i][3] = d4.w ? 0.f : 1.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = w < W && t + j < S;
+          const long long g = ok ? (long long)w * S + t + j : 0;
+          const float r = rewards[g], v = values[g];
+          const unsigned char d = dones[g];
+          pr[i][j] = r;
+          pv[i][j] = ok ? v : 0.f;
+          pm[i][j] = d ? 0.f : 1.f;
+        }
+      }
+    }
+  };
+
+  fetch(n_tiles - 1);
+  float la = 0.f;                              // running advantage of worker w0 + lane (lanes < WPW)
   for (int tile = n_tiles - 1; tile >= 0; --tile) {
     const int t0 = tile * TT;
+    // delta_t = (r_t + gamma * (v_{t+1} * mask_t)) - v_t in the memory layout; v_{t+1} of a lane's last step comes from the
+    // next lane, of a row's last step from the tile scanned before, of step S - 1 from the bootstrap value
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-      const int w = 2 * i + wsub;
-      r_s[w * LS + tsub] = pr[i];
-      v_s[w * (LS + 1) + tsub] = pv[i];
-      m_s[w * LS + tsub] = pm[i];
+    for (int i = 0; i < NI; ++i) {
+      const float nxt_lane = __shfl_down(pv[i][0], 1, 64);
+      float vn3 = (lsub == LPR - 1) ? carry[i] : nxt_lane;
+      const int t = t0 + tsub;
+      float vn[4] = {pv[i][1], pv[i][2], pv[i][3], vn3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t + j == S - 1) vn[j] = lastv[i];
+        const float lv = __fmul_rn(vn[j], pm[i][j]);
+        const float delta = __fsub_rn(__fadd_rn(pr[i][j], __fmul_rn(gamma, lv)), pv[i][j]);
+        d_s[(i * R + rsub) * LS + tsub + j] = delta;
+        m_s[(i * R + rsub) * LS + tsub + j] = pm[i][j];
+      }
+      carry[i] = __shfl(pv[i][0], lane - lsub, 64);          // first value of this tile, for the row's last step of the next one
     }
-    v_s[lane * (LS + 1) + TT] = v_next;
     __syncthreads();
-    if (tile > 0) ETM_GAE_FETCH(tile - 1)          // in flight while this tile is scanned and stored
+    if (tile > 0) fetch(tile - 1);                           // in flight while this tile is scanned and stored
     const int t_hi = min(TT, S - t0);
-    float nv = v_s[lane * (LS + 1) + TT];
-    if (t_hi == TT) {
+    if (lane < WPW) {
+      const int base = lane * LS;
+      if (t_hi == TT) {
 #pragma unroll
-      for (int t = TT - 1; t >= 0; --t) ETM_GAE_STEP(t)
-    } else {
-      for (int t = t_hi - 1; t >= 0; --t) ETM_GAE_STEP(t)
+        for (int t = TT - 1; t >= 0; --t) {
+          la = __fmul_rn(la, m_s[base + t]);
+          la = __fadd_rn(d_s[base + t], __fmul_rn(gamma_lambda, la));
+          d_s[base + t] = la;
+        }
+      } else {
+        for (int t = t_hi - 1; t >= 0; --t) {
+          la = __fmul_rn(la, m_s[base + t]);
+          la = __fadd_rn(d_s[base + t], __fmul_rn(gamma_lambda, la));
+          d_s[base + t] = la;
+        }
+      }
     }
-    v_next = v_s[lane * (LS + 1) + 0];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-      const int w = 2 * i + wsub;
-      if (w0 + w < W && t0 + tsub < S) adv[(long long)(w0 + w) * S + t0 + tsub] = r_s[w * LS + tsub];
+    for (int i = 0; i < NI; ++i) {
+      const int w = w0 + i * R + rsub, t = t0 + tsub;
+      const float *src = d_s + (i * R + rsub) * LS + tsub;
+      if constexpr (VEC) {
+        if (w < W && t < S) *reinterpret_cast<float4 *>(adv + (long long)w * S + t) = make_float4(src[0], src[1], src[2], src[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (w < W && t + j < S) adv[(long long)w * S + t + j] = src[j];
+      }
     }
     __syncthreads();
   }
-#undef ETM_GAE_FETCH
 }
-#undef ETM_GAE_STEP
-#endif  // ETM_DIAG_GAE_V2
 }  // namespace
 
 extern "C" int etm_gae(const float *rewards, const uint8_t *dones, const float *values, const float *last_value, float gamma,
@@ -151,12 +135,15 @@ extern "C" int etm_gae(const float *rewards, const uint8_t *dones, const float *
   if (!rewards || !dones || !values || !last_value || !advantages) return ETM_EINVAL;
   if (W <= 0 || S <= 0) return ETM_EINVAL;
   EtmProfScope prof(ETM_K_GAE, (hipStream_t)stream);
-#if defined(ETM_DIAG_GAE_V2)
-  hipLaunchKernelGGL(gae_kernel_v2, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rewards, dones, values,
-                     last_value, gamma, gamma_lambda, advantages, W, S);
-#else
-  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rewards, dones, values,
-                     last_value, gamma, gamma_lambda, advantages, W, S);
-#endif
+  constexpr int WPW = 16;
+  const dim3 grid((unsigned)((W + WPW - 1) / WPW)), block(64);
+  const bool vec = S % 4 == 0 && ((uintptr_t)rewards % 16 == 0) && ((uintptr_t)values % 16 == 0) && ((uintptr_t)advantages % 16 == 0) &&
+                   ((uintptr_t)dones % 4 == 0);
+  if (vec)
+    hipLaunchKernelGGL((gae_kernel<WPW, true>), grid, block, 0, (hipStream_t)stream, rewards, dones, values, last_value, gamma, gamma_lambda,
+                       advantages, W, S);
+  else
+    hipLaunchKernelGGL((gae_kernel<WPW, false>), grid, block, 0, (hipStream_t)stream, rewards, dones, values, last_value, gamma, gamma_lambda,
+                       advantages, W, S);
   return etm_launch_status();
 }

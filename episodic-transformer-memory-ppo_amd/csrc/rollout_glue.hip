@@ -11,12 +11,17 @@ namespace {
 // used to be launches of their own on the critical path of a rollout step: t_row = t (the staging row the tail of the step
 // writes to) and, in extra workgroups, the K/V-cache reset of workers that start an episode (cache[w] = init when
 // step[w] == 0; a new episode starts from the projection of an all-zero memory).
+// A third rider LATCHES the workers' (episode step, slot) for the tail of the step: `ss` is the [2, W] block the host uploads
+// (row 0 = step, row 1 = slot), `latch` a private [2, W] copy.  The tail (memory-bank write, K/V-cache write) indexes the latch,
+// so the host may upload the NEXT step's (step, slot) while this step's tail is still running -- the tail of step t and the
+// head of step t + 1 are ordered on the group's stream, the upload stream is not.
 constexpr int RESET_CHUNKS = 64;
 __global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__restrict__ step, const unsigned char *__restrict__ mask_table,
                                                              const long long *__restrict__ index_table, const long long *__restrict__ t_dev,
                                                              unsigned char *__restrict__ mask_t, long long *__restrict__ win_t,
                                                              unsigned char *__restrict__ st_mask, long long *__restrict__ st_idx,
-                                                             long long *__restrict__ t_row, float *__restrict__ reset_dst,
+                                                             long long *__restrict__ t_row, long long *__restrict__ latch,
+                                                             float *__restrict__ reset_dst,
                                                              const float *__restrict__ reset_init, long long reset_row_elems, int nb_window,
                                                              int W, int L, int stage_W) {
   if ((int)blockIdx.x >= nb_window) {     // reset role: (worker, chunk)
@@ -38,6 +43,10 @@ __global__ __launch_bounds__(256) void rollout_window_kernel(const long long *__
   const long long r = s < 0 ? 0 : (s > L - 1 ? L - 1 : s);
   const unsigned char m = mask_table[r * L + l];
   const long long idx = index_table[s * L + l];
+  if (latch && l == 0) {
+    latch[w] = s;
+    latch[W + w] = step[W + w];     // the slot row follows the step row in the uploaded [2, W] block
+  }
   mask_t[i] = m;
   win_t[i] = idx;
   st_mask[t * stage_W * L + i] = m;      // staging rows are stage_W workers wide; the caller's pointers are at this group's first worker
@@ -79,10 +88,8 @@ __global__ __launch_bounds__(1024) void rollout_sample_kernel(const float *__res
     float se = 0.f;
     for (int j = 0; j < A; ++j) se += expf(lg[j] - mx);
     const float lse = mx + logf(se);
-    int a;
-    if (forced) {
-      a = (int)forced[w];
-    } else {
+    int a = forced ? (int)forced[t * W + w] : -1;      // forced: time-major table [S, W]; a negative entry means "sample"
+    if (a < 0) {
       const float u = uniforms[t * W + w];
       float c = 0.f;
       a = A - 1;
@@ -139,10 +146,8 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
     float se = 0.f;
     for (int j = 0; j < A; ++j) se += expf(lg[j] - mx);
     const float lse = mx + logf(se);
-    int a;
-    if (forced) {
-      a = (int)forced[w];
-    } else {
+    int a = forced ? (int)forced[t * stage_W + w] : -1;   // forced: time-major table [S, stage_W]; negative = "sample"
+    if (a < 0) {
       const float u = uniforms[t * stage_W + w];
       float c = 0.f;
       a = A - 1;
@@ -212,8 +217,9 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 }  // namespace
 
 extern "C" int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
-                                  uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int64_t *t_row, float *reset_dst,
-                                  const float *reset_init, int64_t reset_row_elems, int W, int L, int stage_W, void *stream) {
+                                  uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx, int64_t *t_row, int64_t *latch,
+                                  float *reset_dst, const float *reset_init, int64_t reset_row_elems, int W, int L, int stage_W,
+                                  void *stream) {
   (void)hipGetLastError();
   if (!step || !mask_table || !index_table || !t_dev || !mask_t || !win_t || !st_mask || !st_idx || W <= 0 || L <= 0 || stage_W < W)
     return ETM_EINVAL;
@@ -225,14 +231,14 @@ extern "C" int etm_rollout_window(const int64_t *step, const uint8_t *mask_table
   const int nbr = reset_dst ? W * RESET_CHUNKS : 0;
   hipLaunchKernelGGL(rollout_window_kernel, dim3((unsigned)(nbw + nbr)), dim3(256), 0, st, (const long long *)step, mask_table,
                      (const long long *)index_table, (const long long *)t_dev, mask_t, (long long *)win_t, st_mask, (long long *)st_idx,
-                     (long long *)t_row, reset_dst, reset_init, (long long)reset_row_elems, nbw, W, L, stage_W);
+                     (long long *)t_row, (long long *)latch, reset_dst, reset_init, (long long)reset_row_elems, nbw, W, L, stage_W);
   return etm_launch_status();
 }
 
 extern "C" int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
                                   int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream) {
   (void)hipGetLastError();
-  if (!logits || !value || (!uniforms && !forced) || !t_dev || !actions || !st_actions || !st_logp || !st_values || W <= 0 || A <= 0)
+  if (!logits || !value || !uniforms || !t_dev || !actions || !st_actions || !st_logp || !st_values || W <= 0 || A <= 0)
     return ETM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_ROLLOUT_SAMPLE, st);
@@ -246,7 +252,7 @@ extern "C" int etm_rollout_policy(const float *h, const float *h_bias, const flo
                                   float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                                   int W, int A, int hid, int stage_W, void *stream) {
   (void)hipGetLastError();
-  if (!h || !wp || !bp || !wv || !bv || (!uniforms && !forced) || !t_dev || !actions || !st_actions || !st_logp || !st_values ||
+  if (!h || !wp || !bp || !wv || !bv || !uniforms || !t_dev || !actions || !st_actions || !st_logp || !st_values ||
       !sync_counter || W <= 0 || A <= 0 || hid <= 0 || stage_W < W)
     return ETM_EINVAL;
   if (host_flag && !host_actions) return ETM_EINVAL;

@@ -16,7 +16,15 @@
 // order differs from the reference (tolerances in tests/test_gpu_parity.py).
 //
 // One workgroup per sample.  Every wave owns RW window rows and keeps them in registers between the two passes (a row is
-// spread over the 64 lanes, float2 per lane per 128 columns), so the window is read from memory exactly once.
+// spread over the 64 lanes, float2 per lane per 128 columns), so the window is read from memory exactly once.  Next to the
+// rows only ONE head is live at a time: the H folded vectors are staged once per workgroup in LDS, the partial sums of a
+// pass are reduced in pairs (4 live sums instead of RW x H), the cross-row reduction steps are gfx950 permlane swaps --
+// 74 VGPRs at (NJ, RW) = (3, 8): three 8-wave workgroups per CU; 125 at (3, 16): two.  (Round 1 shipped a form with all heads
+// in registers -- 106 / 186 VGPRs, two / one workgroups per CU -- that was 12 % slower at L = 64 and 30 % slower at L = 128;
+// results are bit-identical, the summation trees are the same.)
+// Workgroup b handles sample (b % 8) * ceil(N / 8) + b / 8: workgroups are dealt round-robin to the 8 XCDs, so every XCD
+// (each has its own L2) gets a CONTIGUOUS chunk of the samples; with a minibatch sorted by (worker, step) neighbouring
+// samples share most of their window rows and the re-reads become hits of that XCD's L2.
 #include "etm_common.h"
 
 #include <math.h>
@@ -40,9 +48,7 @@ struct WinParams {
   long long vec_hs, vec_ns, out_hs, out_ns;
   int N, L, D, H, bwd;
   float sqrt_d;
-#if defined(ETM_DIAG_WIN_V2)
-  int xcd_chunk;         // > 0: workgroup b handles sample (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk), see launch_pass3
-#endif
+  int xcd_chunk;         // workgroup b handles sample (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk), see launch_pass3
 };
 
 // Value of `v` in lane (lane ^ OFF).  xor 1 / 2 / 8 are single DPP controls (quad_perm, row_ror:8), xor 4 is a row_shl:4
@@ -63,7 +69,7 @@ __device__ __forceinline__ float lane_xor(float v) {
 // Sums NV per-lane values across the 64 lanes of a wave with NV + log-many exchanges instead of 6 NV: at every step half of
 // the values travel to the partner lane.  Offsets ascend (1, 2, 4, ...) so that the steps with many exchanges are the DPP
 // ones.  On return v[0] of lane l holds the total of value  bit_reverse(l mod NV)  (over log2 NV bits).
-// SWAP (gfx950 v_permlane16_swap / v_permlane32_swap, used by the V2 code path): the cross-row steps need neither the LDS
+// SWAP (gfx950 v_permlane16_swap / v_permlane32_swap): the cross-row steps need neither the LDS
 // crossbar nor the send / keep selects -- swapping a = v[k], b = v[k + HALF] between the partner rows leaves (own, partner's)
 // copies of the value this lane keeps in (a, b) or (b, a), so the step is swap + add (same operands as the select form).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -115,25 +121,7 @@ __device__ __forceinline__ long long readlane64(long long v, int l) {
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
-#if defined(ETM_DIAG_WIN_HG)         // diagnostic builds only (tools/diag_variants.sh occ): register pressure experiments
-constexpr int HG = ETM_DIAG_WIN_HG;
-#else
-constexpr int HG = 4;  // heads handled per pass over the register-resident rows
-#endif
-// ETM_DIAG_WIN_V2 (diagnostic builds only until measured, tools/diag_variants.sh occ): one head at a time in registers -- the
-// vec rows come from LDS (loaded once per workgroup instead of once per wave) and the passes keep NJ + RW instead of
-// HG (NJ + RW) live values next to the rows: <= 80 VGPRs at (NJ, RW) = (3, 8), i.e. three workgroups per CU instead of two,
-// <= 128 at (3, 16).  Same summation trees as the default code path (bit-identical results).
-#if defined(ETM_DIAG_WIN_V2)
-constexpr bool V2 = true;
-#else
-constexpr bool V2 = false;
-#endif
-#if defined(ETM_DIAG_WIN_WAVES_PER_EU)
-#define ETM_WIN_OCC __attribute__((amdgpu_waves_per_eu(ETM_DIAG_WIN_WAVES_PER_EU, ETM_DIAG_WIN_WAVES_PER_EU)))
-#else
-#define ETM_WIN_OCC
-#endif
+constexpr int HG = 4;  // heads staged in LDS per chunk (one at a time in registers)
 
 #if defined(ETM_DIAG_TRACE)
 constexpr int WIN_TRACE_WGS = 2048, WIN_TRACE_SLOTS = 16;
@@ -144,21 +132,15 @@ __device__ unsigned long long g_win_trace[WIN_TRACE_WGS * 8 * WIN_TRACE_SLOTS];
 #endif
 
 template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS, bool FULLD>
-__global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const WinParams p) {
+__global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int LP = NW * RW;     // padded window length
   constexpr int DP = NJ * 128;    // padded feature width
-  constexpr int NV = RW * HG;
-#if defined(ETM_DIAG_WIN_V2)
-  // Workgroup b is observed to run on XCD b % 8 (each XCD has its own L2).  With a minibatch sorted by bank address,
-  // neighbouring samples share most of their window rows: giving every XCD a CONTIGUOUS chunk of the samples turns those
-  // re-reads into hits of that XCD's L2.  Placement is a speed matter only; every sample is handled exactly once either way.
-  const int n = p.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // Workgroup b is observed to run on XCD b % 8 (each XCD has its own L2): every XCD gets a contiguous chunk of the samples.
+  // Placement is a speed matter only; every sample is handled exactly once either way.
+  const int n = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
   if (n >= p.N) return;          // whole workgroup, before any barrier
   const int tid = threadIdx.x, lane = tid & 63;
-#else
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L, D = p.D, H = p.H;
 #if defined(ETM_DIAG_TRACE)
@@ -189,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
     }
   }
 
-  // V2: this thread's share of vec[h0 .. h0 + HG) (f32x2 granules of the [HG][DP] staging block in LDS, which aliases the
+  // this thread's share of vec[h0 .. h0 + HG) (f32x2 granules of the [HG][DP] staging block in LDS, which aliases the
   // start of zs: zs is not written before pass 2).  The loads of the first chunk are issued before the row loads.
   constexpr int UI = (HG * NJ + NW - 1) / NW;
   f32x2 ustage[UI];
@@ -210,12 +192,12 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
       if (idx < HG * NJ * 64) *reinterpret_cast<f32x2 *>(&zs[2 * idx]) = ustage[k];
     }
   };
-  if constexpr (V2) load_vec(0, tid);
-  // V2: what the softmax phase reads from memory (the sample's mask bytes; backward: the saved attention of this wave's first
+  load_vec(0, tid);
+  // what the softmax phase reads from memory (the sample's mask bytes; backward: the saved attention of this wave's first
   // head) is requested here, together with the row bookkeeping, instead of as exposed round trips between the two passes
   unsigned mask_pre = 0;
   float att_pre[2] = {0.f, 0.f};
-  if constexpr (V2) {
+  {
     unsigned char mb[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -258,9 +240,9 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WIN_T(2)   // row bookkeeping arrived
 #endif
-  // V2: the vec rows of the first chunk arrived with the row bookkeeping (same round trip); they go to LDS before the row
+  // the vec rows of the first chunk arrived with the row bookkeeping (same round trip); they go to LDS before the row
   // loads are issued, so the barrier in front of pass 1 is reached while the rows are still in flight
-  if constexpr (V2) store_vec();
+  store_vec();
 #pragma unroll
   for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
 #if defined(ETM_DIAG_TRACE)
@@ -280,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
   }
 #endif
   // ---- pass 1: logits[h][l] = x[l] . vec[h]
-  if constexpr (V2) {
+  {
     for (int h0 = 0; h0 < H; h0 += HG) {
       if (h0 > 0) {
         __syncthreads();          // every wave is done with the previous chunk's vec rows
@@ -324,42 +306,16 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
         }
       }
     }
-  } else
-  for (int h0 = 0; h0 < H; h0 += HG) {
-    f32x2 uv[HG][NJ];
-#pragma unroll
-    for (int hh = 0; hh < HG; ++hh)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int hc = h0 + hh < H ? h0 + hh : H - 1;   // heads past H: a valid address, result never stored
-        const f32x2 t = *reinterpret_cast<const f32x2 *>(p.vec + (long long)hc * p.vec_hs + (long long)n * p.vec_ns + cc[j]);
-        uv[hh][j] = cv[j] ? t : f32x2{0.f, 0.f};
-      }
-    float ev[NV];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-#pragma unroll
-      for (int hh = 0; hh < HG; ++hh) {
-        f32x2 s = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) s += x[i][j] * uv[hh][j];
-        ev[i * HG + hh] = s[0] + s[1];
-      }
-    }
-    TransposeReduce<NV, 1>::run(ev, lane);
-    constexpr int LG = ilog2(NV);
-    const int vi = (int)(__brev((unsigned)(lane & (NV - 1))) >> (32 - LG)), i_ = vi / HG, hh_ = vi - i_ * HG;
-    if (lane < NV && h0 + hh_ < H) a_s[(h0 + hh_) * LP + wave * RW + i_] = ev[0];
   }
   WIN_T(4)   // pass 1 + reduction done
   __syncthreads();
   WIN_T(5)
 
   // ---- per head: masked softmax (forward) or its backward (one wave per head; LP <= 128 = 2 values per lane)
-  // V2: later phases see sample index / lane through opaque copies -- their (loop-invariant, 64-bit) address arithmetic would
+  // later phases see sample index / lane through opaque copies -- their (loop-invariant, 64-bit) address arithmetic would
   // otherwise be hoisted above pass 1 and stay live next to the rows.
   int n_l = n, lane_l = lane, tid_l = tid;
-  if constexpr (V2) {
+  {
     asm volatile("" : "+s"(n_l));
     asm volatile("" : "+v"(lane_l));
     asm volatile("" : "+v"(tid_l));
@@ -371,8 +327,7 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
     for (int jj = 0; jj < 2; ++jj) {
       const int l = lane_l + 64 * jj;
       t[jj] = (l < L) ? a_s[h * LP + l] : 0.f;
-      if constexpr (V2) keep[jj] = (l < L) && ((mask_pre >> jj) & 1u) != 0;
-      else keep[jj] = (l < L) && p.mask[(long long)n_l * L + l] != 0;
+      keep[jj] = (l < L) && ((mask_pre >> jj) & 1u) != 0;
     }
     if (!p.bwd) {
       float ev2[2];
@@ -403,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int l = lane_l + 64 * jj;
-        if (V2 && h == wave) a[jj] = (l < L) ? att_pre[jj] : 0.f;
+        if (h == wave) a[jj] = (l < L) ? att_pre[jj] : 0.f;
         else a[jj] = (l < L) ? p.att_in[((long long)n_l * H + h) * L + l] : 0.f;
         dot += a[jj] * t[jj];
       }
@@ -425,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
 
   // ---- pass 2: out[h][:] = sum_l w[h][l] x[l][:]   (w = attention or dE)
   for (int h0 = 0; h0 < H; h0 += HG) {
-    if constexpr (V2) {
+    {
 #pragma unroll 1
       for (int hh = 0; hh < HG; ++hh) {
         if (h0 + hh >= H) break;
@@ -441,26 +396,6 @@ __global__ __launch_bounds__(NW * 64) ETM_WIN_OCC void window_pass_kernel(const 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zq[j];
       }
-    } else {
-    f32x2 zp[HG][NJ];
-#pragma unroll
-    for (int hh = 0; hh < HG; ++hh)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) zp[hh][j] = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-#pragma unroll
-      for (int hh = 0; hh < HG; ++hh) {
-        const int hc = h0 + hh < H ? h0 + hh : H - 1;
-        const float w = a_s[hc * LP + wave * RW + i];   // same address for the whole wave: LDS broadcast
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) zp[hh][j] += w * x[i][j];
-      }
-    }
-#pragma unroll
-    for (int hh = 0; hh < HG; ++hh)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zp[hh][j];
     }
     WIN_T(8)   // pass 2 done
     __syncthreads();
@@ -488,14 +423,9 @@ int launch_pass3(const WinParams &p, hipStream_t st) {
   auto kern = window_pass_kernel<NJ, RW, NW, HAS_LN, HAS_POS, FULLD>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
-#if defined(ETM_DIAG_WIN_V2)
-  static const bool xcd_map = getenv("ETM_WIN_XCD_MAP") != nullptr && atoi(getenv("ETM_WIN_XCD_MAP")) != 0;
   WinParams q = p;
-  q.xcd_chunk = xcd_map ? (p.N + 7) / 8 : 0;
-  hipLaunchKernelGGL(kern, dim3(xcd_map ? 8 * q.xcd_chunk : p.N), dim3(NW * 64), lds, st, q);
-#else
-  hipLaunchKernelGGL(kern, dim3(p.N), dim3(NW * 64), lds, st, p);
-#endif
+  q.xcd_chunk = (p.N + 7) / 8;
+  hipLaunchKernelGGL(kern, dim3(8 * q.xcd_chunk), dim3(NW * 64), lds, st, q);
   return etm_launch_status();
 }
 
@@ -520,11 +450,7 @@ template <int NJ>
 int dispatch_rows(const WinParams &p, hipStream_t st) {
   if constexpr (NJ <= 4) {
     if (p.L <= 32) return launch_pass<NJ, 8, 4>(p, st);
-#if defined(ETM_DIAG_ROWS16)
-    if (p.L <= 64) return launch_pass<NJ, 16, 4>(p, st);
-#else
     if (p.L <= 64) return launch_pass<NJ, 8, 8>(p, st);
-#endif
     return launch_pass<NJ, 16, 8>(p, st);
   } else {
     if (p.L <= 32) return launch_pass<NJ, 8, 4>(p, st);

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 
@@ -29,13 +29,11 @@ SIGNATURES = {
                          _P, _L, _I, _I, _I, _I, _P]),
     "etm_attn_cached": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_reset_rows": (_I, [_P, _P, _P, _I, _L, _P]),
-    "etm_rollout_window": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "etm_rollout_window": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "etm_rollout_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_add_layernorm": (_I, [_P, _P, _I, _P, _P, _P, _F, _P, _I, _I, _P]),
     "etm_conv_relu": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_upload": (_I, [_P, _P, _L, _P]),
-    "etm_upload_record": (_I, [_P, _P, _L, _P, _P]),
-    "etm_step_launch": (_I, [_P, _P, _P, _P, _P]),
     "etm_comm_unique_id": (_I, [_P]),
     "etm_comm_init": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_void_p)]),
     "etm_allreduce_f32": (_I, [_P, _P, _P, _L, _P]),

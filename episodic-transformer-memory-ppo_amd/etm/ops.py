@@ -303,10 +303,12 @@ def reset_rows(dst, init, step):
     return dst
 
 
-def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx, t_row=None, reset=None, w_off=0):
+def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask, st_idx, t_row=None, reset=None, w_off=0,
+                   latch=None):
     """Window-table lookup of one rollout step + staging (all outputs preallocated, in place).  Optional riders of the same
     launch: ``t_row`` (int64 scalar tensor) receives the staging row t, ``reset = (cache [W, ...], init [...])`` performs
-    ``reset_rows(cache, init, step)``.  Worker groups: ``mask_t`` / ``win_t`` / ``step`` (and the cache) cover the W workers of
+    ``reset_rows(cache, init, step)``, ``latch = (ss [2, W], copy [2, W])`` copies the uploaded (episode step, slot) block --
+    ``step`` must be ``ss[0]`` -- into the buffer the tail of the step indexes.  Worker groups: ``mask_t`` / ``win_t`` / ``step`` (and the cache) cover the W workers of
     the group, the staging arrays ``st_mask`` / ``st_idx`` [S, W_total, L] all of them; ``w_off`` is the group's first worker."""
     lib = _lib.load()
     W, L = win_t.shape
@@ -318,14 +320,21 @@ def rollout_window(step, mask_table, index_table, t_dev, mask_t, win_t, st_mask,
         if not rdst.is_contiguous() or not rinit.is_contiguous() or rdst.shape[0] != W:
             raise TypeError("reset needs a contiguous cache [W, ...] and a contiguous initial row")
         relems = rinit.numel()
+    lat = None
+    if latch is not None:
+        ss, lat = latch
+        if (ss.shape != (2, W) or lat.shape != (2, W) or not ss.is_contiguous() or not lat.is_contiguous()
+                or ss.dtype != torch.int64 or lat.dtype != torch.int64 or step.data_ptr() != ss.data_ptr()):
+            raise TypeError("latch needs contiguous int64 [2, W] blocks and step = ss[0]")
     _lib.check(lib.etm_rollout_window(_ptr(step), _ptr(mask_table), _ptr(index_table), _ptr(t_dev), _ptr(mask_t), _ptr(win_t),
                                       st_mask.data_ptr() + w_off * L * st_mask.element_size(),
-                                      st_idx.data_ptr() + w_off * L * st_idx.element_size(), _ptr(t_row), _ptr(rdst), _ptr(rinit),
+                                      st_idx.data_ptr() + w_off * L * st_idx.element_size(), _ptr(t_row), _ptr(lat), _ptr(rdst), _ptr(rinit),
                                       relems, W, L, stage_w, _stream()), "etm_rollout_window")
 
 
 def rollout_sample(logits, value, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values):
-    """Categorical sampling + staging of one rollout step for a single-branch policy (in place; increments t_dev)."""
+    """Categorical sampling + staging of one rollout step for a single-branch policy (in place; increments t_dev).
+    ``forced`` (optional): time-major int64 table [S, W]; entries >= 0 replace the sample of that (step, worker)."""
     lib = _lib.load()
     W, A = logits.shape
     logits, value = _f32c(logits, "logits"), _f32c(value, "value")
@@ -339,7 +348,8 @@ _policy_sync = {}
 def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp, st_values,
                    host_actions=None, host_flag=None, h_bias=None, w_off=0):
     """``rollout_heads`` + ``rollout_sample`` in one launch (single-branch policy); ``host_actions`` / ``host_flag``: pinned
-    int64 tensors that receive the actions and then the incremented step counter (the host spins on the flag)."""
+    int64 tensors that receive the actions and then the incremented step counter (the host spins on the flag).  ``forced``
+    (optional): time-major int64 table [S, W_total]; entries >= 0 replace the sample of that (step, worker)."""
     lib = _lib.load()
     W, A = h2.shape[0], policy_head.weight.shape[0]
     hid = h2.shape[1] // 2
@@ -354,7 +364,7 @@ def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions
     stage_w = st_values.shape[1]
     off = lambda t: None if t is None else t.data_ptr() + w_off * t.element_size()
     _lib.check(lib.etm_rollout_policy(_ptr(h2), _ptr(h_bias), _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight),
-                                      _ptr(value_head.bias), off(uniforms), _ptr(forced), _ptr(t_dev), _ptr(actions), off(st_actions),
+                                      _ptr(value_head.bias), off(uniforms), off(forced), _ptr(t_dev), _ptr(actions), off(st_actions),
                                       off(st_logp), off(st_values), ha, hf, _ptr(sync), W, A, hid, stage_w, _stream()),
                "etm_rollout_policy")
 

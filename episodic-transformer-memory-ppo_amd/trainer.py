@@ -119,7 +119,7 @@ class PPOTrainer:
         # BLAS scratch buffer between them (split-K solutions at a handful of rows per GEMM); the graphs are captured per
         # group stream now (_capture_step_graph), the threshold stays until that has been re-measured.
         n_groups = int(config.get("rollout_groups", 2))
-        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < 8:
+        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < int(config.get("rollout_min_group_size", 8)):
             n_groups = 1
         self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers
@@ -210,6 +210,9 @@ class PPOTrainer:
         self._win_t = torch.zeros((W, L), dtype=torch.int64, device=device)
         self._act_dev = torch.zeros((W, B), dtype=torch.int64, device=device)
         self._uniforms = torch.zeros((S, W), dtype=torch.float32, device=device)
+        # teacher forcing (parity tests): a non-negative entry replaces the sampled action of that (step, worker); the table has
+        # a fixed address, so the captured step graphs read it too -- every rollout path can be driven with recorded actions
+        self._forced_tab = torch.full((S, W), -1, dtype=torch.int64, device=device)
         self._step_graph = None
         self._act_ready = torch.cuda.Event()
         # observation streaming (graph rollout with the fused encoder): rows of the next observation go from pinned memory
@@ -313,6 +316,11 @@ class PPOTrainer:
         g.ss_np = g.ss_pin.numpy()
         g.flag_np = g.flag_pin.numpy()
         g.step_dev, g.slot_dev = g.ss_dev[0], g.ss_dev[1]
+        # (episode step, slot) as LATCHED by the head of a step for its tail: the host uploads the next step's block on the
+        # upload stream while the tail (bank / cache writes under env.step) may still be running, and only the group's own
+        # stream orders tail t before head t + 1 -- so the tail must not read the uploaded block itself
+        g.ss_latch = torch.zeros((2, Wg), dtype=torch.int64, device=dev)
+        g.step_l, g.slot_l = g.ss_latch[0], g.ss_latch[1]
         return g
 
     def _sample_training_data(self, forced_actions=None) -> list:
@@ -327,10 +335,12 @@ class PPOTrainer:
         (``stream_observations``), together with the workers' (episode step, slot) vector; the actions arrive in pinned host
         memory straight from the sampling kernel.
         ``forced_actions`` [W, S] (optional) replays recorded actions instead of sampling (teacher forcing for parity
-        tests -- CPU and GPU RNG streams differ); it always uses the eager path."""
+        tests -- CPU and GPU RNG streams differ) on whichever path the config selects: the sampling
+        kernels read them from a fixed-address table, so the captured graphs, the observation streaming and the worker-group
+        pipeline run exactly as they do when sampling."""
         buf, W, S = self.buffer, self.num_workers, self.config["worker_steps"]
         main = torch.cuda.current_stream(self.device)
-        use_graph = forced_actions is None and self.config.get("hip_graph_rollout", True)
+        use_graph = bool(self.config.get("hip_graph_rollout", True))
         episode_infos = []
         buf.begin_rollout(self._slot_dev)
         self.worker_episode_slot[:] = np.arange(W)
@@ -338,9 +348,9 @@ class PPOTrainer:
         if self._use_kv_cache:
             self._refresh_kv_cache()
         self.model.refresh_rollout_weights()       # encoder weight copies for the fused rollout convolutions
-        forced = None
         if forced_actions is not None:
-            forced = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).to(self.device)
+            fa = torch.as_tensor(np.asarray(forced_actions), dtype=torch.int64).reshape(W, S)
+            self._forced_tab.copy_(fa.t().to(self.device))
         groups = self._groups if use_graph else [self._group_all]
         if use_graph and groups[0].graphs is None:
             self._capture_step_graph(groups)
@@ -361,41 +371,16 @@ class PPOTrainer:
         if stream_obs:
             self._up_stream.wait_stream(main)      # the staging array may still be read by the previous update
 
-        # native_step_launch (default off until measured): the per-step runtime calls of a group go through two entry points of
-        # the library (etm_upload_record, etm_step_launch) instead of ~7 framework calls (stream switch, event wait / record,
-        # two graph replays); same calls, same order, same streams
-        native = use_graph and bool(self.config.get("native_step_launch", False))
-        if native:
-            for g in groups:
-                if getattr(g, "raw", None) is None:
-                    st_g = g.stream if g.stream is not None else main
-                    g.up_done.record(self._up_stream)          # torch creates its events lazily: make the handles exist
-                    g.act_ready.record(st_g)
-                    g.raw = (st_g.cuda_stream, g.up_done.cuda_event, g.graphs[0].raw_cuda_graph_exec(), g.act_ready.cuda_event,
-                             g.graphs[1].raw_cuda_graph_exec(), g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8)
-
         def upload_state(g):
             """(episode step, slot) of the group's workers -> device, after the host bookkeeping of the step."""
             if not g.full:
                 g.ss_np[:] = ss_global[:, g.lo:g.hi]
-            if native:
-                rc = lib.etm_upload_record(g.raw[5], g.raw[6], g.raw[7], up, g.raw[1])
-                if rc:
-                    etm_lib.check(rc, "etm_upload_record")
-                return
             lib.etm_upload(g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8, up)
             g.up_done.record(self._up_stream)
 
         def launch(g, t):
             """Device work of step t of group g (graph mode: two replays on the group's stream)."""
-            if native:
-                if not stream_obs and not g.full:
-                    g.ss_np[:] = ss_global[:, g.lo:g.hi]
-                r = g.raw
-                rc = lib.etm_step_launch(r[0], r[1] if stream_obs else None, r[2], None if host_flag else r[3], r[4])
-                if rc:
-                    etm_lib.check(rc, "etm_step_launch")
-            elif use_graph:
+            if use_graph:
                 if g.stream is not None:
                     torch.cuda.set_stream(g.stream)
                 cur = g.stream if g.stream is not None else main
@@ -411,7 +396,7 @@ class PPOTrainer:
                     torch.cuda.set_stream(main)
             else:
                 with torch.no_grad():
-                    carry = self._rollout_step_head(g, forced[:, t].contiguous() if forced is not None else None)
+                    carry = self._rollout_step_head(g)
                     g.act_ready.record(main)
                     self._rollout_step_tail(g, carry)
 
@@ -468,6 +453,8 @@ class PPOTrainer:
                     t_launch += time.perf_counter() - tl
         for st_ in side_streams:
             main.wait_stream(st_)
+        if forced_actions is not None:
+            self._forced_tab.fill_(-1)
         # time-major staging -> the buffer's [W, S, ...] fields (one strided copy per field)
         self._step_dev.copy_(self._step_pin, non_blocking=True)
         self._slot_dev.copy_(self._slot_pin, non_blocking=True)
@@ -478,12 +465,12 @@ class PPOTrainer:
         self.last_update_timing.update(env_s=t_env, wait_s=t_wait, launch_s=t_launch)
         return episode_infos
 
-    def _rollout_step_device(self, g, forced_t=None, stream_obs=False, host_flag=False):
+    def _rollout_step_device(self, g, stream_obs=False, host_flag=False):
         """Device side of one rollout step of group ``g`` (upstream trainer.py:161-186) = head + tail."""
-        carry = self._rollout_step_head(g, forced_t, stream_obs, host_flag)
+        carry = self._rollout_step_head(g, stream_obs, host_flag)
         self._rollout_step_tail(g, carry, stream_obs)
 
-    def _rollout_step_head(self, g, forced_t=None, stream_obs=False, host_flag=False):
+    def _rollout_step_head(self, g, stream_obs=False, host_flag=False):
         """Everything the ACTIONS of group ``g`` depend on: (observation / step / slot upload,) window lookup, model forward,
         sampling, staging of the step's rows, action hand-over.  Every operand has a fixed address (HIP-graph capturable).
         Returns what the tail needs (the new memory items, block-major)."""
@@ -503,7 +490,8 @@ class PPOTrainer:
         # empty memory)
         ops.rollout_window(g.step_dev, self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
                            st["memory_mask"], st["memory_indices"], t_row=g.t_row,
-                           reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo)
+                           reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo,
+                           latch=(g.ss_dev, g.ss_latch))
         fused_policy = False
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(g.kv, None, win_t, None, mask_t)
@@ -513,8 +501,8 @@ class PPOTrainer:
                 # host_flag_actions, the flag) says the launch is done
                 h2, item = self.model.forward_hidden_cached(obs, kv_spec, items_out=g.item, obs_index=obs_index, raw=True,
                                                             obs_rows=rows)
-                flag = host_flag and forced_t is None
-                ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, forced_t, g.t_dev,
+                flag = host_flag
+                ops.rollout_policy(h2, self.model.policy_branches[0], self.model.value, self._uniforms, self._forced_tab, g.t_dev,
                                    g.act_dev, st["actions"], st["log_probs"], st["values"],
                                    host_actions=g.act_pin, host_flag=g.flag_pin if flag else None,
                                    h_bias=self.model._b_heads, w_off=g.lo)
@@ -533,15 +521,17 @@ class PPOTrainer:
                 raise RuntimeError("worker groups need the fused policy path (single-branch policy, K/V cache)")
             if single:
                 # log-softmax + categorical sample (inverse CDF on pre-drawn uniforms) + log-prob + staging + t += 1: one launch
-                ops.rollout_sample(logits[0], value, self._uniforms, forced_t, g.t_dev, g.act_dev,
+                ops.rollout_sample(logits[0], value, self._uniforms, self._forced_tab, g.t_dev, g.act_dev,
                                    st["actions"], st["log_probs"], st["values"])
                 g.act_pin.copy_(g.act_dev, non_blocking=True)
             else:
                 row = g.t_row.view(1)
                 acts, logps = [], []
+                forced_t = self._forced_tab.index_select(0, row)[0]       # one recorded action per worker, shared by the branches
                 for lg in logits:
                     lsm = torch.log_softmax(lg, dim=-1)
-                    a = forced_t if forced_t is not None else torch.multinomial(lsm.exp(), 1).squeeze(1)
+                    a = torch.multinomial(lsm.exp(), 1).squeeze(1)
+                    a = torch.where(forced_t >= 0, forced_t, a)
                     acts.append(a)
                     logps.append(lsm.gather(1, a.unsqueeze(1)).squeeze(1))
                 g.act_dev.copy_(torch.stack(acts, dim=1))
@@ -559,12 +549,12 @@ class PPOTrainer:
         K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
         buf, st = self.buffer, self._stage
         item = item.transpose(0, 1)                  # block-major staging -> [Wg, blocks, D]
-        buf.bank[g.slot_dev, g.step_dev] = item
+        buf.bank[g.slot_l, g.step_l] = item           # (step, slot) as latched by this step's head, see _make_group
         if self._use_kv_cache:
             tr = self.model.transformer
             pos = tr._pos()
-            pos_rows = pos.index_select(0, g.step_dev) if pos is not None else None
-            g.kv[g.ids, g.step_dev] = tr.project_memory(item, pos_rows, self._kv_weights)
+            pos_rows = pos.index_select(0, g.step_l) if pos is not None else None
+            g.kv[g.ids, g.step_l] = tr.project_memory(item, pos_rows, self._kv_weights)
         if not stream_obs:
             st["obs"][:, g.lo:g.hi].index_copy_(0, g.t_row.view(1), g.obs_dev.unsqueeze(0))
 
@@ -601,6 +591,15 @@ class PPOTrainer:
         if len(groups) > 1 and not fusable:
             raise RuntimeError("rollout_groups > 1 needs a single-branch policy and the K/V cache (set rollout_groups: 1)")
         so, hf = self._stream_obs, self._host_flag
+        # the warm-up executions below write the CURRENT step's memory item (and its K/V projection) into the bank / cache rows
+        # (slot, step) of every worker.  A worker at episode step 0 attends over a fully masked window -- uniform weights over
+        # ALL L rows, row 0 included (upstream quirk, transformer.py:66-68 with an all-zero mask row) -- so a row 0 left behind by
+        # the warm-up would leak into the real step 0.  Keep the rows as they were.
+        with torch.no_grad():
+            ss = torch.from_numpy(self._ss_pin.numpy().copy()).to(self.device)
+            all_ids = torch.arange(self.num_workers, device=self.device)
+            saved_bank = self.buffer.bank[ss[1], ss[0]].clone()
+            saved_kv = self._kv_cache[all_ids, ss[0]].clone()
         for g in groups:
             g.t_dev.zero_()
             # warm-up and capture run on the stream the group's graphs are replayed on: the BLAS workspace of the library
@@ -610,18 +609,22 @@ class PPOTrainer:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(3):
-                    self._rollout_step_device(g, None, so, hf)
+                    self._rollout_step_device(g, so, hf)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             pool = torch.cuda.graph_pool_handle()
             head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             # thread_local: only this thread's calls are checked during capture (RCCL's watchdog thread may query events)
             with torch.no_grad(), torch.cuda.graph(head, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
-                self._rollout_step_head(g, None, so, hf)
+                self._rollout_step_head(g, so, hf)
             with torch.no_grad(), torch.cuda.graph(tail, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
                 self._rollout_step_tail(g, g.item, so)
             g.graphs = (head, tail)
             g.t_dev.zero_()
+        with torch.no_grad():
+            torch.cuda.synchronize(self.device)
+            self.buffer.bank[ss[1], ss[0]] = saved_bank
+            self._kv_cache[all_ids, ss[0]] = saved_kv
         self.buffer.address_captured = True
         self._step_graph = groups[0].graphs
 
@@ -650,19 +653,20 @@ class PPOTrainer:
             self._bank_pos = self._bank_with_positions()
             self._obs_train = self._observations_channels_last()
         mbs = self.buffer.batch_size // self.buffer.n_mini_batches
-        # sort_minibatch (default off until measured): the samples of a minibatch in ascending flat (worker, step) order.  The
-        # minibatch is the same SET (every loss term is a mean over it; only summation order changes), but neighbouring samples
-        # then share most of their window rows, which a cache-aware sample -> workgroup mapping can turn into L2 hits.
-        sort_mb = bool(self.config.get("sort_minibatch", False))
+        # sort_minibatch (default on): the samples of a minibatch in ascending flat (worker, step) order.  The minibatch is the
+        # same SET (every loss term is a mean over it; only summation order changes), but neighbouring samples then share most of
+        # their window rows, which the window pass -- every XCD handles a contiguous chunk of the samples -- turns into L2 hits
+        # (measured at config 3: 37.9 -> 29.9 us per pass).  One sort per epoch covers all of its minibatches.
+        sort_mb = bool(self.config.get("sort_minibatch", True))
         for epoch in range(self.config["epochs"]):
             if perms is None:
                 perm = torch.randperm(self.buffer.batch_size, device=self.device)
             else:
                 perm = torch.as_tensor(perms[epoch], device=self.device, dtype=torch.long)
+            if sort_mb and perm.numel() % mbs == 0:
+                perm = perm.view(-1, mbs).sort(dim=1).values.reshape(-1)
             for start in range(0, self.buffer.batch_size, mbs):
                 idx = perm[start: start + mbs]
-                if sort_mb:
-                    idx = idx.sort().values
                 if self._use_train_graph and idx.numel() == mbs:
                     st_row, norm_row = self._train_step_graph(idx, learning_rate, clip_range, beta, monitor)
                     stats.append(st_row)

@@ -168,16 +168,22 @@ int etm_reset_rows(float *dst, const float *init, const int64_t *step, int W, in
  * workers as a software pipeline: one group's head graph runs while the host steps the other group's environments).
  *   etm_rollout_window: mask_t[w] = mask_table[clip(step[w], 0, L-1)], win_t[w] = index_table[step[w]] (trainer.py:165-166),
  *                       also stored to row *t_dev of st_mask / st_idx.  Optional riders of the same launch: *t_row = *t_dev
- *                       (t_row non-NULL) and etm_reset_rows(reset_dst, reset_init, step, W, reset_row_elems) (reset_dst non-NULL).
+ *                       (t_row non-NULL), etm_reset_rows(reset_dst, reset_init, step, W, reset_row_elems) (reset_dst non-NULL), and
+ *                       the (step, slot) LATCH (latch non-NULL): `step` is then row 0 of a contiguous [2, W] block whose row 1
+ *                       holds the workers' episode slots, and latch[2, W] receives a copy of the block.  The tail of the step
+ *                       (bank / cache writes, trainer.py:174) indexes the latch, so the host may upload the next step's block
+ *                       on another stream while the tail is still running.
  *   etm_rollout_sample: per worker log-softmax of logits [W,A], categorical sample by inverse CDF with the pre-drawn
- *                       uniform uniforms[*t_dev, w] (or forced[w] if non-NULL), log-prob; writes actions [W] and row *t_dev
+ *                       uniform uniforms[*t_dev, w], log-prob; writes actions [W] and row *t_dev
+ *                       (forced, optional: time-major int64 table like `uniforms`; a non-negative entry forced[*t_dev, w] is
+ *                       taken instead of sampling -- teacher forcing for parity tests -- a negative entry means "sample")
  *                       of st_actions / st_logp / st_values, then *t_dev += 1 (trainer.py:179-186).
  *   etm_add_layernorm:  out = LayerNorm(act(a + a_bias) + b) (residual + post-LN, transformer.py:145-149 / :166-170), forward only,
  *                       D <= 1024; a_bias [D] (or NULL) and relu fold the bias / ReLU of the linear layer that produced `a`.
  */
 int etm_rollout_window(const int64_t *step, const uint8_t *mask_table, const int64_t *index_table, const int64_t *t_dev,
                        uint8_t *mask_t, int64_t *win_t, uint8_t *st_mask, int64_t *st_idx,
-                       int64_t *t_row, float *reset_dst, const float *reset_init, int64_t reset_row_elems,
+                       int64_t *t_row, int64_t *latch, float *reset_dst, const float *reset_init, int64_t reset_row_elems,
                        int W, int L, int stage_W, void *stream);
 int etm_rollout_sample(const float *logits, const float *value, const float *uniforms, const int64_t *forced, int64_t *t_dev,
                        int64_t *actions, int64_t *st_actions, float *st_logp, float *st_values, int W, int A, void *stream);
@@ -199,7 +205,8 @@ int etm_rollout_heads(const float *h, const float *wp, const float *bp, const fl
  * hidden heads and relu(h + h_bias) is applied on the fly (the concatenated hidden-head GEMM then runs without an epilogue).  host_flag (optional, needs host_actions): after a
  * system-scope fence the new step counter (*t_dev after the increment) is stored to *host_flag, so the host can spin on
  * the flag instead of waiting for an event.  sync_counter: one device int32, zero before the first call (the workgroups of a
- * launch count themselves in; the last one advances *t_dev and resets the counter). */
+ * launch count themselves in; the last one advances *t_dev and resets the counter).  forced: as in etm_rollout_sample, a
+ * time-major table [S, stage_W] already offset to the group's first worker. */
 int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, const float *bp, const float *wv, const float *bv,
                        const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                        float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
@@ -220,14 +227,6 @@ int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_str
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
 int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
-
-/* Host-loop helpers of the sampling loop (trainer.py:161-218 of the reference has no counterpart: it issues framework calls).
- * etm_upload_record: etm_upload, then hipEventRecord(done_event, stream).
- * etm_step_launch:   one rollout step of one worker group on `stream`:
- *                    [hipStreamWaitEvent(wait_event)]  hipGraphLaunch(graph_head)  [hipEventRecord(record_event)]
- *                    [hipGraphLaunch(graph_tail)] -- graph_* are instantiated graphs (hipGraphExec_t), events may be NULL. */
-int etm_upload_record(void *dst, const void *src, int64_t bytes, void *stream, void *done_event);
-int etm_step_launch(void *stream, void *wait_event, void *graph_head, void *record_event, void *graph_tail);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).

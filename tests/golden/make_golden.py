@@ -376,6 +376,13 @@ def golden_rollout(only=None):
                              value_loss_coefficient=0.25, hidden_layer_size=32, max_grad_norm=0.5,
                              transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8,
                                               positional_encoding="relative", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))),
+        # the benchmarked rollout configuration (bench.py: 32 workers, visual observations => HIP-graph replay, observation
+        # streaming, two worker groups of 16) at a fixture-sized model: the GPU test drives exactly that path with these actions
+        "img32": dict(env=dict(obs_shape=(3, 36, 36), num_actions=3, max_episode_steps=12, seed=13, p_done=0.08, p_reward=0.3, pool=8),
+                      cfg=dict(gamma=0.99, lamda=0.95, updates=2, epochs=2, n_workers=32, worker_steps=24, n_mini_batch=2,
+                               value_loss_coefficient=0.25, hidden_layer_size=32, max_grad_norm=0.5,
+                               transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8,
+                                                positional_encoding="relative", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))),
     }
     sched = dict(initial=3e-4, final=1e-4, power=1.0, max_decay_steps=10)
     for name, case in cases.items():
@@ -422,7 +429,12 @@ def golden_rollout(only=None):
                         tag + "memory_index": b.memory_index.clone(), tag + "memory_indices": b.memory_indices.clone(),
                         tag + "ep_step_after": tr.worker_current_episode_step.clone()})
             b.prepare_batch_dict()
-            out[tag + "memories"] = b.memories.clone()
+            if b.memories.numel() > 100_000:   # many episodes: deterministic subsample + sum + episode count
+                out[tag + "memories_sample"] = dg.sample(b.memories.numpy(), 32768)
+                out[tag + "memories_sum"] = np.float64(b.memories.double().sum())
+                out[tag + "memories_shape"] = np.array(b.memories.shape, dtype=np.int64)
+            else:
+                out[tag + "memories"] = b.memories.clone()
             perms_all.clear()
             torch.randperm = rec_randperm
             try:

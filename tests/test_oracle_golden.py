@@ -208,7 +208,7 @@ def test_polynomial_decay(golden_dir):
 
 
 # ------------------------------------------------------------------ teacher-forced rollout + updates
-@pytest.mark.parametrize("name", ["vec", "gtrxl", "img"])
+@pytest.mark.parametrize("name", ["vec", "gtrxl", "img", "img32"])
 def test_teacher_forced_rollout_and_update(golden_dir, name):
     from environments.synthetic import SyntheticVecEnv
     z = load(golden_dir, f"rollout_{name}.npz")
@@ -236,7 +236,13 @@ def test_teacher_forced_rollout_and_update(golden_dir, name):
         close(buf["values"], z[tag + "values"], atol=2e-5)
         close(buf["log_probs"], z[tag + "log_probs"], atol=2e-5)
         close(buf["advantages"], z[tag + "advantages"], atol=1e-4)
-        close(buf["memories"], z[tag + "memories"], atol=2e-5)
+        if tag + "memories" in z:
+            close(buf["memories"], z[tag + "memories"], atol=2e-5)
+        else:      # many episodes: subsample + sum + shape
+            mem = np.asarray(buf["memories"])
+            assert tuple(mem.shape) == tuple(z[tag + "memories_shape"])
+            close(dg.sample(mem, 32768), z[tag + "memories_sample"], atol=2e-5)
+            assert abs(float(mem.astype(np.float64).sum()) - float(z[tag + "memories_sum"])) < 1e-3 * max(1.0, abs(float(z[tag + "memories_sum"])))
         close(stats, z[tag + "stats"], atol=2e-5, rtol=1e-3)
         lr, clip, beta = z[tag + "hp"]
         for k, v in tr.sd.items():

@@ -18,20 +18,12 @@ build() {  # name, flags...
   echo built $name
 }
 if [ "$1" = "window" ]; then
-  # v2: the lower-register form of the pass (three workgroups per CU at config 3, two at L = 128; see window_attn.hip)
-  for v in base loadonly trace v2 v2trace; do
+  for v in base loadonly trace; do
     fl=""; [ $v = loadonly ] && fl="-DETM_DIAG_LOAD_ONLY"; [ $v = trace ] && fl="-DETM_DIAG_TRACE"
-    [ $v = v2 ] && fl="-DETM_DIAG_WIN_V2"; [ $v = v2trace ] && fl="-DETM_DIAG_WIN_V2 -DETM_DIAG_TRACE"
     /opt/rocm/bin/hipcc $FLAGS $fl -c $SRC/window_attn.hip -o $OUT/win_$v.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/win_$v.o $(ls $SRC/build/*.o | grep -v window_attn.o) -o $OUT/libetm_win_$v.so
     rm -f $OUT/win_$v.o; echo built win_$v
   done
-  exit 0
-fi
-if [ "$1" = "gae" ]; then   # register-prefetch candidate of the GAE scan
-  /opt/rocm/bin/hipcc $FLAGS -DETM_DIAG_GAE_V2 -c $SRC/gae.hip -o $OUT/gae_v2.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/gae_v2.o $(ls $SRC/build/*.o | grep -v /gae.o) -o $OUT/libetm_gae_v2.so
-  rm -f $OUT/gae_v2.o; echo built gae_v2
   exit 0
 fi
 if [ "$1" = "prio" ]; then
