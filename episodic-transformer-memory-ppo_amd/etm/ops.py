@@ -33,13 +33,30 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_frozen = set()
+_retired = []
+
+
 def workspace(nbytes, device, tag="ws"):
+    """Scratch buffer of at least ``nbytes`` per (tag, device), grown on demand.  Once a HIP graph has captured a buffer's
+    address (``freeze_workspaces``) that buffer is never freed: a later, larger request gets a NEW buffer and the old one is
+    retired but kept alive, so replays of the captured graph keep writing to memory they own."""
     key = (tag, device.index)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and key in _frozen:
+            _retired.append(buf)
+            _frozen.discard(key)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
+
+
+def freeze_workspaces(device):
+    """Called by the trainer right after a graph capture: the scratch buffers that exist now are referenced by the graph."""
+    for key in _workspaces:
+        if key[1] == device.index:
+            _frozen.add(key)
 
 
 class WindowSpec:
@@ -413,6 +430,108 @@ def add_layernorm(a, b, norm, out=None, bias=None, relu=False):
     _lib.check(lib.etm_add_layernorm(_ptr(a), _ptr(bias), 1 if relu else 0, _ptr(b), _ptr(norm.weight), _ptr(norm.bias), float(norm.eps),
                                      _ptr(out), N, D, _stream()), "etm_add_layernorm")
     return out
+
+
+class _FusedLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(act(a + bias) + res) * gamma + beta with hand-written forward and backward (csrc/block_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, a, bias, res, gamma, beta, relu, eps):
+        lib = _lib.load()
+        _need_dev(a, bias, res, gamma, beta)
+        a, bias, res = _f32c(a, "a"), _f32c(bias, "bias"), _f32c(res, "res")
+        gamma, beta = _f32c(gamma, "gamma"), _f32c(beta, "beta")
+        N, D = a.shape
+        need = any(ctx.needs_input_grad[:5])
+        y = torch.empty_like(a)
+        s = torch.empty_like(a) if need else None
+        stats = torch.empty((N, 2), dtype=torch.float32, device=a.device) if need else None
+        _lib.check(lib.etm_ln_train_fwd(_ptr(a), _ptr(bias), 1 if relu else 0, _ptr(res), _ptr(gamma), _ptr(beta), float(eps), _ptr(y),
+                                        _ptr(s), _ptr(stats), N, D, _stream()), "etm_ln_train_fwd")
+        if need:
+            ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, res is not None
+            ctx.save_for_backward(s, stats, gamma, a if relu else None, bias if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        s, stats, gamma, a, bias = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        N, D = s.shape
+        ds = torch.empty_like(s)
+        da = torch.empty_like(s) if ctx.relu else None
+        sums = torch.empty((3, D), dtype=torch.float32, device=s.device)
+        nbytes = lib.etm_ln_train_bwd_workspace_bytes(N, D)
+        ws = workspace(nbytes, s.device, "ln_bwd")
+        _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0, _ptr(ds),
+                                        _ptr(da), _ptr(sums), _ptr(ws), nbytes, N, D, _stream()), "etm_ln_train_bwd")
+        d_a = da if ctx.relu else ds
+        return d_a, (sums[2] if ctx.has_bias else None), (ds if ctx.has_res else None), sums[0], sums[1], None, None
+
+
+def fused_layernorm(a, norm, bias=None, res=None, relu=False):
+    """``norm(act(a + bias) + res)`` (``norm``: an nn.LayerNorm over the last dimension of the [N, D] input) as one forward and
+    one backward kernel (+ a tiny fixed-order column-sum kernel): the bias / ReLU of the linear layer that produced ``a`` and the
+    residual add ride along, so that layer runs as a plain GEMM.  Training path (differentiable); the rollout uses
+    ``add_layernorm``."""
+    return _FusedLayerNormFn.apply(a, bias, res, norm.weight, norm.bias, relu, norm.eps)
+
+
+class _GruGateFn(torch.autograd.Function):
+    """GTrXL gate (transformer.py:287-298): out = (1 - z) x + z tanh(Wg y + Ug (r x)), r = sigmoid(Wr y + Ur x),
+    z = sigmoid(Wz y + Uz x - bg).  Three concatenated library GEMMs + two kernels forward; six GEMMs + two kernels (+ the
+    column-sum kernel for d bg) backward, instead of six small GEMMs + ~10 element-wise launches forward and twice that backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, wr, ur, wz, uz, wg, ug, bg):
+        lib = _lib.load()
+        _need_dev(x, y, wr, ur, wz, uz, wg, ug, bg)
+        x, y = _f32c(x, "x"), _f32c(y, "y")
+        N, D = x.shape
+        wy = torch.cat((wr, wz, wg), dim=0)            # [3D, D]
+        ux = torch.cat((ur, uz), dim=0)                # [2D, D]
+        A = torch.mm(y, wy.t())
+        B = torch.mm(x, ux.t())
+        r, z, rx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        _lib.check(lib.etm_gate_train_rz(_ptr(A), _ptr(B), _ptr(bg), _ptr(x), _ptr(r), _ptr(z), _ptr(rx), N, D, _stream()), "etm_gate_train_rz")
+        C = torch.mm(rx, ug.t())
+        hh, out = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(lib.etm_gate_train_out(_ptr(A), _ptr(C), _ptr(z), _ptr(x), _ptr(hh), _ptr(out), N, D, _stream()), "etm_gate_train_out")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, y, r, z, rx, hh, wy, ux, ug)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, y, r, z, rx, hh, wy, ux, ug = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        N, D = x.shape
+        dev = x.device
+        dA = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
+        dB = torch.empty((N, 2 * D), dtype=torch.float32, device=dev)
+        dx1, dbg = torch.empty_like(x), torch.empty((D,), dtype=torch.float32, device=dev)
+        nbytes = lib.etm_gate_train_bwd_workspace_bytes(N, D)
+        ws = workspace(nbytes, dev, "gate_bwd")
+        _lib.check(lib.etm_gate_train_bwd1(_ptr(dout), _ptr(z), _ptr(hh), _ptr(x), _ptr(dA), _ptr(dB), _ptr(dx1), _ptr(dbg), _ptr(ws), nbytes,
+                                           N, D, _stream()), "etm_gate_train_bwd1")
+        dC = dA[:, 2 * D:]                              # d pre_h, a strided view (row stride 3D): GEMM operand in place
+        drx = torch.mm(dC, ug)
+        dx2 = torch.empty_like(x)
+        _lib.check(lib.etm_gate_train_bwd2(_ptr(drx), _ptr(x), _ptr(r), _ptr(dx1), _ptr(dA), _ptr(dB), _ptr(dx2), N, D, _stream()),
+                   "etm_gate_train_bwd2")
+        dy = torch.mm(dA, wy)
+        dx = torch.addmm(dx2, dB, ux)
+        dwy = torch.mm(dA.t(), y)                       # [3D, D] = d [Wr; Wz; Wg]
+        dux = torch.mm(dB.t(), x)                       # [2D, D] = d [Ur; Uz]
+        dug = torch.mm(dC.t(), rx)
+        return dx, dy, dwy[:D], dux[:D], dwy[D:2 * D], dux[D:], dwy[2 * D:], dug, dbg
+
+
+def gru_gate_train(gate, x, y):
+    """Differentiable GTrXL gate of ``gate`` (a transformer.GRUGate) on [N, D] inputs."""
+    return _GruGateFn.apply(x, y, gate.Wr.weight, gate.Ur.weight, gate.Wz.weight, gate.Uz.weight, gate.Wg.weight, gate.Ug.weight, gate.bg)
 
 
 def conv_pack_weights(weight2d):

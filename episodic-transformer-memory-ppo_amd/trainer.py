@@ -25,13 +25,13 @@ from collections import deque
 
 import numpy as np
 import torch
-from torch import optim
 
 from buffer import Buffer
 from environments.vec_env import make_vec_env
 from etm import lib as etm_lib
 from etm import ops
 from etm.ops import WindowSpec
+from etm.optim import FlatAdamW
 from model import ActorCriticModel
 from utils import polynomial_decay, process_episode_info
 
@@ -158,23 +158,16 @@ class PPOTrainer:
         self._train_warm = 0
         self._obs_train = None
         if self._use_train_graph:
-            self._lr_dev = torch.tensor(float(self.lr_schedule["initial"]), dtype=torch.float32, device=device)
             self._dyn = torch.zeros(2, dtype=torch.float64, device=device)      # (clip range, entropy coefficient)
             self._sched_host = [None, None, None]   # (lr, clip, beta) currently on the device
             self.profile_sample_every = 0     # bench.py: run every k-th minibatch eagerly so that per-kernel events exist
             self._mb_counter = 0
-            self.optimizer = optim.AdamW(self.params, lr=self._lr_dev, fused=True, capturable=True)
-        else:
-            self.optimizer = optim.AdamW(self.params, lr=self.lr_schedule["initial"], fused=True)
-        # one flat gradient bucket aliased by every p.grad (the all-reduce message; also makes clipping 3 launches)
-        total = sum(p.numel() for p in self.params)
-        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=device)
-        off = 0
-        self._grad_views = []
-        for p in self.params:
-            p.grad = self.flat_grads[off: off + p.numel()].view_as(p)
-            self._grad_views.append(p.grad)
-            off += p.numel()
+        # AdamW (torch defaults, like upstream's optim.AdamW(parameters, lr)) + global-norm clipping on flat arenas: parameters,
+        # gradients and both moments share one layout, the step is two launches (etm/optim.py, csrc/optim.hip); lr and the step
+        # counter live on the device.  The gradient arena is the one bucket the data-parallel all-reduce sums.
+        self.optimizer = FlatAdamW(self.params, lr=self.lr_schedule["initial"])
+        self.flat_grads = self.optimizer.flat_grads[: self.optimizer.total]
+        self._grad_views = self.optimizer.grad_views
         if self.dp is not None:
             self.dp.flat = self.flat_grads
         self._build_grad_groups()
@@ -626,6 +619,7 @@ class PPOTrainer:
             self.buffer.bank[ss[1], ss[0]] = saved_bank
             self._kv_cache[all_ids, ss[0]] = saved_kv
         self.buffer.address_captured = True
+        ops.freeze_workspaces(self.device)
         self._step_graph = groups[0].graphs
 
     def get_last_value(self):
@@ -706,20 +700,12 @@ class PPOTrainer:
         loss.backward()
         if self.dp is not None:
             self.dp.all_reduce_grads()
-        # global-norm clipping, same rule as torch.nn.utils.clip_grad_norm_ (upstream :311), on the flat bucket
-        total_norm = torch.linalg.vector_norm(self.flat_grads)
-        self.flat_grads.mul_(torch.clamp(self.config["max_grad_norm"] / (total_norm + 1e-6), max=1.0))
-        self.optimizer.step()
+        # global-norm clipping (the rule of torch.nn.utils.clip_grad_norm_, upstream :311) + AdamW on the flat arenas: 2 launches
+        self.optimizer.step(self.config["max_grad_norm"])
         return stats
 
     def _set_lr(self, learning_rate: float):
-        if self._use_train_graph:
-            if self._sched_host[0] != learning_rate:
-                self._lr_dev.fill_(float(learning_rate))
-                self._sched_host[0] = learning_rate
-        else:
-            for pg in self.optimizer.param_groups:
-                pg["lr"] = learning_rate
+        self.optimizer.set_lr(learning_rate)
 
     def _bank_with_positions(self):
         """Episode bank with the sinusoidal positional rows pre-added, in a buffer that keeps its address (the captured
@@ -784,9 +770,7 @@ class PPOTrainer:
     def _train_body_b(self, monitor):
         """Second half: global-norm clipping (same rule as torch.nn.utils.clip_grad_norm_, upstream :311) on the flat bucket,
         fused AdamW, monitored gradient norms."""
-        total_norm = torch.linalg.vector_norm(self.flat_grads)
-        self.flat_grads.mul_(torch.clamp(self.config["max_grad_norm"] / (total_norm + 1e-6), max=1.0))
-        self.optimizer.step()
+        self.optimizer.step(self.config["max_grad_norm"])
         return self._grad_group_norms() if monitor else None
 
     def _train_step_graph(self, idx, learning_rate, clip_range, beta, monitor):
@@ -829,6 +813,7 @@ class PPOTrainer:
                     self._tg_norms = self._train_body_b(monitor)
             self._train_graph, self._tg_key = (ga, gb), key
             self.buffer.address_captured = True
+            ops.freeze_workspaces(self.device)
         ga, gb = self._train_graph
         ga.replay()
         if gb is not None:

@@ -34,14 +34,17 @@ class MultiHeadAttention(nn.Module):
         self.queries = nn.Linear(embed_dim, embed_dim, bias=False)
         self.fc_out = nn.Linear(embed_dim, embed_dim)
 
-    def attend(self, query, spec: WindowSpec, block=0, pos=None, norm_kv=None):
-        """query [N, D] -> (output [N, D], attention [N, H, L]); window rows come from ``spec``."""
+    def attend(self, query, spec: WindowSpec, block=0, pos=None, norm_kv=None, raw=False):
+        """query [N, D] -> (output [N, D], attention [N, H, L]); window rows come from ``spec``.  ``raw``: the output is
+        ``ctx fc_out.weight^T`` WITHOUT ``fc_out.bias`` (the caller folds the bias into the kernel that follows)."""
         q = self.queries(query)
         ln_g = ln_b = None
         eps = 1e-5
         if norm_kv is not None:
             ln_g, ln_b, eps = norm_kv.weight, norm_kv.bias, norm_kv.eps
         ctx, att = ops.mha(q, self.keys.weight, self.values.weight, spec, block, self.num_heads, ln_g, ln_b, pos, eps)
+        if raw:
+            return torch.nn.functional.linear(ctx, self.fc_out.weight), att
         return self.fc_out(ctx), att
 
     def forward(self, values, keys, queries, mask):
@@ -90,6 +93,8 @@ class GRUGate(nn.Module):
             if not torch.cuda.is_current_stream_capturing() and self._wver != self._versions():
                 self.refresh_rollout_weights()       # weights moved since the copies were made (optimizer step, load)
             return ops.gru_gate(x, y, self._wy, self._ux, self.Ug.weight, self.bg)
+        if torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.shape[1] <= 1024:
+            return ops.gru_gate_train(self, x, y)       # training: concatenated GEMMs + fused forward / backward kernels
         r = torch.sigmoid(self.Wr(y) + self.Ur(x))
         z = torch.sigmoid(self.Wz(y) + self.Uz(x) - self.bg)
         cand = torch.tanh(self.Wg(y) + self.Ug(r * x))
@@ -114,9 +119,22 @@ class TransformerBlock(Module):
     def forward_window(self, h, spec: WindowSpec, block=0, pos=None):
         """h [N, D] query state; returns (new state [N, D], attention [N, H, L])."""
         pre = self.layer_norm == "pre"
-        q_in = self.norm1(h) if pre else h
+        fused = self._fused_train(h)
+        q_in = (ops.fused_layernorm(h, self.norm1) if fused else self.norm1(h)) if pre else h
+        if fused and self.layer_norm == "post" and not self.use_gtrxl:
+            # training, post-LN: fc_out and fc run as plain GEMMs; bias, ReLU, residual add and LayerNorm (and all of their
+            # gradients) are one forward and one backward kernel each (transformer.py:143-149, :160-170)
+            att_raw, att_w = self.attention.attend(q_in, spec, block, pos, None, raw=True)
+            x = ops.fused_layernorm(att_raw, self.norm1, bias=self.attention.fc_out.bias, res=h)
+            fc = self.fc[0]
+            f_raw = torch.nn.functional.linear(x, fc.weight)
+            return ops.fused_layernorm(f_raw, self.norm2, bias=fc.bias, res=x, relu=True), att_w
         att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
         return self._after_attention(h, att_out), att_w
+
+    @staticmethod
+    def _fused_train(h):
+        return torch.is_grad_enabled() and h.is_cuda and h.dim() == 2 and h.shape[1] <= 1024
 
     def forward_cached(self, h, kv_spec: WindowSpec, block=0, out=None):
         """Rollout path: attention over cached K/V projections (no grad).  ``out``: contiguous destination of the result."""
@@ -136,13 +154,15 @@ class TransformerBlock(Module):
             # no-grad path with materialised att_out: residual + LayerNorm and Linear + ReLU are one launch each
             x = ops.add_layernorm(att_out, h, self.norm1)
             return ops.add_layernorm(ops.linear_relu(self.fc[0], x), x, self.norm2, out=out)
+        fused = self._fused_train(h)
+        ln = (lambda t, norm: ops.fused_layernorm(t, norm)) if fused else (lambda t, norm: norm(t))
         x = self.gate1(h, att_out) if self.use_gtrxl else att_out + h
         if post:
-            x = self.norm1(x)
-        f = ops.linear_relu(self.fc[0], self.norm2(x) if pre else x)
+            x = ln(x, self.norm1)
+        f = ops.linear_relu(self.fc[0], ln(x, self.norm2) if pre else x)
         res = self.gate2(x, f) if self.use_gtrxl else f + x
         if post:
-            res = self.norm2(res)
+            res = ln(res, self.norm2)
         return res if out is None else out.copy_(res)
 
     def forward(self, value, key, query, mask):

@@ -195,6 +195,59 @@ int etm_add_layernorm(const float *a, const float *a_bias, int relu, const float
  *   etm_gru_gate_out: out = (1 - z) * x + z * tanh(a_g + c) */
 int etm_gru_gate_rz(const float *a, const float *b, const float *bg, const float *x, float *rx, float *z, int N, int D, void *stream);
 int etm_gru_gate_out(const float *a, const float *c, const float *z, const float *x, float *out, int N, int D, void *stream);
+/* ---------------------------------------------------------------------------------------------
+ * Training-side epilogues of a transformer block, forward and backward (transformer.py:117-172, :287-298); csrc/block_train.hip.
+ * Called from the autograd functions behind TransformerBlock / GRUGate (etm/ops.py: fused_layernorm, gru_gate_train); the
+ * dense [N, D] x [D, D] products in between stay library GEMMs.
+ *   etm_ln_train_fwd: y = LayerNorm(act(a + a_bias) + b) * gamma + beta.  a [N,D] = raw output of the linear layer in front
+ *                     (a_bias [D] / relu = its bias / ReLU; NULL / 0 for none), b [N,D] = residual branch (or NULL).
+ *                     s_out [N,D] (optional) receives the LayerNorm input, stats [N,2] (optional) = (mean, 1/std) per row:
+ *                     what etm_ln_train_bwd needs.  Replaces `self.norm1(attention + query)`, `self.norm2(forward + h)`
+ *                     (post-LN, transformer.py:145-149, :166-170) and the plain `self.norm1(query)` / `self.norm2(h)` of the
+ *                     pre-LN layout (:131-141).
+ *   etm_ln_train_bwd: dy [N,D] -> ds [N,D] (gradient of the LayerNorm input = gradient of the residual branch b, and of `a`
+ *                     when relu == 0), da [N,D] (relu != 0 only: ds where a + a_bias > 0), and dgamma_dbeta_dbias [3,D] =
+ *                     column sums of (dy * xhat, dy, da).  Two launches (rows, then a fixed-order sum of per-workgroup
+ *                     partial sums held in `workspace`, etm_ln_train_bwd_workspace_bytes(N, D) bytes): deterministic.
+ *   etm_gate_train_*: the GTrXL GRU gate around three concatenated GEMMs A = y [Wr;Wz;Wg]^T [N,3D], B = x [Ur;Uz]^T [N,2D],
+ *                     C = (r x) Ug^T [N,D]:
+ *       rz  : r = sigmoid(A_r + B_r), z = sigmoid(A_z + B_z - bg), rx = r x              (writes r, z, rx)
+ *       out : hh = tanh(A_g + C), out = (1 - z) x + z hh                                  (writes hh, out)
+ *       bwd1: dout -> dA[:, 2D:3D] = dout z (1 - hh^2); dA[:, D:2D] = dB[:, D:2D] = dout (hh - x) z (1 - z);
+ *             dx1 = dout (1 - z); dbg [D] = - column sums of dA[:, D:2D]   (then the caller forms drx = dA[:, 2D:3D] Ug)
+ *       bwd2: drx -> dA[:, 0:D] = dB[:, 0:D] = drx x r (1 - r); dx2 = dx1 + drx r
+ *             (then dy = dA [Wr;Wz;Wg], dx = dx2 + dB [Ur;Uz], d[Wr;Wz;Wg] = dA^T y, d[Ur;Uz] = dB^T x, dUg = dA[:, 2D:3D]^T rx)
+ */
+int etm_ln_train_fwd(const float *a, const float *a_bias, int relu, const float *b, const float *gamma, const float *beta, float eps,
+                     float *y, float *s_out, float *stats, int N, int D, void *stream);
+int64_t etm_ln_train_bwd_workspace_bytes(int N, int D);
+int etm_ln_train_bwd(const float *dy, const float *s, const float *stats, const float *gamma, const float *a, const float *a_bias,
+                     int relu, float *ds, float *da, float *dgamma_dbeta_dbias, float *workspace, int64_t workspace_bytes, int N, int D,
+                     void *stream);
+int etm_gate_train_rz(const float *A, const float *B, const float *bg, const float *x, float *r, float *z, float *rx, int N, int D,
+                      void *stream);
+int etm_gate_train_out(const float *A, const float *C, const float *z, const float *x, float *hh, float *out, int N, int D, void *stream);
+int64_t etm_gate_train_bwd_workspace_bytes(int N, int D);
+int etm_gate_train_bwd1(const float *dout, const float *z, const float *hh, const float *x, float *dA, float *dB, float *dx1, float *dbg,
+                        float *workspace, int64_t workspace_bytes, int N, int D, void *stream);
+int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const float *dx1, float *dA, float *dB, float *dx2, int N, int D,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser step on flat fp32 arenas, replaces `clip_grad_norm_(parameters, max_grad_norm)` + `optimizer.step()` of
+ * trainer.py:311-312 (torch.optim.AdamW: betas (0.9, 0.999), eps 1e-8, weight_decay 0.01 unless the caller says otherwise).
+ * p / g / m / v: parameter, gradient, exp_avg, exp_avg_sq arenas of n floats (n % 4 == 0, 16-byte aligned; padding zero).
+ *   etm_grad_sqnorm: partial[i] = sum of g^2 over chunk i (n_partial <= 4096 workgroups, fixed chunking), *step += 1 (step may
+ *                    be NULL).  Runs after the data-parallel all-reduce of g.
+ *   etm_adamw_clip : total norm = sqrt(sum partial) -> coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping);
+ *                    g *= coef (written back), decoupled weight decay, AdamW update with bias corrections from *step, lr read
+ *                    from *lr_dev.  norm_out (optional) receives the un-clipped total norm.
+ * Device-resident lr / step make the pair replayable inside a captured HIP graph. */
+int etm_grad_sqnorm(const float *g, int64_t n, float *partial, int n_partial, int64_t *step, void *stream);
+int etm_adamw_clip(float *p, float *g, float *m, float *v, int64_t n, const float *partial, int n_partial, const float *lr_dev,
+                   const int64_t *step, double beta1, double beta2, double eps, double weight_decay, float max_norm, float *norm_out,
+                   void *stream);
+
 /* Output heads on the rollout path (model.py:108-110): h [W, 2*hid] = [relu(lin_policy) | relu(lin_value)] rows;
  * logits [W,A] = h_pol Wp^T + bp, value [W] = h_val . wv + bv.  One launch instead of two small library GEMMs. */
 int etm_rollout_heads(const float *h, const float *wp, const float *bp, const float *wv, const float *bv, float *logits, float *value,

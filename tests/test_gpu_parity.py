@@ -432,12 +432,11 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 
 
 # SURVEY 8c asks for post-step parameters within 1e-4 relative.  Stated on the MOVEMENT of the update (2 - 4 AdamW steps per
-# update) over all tensors: measured 0.6e-4 ... 1.8e-4 on the MI355X for the four fixtures (the CPU oracle reaches 4e-6 ... 2e-5
-# against the same fixtures); 4e-4 leaves room for the summation-order differences of other library GEMM selections.  Per tensor
-# the bound is looser: AdamW moves an element by ~lr * g / (|g| + eps) in its first steps, so elements whose gradient is at the
-# rounding-noise level move by +-lr with a sign that depends on summation order; tensors made of such elements (biases next to
-# LayerNorms, gate biases) show up to 2e-2 of their (tiny) movement.
-TF_MOVE_TOL_ALL, TF_MOVE_TOL_TENSOR = 4e-4, 5e-2
+# update) over all tensors: measured 5e-6 ... 7.6e-5 on the MI355X for the four fixtures (the CPU oracle reaches 4e-6 ... 2e-5
+# against the same fixtures), worst single tensor 5.1e-4 (a GRU-gate matrix of the gtrxl case).  The optimiser kernel follows the
+# arithmetic of the reference's single-tensor AdamW operation by operation (csrc/optim.hip); with the framework's fused AdamW,
+# which evaluates the update in double precision, the same comparison gave 1.4e-4 / 2e-2.
+TF_MOVE_TOL_ALL, TF_MOVE_TOL_TENSOR = 1.5e-4, 2e-3
 
 
 def test_trainer_self_consistency_and_free_run():
@@ -1000,6 +999,106 @@ def test_fused_gru_gate_vs_module_ops():
             z = torch.sigmoid(gate.Wz(y) + gate.Uz(x) - gate.bg)
             h = torch.tanh(gate.Wg(y) + gate.Ug(r * x))
             close(got2, ((1 - z) * x + z * h).cpu().numpy(), atol=2e-6, rtol=1e-5, what=f"gate updated D={D}")
+
+
+def _grads(out, wrt, go):
+    gs = torch.autograd.grad(out, wrt, go, allow_unused=True)
+    return [g for g in gs]
+
+
+def _rel(a, b):
+    return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+
+@pytest.mark.parametrize("N,D", [(2048, 384), (37, 128), (5, 64), (3, 1024), (130, 96)])
+@pytest.mark.parametrize("has_bias,relu,has_res", [(True, False, True), (True, True, True), (False, False, False), (False, False, True),
+                                                   (True, False, False)])
+def test_fused_layernorm_fwd_bwd_vs_torch(N, D, has_bias, relu, has_res):
+    """Training-side fused LayerNorm(act(a + bias) + res): forward and every gradient against the framework ops it replaces
+    (transformer.py:131-149, :160-170), on the device in fp32 (tolerance: summation order only)."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(N + D)
+    norm = torch.nn.LayerNorm(D).to(dev)
+    with torch.no_grad():
+        norm.weight.add_(0.2 * torch.randn(D, device=dev))
+        norm.bias.add_(0.2 * torch.randn(D, device=dev))
+    a = torch.randn((N, D), device=dev, requires_grad=True)
+    bias = (0.3 * torch.randn(D, device=dev)).requires_grad_(True) if has_bias else None
+    res = torch.randn((N, D), device=dev, requires_grad=True) if has_res else None
+    go = torch.randn((N, D), device=dev)
+    got = ops.fused_layernorm(a, norm, bias=bias, res=res, relu=relu)
+    t = a if bias is None else a + bias
+    if relu:
+        t = torch.relu(t)
+    if res is not None:
+        t = t + res
+    want = norm(t)
+    close(got, want.detach().cpu().numpy(), atol=3e-6, rtol=1e-5, what="forward")
+    wrt = [x for x in (a, bias, res, norm.weight, norm.bias) if x is not None]
+    names = [n for n, x in zip(["a", "bias", "res", "gamma", "beta"], (a, bias, res, norm.weight, norm.bias)) if x is not None]
+    for name, g, w in zip(names, _grads(got, wrt, go), _grads(want, wrt, go)):
+        assert _rel(g, w) < 2e-5, (name, _rel(g, w))
+
+
+@pytest.mark.parametrize("N,D,bg", [(2048, 384, 0.0), (33, 128, 2.0), (4, 64, 0.0)])
+def test_gru_gate_train_fwd_bwd_vs_torch(N, D, bg):
+    """Training-side GTrXL gate (concatenated GEMMs + fused kernels, hand-written backward) against the six-map formulation of
+    transformer.py:287-298 with framework autograd."""
+    from etm import ops
+    from transformer import GRUGate
+    dev = _dev()
+    torch.manual_seed(D)
+    gate = GRUGate(D, bg).to(dev)
+    with torch.no_grad():
+        gate.bg.add_(0.1 * torch.randn(D, device=dev))
+    x = torch.randn((N, D), device=dev, requires_grad=True)
+    y = torch.randn((N, D), device=dev, requires_grad=True)
+    go = torch.randn((N, D), device=dev)
+    got = ops.gru_gate_train(gate, x, y)
+    r = torch.sigmoid(gate.Wr(y) + gate.Ur(x))
+    z = torch.sigmoid(gate.Wz(y) + gate.Uz(x) - gate.bg)
+    want = (1 - z) * x + z * torch.tanh(gate.Wg(y) + gate.Ug(r * x))
+    close(got, want.detach().cpu().numpy(), atol=3e-6, rtol=1e-5, what="forward")
+    wrt = [x, y] + [p for p in gate.parameters()]
+    names = ["x", "y"] + [n for n, _ in gate.named_parameters()]
+    for name, g, w in zip(names, _grads(got, wrt, go), _grads(want, wrt, go)):
+        assert _rel(g, w) < 3e-5, (name, _rel(g, w))
+    assert gate(x, y).grad_fn is not None and type(gate(x, y).grad_fn).__name__.startswith("_GruGateFn"), "the module must route training through the fused gate"
+
+
+def test_flat_adamw_with_clipping_vs_torch():
+    """clip_grad_norm_ + torch.optim.AdamW (upstream trainer.py:311-312; single-tensor CPU path = the reference's arithmetic) against
+    the two-launch step on flat arenas, five steps with a changing learning rate; parameter views must stay live nn.Parameters."""
+    from etm.optim import FlatAdamW
+    dev = _dev()
+    torch.manual_seed(21)
+    shapes = [(64, 33), (7,), (3, 5, 2, 2), (1,), (130, 64), (64,)]
+    ref = [torch.nn.Parameter(torch.randn(s) * 0.3) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref]
+    opt_ref = torch.optim.AdamW(ref, lr=3e-4, foreach=False, fused=False)
+    opt = FlatAdamW(mine, lr=3e-4)
+    assert all(p.data_ptr() >= opt.flat_params.data_ptr() for p in mine)
+    for it in range(5):
+        lr = 3e-4 * (1 - 0.1 * it)
+        scale = 10.0 if it % 2 == 0 else 0.01            # clipped / not clipped
+        grads = [torch.randn(s) * scale for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, max_norm=0.5)
+        for pg in opt_ref.param_groups:
+            pg["lr"] = lr
+        opt_ref.step()
+        for v, g in zip(opt.grad_views, grads):
+            v.copy_(g.to(dev))
+        opt.set_lr(lr)
+        opt.step(0.5)
+        want_norm = float(torch.cat([g.reshape(-1) for g in grads]).norm())
+        assert abs(float(opt.total_norm) - want_norm) <= 1e-5 * want_norm
+        for p, q, g in zip(ref, mine, opt.grad_views):
+            close(q, p.detach().numpy(), atol=1e-7, rtol=2e-6, what=f"param step {it}")
+            close(g, p.grad.numpy(), atol=1e-8, rtol=2e-6, what=f"clipped grad step {it}")
+    assert int(opt.step_dev) == 5
 
 
 def test_poc_memory_env_learns():
