@@ -12,8 +12,12 @@ environments; gradients are all-reduced with RCCL.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline     the dominant kernel's achieved rate from HIP events recorded around its launches inside the timed
-               region (libetm_hip.so's etm_profile_* facility): the folded window-attention pass against the HBM peak
-               (or, with --attention dense, the fp32-MFMA contraction against the fp32 MFMA peak of gfx950);
+               region (libetm_hip.so's etm_profile_* facility): the folded window-attention pass against the HBM peak,
+               bytes_per_launch = N * L * D * 4 -- or, with --attention dense, the fp32-MFMA
+               contraction against the fp32 MFMA peak of gfx950;
+  rooflines    kernel micro-benchmarks run AFTER the timed region (tools/kernel_rooflines.py): window pass with every byte
+               from HBM and with the training access pattern, the dense north-star attention kernels against the fp32
+               MFMA peak at config 3 and config 5 dims, GAE and PPO loss against the HBM peak at config and scaled sizes;
   cpu_baseline the CPU oracle (oracle/ref_algo.OracleTrainer, a validated restatement of the reference trainer)
                timed on this host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
 """
@@ -25,7 +29,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "episodic-transformer-memory-ppo_amd")
-for _p in (REPO, PKG):
+for _p in (REPO, PKG, os.path.join(REPO, "tools")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
@@ -44,10 +48,9 @@ def load_config():
 def kernel_work(name, N, L, D, H):
     """Algorithmic work of one launch at the training shape (DESIGN.md section 'Kernels'): ("hbm", bytes) or ("mfma", flops)."""
     if name in ("window_fwd_kernel", "window_bwd_kernel"):
-        # folded attention pass: one read of the gathered window (L*D*4 B per sample and block, SURVEY.md 8d) + the H folded
-        # vectors in and out + the attention weights (backward also re-reads them)
-        per_sample = 4.0 * (L * D + 2 * H * D + H * L * (2 if name.endswith("bwd_kernel") else 1))
-        return "hbm", N * per_sample
+        # folded attention pass: the read of the gathered window, L*D*4 B per sample and block (SURVEY.md 8d's algorithmic
+        # figure; the H folded vectors in / out and the attention weights are reported separately as extra_bytes_per_launch)
+        return "hbm", N * 4.0 * L * D
     if name == "mha_fwd_kernel":      # dense variant: K and V projections of the window + QK^T + att.V
         return "mfma", N * 2.0 * (2 * L * D * D + 2 * L * D)
     if name == "bwd_dw_kernel":       # dense variant: dWk and dWv: [2D, N*L] x [N*L, D]
@@ -57,15 +60,18 @@ def kernel_work(name, N, L, D, H):
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of ``kernel`` at the training shape from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary.json, produced by tools/run_pmc.sh in separate --pmc passes): FETCH_SIZE KiB x 2 (gfx950 reports
-    half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KiB.  None if no profile is present."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    (profiles/r02_pmc_summary.json if present, else round 1's; produced by tools/run_pmc.sh in separate --pmc passes):
+    FETCH_SIZE KiB x 2 (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KiB.
+    None if no profile is present."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
+    if not os.path.exists(path):
+        path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
     symbol = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel"}.get(kernel, kernel)
     try:
         with open(path) as f:
             k = json.load(f)[symbol]
         return {"bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"]["mean"] + 1024 * k["WRITE_SIZE"]["mean"],
-                "source": f"profiles/r01_pmc_summary.json, kernel symbol {symbol} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "source": f"profiles/{os.path.basename(path)}, kernel symbol {symbol} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                           "N=2048 L=64 D=384 H=4; forward and backward launches of the window pass averaged)",
                 "mfma_busy_fraction_pmc": k.get("derived", {}).get("mfma_busy_fraction")}
     except Exception:
@@ -107,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-rooflines", action="store_true", help="skip the kernel micro-benchmarks after the timed region")
     ap.add_argument("--dist-backend", default=None, help="testing only: torch.distributed backend instead of nccl (= RCCL), e.g. gloo")
     ap.add_argument("--dp-collective", choices=("torch", "etm"), default="torch",
                     help="gradient all-reduce through torch.distributed (RCCL backend) or through the library's own RCCL communicator")
@@ -248,6 +255,12 @@ def main():
             if tr_pmc and kind == "mfma":
                 roofline["mfma_busy_fraction_pmc"] = tr_pmc.get("mfma_busy_fraction_pmc")
             roofline.update(extra)
+            if kind == "hbm":
+                roofline["extra_bytes_per_launch"] = N * 4.0 * (2 * H * D + H * L * (2 if dom.endswith("bwd_kernel") else 1))
+                roofline["note"] = ("bytes_per_launch = N*L*D*4, the un-deduplicated window read of SURVEY 8d; minibatches are sorted by "
+                                    "(worker, step) and every XCD takes a contiguous chunk of the samples, so part of that stream is "
+                                    "served by L2 / Infinity Cache (unique window rows per block <= 61 MB): see rooflines.window.cold_hbm "
+                                    "for the same kernel with every byte coming from HBM")
         rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
         out = {
             "metric": "env-steps/sec (whole node) MinigridMemory 3x84x84",
@@ -264,7 +277,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE config (3)/(4): configs/synthetic_minigrid.yaml -- per GPU n_workers=32 x worker_steps=512 "
                                    "= 16384 env steps per update, 5 epochs x 8 minibatches of 2048, TrXL 3 blocks D=384 H=4 L=64, "
-                                   "synthetic U[0,1) 3x84x84 observations, random-init weights",
+                                   "synthetic 3x84x84 observations: every worker replays a ring of 64 frames drawn once from U[0,1) "
+                                   "(numpy default_rng(seed + worker id)); rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); "
+                                   "environments stepped in-process on the host (part of the timed region); random-init weights",
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
@@ -273,11 +288,24 @@ def main():
             "kernels_train": kernels,
             "kernels_rollout": rollout_k,
         }
+        if not args.no_rooflines:
+            try:
+                import kernel_rooflines
+                trainer.close()
+                del trainer
+                torch.cuda.empty_cache()
+                out["rooflines"] = kernel_rooflines.all_rooflines(device)
+            except Exception as exc:       # reporting only: never lose the throughput line over it
+                out["rooflines"] = {"error": repr(exc)}
+            trainer = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    trainer.close()
+        print(json.dumps(out), flush=True)
+    if dp is not None:
+        dp.barrier()            # rank 0 ran the kernel micro-benchmarks: leave together
+    if trainer is not None:
+        trainer.close()
     if dp is not None:
         dp.close()
 
