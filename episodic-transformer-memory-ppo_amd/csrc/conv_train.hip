@@ -1,0 +1,519 @@
+// Training-side observation encoder (/root/reference model.py:40-56, :90-94): the three
+// `relu(conv2d(x))` layers forward, backward-data and backward-weight as fp32-MFMA implicit GEMMs with the bias, the ReLU,
+// the ReLU mask of the backward pass and the bias gradient fused in -- no library convolution, no element-wise launches.
+// Activations are NHWC (channels-last) throughout; the weight matrices are re-packed per optimiser step (they change every
+// step) into the MFMA fragment order of etm_conv_relu (include/etm_hip.h).
+//
+// Forward / backward-data (one kernel template, `conv_gemm_kernel`)
+//   out[m, co] = sum_k A[m, k] * Wp[k, co],  m = output pixel, k = (segment, offset): a segment is a memory-contiguous run of
+//   the source tensor (forward: the KW x C floats of one kernel row under the pixel; backward-data: the T x Cout gradient
+//   floats of the output pixels that touch the input pixel in one kernel row, T = K / S taps per dimension, pixels grouped by
+//   their stride-parity class so that every class is a dense small convolution).  A fragments go straight from L2 to
+//   registers with 16-byte loads (lane = pixel row of the 32 x 32 x 2 MFMA, k-offset by half-wave), B fragments are one
+//   coalesced 1 KB load per wave; a wave owns MT pixel tiles x NT channel tiles (8 accumulator tiles) so that every operand
+//   load feeds 4 NT (A) or 4 MT (B) MFMAs, and the operands of k-group g + 1 are requested before the MFMAs of group g.
+//   Epilogue: forward  y = relu(acc + bias)      (NHWC; the consumer of the last layer permutes ITS weight columns instead, so
+//                                                 upstream's (c, h, w) flatten order of model.py:94 never has to be materialised)
+//             backward dx = acc * (y_prev > 0)   (the ReLU mask of the layer below: its pre-activation gradient, NHWC)
+// Backward-weight (`conv_wgrad_kernel`)
+//   dW[k, co] = sum_m A[m, k] * dY[m, co]: the reduction runs over the pixels.  A workgroup owns a range of k (KT tiles) x all
+//   channels and a contiguous slice of the pixels; chunks of 32 pixels are staged through LDS (coalesced 16-byte global loads,
+//   double-buffered), each of the 4 waves takes 8 of the 32 pixels of a chunk for all KT x CT accumulator tiles, the waves and
+//   then the pixel slices are summed in a fixed order (second kernel): deterministic.  The column sums of dY (the bias
+//   gradient) are accumulated by the threads that stage dY.
+#include "etm_common.h"
+
+#include <type_traits>
+
+namespace {
+
+__device__ __forceinline__ int fast_div(int m, int d, float inv) {      // floor(m / d) for 0 <= m < 2^24
+  int q = __float2int_rz(__int2float_rn(m) * inv);
+  int r = m - q * d;
+  if (r >= d) ++q;
+  if (r < 0) --q;
+  return q;
+}
+
+struct ConvG {
+  const float *src;      // forward: x NHWC [N,H,W,C]; backward-data: dY NHWC [N,Ho,Wo,Cout]
+  const float *wp;       // packed weights (fragment order), one block of `groups * NT * 256` floats per parity class
+  const float *bias;     // forward only
+  const float *ymask;    // backward-data: output of the layer below (NHWC, same shape as the result); NULL: no mask
+  float *out;
+  int N;
+  int sH, sW, sC;        // source tensor dims (rows, cols, channels)
+  int oH, oW, oC;        // result tensor dims (forward: Ho, Wo, Cout; backward-data: H, W, C)
+  int S;                 // stride of the convolution
+  int T;                 // backward-data: taps per dimension (K / S); forward: unused
+  int n_seg, seg_len, groups;   // K = n_seg * seg_len, groups = K / 8
+  int cH, cW;            // pixels per image and class (forward: oH, oW; backward-data: oH / S, oW / S)
+  int Mc;                // pixels per class = N * cH * cW (< 2^24)
+  int out_nchw;
+  float inv_chw, inv_cw; // 1 / (cH * cW), 1 / cW
+};
+
+constexpr int CG_WAVES = 4;
+// pixel tiles per wave (x NT channel tiles = accumulator tiles): 4 accumulator tiles keep a wave at 64 AGPRs + ~90 VGPRs, i.e.
+// three waves per SIMD -- the operand loads come straight from L2 / HBM and need that occupancy to hide their latency
+#ifndef ETM_CONV_MT32
+#define ETM_CONV_MT32 4
+#endif
+#ifndef ETM_CONV_MINW
+#define ETM_CONV_MINW 3      // waves per SIMD the register allocation must leave room for
+#endif
+#ifndef ETM_CONV_MT64
+#define ETM_CONV_MT64 2
+#endif
+
+template <int MT, int NT, bool DGRAD>
+__global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel(const ConvG p) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int cls = blockIdx.y;                       // parity class (backward-data), 0 for forward
+  const int py = DGRAD ? cls / p.S : 0, px = DGRAD ? cls - py * p.S : 0;
+  const int tile0 = ((int)blockIdx.x * CG_WAVES + wave) * MT;
+  if (tile0 * 32 >= p.Mc) return;                   // whole wave; no barriers in this kernel
+
+  // per pixel tile: this lane's pixel as a 32-bit ELEMENT offset from the source tensor (the k walk below adds wave-uniform
+  // offsets to the base pointer, so a load is `base(SGPR) + offset(VGPR)`: no per-lane address arithmetic inside the loop),
+  // and (backward-data) the source row / column of the lane's first tap for the validity tests
+  int loff[MT], vy0[MT], vx0[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = min((tile0 + mt) * 32 + col, p.Mc - 1);
+    const int n = fast_div(m, p.cH * p.cW, p.inv_chw);
+    const int rem = m - n * (p.cH * p.cW);
+    const int cy = fast_div(rem, p.cW, p.inv_cw), cx = rem - cy * p.cW;
+    if (!DGRAD) {
+      loff[mt] = ((n * p.sH + cy * p.S) * p.sW + cx * p.S) * p.sC + half * 4;
+      vy0[mt] = vx0[mt] = 0;
+    } else {
+      // input pixel (iy, ix) = (S cy + py, S cx + px); tap (a, j): source pixel (cy - a, cx - (T - 1) + j)
+      vy0[mt] = cy;
+      vx0[mt] = cx - (p.T - 1);
+      loff[mt] = ((n * p.sH + cy) * p.sW + (cx - (p.T - 1))) * p.sC + half * 4;      // may point before a row start: only used when valid
+    }
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
+
+  const float *wbase = p.wp + (long long)cls * p.groups * NT * 256;
+  const int wl = lane * 4;
+  const int row_elems = p.sW * p.sC;
+  // the k walk: segment `seg` (a kernel row), then 8-float groups inside it; backward-data additionally tracks the tap column
+  // (sC / 8 groups per source pixel) for the validity of the lane's taps.  All of it is wave-uniform.
+  const int gps = p.seg_len / 8;                    // groups per segment
+  const int gpp = DGRAD ? p.sC / 8 : gps;           // groups per source pixel (backward-data)
+
+  f32x4 a_reg[3][MT], b_reg[3][NT];               // three k-groups in flight: the loads of group g + 2 are issued before the MFMAs of group g
+  auto load_group = [&](int seg, int gi, int g, int buf) {
+    const int koff = (DGRAD ? -seg : seg) * row_elems + gi * 8;      // uniform
+    const float *abase = p.src + koff;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!DGRAD) {
+        a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + loff[mt]);
+      } else {
+        const int sy = vy0[mt] - seg, sx = vx0[mt] + gi / gpp;
+        const bool ok = sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? abase + loff[mt] : p.src + half * 4);
+        a_reg[buf][mt] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float *bb = wbase + (long long)g * NT * 256;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + t * 256 + wl);
+  };
+  auto mfma_group = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_reg[buf][mt][j], b_reg[buf][t][j], acc[mt][t], 0, 0, 0);
+  };
+
+  // software pipeline over the groups (seg-major), prefetch distance 2: a load has two MFMA bursts of this wave (and those of the
+  // other waves of the SIMD) to arrive.  Three k-groups per iteration: the buffers rotate without copies.
+  int seg_n = 0, gi_n = 0, g_n = 0;                 // coordinates of the NEXT group to load
+  auto load_next = [&](int buf) {
+    if (g_n < p.groups) {
+      load_group(seg_n, gi_n, g_n, buf);
+      ++g_n;
+      if (++gi_n == gps) { gi_n = 0; ++seg_n; }
+    }
+  };
+  load_next(0);
+  load_next(1);
+  for (int g = 0; g < p.groups; g += 3) {
+    load_next(2);
+    mfma_group(0);
+    load_next(0);
+    if (g + 1 < p.groups) mfma_group(1);
+    load_next(1);
+    if (g + 2 < p.groups) mfma_group(2);
+  }
+
+  // epilogue: bias / mask operands are requested up front (no wait per row), rows past the end are clamped and not stored
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = DGRAD ? 0.f : p.bias[t * 32 + col];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long long o_pix[16];
+    bool okr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mraw = (tile0 + mt) * 32 + mfma32_row(r, lane);
+      okr[r] = mraw < p.Mc;
+      const int mm = okr[r] ? mraw : p.Mc - 1;
+      // forward: the pixel index IS the NHWC row; backward-data decodes the class-local pixel (float-reciprocal division)
+      o_pix[r] = (long long)mm * p.oC;
+      if (DGRAD) {
+        const int n = fast_div(mm, p.cH * p.cW, p.inv_chw);
+        const int rem = mm - n * (p.cH * p.cW);
+        const int cy = fast_div(rem, p.cW, p.inv_cw), cx = rem - cy * p.cW;
+        o_pix[r] = (((long long)n * p.oH + cy * p.S + py) * p.oW + cx * p.S + px) * p.oC;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int co = t * 32 + col;
+      float mk[16];
+      if (DGRAD && p.ymask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = p.ymask[o_pix[r] + co];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[mt][t][r];
+        if (!DGRAD) v = fmaxf(v + bv[t], 0.f);
+        else if (p.ymask) v = (mk[r] > 0.f) ? v : 0.f;
+        if (okr[r]) p.out[o_pix[r] + co] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvW {
+  const float *x;        // layer input NHWC [N,H,W,C]
+  const float *dy;       // pre-activation gradient of the layer output, NHWC [N,Ho,Wo,Cout]
+  float *partial;        // [splits][K * Cout + Cout]: dW in (k, co) order, then the column sums of dy
+  int N, H, W, C, Cout, S, Ho, Wo;
+  int seg_len, n_seg, K;
+  int M, rows_per_split;
+  float inv_hw, inv_w;   // 1 / (Ho * Wo), 1 / Wo (row decode without integer division; exact below 2^24 pixels)
+};
+
+constexpr int WG_MC = 32;      // pixels per staged chunk
+
+template <int KT, int CT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
+  constexpr int KW_ = KT * 32, CW_ = CT * 32;          // k-range and channels of this workgroup
+  constexpr int A_LD = KW_ + 32, D_LD = CT == 1 ? 32 : 96;   // LDS row strides = 32 mod 64 floats: the two pixel rows of a k-step hit disjoint banks
+  constexpr int A_J = KW_ / 32, D_J = CW_ / 32;        // float4s per thread and chunk (8 threads per pixel row)
+  constexpr int A_SZ = WG_MC * A_LD, D_SZ = WG_MC * D_LD;
+  extern __shared__ __attribute__((aligned(16))) float wg_lds[];   // [2][A_SZ] then [2][D_SZ]: two chunks in flight
+  float *a_s = wg_lds, *d_s = wg_lds + 2 * A_SZ;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int k_base = blockIdx.y * KW_;
+  const int split = blockIdx.x;
+  const int m_lo = split * p.rows_per_split, m_hi = min(m_lo + p.rows_per_split, p.M);
+  const int srow = tid >> 3, t8 = tid & 7;             // staging: thread -> (pixel row of the chunk, 16-byte column slot)
+
+  f32x16 acc[KT][CT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][ct][r] = 0.f;
+
+  // k offsets of this thread's A slots do not depend on the pixel: (kernel row, offset in the row) -> element offset
+  long long a_off[A_J];
+  bool a_ok[A_J];
+#pragma unroll
+  for (int j = 0; j < A_J; ++j) {
+    const int k = k_base + (t8 + 8 * j) * 4;
+    a_ok[j] = k < p.K;
+    const int kc = a_ok[j] ? k : 0;
+    const int seg = kc / p.seg_len, off = kc - seg * p.seg_len;
+    a_off[j] = (long long)seg * p.W * p.C + off;
+  }
+  f32x4 a_st[2][A_J], d_st[2][D_J];                      // two chunks in flight between global memory and LDS
+  float bsum[D_J][4];
+#pragma unroll
+  for (int j = 0; j < D_J; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bsum[j][q] = 0.f;
+
+  auto fetch = [&](int m0, int rb) {
+    const int m = m0 + srow;
+    const bool ok = m < m_hi;
+    const int mc = ok ? m : m_lo;
+    const int n = fast_div(mc, p.Ho * p.Wo, p.inv_hw);
+    const int rem = mc - n * (p.Ho * p.Wo);
+    const int oy = fast_div(rem, p.Wo, p.inv_w), ox = rem - oy * p.Wo;
+    const float *xrow = p.x + (((long long)n * p.H + oy * p.S) * p.W + ox * p.S) * p.C;
+    const float *drow = p.dy + (long long)mc * p.Cout;
+#pragma unroll
+    for (int j = 0; j < A_J; ++j) {
+      const f32x4 val = *reinterpret_cast<const f32x4 *>(xrow + a_off[j]);
+      a_st[rb][j] = (ok && a_ok[j]) ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < D_J; ++j) {
+      const f32x4 val = *reinterpret_cast<const f32x4 *>(drow + (t8 + 8 * j) * 4);
+      d_st[rb][j] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stash = [&](int buf, int rb) {
+#pragma unroll
+    for (int j = 0; j < A_J; ++j) *reinterpret_cast<f32x4 *>(&a_s[buf * A_SZ + srow * A_LD + (t8 + 8 * j) * 4]) = a_st[rb][j];
+#pragma unroll
+    for (int j = 0; j < D_J; ++j) {
+      *reinterpret_cast<f32x4 *>(&d_s[buf * D_SZ + srow * D_LD + (t8 + 8 * j) * 4]) = d_st[rb][j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bsum[j][q] += d_st[rb][j][q];
+    }
+  };
+
+  // chunk c is computed from LDS buffer c & 1 while chunk c + 1 sits in registers (fetched one iteration ago) and the loads of
+  // chunk c + 2 are issued: a global load has two MFMA bursts (~1.7 us) to arrive
+  fetch(m_lo, 0);
+  stash(0, 0);
+  if (m_lo + WG_MC < m_hi) fetch(m_lo + WG_MC, 1);
+  __syncthreads();
+  auto chunk = [&](int m0, auto bufc) {                 // bufc: compile-time buffer index (register sets must not be indexed at run time)
+    constexpr int buf = decltype(bufc)::value;
+    const bool more = m0 + WG_MC < m_hi;
+    if (m0 + 2 * WG_MC < m_hi) fetch(m0 + 2 * WG_MC, buf);   // register set `buf` was stashed into LDS buffer `buf` two chunks ago
+    // wave w takes pixel rows 8 w .. 8 w + 7 of the chunk: 4 MFMA k-steps of 2 rows
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int row = wave * 8 + s * 2 + half;
+      float av[KT], dv[CT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) av[kt] = a_s[buf * A_SZ + row * A_LD + kt * 32 + col];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) dv[ct] = d_s[buf * D_SZ + row * D_LD + ct * 32 + col];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[kt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], dv[ct], acc[kt][ct], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1, buf ^ 1);                  // the other buffer: its last readers passed the barrier of the previous chunk
+    __syncthreads();
+  };
+  for (int m0 = m_lo; m0 < m_hi; m0 += 2 * WG_MC) {
+    chunk(m0, std::integral_constant<int, 0>());
+    if (m0 + WG_MC < m_hi) chunk(m0 + WG_MC, std::integral_constant<int, 1>());
+  }
+
+  // cross-wave sum through LDS (reusing the A staging buffer: 4 waves x 16 registers x 64 lanes = 16 KB), then the partial
+  // result of this pixel slice
+  float *red = a_s;
+  static_assert(2 * A_SZ >= 4 * 16 * 64, "reduction scratch");
+  float *dst = p.partial + (long long)split * ((long long)p.K * p.Cout + p.Cout);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[kt][ct][r];
+      __syncthreads();
+      for (int e = tid; e < 16 * 64; e += 256) {
+        const int r = e >> 6, l = e & 63;
+        const float v = (red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l]) + (red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l]);
+        const int krow = k_base + kt * 32 + mfma32_row(r, l), co = ct * 32 + (l & 31);
+        if (krow < p.K) dst[(long long)krow * p.Cout + co] = v;
+      }
+    }
+  if (blockIdx.y == 0) {                                // bias gradient: the 32 staging rows of a channel are added in row order
+    __syncthreads();
+    float *bs = a_s;                                    // [256 threads][D_J * 4] floats
+#pragma unroll
+    for (int j = 0; j < D_J; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bs[tid * (D_J * 4) + j * 4 + q] = bsum[j][q];
+    __syncthreads();
+    if (tid < CW_) {
+      const int c4 = tid >> 2, q = tid & 3, j = c4 >> 3, slot = c4 & 7;
+      float t = 0.f;
+      for (int row = 0; row < WG_MC; ++row) t += bs[(row * 8 + slot) * (D_J * 4) + j * 4 + q];
+      dst[(long long)p.K * p.Cout + tid] = t;
+    }
+  }
+}
+
+// out[e] = sum over the pixel slices, fixed order
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int splits, long long elems,
+                                                                float *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= elems) return;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {
+    t0 += partial[(long long)s * elems + e];
+    t1 += partial[(long long)(s + 1) * elems + e];
+    t2 += partial[(long long)(s + 2) * elems + e];
+    t3 += partial[(long long)(s + 3) * elems + e];
+  }
+  for (; s < splits; ++s) t0 += partial[(long long)s * elems + e];
+  out[e] = (t0 + t1) + (t2 + t3);
+}
+
+// out = g * (y > 0): the ReLU backward of the last encoder layer (everything NHWC), 16 bytes per thread
+__global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4 *__restrict__ g, const f32x4 *__restrict__ y, f32x4 *__restrict__ out,
+                                                        long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 gv = g[i], yv = y[i];
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = yv[k] > 0.f ? gv[k] : 0.f;
+  out[i] = o;
+}
+}  // namespace
+
+static int conv_geometry_ok(int C, int Cout, int KH, int KW, int S, int W) {
+  if (Cout != 32 && Cout != 64) return 0;
+  if ((KW * C) % 8 != 0 || (W * C) % 4 != 0 || (S * C) % 4 != 0) return 0;
+  return 1;
+}
+
+extern "C" int etm_conv_train_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W, int Cout,
+                                  int KH, int KW, int S, int out_nchw, void *stream) {
+  (void)hipGetLastError();
+  if (!x || !w_packed || !bias || !y || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
+  if (!conv_geometry_ok(C, Cout, KH, KW, S, W)) return ETM_EUNSUPPORTED;
+  ConvG p{};
+  p.src = x; p.wp = w_packed; p.bias = bias; p.ymask = nullptr; p.out = y; p.N = N;
+  p.sH = H; p.sW = W; p.sC = C;
+  p.oH = (H - KH) / S + 1; p.oW = (W - KW) / S + 1; p.oC = Cout;
+  p.S = S; p.T = 0; p.n_seg = KH; p.seg_len = KW * C; p.groups = KH * KW * C / 8;
+  p.cH = p.oH; p.cW = p.oW; p.Mc = N * p.oH * p.oW; p.out_nchw = 0;
+  if (out_nchw) return ETM_EUNSUPPORTED;      // NHWC only: the caller permutes the consumer's weight columns instead
+  if (p.Mc >= (1 << 24)) return ETM_EUNSUPPORTED;
+  p.inv_chw = 1.0f / (float)(p.cH * p.cW); p.inv_cw = 1.0f / (float)p.cW;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_CONV_TRAIN_FWD, st);
+  const int tiles = (p.Mc + 31) / 32;
+  if (Cout == 32) {
+    constexpr int MT = ETM_CONV_MT32;
+    hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, false>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), 1), dim3(CG_WAVES * 64), 0, st, p);
+  } else {
+    constexpr int MT = ETM_CONV_MT64;
+    hipLaunchKernelGGL((conv_gemm_kernel<MT, 2, false>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), 1), dim3(CG_WAVES * 64), 0, st, p);
+  }
+  return etm_launch_status();
+}
+
+// dx[N,H,W,C] (NHWC) = conv_transpose(dy) * (y_below > 0).  w_packed: S*S class blocks, see etm.ops.conv_pack_dgrad_weights.
+extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W,
+                                    int Cout, int KH, int KW, int S, void *stream) {
+  (void)hipGetLastError();
+  if (!dy || !w_packed || !dx || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
+  if (KH != KW || KH % S != 0 || H % S != 0 || W % S != 0 || Cout % 8 != 0 || (C != 32 && C != 64)) return ETM_EUNSUPPORTED;
+  const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1;
+  ConvG p{};
+  p.src = dy; p.wp = w_packed; p.bias = nullptr; p.ymask = y_below; p.out = dx; p.N = N;
+  p.sH = Ho; p.sW = Wo; p.sC = Cout;
+  p.oH = H; p.oW = W; p.oC = C;
+  p.S = S; p.T = KH / S; p.n_seg = p.T; p.seg_len = p.T * Cout; p.groups = p.T * p.T * Cout / 8;
+  p.cH = H / S; p.cW = W / S; p.Mc = N * p.cH * p.cW; p.out_nchw = 0;
+  if (p.Mc >= (1 << 24)) return ETM_EUNSUPPORTED;
+  p.inv_chw = 1.0f / (float)(p.cH * p.cW); p.inv_cw = 1.0f / (float)p.cW;
+  if ((p.T * p.T * Cout) % 8 != 0) return ETM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_CONV_TRAIN_DGRAD, st);
+  const int tiles = (p.Mc + 31) / 32;
+  const unsigned classes = (unsigned)(S * S);
+  if (C == 32) {
+    constexpr int MT = ETM_CONV_MT32;
+    hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, true>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64), 0, st, p);
+  } else {
+    constexpr int MT = ETM_CONV_MT64;
+    hipLaunchKernelGGL((conv_gemm_kernel<MT, 2, true>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64), 0, st, p);
+  }
+  return etm_launch_status();
+}
+
+static int wgrad_splits(int M, int k_ranges) {
+  int s = 768 / k_ranges;             // ~3 workgroups per CU over all k-ranges
+  const int cap = (M + 255) / 256;    // at least 256 pixels per slice
+  if (s > cap) s = cap;
+  if (s > 512) s = 512;
+  if (s < 1) s = 1;
+  return s;
+}
+static int wgrad_k_ranges(int Cout, int K) { const int kw = (Cout == 32 ? 6 : 4) * 32; return (K + kw - 1) / kw; }
+
+extern "C" int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cout, int KH, int KW, int S) {
+  const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1;
+  const long long K = (long long)KH * KW * C;
+  return (int64_t)wgrad_splits(N * Ho * Wo, wgrad_k_ranges(Cout, (int)K)) * (K * Cout + Cout) * (int64_t)sizeof(float);
+}
+
+// dw_kc [K, Cout] (k ordered (ky, kx, c)) followed by dbias [Cout], in one buffer of K * Cout + Cout floats.
+extern "C" int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N,
+                                    int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
+  (void)hipGetLastError();
+  if (!x || !dy || !dw_kc_dbias || !workspace || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
+  if (!conv_geometry_ok(C, Cout, KH, KW, S, W)) return ETM_EUNSUPPORTED;
+  if (workspace_bytes < etm_conv_train_wgrad_workspace_bytes(N, C, H, W, Cout, KH, KW, S)) return ETM_EWORKSPACE;
+  ConvW p{};
+  p.x = x; p.dy = dy; p.partial = workspace; p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.S = S;
+  p.Ho = (H - KH) / S + 1; p.Wo = (W - KW) / S + 1;
+  p.seg_len = KW * C; p.n_seg = KH; p.K = KH * KW * C;
+  p.M = N * p.Ho * p.Wo;
+  if (p.M >= (1 << 24)) return ETM_EUNSUPPORTED;
+  p.inv_hw = 1.0f / (float)(p.Ho * p.Wo); p.inv_w = 1.0f / (float)p.Wo;
+  const int splits = wgrad_splits(p.M, wgrad_k_ranges(Cout, p.K));
+  p.rows_per_split = ((p.M + splits - 1) / splits + WG_MC - 1) / WG_MC * WG_MC;
+  const int splits_used = (p.M + p.rows_per_split - 1) / p.rows_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    EtmProfScope prof(ETM_K_CONV_TRAIN_WGRAD, st);
+    if (Cout == 32) {
+      constexpr int KT = 6;            // 192 k per workgroup
+      if (p.K % 32 != 0) return ETM_EUNSUPPORTED;
+      constexpr size_t lds = 2 * (size_t)WG_MC * ((KT * 32 + 32) + 32) * sizeof(float);
+      auto kern = conv_wgrad_kernel<KT, 1>;
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3((unsigned)splits_used, (unsigned)((p.K + KT * 32 - 1) / (KT * 32))), dim3(256), lds, st, p);
+    } else {
+      constexpr int KT = 4;            // 128 k per workgroup
+      if (p.K % 32 != 0) return ETM_EUNSUPPORTED;
+      constexpr size_t lds = 2 * (size_t)WG_MC * ((KT * 32 + 32) + 96) * sizeof(float);
+      auto kern = conv_wgrad_kernel<KT, 2>;
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3((unsigned)splits_used, (unsigned)((p.K + KT * 32 - 1) / (KT * 32))), dim3(256), lds, st, p);
+    }
+    int rc = etm_launch_status();
+    if (rc) return rc;
+  }
+  EtmProfScope prof(ETM_K_CONV_TRAIN_WGRAD, st);
+  const long long elems = (long long)p.K * Cout + Cout;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, workspace, splits_used, elems, dw_kc_dbias);
+  return etm_launch_status();
+}
+
+extern "C" int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *stream) {
+  (void)hipGetLastError();
+  if (!g || !y || !out || n <= 0 || n % 4 != 0) return ETM_EINVAL;
+  if ((uintptr_t)g % 16 || (uintptr_t)y % 16 || (uintptr_t)out % 16) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_CONV_TRAIN_DGRAD, st);
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const f32x4 *)g, (const f32x4 *)y, (f32x4 *)out,
+                     (long long)(n / 4));
+  return etm_launch_status();
+}

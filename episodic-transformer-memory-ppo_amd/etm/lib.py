@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 
@@ -50,6 +50,11 @@ SIGNATURES = {
     "etm_gate_train_bwd_workspace_bytes": (_L, [_I, _I]),
     "etm_gate_train_bwd1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_gate_train_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "etm_conv_train_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_train_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_train_wgrad_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "etm_conv_train_wgrad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_relu_mask": (_I, [_P, _P, _P, _L, _P]),
     "etm_grad_sqnorm": (_I, [_P, _L, _P, _I, _P, _P]),
     "etm_adamw_clip": (_I, [_P, _P, _P, _P, _L, _P, _I, _P, _P, _D, _D, _D, _D, _F, _P, _P]),
     "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),

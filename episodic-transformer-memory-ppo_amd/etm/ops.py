@@ -578,6 +578,113 @@ def conv_relu(x, weight2d, bias, C, H, W, KH, KW, S, in_nhwc, out_nchw, index=No
     return out
 
 
+def conv_pack_dgrad_weights(weight, stride):
+    """conv weight [Cout, C, KH, KW] -> the S*S stride-parity class blocks etm_conv_train_dgrad reads (include/etm_hip.h):
+    class (py, px) packs Wd[c][(a*T + j)*Cout + co] = w[co][c][py + S a][px + S (T-1-j)], T = KH / S."""
+    Cout, C, KH, KW = weight.shape
+    S = int(stride)
+    T = KH // S
+    blocks = []
+    for py in range(S):
+        for px in range(S):
+            sub = weight[:, :, py::S, px::S].flip(3)                   # [Cout, C, a, j]
+            blocks.append(conv_pack_weights(sub.permute(1, 2, 3, 0).reshape(C, T * T * Cout)))
+    return torch.stack(blocks).contiguous()
+
+
+def encoder_train_supported(obs_shape, convs):
+    """Can the hand-written training kernels run this encoder?  (model.py:40-56 geometry with 84 x 84 or similar inputs.)"""
+    c, h, w = obs_shape
+    for conv in convs:
+        kh, kw = conv.kernel_size
+        s = conv.stride[0]
+        if (kh != kw or conv.stride[0] != conv.stride[1] or conv.padding != (0, 0) or conv.dilation != (1, 1) or conv.groups != 1
+                or conv.out_channels not in (32, 64) or (kw * c) % 8 or (w * c) % 4 or (s * c) % 4 or (kh * kw * c) % 32
+                or h < kh or w < kw):
+            return False
+        if conv is not convs[0] and (kh % s or h % s or w % s or c not in (32, 64)):     # backward-data of the layers above the first
+            return False
+        h, w, c = (h - kh) // s + 1, (w - kw) // s + 1, conv.out_channels
+    return True
+
+
+class _EncoderFn(torch.autograd.Function):
+    """The three relu(conv2d) layers of model.py:90-92 on NHWC activations: 3 forward launches; backward = 1 mask/layout kernel,
+    3 weight-gradient kernels (+ their fixed-order reductions) and 2 data-gradient kernels, with bias, ReLU, ReLU masks and
+    bias gradients fused in (csrc/conv_train.hip).  Returns the features NHWC-flattened [N, Ho*Wo*Cout]: the consumer permutes
+    the columns of ITS weight (a 4.8 MB copy at config 3) instead of the features being transposed to upstream's (c, h, w)
+    flatten order (model.py:94) and back."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, w1, b1, w2, b2, w3, b3, strides):
+        lib = _lib.load()
+        _need_dev(x_nhwc, w1, b1, w2, b2, w3, b3)
+        x = _f32c(x_nhwc, "obs")
+        st = _stream()
+        acts, shapes = [x], []
+        n, h, w, c = x.shape
+        for i, (wt, bs, s) in enumerate(((w1, b1, strides[0]), (w2, b2, strides[1]), (w3, b3, strides[2]))):
+            cout, _, kh, kw = wt.shape
+            ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
+            packed = conv_pack_weights(wt.detach().permute(0, 2, 3, 1).reshape(cout, -1))
+            y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+            _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(packed), _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s,
+                                              0, st), "etm_conv_train_fwd")
+            shapes.append((c, h, w, cout, kh, kw, s, ho, wo))
+            acts.append(y)
+            h, w, c = ho, wo, cout
+        ctx.shapes = shapes
+        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], w2, w3)
+        return acts[3].view(n, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x0, y1, y2, y3, w2, w3 = ctx.saved_tensors
+        st = _stream()
+        dev = x0.device
+        n = x0.shape[0]
+        g = _f32c(g, "d_features")
+        c3, h3, w3_, cout3, _, _, _, ho3, wo3 = ctx.shapes[2]
+        dy = torch.empty((n, ho3, wo3, cout3), dtype=torch.float32, device=dev)
+        _lib.check(lib.etm_relu_mask(_ptr(g), _ptr(y3), _ptr(dy), dy.numel(), st), "etm_relu_mask")
+        grads = [None] * 6
+        inputs = (x0, y1, y2)
+        weights = (None, w2, w3)
+        for i in (2, 1, 0):
+            c, h, w, cout, kh, kw, s, ho, wo = ctx.shapes[i]
+            K = kh * kw * c
+            buf = torch.empty(K * cout + cout, dtype=torch.float32, device=dev)
+            nbytes = lib.etm_conv_train_wgrad_workspace_bytes(n, c, h, w, cout, kh, kw, s)
+            ws = workspace(nbytes, dev, "conv_wgrad")
+            _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w, cout, kh, kw, s, st),
+                       "etm_conv_train_wgrad")
+            grads[2 * i] = buf[: K * cout].view(kh, kw, c, cout).permute(3, 2, 0, 1)       # -> [Cout, C, KH, KW]
+            grads[2 * i + 1] = buf[K * cout:]
+            if i > 0:
+                packed = conv_pack_dgrad_weights(weights[i].detach(), s)
+                dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
+                _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(packed), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
+                           "etm_conv_train_dgrad")
+                dy = dx
+        return (None, *grads, None)
+
+
+def encoder_train(obs_nhwc, conv1, conv2, conv3):
+    """Differentiable encoder forward on an NHWC observation batch [N, H, W, C]: features [N, Ho * Wo * Cout], NHWC-flattened
+    (``nhwc_columns`` gives the matching column order of the following linear layer's weight).  Gradients flow to the
+    convolution weights and biases (observations need none)."""
+    return _EncoderFn.apply(obs_nhwc, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias,
+                            (conv1.stride[0], conv2.stride[0], conv3.stride[0]))
+
+
+def nhwc_columns(weight, channels):
+    """Weight [out, C*H*W] of a linear layer that consumes upstream's (c, h, w)-flattened features -> the same map on
+    (h, w, c)-flattened features (differentiable: the gradient is permuted back)."""
+    out, feat = weight.shape
+    return weight.view(out, channels, feat // channels).transpose(1, 2).reshape(out, feat)
+
+
 def upload(dst, src_pinned, stream):
     """Asynchronous pinned-host -> device copy of a contiguous block on ``stream`` (a torch.cuda.Stream)."""
     lib = _lib.load()

@@ -26,6 +26,8 @@ class ActorCriticModel(nn.Module):
         self.visual = len(self.observation_space_shape) > 1
         self.channels_last = bool(config.get("encoder_channels_last", True))
         self.fused_encoder = bool(config.get("fused_rollout_encoder", True))
+        self.train_encoder = bool(config.get("fused_train_encoder", True))     # False: library convolutions in the optimisation phase
+        self._train_encoder_ok = None
         if self.visual:
             c = self.observation_space_shape[0]
             self.conv1 = nn.Conv2d(c, 32, 8, 4)
@@ -119,6 +121,15 @@ class ActorCriticModel(nn.Module):
         h = obs
         if self._fused_encoder_ok(obs):
             return self._encode_fused(obs)
+        if self.visual and self.train_encoder and obs.is_cuda and torch.is_grad_enabled() and obs.dim() == 4:
+            if self._train_encoder_ok is None:
+                self._train_encoder_ok = ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3))
+            if self._train_encoder_ok:
+                # optimisation phase: the three relu(conv2d) layers forward and backward on the hand-written MFMA kernels
+                # (NHWC activations; the trainer hands over an NCHW view of NHWC memory, which permutes back for free)
+                feats = ops.encoder_train(obs.permute(0, 2, 3, 1), self.conv1, self.conv2, self.conv3)      # (h, w, c) flatten order
+                w_nhwc = ops.nhwc_columns(self.lin_hidden.weight, self.conv3.out_channels)
+                return torch.relu(F.linear(feats, w_nhwc, self.lin_hidden.bias))
         if self.visual:
             if self.channels_last and h.is_cuda:
                 # NHWC activations: MIOpen's implicit-GEMM kernels run without layout transposes (1.35 vs 2.1 ms for

@@ -277,6 +277,33 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
 int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_stride, const float *w, const float *bias, float *out,
                   int N, int C, int H, int W, int Cout, int KH, int KW, int S, int in_nhwc, int out_nchw, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-side encoder (model.py:40-56, :90-94): `relu(conv2d(x))` forward, backward-data and backward-weight as fp32-MFMA
+ * implicit GEMMs with bias / ReLU / ReLU mask / bias gradient fused (csrc/conv_train.hip).  Activations are NHWC; no padding,
+ * dilation or groups; Cout in {32, 64}; (KW * C) % 8 == 0, (W * C) % 4 == 0, (S * C) % 4 == 0; fewer than 2^24 output pixels.
+ *   etm_conv_train_fwd  : y = relu(conv(x) + bias).  x NHWC [N,H,W,C]; w_packed = the [Cout, KH*KW*C] matrix (k ordered
+ *                         (ky, kx, c)) in the fragment order of etm_conv_relu; y NHWC [N,Ho,Wo,Cout] (out_nchw must be 0: the
+ *                         consumer of the last layer permutes its weight columns instead of the features, model.py:94).
+ *   etm_conv_train_dgrad: dx = conv_transpose(dy) * (y_below > 0): gradient wrt the layer INPUT x [N,H,W,C], multiplied by the
+ *                         ReLU mask of the layer below (y_below = x itself, the post-ReLU output of that layer; NULL: no mask),
+ *                         i.e. the pre-activation gradient the next etm_conv_train_wgrad / _dgrad call consumes.  dy NHWC
+ *                         [N,Ho,Wo,Cout] is a pre-activation gradient.  Needs KH == KW, KH % S == 0, H % S == 0, W % S == 0,
+ *                         C in {32, 64}.  w_packed: S*S blocks, one per stride-parity class (py, px) of the input pixels, each the
+ *                         fragment-order packing of Wd[c][(a*T + j)*Cout + co] = w[co][c][py + S a][px + S (T-1-j)], T = KH / S
+ *                         (etm.ops.conv_pack_dgrad_weights).
+ *   etm_conv_train_wgrad: dw_kc_dbias[k*Cout + co] = sum over pixels of x-window[k] * dy[co] (k ordered (ky, kx, c)), followed by
+ *                         dbias[Cout] = column sums of dy, in one buffer of KH*KW*C*Cout + Cout floats.  Pixel slices are summed
+ *                         in a fixed order through `workspace` (etm_conv_train_wgrad_workspace_bytes): deterministic.
+ *   etm_relu_mask       : out = g * (y > 0) over n floats (n % 4 == 0, 16-byte aligned): the ReLU backward of the last layer. */
+int etm_conv_train_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W, int Cout, int KH,
+                       int KW, int S, int out_nchw, void *stream);
+int etm_conv_train_dgrad(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
+                         int KH, int KW, int S, void *stream);
+int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
+int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N, int C,
+                         int H, int W, int Cout, int KH, int KW, int S, void *stream);
+int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *stream);
+
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
 int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);

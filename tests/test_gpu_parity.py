@@ -1101,6 +1101,70 @@ def test_flat_adamw_with_clipping_vs_torch():
     assert int(opt.step_dev) == 5
 
 
+@pytest.mark.parametrize("N,hw", [(5, 84), (64, 84), (7, 36), (33, 36)])
+def test_train_encoder_fwd_bwd_vs_float64_convs(N, hw):
+    """Training-side encoder kernels (fp32-MFMA implicit GEMMs with fused bias / ReLU / mask / bias gradient) against the
+    convolutions of model.py:90-94 evaluated in float64 on the host: features and every weight / bias gradient.  (The library's
+    fp32 weight-gradient kernels are themselves ~1e-3 off the float64 result, so they are not the yardstick.)"""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(N + hw)
+    convs = [torch.nn.Conv2d(3, 32, 8, 4), torch.nn.Conv2d(32, 64, 4, 2), torch.nn.Conv2d(64, 64, 3, 1)]
+    for c in convs:
+        with torch.no_grad():
+            c.bias.add_(0.05 * torch.randn_like(c.bias))
+    ref = [torch.nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride).double() for c in convs]
+    for r, c in zip(ref, convs):
+        r.load_state_dict({k: v.double() for k, v in c.state_dict().items()})
+        c.to(dev)
+    assert ops.encoder_train_supported((3, hw, hw), convs)
+    x = torch.rand((N, 3, hw, hw))
+    got = ops.encoder_train(x.to(dev).permute(0, 2, 3, 1).contiguous(), *convs)            # (h, w, c) flatten order
+    h = x.double()
+    for r in ref:
+        h = torch.relu(r(h))
+    want = h.permute(0, 2, 3, 1).reshape(N, -1)
+    assert got.shape == want.shape
+    close(got, want.detach().numpy(), atol=2e-5, rtol=1e-4, what="features")
+    go = torch.randn(want.shape)
+    g_got = torch.autograd.grad(got, [p for c in convs for p in (c.weight, c.bias)], go.to(dev))
+    g_want = torch.autograd.grad(want, [p for r in ref for p in (r.weight, r.bias)], go.double())
+    for i, (a, b) in enumerate(zip(g_got, g_want)):
+        # SURVEY 8c: gradients within 2e-4 of the tensor norm; measured ~1e-6 (fp32 summation order only)
+        assert a.shape == b.shape and _rel(a.cpu().double(), b) < 2e-5, (i, _rel(a.cpu().double(), b))
+
+
+def test_train_encoder_minibatch_size_properties():
+    """At the minibatch size of BASELINE config 3 (N = 2048, 3 x 84 x 84; too large for the float64 host reference): the features
+    agree with the library convolutions, and the weight / bias gradients are ADDITIVE over the batch -- the gradient of the
+    full batch equals the sum of the gradients of its eight slices (each slice covered by the float64 test's size range)."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(5)
+    N = 2048
+    convs = [torch.nn.Conv2d(3, 32, 8, 4).to(dev), torch.nn.Conv2d(32, 64, 4, 2).to(dev), torch.nn.Conv2d(64, 64, 3, 1).to(dev)]
+    params = [p for c in convs for p in (c.weight, c.bias)]
+    x = torch.rand((N, 3, 84, 84), device=dev)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    got = ops.encoder_train(x_nhwc, *convs)
+    with torch.no_grad():
+        h = x
+        for c in convs:
+            h = torch.relu(c(h))
+        want = h.permute(0, 2, 3, 1).reshape(N, -1)
+    close(got, want.cpu().numpy(), atol=5e-5, rtol=1e-3, what="features vs library convolutions")
+    go = torch.randn_like(got)
+    full = torch.autograd.grad(got, params, go)
+    parts = [torch.zeros_like(p) for p in params]
+    for k in range(8):
+        sl = slice(k * 256, (k + 1) * 256)
+        gs = torch.autograd.grad(ops.encoder_train(x_nhwc[sl].contiguous(), *convs), params, go[sl].contiguous())
+        for acc, g in zip(parts, gs):
+            acc += g
+    for i, (a, b) in enumerate(zip(full, parts)):
+        assert _rel(a, b) < 5e-6, (i, _rel(a, b))
+
+
 def test_poc_memory_env_learns():
     """BASELINE config (1) end to end on the MI355X path: PocMemoryEnv (goal cue visible only in the first two steps)
     through subprocess workers; the policy must learn to use its episodic memory (success >= 0.9 within 30 updates)."""
