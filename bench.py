@@ -119,6 +119,9 @@ def main():
                     help="gradient all-reduce through torch.distributed (RCCL backend) or through the library's own RCCL communicator")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="testing only: every rank uses this device index (exercises the multi-process path on a 1-GPU box)")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="testing only, no GPU needed: run the multi-process skeleton of this script (rank / world parsing, process "
+                         "group, sharding, barrier, flat-bucket all-reduce, max over ranks, rank-0 JSON line) on CPU tensors over gloo")
     ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
                     help="kernel family of the window attention (etm.ops.set_attention_impl); folded is the product default")
     args = ap.parse_args()
@@ -130,6 +133,31 @@ def main():
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
                              f"--nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
+    if args.plumbing_check:
+        from etm.dist import DataParallel
+        dp = DataParallel(torch.device("cpu"), backend="gloo", collective="torch") if world > 1 else None
+        first, count = (dp.shard(32 * world) if dp is not None else (0, 32))
+        assert (first, count) == (rank * 32, 32)
+        flat = torch.full((1000,), float(rank + 1))
+        if dp is not None:
+            dp.flat = flat
+            dp.barrier()
+        t0 = time.perf_counter()
+        if dp is not None:
+            dp.all_reduce_grads()
+            dp.barrier()
+        elapsed = time.perf_counter() - t0
+        if dp is not None:
+            elapsed = dp.max_over_ranks(elapsed)
+        want = sum(range(1, world + 1)) / world
+        assert abs(float(flat[0]) - want) < 1e-6, (float(flat[0]), want)
+        if rank == 0:
+            print(json.dumps({"metric": "plumbing-check", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "first_worker_of_last_rank": (world - 1) * 32, "allreduce_mean": float(flat[0]), "elapsed_s": elapsed}), flush=True)
+        if dp is not None:
+            dp.barrier()
+            dp.close()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the MI355X path; no HIP device is visible (there is no CPU fallback)")
     device = torch.device("cuda", local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device)

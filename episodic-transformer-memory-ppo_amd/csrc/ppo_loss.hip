@@ -57,6 +57,11 @@ struct LossParams {
   int N, A;
 };
 
+// SPT samples per thread.  SPT = 4 (large batches, unit strides, A = 3, N % 4 == 0): the four samples' operands come in as
+// 16-byte loads (logits: three float4 = 12 floats; advantages, values, old log-probs: one float4 each; actions: two 16-byte
+// loads) and the gradients leave the same way -- a quarter of the load / store instructions of the one-sample form, which
+// is what bounds this kernel at large N (28 + 8 A = 52 bytes per sample against ~10 scalar memory instructions).
+template <int SPT>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p0) {
   LossParams p = p0;
   if (p.dyn) {   // schedules that change between replays of a captured training step
@@ -66,40 +71,66 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p0) {
   }
   __shared__ float red[4][5];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.x * 256 + tid;
+  const int n0 = (blockIdx.x * 256 + tid) * SPT;
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // policy, value, entropy, kl, clip fraction
+  // operands of this thread's samples
+  float lgv[SPT][SPT == 1 ? 1 : 3], advv[SPT], oldlp[SPT], vv[SPT], vov[SPT], dlv[SPT][SPT == 1 ? 1 : 3], dvv[SPT];
+  int actv[SPT];
+  if (SPT == 4 && n0 < p.N) {
+    const f32x4 *lq = reinterpret_cast<const f32x4 *>(p.logits + (long long)n0 * 3);
+    const f32x4 l0 = lq[0], l1 = lq[1], l2 = lq[2];
+    const float flat[12] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3], l2[0], l2[1], l2[2], l2[3]};
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(p.adv + n0), o4 = *reinterpret_cast<const f32x4 *>(p.old_logp + n0);
+    const longlong2 c0 = *reinterpret_cast<const longlong2 *>(p.actions + n0), c1 = *reinterpret_cast<const longlong2 *>(p.actions + n0 + 2);
+    const long long acts[4] = {c0.x, c0.y, c1.x, c1.y};
+    f32x4 v4 = {0.f, 0.f, 0.f, 0.f}, vo4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.include_value) { v4 = *reinterpret_cast<const f32x4 *>(p.value + n0); vo4 = *reinterpret_cast<const f32x4 *>(p.old_value + n0); }
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+      for (int j = 0; j < (SPT == 1 ? 1 : 3); ++j) lgv[s][j] = flat[(s * 3 + j) % 12];
+      advv[s] = a4[s & 3]; oldlp[s] = o4[s & 3]; vv[s] = v4[s & 3]; vov[s] = vo4[s & 3]; actv[s] = (int)acts[s & 3];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SPT; ++s) {
+  const int n = n0 + s;
   if (n < p.N) {
     const int A = p.A;
     const float cnt = p.adv_stats3[0], mean = p.adv_stats3[1], m2 = p.adv_stats3[2];
     const float stdv = sqrtf(m2 / (cnt - 1.0f));            // torch.std: unbiased
-    const float a_raw = p.adv[n];
+    const float a_raw = SPT == 4 ? advv[s] : p.adv[n];
     const float a_n = (a_raw - mean) / (stdv + 1e-8f);
-    const float *lg = p.logits + (long long)n * A;
+    float lgl[3];
+    if (SPT == 4) { lgl[0] = lgv[s][0]; lgl[1] = lgv[s][SPT == 1 ? 0 : 1]; lgl[2] = lgv[s][SPT == 1 ? 0 : 2]; }
+    const float *lg = SPT == 4 ? lgl : p.logits + (long long)n * A;
     float mx = -INFINITY;
     for (int j = 0; j < A; ++j) mx = fmaxf(mx, lg[j]);
     float se = 0.f;
     for (int j = 0; j < A; ++j) se += expf(lg[j] - mx);
     const float lse = mx + logf(se);
-    const int act = (int)p.actions[(long long)n * p.action_stride];
-    const float lp = lg[act] - lse;
+    const int act = SPT == 4 ? actv[s] : (int)p.actions[(long long)n * p.action_stride];
+    float lg_act = lg[0];
+    if (SPT == 4) { lg_act = act == 1 ? lgl[1] : (act == 2 ? lgl[2] : lgl[0]); } else { lg_act = lg[act]; }
+    const float lp = lg_act - lse;
     float ent = 0.f;
     for (int j = 0; j < A; ++j) {
       const float l = lg[j] - lse;
       ent -= expf(l) * l;
     }
-    const float log_ratio = lp - p.old_logp[(long long)n * p.logp_stride];
+    const float log_ratio = lp - (SPT == 4 ? oldlp[s] : p.old_logp[(long long)n * p.logp_stride]);
     const float ratio = expf(log_ratio);
     const bool in_range = (ratio >= p.clip_lo) && (ratio <= p.clip_hi);
     const float s1 = ratio * a_n;
     const float s2 = fminf(fmaxf(ratio, p.clip_lo), p.clip_hi) * a_n;
-    acc[0] = fminf(s1, s2);
+    acc[0] += fminf(s1, s2);
     float g_ratio;  // d min(s1, s2) / d ratio
     if (s1 < s2) g_ratio = a_n;
     else if (s1 > s2) g_ratio = in_range ? a_n : 0.f;
     else g_ratio = 0.5f * a_n + (in_range ? 0.5f * a_n : 0.f);
-    acc[2] = ent;
-    acc[3] = (ratio - 1.0f) - log_ratio;
-    acc[4] = (fabsf(ratio - 1.0f) > p.clip) ? 1.f : 0.f;
+    acc[2] += ent;
+    acc[3] += (ratio - 1.0f) - log_ratio;
+    acc[4] += (fabsf(ratio - 1.0f) > p.clip) ? 1.f : 0.f;
     // d loss / d logits
     const float cpol = -p.pol_scale * g_ratio * ratio;
     const float cent = -p.beta * p.ent_scale;
@@ -109,24 +140,38 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossParams p0) {
       const float pj = expf(l);
       const float d_lp = ((j == act) ? 1.f : 0.f) - pj;   // d log p[act] / d logit_j
       const float d_ent = -pj * (l + ent);                // d entropy / d logit_j
-      dl[j] = cpol * d_lp + cent * d_ent;
+      const float g = cpol * d_lp + cent * d_ent;
+      if (SPT == 4) dlv[s][SPT == 1 ? 0 : j] = g; else dl[j] = g;
     }
     if (p.include_value) {
-      const float v = p.value[n], vo = p.old_value[n];
+      const float v = SPT == 4 ? vv[s] : p.value[n], vo = SPT == 4 ? vov[s] : p.old_value[n];
       const float ret = vo + a_raw;
       const float dv = v - vo;
       const bool in_v = (dv >= -p.clip) && (dv <= p.clip);
       const float vc = vo + fminf(fmaxf(dv, -p.clip), p.clip);
       const float e1 = v - ret, e2 = vc - ret;
       const float v1 = e1 * e1, v2 = e2 * e2;
-      acc[1] = fmaxf(v1, v2);
+      acc[1] += fmaxf(v1, v2);
       const float g2 = in_v ? 2.f * e2 : 0.f;
       float gv;
       if (v1 > v2) gv = 2.f * e1;
       else if (v1 < v2) gv = g2;
       else gv = e1 + 0.5f * g2;
-      p.d_value[n] = p.vf_coef * p.val_scale * gv;
+      if (SPT == 4) dvv[s] = p.vf_coef * p.val_scale * gv; else p.d_value[n] = p.vf_coef * p.val_scale * gv;
     }
+  }
+  }
+  if (SPT == 4 && n0 < p.N) {
+    f32x4 *dq = reinterpret_cast<f32x4 *>(p.d_logits + (long long)n0 * 3);
+    float flat[12];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s)
+#pragma unroll
+      for (int j = 0; j < (SPT == 1 ? 1 : 3); ++j) flat[(s * 3 + j) % 12] = dlv[s][j];
+    dq[0] = f32x4{flat[0], flat[1], flat[2], flat[3]};
+    dq[1] = f32x4{flat[4], flat[5], flat[6], flat[7]};
+    dq[2] = f32x4{flat[8], flat[9], flat[10], flat[11]};
+    if (p.include_value) *reinterpret_cast<f32x4 *>(p.d_value + n0) = f32x4{dvv[0], dvv[SPT == 1 ? 0 : 1], dvv[SPT == 1 ? 0 : 2], dvv[SPT == 1 ? 0 : 3]};
   }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
@@ -171,6 +216,7 @@ extern "C" int etm_adv_stats(const float *adv, int N, float *stats3, void *strea
 }
 
 extern "C" int64_t etm_ppo_loss_workspace_bytes(int N) { return N <= 0 ? 0 : (int64_t)((N + 255) / 256) * 8 * sizeof(float); }
+static bool al16(const void *q) { return ((uintptr_t)q % 16) == 0; }
 
 extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t action_stride, const float *old_logp,
                             int64_t logp_stride, const float *adv, const float *old_value, const float *value,
@@ -191,11 +237,15 @@ extern "C" int etm_ppo_loss(const float *logits, const int64_t *actions, int64_t
   p.dyn = dyn_clip_beta;
   p.include_value = include_value; p.d_logits = d_logits; p.d_value = d_value; p.partials = (float *)partials;
   p.N = N; p.A = A;
-  const int nb = (N + 255) / 256;
+  // four samples per thread when every operand can move in 16-byte pieces and there are enough samples to fill the chip
+  const bool vec = A == 3 && N % 4 == 0 && N >= (1 << 16) && action_stride == 1 && logp_stride == 1 && al16(logits) && al16(actions) &&
+                   al16(old_logp) && al16(adv) && al16(d_logits) && (!include_value || (al16(value) && al16(old_value) && al16(d_value)));
+  const int nb = vec ? (N / 4 + 255) / 256 : (N + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
   {
     EtmProfScope prof(ETM_K_PPO_LOSS, st);
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(256), 0, st, p);
+    if (vec) hipLaunchKernelGGL(ppo_loss_kernel<4>, dim3(nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(ppo_loss_kernel<1>, dim3(nb), dim3(256), 0, st, p);
   }
   int rc = etm_launch_status();
   if (rc) return rc;

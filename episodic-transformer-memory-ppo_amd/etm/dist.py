@@ -15,10 +15,13 @@ import torch.distributed as dist
 
 class DataParallel:
     def __init__(self, device=None, backend=None, collective=None):
-        """``collective``: who issues the gradient all-reduce -- "torch" (default: torch.distributed, backend nccl = RCCL) or
-        "etm" (the library's own RCCL communicator, ``etm_comm_*`` / ``etm_allreduce_f32``, enqueued on the current stream;
-        HIP device tensors only; rendezvous id distributed through torch.distributed).  ETM_DP_COLLECTIVE overrides."""
-        self.collective = os.environ.get("ETM_DP_COLLECTIVE") or collective or "torch"
+        """``collective``: who issues the gradient all-reduce -- "etm" (default: the library's own RCCL communicator,
+        ``etm_comm_*`` / ``etm_allreduce_f32`` of include/etm_hip.h, enqueued on the current stream; HIP device tensors and the
+        nccl (= RCCL) process-group backend only; rendezvous id carried by torch.distributed) or "torch" (torch.distributed's
+        all_reduce).  The environment variable ETM_DP_COLLECTIVE is used when the argument is None.  If the library
+        communicator cannot be created (CPU tensors, gloo backend, several ranks on one device, RCCL not loadable) the torch
+        collective takes over with a message -- a transport choice, the summed gradients are the same."""
+        self.collective = collective or os.environ.get("ETM_DP_COLLECTIVE") or "etm"     # an explicit argument wins over the environment
         if self.collective not in ("torch", "etm"):
             raise ValueError(f"collective must be 'torch' or 'etm', got {self.collective!r}")
         self._comm = None
@@ -36,6 +39,8 @@ class DataParallel:
             if backend == "nccl":
                 kw["device_id"] = torch.device(device)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+        if self.world > 1 and self.collective == "etm":
+            self._start_etm_comm()
 
     @property
     def active(self):
@@ -64,6 +69,42 @@ class DataParallel:
             p.grad = self.flat[off: off + p.numel()].view_as(p)
             off += p.numel()
         return self.flat
+
+    def _start_etm_comm(self):
+        """Create the library communicator now (not inside the first optimisation step, which may be under graph capture) and
+        check it with a one-element all-reduce; any failure selects the torch collective."""
+        why = None
+        try:
+            if self.device is None or torch.device(self.device).type != "cuda" or dist.get_backend() != "nccl":
+                why = "needs HIP device tensors and the nccl (RCCL) backend"
+            else:
+                from . import lib as _lib
+                comm = self._etm_comm()
+                dev = torch.device(self.device)
+                probe = torch.ones(4, dtype=torch.float32, device=dev)
+                rc = _lib.load().etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(rc, "etm_allreduce_f32")
+                torch.cuda.synchronize(dev)
+                if probe.tolist() != [float(self.world)] * 4:
+                    why = f"self-test all-reduce returned {probe.tolist()}"
+        except Exception as exc:           # noqa: BLE001 -- any failure: use the framework's collective
+            why = repr(exc)
+        # all ranks must agree on the transport
+        flag = torch.tensor([0 if why is None else 1], dtype=torch.int32,
+                            device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            if self.rank == 0 or why is not None:
+                print(f"[etm.dist] rank {self.rank}: library RCCL communicator not used ({why or 'another rank could not create it'}); "
+                      "gradient all-reduce goes through torch.distributed", flush=True)
+            if self._comm is not None:
+                try:
+                    from . import lib as _lib
+                    _lib.load().etm_comm_destroy(self._comm)
+                except Exception:          # noqa: BLE001
+                    pass
+                self._comm = None
+            self.collective = "torch"
 
     def _etm_comm(self):
         """Library-owned RCCL communicator (created on first use): rank 0 draws the rendezvous id, torch.distributed carries
@@ -103,17 +144,18 @@ class DataParallel:
         self.flat.div_(self.world)
 
     def merge_adv_stats(self, stats3: torch.Tensor) -> torch.Tensor:
-        """Merge per-rank (count, mean, M2) into global statistics (Chan et al. pairwise update)."""
+        """Merge per-rank (count, mean, M2) into global statistics (Chan et al. pairwise update).  ``stats3`` is [3] or
+        [k, 3] (k independent minibatches merged row-wise with ONE all-gather)."""
         if not self.active:
             return stats3
         gathered = [torch.empty_like(stats3) for _ in range(self.world)]
-        dist.all_gather(gathered, stats3)
-        allst = torch.stack(gathered)               # [world, 3]
-        n, mean, m2 = allst[:, 0], allst[:, 1], allst[:, 2]
-        tot = n.sum()
-        gmean = (n * mean).sum() / tot
-        gm2 = (m2 + n * (mean - gmean) ** 2).sum()
-        return torch.stack([tot, gmean, gm2])
+        dist.all_gather(gathered, stats3.contiguous())
+        allst = torch.stack(gathered)               # [world, (k,) 3]
+        n, mean, m2 = allst[..., 0], allst[..., 1], allst[..., 2]
+        tot = n.sum(dim=0)
+        gmean = (n * mean).sum(dim=0) / tot
+        gm2 = (m2 + n * (mean - gmean) ** 2).sum(dim=0)
+        return torch.stack([tot, gmean, gm2], dim=-1)
 
     def max_over_ranks(self, value: float) -> float:
         if not self.active:

@@ -138,7 +138,9 @@ class PPOTrainer:
                 tunable.enable(True)
                 tunable.tuning_enable(True)
                 # results file (written by the library at exit) goes to the temp directory, not the working directory
-                tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "etm_tunableop_results.csv"), True)
+                # one results file per rank: data-parallel ranks tune independently and must not write the same file
+                rank_tag = "" if dp is None else f"_rank{dp.rank}"
+                tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"etm_tunableop_results{rank_tag}.csv"), True)
                 tunable.set_max_tuning_duration(30)
                 tunable.set_max_tuning_iterations(20)
             except Exception as exc:        # an older / newer torch without this API: run with the default heuristics
@@ -271,11 +273,19 @@ class PPOTrainer:
                 head = "{:4} (no finished episode yet)".format(update)
             if "success_percent" in episode_result:
                 head += " success={:.2f}".format(episode_result["success_percent"])
-            print(head + " pi_loss={:3f} v_loss={:3f} entropy={:.3f} loss={:3f} value={:.3f} advantage={:.3f} steps/s={:.0f}".format(
-                training_stats[0], training_stats[1], training_stats[3], training_stats[2], vmean, amean, steps_per_s))
+            if self._is_main:
+                print(head + " pi_loss={:3f} v_loss={:3f} entropy={:.3f} loss={:3f} value={:.3f} advantage={:.3f} steps/s={:.0f}".format(
+                    training_stats[0], training_stats[1], training_stats[3], training_stats[2], vmean, amean, steps_per_s))
             self._write_gradient_summary(update, grad_info)
             self._write_training_summary(update, training_stats, episode_result, vmean, amean, steps_per_s)
-        self._save_model()
+        if self._is_main:              # replicas are identical: one rank writes the checkpoint
+            self._save_model()
+        if self.dp is not None:
+            self.dp.barrier()
+
+    @property
+    def _is_main(self):
+        return self.dp is None or self.dp.rank == 0
 
     def schedules(self, update: int):
         s = lambda c: polynomial_decay(c["initial"], c["final"], c["max_decay_steps"], c["power"], update)
@@ -659,8 +669,16 @@ class PPOTrainer:
                 perm = torch.as_tensor(perms[epoch], device=self.device, dtype=torch.long)
             if sort_mb and perm.numel() % mbs == 0:
                 perm = perm.view(-1, mbs).sort(dim=1).values.reshape(-1)
+            self._epoch_stats3 = None
+            if self.dp is not None and self.dp.active and perm.numel() % mbs == 0:
+                # data parallel: the global-minibatch advantage statistics of ALL minibatches of the epoch from one all-gather
+                # (they depend only on the advantages and the permutation, not on the weights)
+                adv = self.buffer.samples_flat["advantages"].index_select(0, perm).view(-1, mbs)
+                local = torch.stack([ops.adv_stats(adv[i]) for i in range(adv.shape[0])])
+                self._epoch_stats3 = self.dp.merge_adv_stats(local)
             for start in range(0, self.buffer.batch_size, mbs):
                 idx = perm[start: start + mbs]
+                self._mb_stats3 = self._epoch_stats3[start // mbs] if self._epoch_stats3 is not None else None
                 if self._use_train_graph and idx.numel() == mbs:
                     st_row, norm_row = self._train_step_graph(idx, learning_rate, clip_range, beta, monitor)
                     stats.append(st_row)
@@ -673,6 +691,7 @@ class PPOTrainer:
                     norms.append(self._grad_group_norms())
         train_info = torch.stack(stats).cpu().numpy()          # the only host sync of the optimisation phase
         self._bank_pos = None
+        self._mb_stats3 = self._epoch_stats3 = None
         grad_info = {}
         if norms:
             allnorms = torch.stack(norms).cpu().numpy()
@@ -690,9 +709,11 @@ class PPOTrainer:
             spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
                                         samples["memory_mask"])
         logits, value, _ = self.model.forward_logits(samples["obs"], spec)
-        stats3 = ops.adv_stats(samples["advantages"])
-        if self.dp is not None:
-            stats3 = self.dp.merge_adv_stats(stats3)
+        stats3 = getattr(self, "_mb_stats3", None)
+        if stats3 is None:
+            stats3 = ops.adv_stats(samples["advantages"])
+            if self.dp is not None:
+                stats3 = self.dp.merge_adv_stats(stats3)
         loss, stats = ops.ppo_loss(logits, value, samples["actions"], samples["log_probs"], samples["advantages"],
                                    samples["values"], clip_range, self.config["value_loss_coefficient"], beta, stats3)
         self._set_lr(learning_rate)
@@ -787,8 +808,11 @@ class PPOTrainer:
             self._dyn.copy_(torch.tensor([clip_range, beta], dtype=torch.float64))
             self._sched_host[1:] = [clip_range, beta]
         if dp is not None:
-            adv = self.buffer.samples_flat["advantages"].index_select(0, self._tg_idx)
-            self._tg_stats3.copy_(dp.merge_adv_stats(ops.adv_stats(adv)))
+            if getattr(self, "_mb_stats3", None) is not None:
+                self._tg_stats3.copy_(self._mb_stats3)
+            else:
+                adv = self.buffer.samples_flat["advantages"].index_select(0, self._tg_idx)
+                self._tg_stats3.copy_(dp.merge_adv_stats(ops.adv_stats(adv)))
         self._mb_counter += 1
         sample_eager = self.profile_sample_every and self._mb_counter % self.profile_sample_every == 0
         key = (monitor, self._bank_pos is not None)
@@ -862,8 +886,10 @@ class PPOTrainer:
         """``pickle((state_dict, config))`` to ./models/<run_id>.nn -- upstream's checkpoint format (trainer.py:356-362)."""
         os.makedirs("./models", exist_ok=True)
         state = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
-        with open("./models/" + self.run_id + ".nn", "wb") as f:
+        path = "./models/" + self.run_id + ".nn"
+        with open(path + ".tmp", "wb") as f:
             pickle.dump((state, self.config), f)
+        os.replace(path + ".tmp", path)                # never a torn file at the final path
         print("Model saved to " + "./models/" + self.run_id + ".nn")
 
     def close(self, exit_process: bool = False) -> None:

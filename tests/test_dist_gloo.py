@@ -79,3 +79,20 @@ def test_single_process_is_passthrough():
     assert not dp.active and dp.shard(32) == (0, 32)
     s = torch.tensor([4.0, 1.0, 2.0])
     assert dp.merge_adv_stats(s) is s and dp.max_over_ranks(3.5) == 3.5
+
+
+def test_bench_multi_process_plumbing_on_cpu():
+    """The driver's multi-GPU invocation of bench.py (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...):
+    rank / world parsing, process group, sharding, barriers, flat-bucket all-reduce, max over ranks and the rank-0 JSON line,
+    with CPU tensors over gloo (--plumbing-check: the trainer itself needs the GPU)."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--plumbing-check"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and abs(rec["allreduce_mean"] - 1.5) < 1e-6

@@ -197,13 +197,12 @@ def test_mha_banked_vs_oracle(D, H, L, N, ln, pos, attn_impl):
         x = x + pt[pidx]
     if ln:
         x = torch.nn.functional.layer_norm(x, (D,), lg, lb, 1e-5)
-    hd = D // H
-    k = (x @ wk.t()).reshape(N, L, H, hd)
-    v = (x @ wv.t()).reshape(N, L, H, hd)
-    e = torch.einsum("nhd,nkhd->nhk", q.reshape(N, H, hd), k)
-    e = e.masked_fill(mask[:, None, :] == 0, float("-1e20"))
-    a = torch.softmax(e / (D ** 0.5), dim=2)
-    ctx = torch.einsum("nhl,nlhd->nhd", a, v).reshape(N, D)
+    # the attention itself is the oracle's restatement of transformer.py:31-86 (oracle.ref_model.mha); the test hands over already
+    # projected queries and takes the context before fc_out, so those two maps are the identity here
+    eye = torch.eye(D)
+    sd = {"a.values.weight": wv, "a.keys.weight": wk, "a.queries.weight": eye, "a.fc_out.weight": eye, "a.fc_out.bias": torch.zeros(D)}
+    ctx3, a4 = rm.mha(sd, "a", H, x, x, q.unsqueeze(1), mask)
+    ctx, a = ctx3[:, 0], a4[:, :, 0]
     (ctx * gout).sum().backward()
     ref = dict(ctx=ctx.detach(), att=a.detach(), q=q.grad, wk=wk.grad, wv=wv.grad, lg=lg.grad, lb=lb.grad, pt=pt.grad)
 
@@ -331,6 +330,33 @@ def test_ppo_loss_multi_branch_vs_oracle():
     for a, b in zip(lgd, lg):
         close(a.grad, b.grad.numpy(), atol=1e-8, rtol=2e-3, what="glogits")
     close(vd.grad, value.grad.numpy(), atol=1e-8, rtol=2e-3, what="gvalue")
+
+
+def test_ppo_loss_vectorised_path_vs_oracle():
+    """Large-batch form of the loss kernel (four samples per thread, 16-byte operand moves; taken from 65,536 samples with three
+    actions) against the oracle's restatement of trainer.py:276-304, including ties of the clipping rules (exact 1.0 ratios)."""
+    from etm import ops
+    from oracle import ref_algo as ra
+    dev = _dev()
+    g = torch.Generator().manual_seed(14)
+    N = 1 << 16
+    lg = [torch.randn((N, 3), generator=g).requires_grad_(True)]
+    value = torch.randn((N,), generator=g).requires_grad_(True)
+    actions = torch.randint(0, 3, (N, 1), generator=g)
+    with torch.no_grad():
+        lsm = torch.log_softmax(lg[0], dim=1).gather(1, actions)
+    old = lsm + torch.randn((N, 1), generator=g) * 0.2
+    old[::7] = lsm[::7]                                        # ratio exactly 1: the tie branches of min / clamp
+    adv, oldv = torch.randn((N,), generator=g), torch.randn((N,), generator=g)
+    loss, stats = ra.ppo_loss(lg, value, actions, old, adv, oldv, 0.2, 0.3, 0.01)
+    loss.backward()
+    lgd = [lg[0].detach().to(dev).requires_grad_(True)]
+    vd = value.detach().to(dev).requires_grad_(True)
+    l2, s2 = ops.ppo_loss(lgd, vd, actions.to(dev), old.to(dev), adv.to(dev), oldv.to(dev), 0.2, 0.3, 0.01)
+    l2.backward()
+    close(s2, stats.numpy(), atol=2e-6, rtol=2e-4, what="stats")
+    close(lgd[0].grad, lg[0].grad.numpy(), atol=1e-10, rtol=2e-3, what="glogits")
+    close(vd.grad, value.grad.numpy(), atol=1e-10, rtol=2e-3, what="gvalue")
 
 
 # ------------------------------------------------------------------ whole path: teacher-forced rollout + updates vs the reference
@@ -949,6 +975,11 @@ def test_train_cli_and_checkpoint_format(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(pkg, "train.py"), "--config", str(cfg_path), "--cpu"], cwd=tmp_path,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "no CPU trainer" in (bad.stderr + bad.stdout)
+    # enjoy.py (upstream enjoy.py:48-96) loads that checkpoint and plays one episode with the model on the device
+    play = subprocess.run([sys.executable, os.path.join(pkg, "enjoy.py"), "--model", str(tmp_path / "models" / "clitest.nn")], cwd=tmp_path,
+                          capture_output=True, text=True, timeout=300)
+    assert play.returncode == 0, play.stderr[-2000:]
+    assert "Episode length:" in play.stdout and "Episode reward:" in play.stdout
 
 
 def test_fused_rollout_encoder_vs_library_convs():
