@@ -110,8 +110,9 @@ class SyntheticVecEnv:
         self._pool = pool
         streams = [_WorkerStream(first_worker_id + w, obs_shape, seed, pool) for w in range(self.num_envs)]
         self._rngs = [s.rng for s in streams]
-        # [W, pool, *obs]: one strided copy per step (all cursors advance in lock-step)
-        self._frames = np.stack([s.frames for s in streams], axis=0)
+        # [pool, W, *obs]: all cursors advance in lock-step, so the observations of one step are ONE contiguous block
+        # (a single memcpy per step / per row chunk instead of W strided ones)
+        self._frames = np.ascontiguousarray(np.stack([s.frames for s in streams], axis=1))
         self._u = np.empty((self.num_envs, _CHUNK, 2))
         self._upos = _CHUNK
         self._cursor = 0
@@ -122,7 +123,7 @@ class SyntheticVecEnv:
     MIN_CHUNKED_ENVS = 16   # fewer environments (a small worker group): one notification for all rows
 
     def _emit(self, out, on_rows=None):
-        frame = self._frames[:, self._cursor % self._pool]
+        frame = self._frames[self._cursor % self._pool]
         self._cursor += 1
         if out is None:
             out = np.empty_like(frame)

@@ -371,10 +371,11 @@ _ROLLOUT_PATHS = {
     "groups4": {"rollout_groups": 4},
     "host_flag": {"host_flag_actions": True},
     "eager_train": {"hip_graph_train": False},
+    "library_convs": {"fused_train_encoder": False},          # optimisation phase on the library convolutions
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
-             ("img32", "groups4"), ("img32", "host_flag"), ("img32", "eager_train")]
+             ("img32", "groups4"), ("img32", "host_flag"), ("img32", "eager_train"), ("img32", "library_convs")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -450,6 +451,7 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
     if name == "img32" and path == "default":
         assert tr._step_graph is not None and tr._stream_obs and len(tr._groups) == 2 and tr._train_graph is not None, \
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
+        assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
     if path == "groups4":
         assert len(tr._groups) == 4
     if path == "host_flag":

@@ -1,18 +1,36 @@
 #!/bin/bash
-# PMC passes for kernel #1 at the training shape (run on the MI355X box; counters in separate passes, no tracing domains
-# besides --kernel-trace, as the profiling guide prescribes).  Output: gpurun_out/pmc/<pass>/*counter_collection.csv
+# rocprofv3 PMC passes of the kernel micro-benchmarks (tools/kernel_rooflines.py) and of the encoder kernels
+# (tools/conv_time.py); run on the MI355X box.  Counters are collected in separate passes with --kernel-trace only (no other
+# tracing domain), as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2).
+#   bash tools/run_pmc.sh [targets...]          default targets: window_cold window_train window_cold128 mfma3 gae ppo conv
+# Output: gpurun_out/pmc_r02/<target>/<pass>/*counter_collection.csv  ->  python tools/pmc_summarize.py gpurun_out/pmc_r02 profiles/r02_pmc_summary.json
 set -u
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-IMPL=${ETM_ATTENTION:-folded}
-export ETM_ATTENTION=$IMPL
-OUT=$ROOT/gpurun_out/pmc_$IMPL
-mkdir -p $OUT
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_${IMPL}_$tag -o pmc -- python $ROOT/tools/mha_shape_run.py 3 > /tmp/pmc_${IMPL}_$tag.log 2>&1
-  mkdir -p $OUT/$tag
-  for f in $(find /tmp/pmc_${IMPL}_$tag -name "*counter_collection.csv"); do cp $f $OUT/$tag/; done
-  tail -1 /tmp/pmc_${IMPL}_$tag.log
+OUT=$ROOT/gpurun_out/pmc_r02
+TARGETS=${@:-window_cold window_train window_cold128 mfma3 gae ppo conv}
+for target in $TARGETS; do
+  if [ $target = conv ]; then cmd="python $ROOT/tools/conv_time.py"; else cmd="python $ROOT/tools/kernel_rooflines.py $target 6"; fi
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
+    rm -rf /tmp/pmc_run
+    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_run -o pmc -- $cmd > /tmp/pmc_run.log 2>&1
+    mkdir -p $OUT/$target/$tag
+    for f in $(find /tmp/pmc_run -name "*counter_collection.csv"); do
+      # keep the rows of this build's kernels only (the csv of a whole process is tens of MB)
+      python - "$f" "$OUT/$target/$tag/counters.csv" <<'PY'
+import csv, sys
+src, dst = sys.argv[1], sys.argv[2]
+with open(src) as f, open(dst, "w", newline="") as g:
+    r = csv.DictReader(f)
+    w = csv.DictWriter(g, fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value"])
+    w.writeheader()
+    for row in r:
+        n = row["Kernel_Name"]
+        if "anonymous namespace" in n and "at::native" not in n and " ck::" not in n:
+            w.writerow({k: row[k] for k in ("Kernel_Name", "Counter_Name", "Counter_Value")})
+PY
+    done
+    echo "$target / $tag: $(wc -l < $OUT/$target/$tag/counters.csv 2>/dev/null) rows"
+  done
 done
-ls -R $OUT | head -30
