@@ -369,13 +369,13 @@ _ROLLOUT_PATHS = {
     "graph_one_group": {"rollout_groups": 1},
     "graph_unstreamed": {"stream_observations": False},
     "groups4": {"rollout_groups": 4},
-    "host_flag": {"host_flag_actions": True},
+    "event_handover": {"host_flag_actions": False},          # head graph, event, tail graph instead of one graph + pinned flag
     "eager_train": {"hip_graph_train": False},
     "library_convs": {"fused_train_encoder": False},          # optimisation phase on the library convolutions
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
-             ("img32", "groups4"), ("img32", "host_flag"), ("img32", "eager_train"), ("img32", "library_convs")]
+             ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -454,8 +454,8 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
     if path == "groups4":
         assert len(tr._groups) == 4
-    if path == "host_flag":
-        assert tr._host_flag
+    if path == "event_handover":
+        assert not tr._host_flag
     tr.close()
 
 
@@ -607,11 +607,11 @@ def _rollout_variants_agree(variants, n_workers=16, checks=True):
             snap[-1]["rewards"] = torch.from_numpy(np.asarray(b.rewards).copy())
             tr._train_epochs(3e-4, 0.1, 1e-3, perms=[np.arange(n_workers * 40)])
         if not over and checks:
-            assert tr._stream_obs and not tr._host_flag and len(tr._groups) == 2, "default config: streamed, two worker groups"
+            assert tr._stream_obs and tr._host_flag and len(tr._groups) == 2, "default config: streamed, flag hand-over, two worker groups"
         if "rollout_groups" in over:
             assert len(tr._groups) == over["rollout_groups"]
-        if over.get("host_flag_actions"):
-            assert tr._host_flag
+        if over.get("host_flag_actions") is False:
+            assert not tr._host_flag
         results.append(snap)
         tr.close()
     for other in results[1:]:
@@ -625,7 +625,7 @@ def _rollout_variants_agree(variants, n_workers=16, checks=True):
 def test_rollout_fast_paths_agree():
     """Graph rollout with observation streaming + host-flag action hand-over (defaults), the graph without them, and the eager
     step must sample the same actions and fill the buffer identically."""
-    _rollout_variants_agree([dict(host_flag_actions=True), dict(), dict(rollout_groups=1), dict(stream_observations=False),
+    _rollout_variants_agree([dict(), dict(host_flag_actions=False), dict(rollout_groups=1), dict(stream_observations=False),
                              dict(stream_observations=False, rollout_groups=1), dict(hip_graph_rollout=False)])
 
 
@@ -674,7 +674,7 @@ def test_small_worker_groups_stress():
 
 def test_rollout_group_counts_agree():
     """One, two and four pipelined worker groups (and the host-flag hand-over) against the shipped defaults at 32 workers."""
-    _rollout_variants_agree([dict(), dict(rollout_groups=4), dict(rollout_groups=1), dict(rollout_groups=4, host_flag_actions=True)],
+    _rollout_variants_agree([dict(), dict(rollout_groups=4), dict(rollout_groups=1), dict(rollout_groups=4, host_flag_actions=False)],
                             n_workers=32)
 
 

@@ -46,7 +46,7 @@ if tr._step_graph is not None:
     for _ in range(n):
         tr._step_graph[0].replay()
     e1.record()
-    for _ in range(n):
+    for _ in range(n if tr._step_graph[1] is not None else 0):
         tr._step_graph[1].replay()
     e2.record(); torch.cuda.synchronize()
     print(f"step graphs of one group ({g0.W} workers) back-to-back: head {e0.elapsed_time(e1) / n * 1e3:.1f} us, "
