@@ -81,7 +81,7 @@ enum EtmKernelId {
   ETM_K_GAE, ETM_K_ADV_STATS, ETM_K_PPO_LOSS, ETM_K_PPO_FINAL, ETM_K_ATTN_CACHED, ETM_K_RESET_ROWS,
   ETM_K_ROLLOUT_WINDOW, ETM_K_ROLLOUT_SAMPLE, ETM_K_ADD_LN, ETM_K_CONV_RELU, ETM_K_ROLLOUT_HEADS, ETM_K_GRU_GATE, ETM_K_WINDOW_FWD, ETM_K_WINDOW_BWD,
   ETM_K_LN_TRAIN_FWD, ETM_K_LN_TRAIN_BWD, ETM_K_COLSUM, ETM_K_GATE_TRAIN, ETM_K_OPTIM,
-  ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_TRAIN_DGRAD, ETM_K_CONV_TRAIN_WGRAD,
+  ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_TRAIN_DGRAD, ETM_K_CONV_TRAIN_WGRAD, ETM_K_ROLLOUT_FUSED,
   ETM_K_COUNT
 };
 // LayerNorm statistics of the gathered window rows (defined in mha_fwd.hip; shared by the dense and the folded attention).

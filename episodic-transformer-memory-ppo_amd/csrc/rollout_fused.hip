@@ -1,0 +1,600 @@
+// Rollout step, transformer + heads + sampling of one worker group as ONE launch (SURVEY.md section 8 f1;
+// /root/reference trainer.py:163-186 -> model.py:96-112 -> transformer.py:222-253 for the post-LN layout without gates).
+//
+// At 16 - 32 workers a rollout step is not bound by flops or bytes but by the NUMBER of dependent launches on the device
+// (5 - 7 us each) and, on the host, by the cost of launching the captured step, which grows with the number of graph nodes
+// (~1 us per node).  The block loop of the multi-launch path is 6 launches per block (q GEMM, cached attention, fc_out GEMM,
+// residual + LayerNorm, fc GEMM, residual + LayerNorm) + embedding + hidden heads + policy = 21 launches for 3 blocks.
+// Workers are independent, so the whole chain of ONE worker is a sequence of matrix-VECTOR products over weights shared by all
+// workers.  One workgroup per worker is not enough: a D x D product streams 0.6 MB of weights and one CU takes ~7 us for that
+// (measured), no faster than the launch it replaces.  So a worker is handled by a TEAM of P workgroups (P = 4 at H = 4): every
+// member owns D / P columns of each product (and H / P heads of the attention), reads a quarter of the weights, and the members
+// exchange their pieces through memory (see "team exchange" below).  A team sits on ONE XCD (workgroup b is observed to run on
+// XCD b % 8; the block -> (worker, member) map uses that); every spin is bounded (a partner that never shows up sets an error
+// word instead of hanging the device).
+//
+// With the weights split four ways every phase is ONE memory round trip (~2.5 us from the Infinity Cache: the weights do not stay
+// in a 4 MB L2 from step to step) and there are ~25 dependent phases, so the kernel is latency-bound, not bandwidth-bound
+// (timeline: tools/rollout_stamps.py).  Therefore nothing a phase needs is loaded when the phase starts: the slice of the NEXT
+// product sits in registers (512 threads x up to 32 float4) from the moment the previous product has consumed them, the K and V
+// columns of the window rows are loaded at the top of the block, biases / gains / mask / sampling inputs before they are needed,
+// and the workgroup barriers are bare s_barrier + LDS waits (a __syncthreads() would drain the loads in flight: its release
+// fence is s_waitcnt vmcnt(0), loads and stores share that counter on this part).
+//
+//   exchange E0   h = relu(W_emb x + b)                        each member: its D / P columns           (transformer.py:232)
+//   per block b:  item[b] = h (member 0);  q_mine = Wq[:, mine] h;  attention of my heads over the worker's cached K | V rows
+//                 (masked_fill(-1e20) BEFORE the / sqrt(D), softmax, att . V: transformer.py:59-75)  -> ctx_mine
+//   exchange Ea   partial fc_out products  Wo[mine rows, :] ctx_mine  (all D outputs, summed over the members in member order)
+//                 x = LN1(sum + bo + h)                                                                  (transformer.py:143-149)
+//   exchange Eb   f_mine = relu(Wfc[:, mine] x + bfc);  h = LN2([f] + x)                                 (transformer.py:160-170)
+//   exchange Ez   hidden heads h2_mine = relu(W_heads[:, mine] h + b); partial output-head dot products over h2_mine
+//                 member 0: logits / value = sum of the partials + bias, log-softmax, inverse-CDF sample on the pre-drawn uniform
+//                 (or the forced action), log-prob, staging rows, action hand-over                       (model.py:104-110)
+// Only summation order differs from the multi-launch path.
+#include "etm_common.h"
+
+namespace {
+constexpr int RF_T = 512;                  // 8 waves, up to 256 VGPRs each: room for a whole product slice in flight
+constexpr int RF_WAVES = RF_T / 64;
+constexpr int RF_MAXB = 8;
+constexpr int RF_SPIN_LIMIT = 1 << 22;     // ~1 s of polling: a partner that never ran
+
+struct RfBlock {
+  const float *wq_t, *wo_t, *bo, *g1, *b1, *wfc_t, *bfc, *g2, *b2;
+};
+struct RfParams {
+  const float *h_in;                 // [W, D] input of the transformer (model.py:96-100 output)
+  const float *wemb_t, *bemb;        // [D, D] transposed, [D]
+  RfBlock blk[RF_MAXB];
+  int nb;
+  const float *kv;                   // K | V cache [W, T, nb, 2D]
+  long long kv_w_stride, kv_row_stride;
+  const long long *win;              // [W, L] window rows
+  const unsigned char *mask;         // [W, L]
+  float *items;                      // [nb, W, D] block-major new memory items
+  const float *wh_t, *bh;            // [D, 2 hid] transposed [lin_policy ; lin_value], [2 hid]
+  const float *wp, *bp, *wv, *bv;    // output heads [A, hid], [A], [hid], [1]
+  const float *uniforms;
+  const long long *forced;
+  long long *t_dev, *actions, *st_actions;
+  float *st_logp, *st_values;
+  long long *host_actions, *host_flag;
+  int *sync_counter;
+  float *xbuf;                       // exchange slots [W][n_slots][P][2 D]
+  long long *ctl;                    // launch counter [1], error word [1]
+  int n_slots;
+  int W, D, H, L, hid, A, stage_W, P;
+  float eps, sqrt_d;
+};
+
+// Workgroup barrier that leaves global loads in flight: LDS traffic of this wave done, then s_barrier.
+__device__ __forceinline__ void rf_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- matrix-vector products.  Thread (c, o4) of a product over rows [k0, k1) and this member's OUTS columns (from o0) of a
+// [K, OUT] row-major matrix owns 4 columns and the rows k0 + c, k0 + c + kch, ...  (kch = RF_T / (OUTS / 4) row chunks; threads
+// beyond kch * OUTS / 4 carry dead values).  gemv_issue puts GR of those rows in flight, gemv_fma consumes them; part[c][o]
+// holds the chunk sums, gemv_sum adds the chunks in chunk order.
+// The loads go through a buffer descriptor of the whole [KTOT, OUT] matrix: one 32-bit offset register per load instead of a
+// 64-bit address, and rows past the end of the matrix (a thread's last rows when kch does not divide the row count) read as
+// zeros instead of needing a clamp (their x factor is zero as well).
+template <int GR>
+__device__ __forceinline__ void gemv_issue(f32x4 (&w)[GR], const float *__restrict__ wt, int KTOT, int k0, int OUT, int o0, int OUTS, int ubase) {
+  const int cols4 = OUTS >> 2, kch = RF_T / cols4;
+  const int c = threadIdx.x / cols4, o4 = threadIdx.x - c * cols4;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, (short)0, KTOT * OUT * 4, 0x00020000);
+  int off0 = ((k0 + (c < kch ? c : 0) + ubase * kch) * OUT + o0 + o4 * 4) * 4, step = kch * OUT * 4;
+  // opaque to the optimiser: everything but the matrix is the same in every block, and GR hoisted offsets per product would
+  // occupy (and spill) more registers than the slices themselves
+  asm volatile("" : "+v"(off0), "+s"(step));
+#pragma unroll
+  for (int u = 0; u < GR; ++u) w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off0 + u * step, 0, 0));
+}
+template <int GR>
+__device__ __forceinline__ void gemv_fma(f32x4 &acc, const f32x4 (&w)[GR], const float *x_s, int k0, int k1, int OUTS, int ubase) {
+  const int cols4 = OUTS >> 2;
+  int kch = RF_T / cols4;
+  const int c = threadIdx.x / cols4;
+  int kfirst = k0 + (c < kch ? c : 0) + ubase * kch;
+  asm volatile("" : "+v"(kfirst), "+s"(kch));     // as in gemv_issue
+#pragma unroll
+  for (int u = 0; u < GR; ++u) {
+    const int kk = kfirst + u * kch;
+    acc += (kk < k1 ? x_s[kk] : 0.f) * w[u];
+  }
+}
+// The rest of a product whose first GR rows per thread are already in w (issued a phase earlier): consume, fetch what is left.
+template <int GR>
+__device__ __forceinline__ void gemv_finish(f32x4 (&w)[GR], const float *__restrict__ wt, int KTOT, const float *x_s, float *part_s, int k0,
+                                            int k1, int OUT, int o0, int OUTS) {
+  const int cols4 = OUTS >> 2, kch = RF_T / cols4;
+  const int c = threadIdx.x / cols4, o4 = threadIdx.x - c * cols4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int ub = 0;;) {
+    gemv_fma<GR>(acc, w, x_s, k0, k1, OUTS, ub);
+    ub += GR;
+    asm volatile("" ::: "memory");               // the registers are consumed before anything new is put in flight
+    if (k0 + ub * kch >= k1) break;
+    gemv_issue<GR>(w, wt, KTOT, k0, OUT, o0, OUTS, ub);
+  }
+  if (c < kch) *reinterpret_cast<f32x4 *>(&part_s[c * OUTS + o4 * 4]) = acc;
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ float gemv_sum(const float *part_s, int OUTS, int o) {
+  const int kch = RF_T / (OUTS >> 2);
+  float s = 0.f;
+  for (int c = 0; c < kch; ++c) s += part_s[c * OUTS + o];
+  return s;
+}
+// LayerNorm statistics of the D values in v_s (LDS, published by a barrier): every wave reduces the whole row on its own.
+__device__ __forceinline__ void row_stats(const float *v_s, int D, float eps, float &mean, float &rstd) {
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += v_s[c];
+  mean = wave_sum(s) / (float)D;
+  float m2 = 0.f;
+  for (int c = lane; c < D; c += 64) { const float d = v_s[c] - mean; m2 += d * d; }
+  rstd = 1.0f / sqrtf(wave_sum(m2) / (float)D + eps);
+}
+
+#ifdef ETM_RF_STAMPS   // diagnostic build only (tools/rollout_stamps.py): 100 MHz timestamps of workgroup 0's phases
+__device__ long long rf_stamps[64];
+#define RF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) rf_stamps[k] = (long long)wall_clock64(); } while (0)
+#else
+#define RF_STAMP(k) do { } while (0)
+#endif
+
+// ---- team exchange.  A piece travels as 16-byte PACKETS {tag, a, b, tag}: two payload floats between two copies of the exchange's
+// sequence number.  The reader polls the packet itself (system-scope 16-byte loads that bypass the non-coherent caches) until
+// both tags carry the expected number -- data and "ready" arrive in ONE memory round trip (~2 us per exchange, measured), and a
+// packet that were ever observed half-written would show two different tags.  Measured and rejected: separate sequence flags
+// (a second dependent round trip per exchange); release / acquire FENCES (they write back / invalidate whole caches on this
+// multi-XCD part: ~20 us per exchange).
+struct Team {
+  float *slots;          // this worker's exchange slots [n_slots][P][2 D]
+  long long *err;        // error word of the launch
+  long long base;        // sequence number of this launch's exchange 0
+  int P, me, D;
+};
+__device__ __forceinline__ void packet_store(float *dst, float tagf, float a, float b) {
+  const f32x4 v = {tagf, a, b, tagf};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 packet_load(const float *src) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+  return v;
+}
+// Publish `n` floats (LDS `src`) as this member's piece of exchange `ex` (slot row of 2 D floats = room for D payload floats).
+__device__ __forceinline__ void team_publish(const Team &t, int ex, const float *src, int n) {
+  float *dst = t.slots + ((long long)ex * t.P + t.me) * (2 * t.D);
+  const float tagf = __int_as_float((int)(t.base + ex + 1));
+  for (int i = threadIdx.x; 2 * i < n; i += RF_T) packet_store(dst + 4 * i, tagf, src[2 * i], (2 * i + 1 < n) ? src[2 * i + 1] : 0.f);
+}
+// Collect the first `n` floats of member m's piece of exchange `ex` into LDS `dst` (bounded polling).  Call from all threads; the
+// caller barriers afterwards.  Threads `first`, `first` + 1, ... do the polling (so that several partners are polled at once).
+__device__ __forceinline__ void team_collect(const Team &t, int ex, int m, float *dst, int n, int first) {
+  const float *src = t.slots + ((long long)ex * t.P + m) * (2 * t.D);
+  const int want = (int)(t.base + ex + 1);
+  const int i = (int)threadIdx.x - first;
+  if (i >= 0 && 2 * i < n) {
+    f32x4 v = packet_load(src + 4 * i);
+    int spins = 0;
+    while (__float_as_int(v[0]) != want || __float_as_int(v[3]) != want) {
+      if (++spins > RF_SPIN_LIMIT) { *t.err = 1; break; }
+      v = packet_load(src + 4 * i);
+    }
+    dst[2 * i] = v[1];
+    if (2 * i + 1 < n) dst[2 * i + 1] = v[2];
+  }
+}
+
+// GR: rows of a product slice in registers per thread; LMAX: window rows the K / V registers are sized for.
+template <int GR, int LMAX>
+__global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
+  constexpr int KR = LMAX / RF_WAVES;                             // window rows per wave (energies)
+  constexpr int VR = LMAX / 16;                                   // window rows per thread (context): >= 16 row groups (D / P <= 128)
+  __shared__ __attribute__((aligned(16))) float x_s[RF_T];        // current hidden state h_b (full row, every member)
+  __shared__ __attribute__((aligned(16))) float y_s[RF_T];        // q (mine) / ctx (mine) / x (full) / hidden heads (mine)
+  __shared__ __attribute__((aligned(16))) float part_s[4 * RF_T + 16];
+  __shared__ float t_s[RF_T];                                     // LayerNorm inputs / pieces to publish
+  __shared__ float e_s[8 * 128];
+  __shared__ long long off_s[128];
+  __shared__ unsigned char mask_s[128];
+  __shared__ float out_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = p.D, L = p.L, H = p.H, hd = D / H, P = p.P;
+  // block -> (worker, member): the members of a team get the same b % 8, i.e. (as observed) the same XCD and L2
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int me = idx % P, w = (idx / P) * 8 + xcd;
+  if (w >= p.W) return;
+  const int DS = D / P, d0 = me * DS;                              // my columns of every D-wide product
+  const int HS = H / P;                                            // my heads: me * HS ...
+  const int OUTH = 2 * p.hid, OS = OUTH / P, o0 = me * OS;         // my columns of the hidden heads
+  Team team;
+  team.P = P; team.me = me; team.D = D;
+  team.slots = p.xbuf + (long long)w * p.n_slots * P * 2 * D;
+  team.err = p.ctl + 1;
+  team.base = p.ctl[0] * 64;                                       // launch counter (bumped by the last workgroup of a launch)
+  int ex = 0;
+
+  RF_STAMP(0);
+  f32x4 wr[GR];                                                    // the product slice in flight
+  gemv_issue<GR>(wr, p.wemb_t, D, 0, D, d0, DS, 0);
+  // inputs of the sampling at the very end (thread 0 of member 0)
+  long long t_now = 0;
+  int a_forced = -1;
+  float u_draw = 0.f;
+  if (me == 0 && tid == 0) {
+    t_now = *p.t_dev;
+    if (p.forced) a_forced = (int)p.forced[t_now * p.stage_W + w];
+    u_draw = p.uniforms[t_now * p.stage_W + w];
+  }
+  if (tid < D) x_s[tid] = p.h_in[(long long)w * D + tid];
+  if (tid < L) {                                                   // the window rows of this worker in the K | V cache (block 0's offsets)
+    off_s[tid] = (long long)w * p.kv_w_stride + p.win[(long long)w * L + tid] * p.kv_row_stride;
+    mask_s[tid] = p.mask[(long long)w * L + tid];
+  }
+  const float bemb_r = (tid < DS) ? p.bemb[d0 + tid] : 0.f;
+  rf_sync();
+  // E0: linear_embedding + ReLU, my columns; collect the full row
+  gemv_finish<GR>(wr, p.wemb_t, D, x_s, part_s, 0, D, D, d0, DS);
+  gemv_issue<GR>(wr, p.blk[0].wq_t, D, 0, D, d0, DS, 0);
+  rf_sync();
+  if (tid < DS) t_s[tid] = fmaxf(gemv_sum(part_s, DS, tid) + bemb_r, 0.f);
+  rf_sync();
+  RF_STAMP(1);
+  if (P > 1) {
+    team_publish(team, ex, t_s, DS);
+    if (tid < DS) x_s[d0 + tid] = t_s[tid];
+    for (int m = 0; m < P; ++m)
+      if (m != me) team_collect(team, ex, m, x_s + m * DS, DS, 64 * (m - (m > me)));   // one wave per partner
+    ++ex;
+  } else {
+    if (tid < D) x_s[tid] = t_s[tid];
+  }
+  rf_sync();
+  RF_STAMP(2);
+
+  // mappings of the attention phases
+  const int cpl = (DS + 63) / 64;                                  // energies: my columns per lane (DS = 96 -> 2 on 48 lanes)
+  const int lanes_used = DS / cpl, lph = lanes_used / HS;          // lanes per head
+  const int cols4 = DS >> 2, vgroups = RF_T / cols4;               // context: thread = (row group, 4 columns)
+  const int vg = tid / cols4, vc4 = tid - vg * cols4;
+
+  for (int b = 0; b < p.nb; ++b) {
+    const RfBlock &B = p.blk[b];
+    const float *kvb = p.kv + (long long)b * 2 * D;                // this block's K | V columns of a cache row
+    if (me == 0 && tid < D) p.items[((long long)b * p.W + w) * D + tid] = x_s[tid];   // the block's input is the new memory item
+    // K and V of my columns: in flight now, used two and three phases later
+    float kreg[KR][2];
+    f32x4 vreg[VR];
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+      const int l = wave + j * RF_WAVES;
+      kreg[j][0] = 0.f; kreg[j][1] = 0.f;
+      if (l < L && lane < lanes_used) {
+        const float *krow = kvb + off_s[l] + d0 + lane * cpl;
+        kreg[j][0] = krow[0];
+        if (cpl == 2) kreg[j][1] = krow[1];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VR; ++j) {
+      const int l = vg + j * vgroups;
+      vreg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (vg < vgroups && l < L) vreg[j] = *reinterpret_cast<const f32x4 *>(kvb + off_s[l] + D + d0 + vc4 * 4);
+    }
+    // this block's biases and gains of my rows
+    float bo_r = 0.f, g1_r = 0.f, b1_r = 0.f, g2_r = 0.f, b2_r = 0.f, bfc_r = 0.f;
+    if (tid < D) { bo_r = B.bo[tid]; g1_r = B.g1[tid]; b1_r = B.b1[tid]; g2_r = B.g2[tid]; b2_r = B.b2[tid]; }
+    if (tid < DS) bfc_r = B.bfc[d0 + tid];
+    // q (my columns = my heads)
+    gemv_finish<GR>(wr, B.wq_t, D, x_s, part_s, 0, D, D, d0, DS);
+    gemv_issue<GR>(wr, B.wo_t, D, d0, D, 0, D, 0);
+    rf_sync();
+    if (tid < DS) y_s[tid] = gemv_sum(part_s, DS, tid);
+    rf_sync();
+    RF_STAMP(3 + 8 * b);
+    // energies of my heads: one wave per window row (rows wave, wave + 8, ...), lanes over my DS columns
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+      const int l = wave + j * RF_WAVES;
+      if (l < L) {                                                 // wave-uniform
+        float sdot = 0.f;
+        if (lane < lanes_used) {
+          sdot = kreg[j][0] * y_s[lane * cpl];
+          if (cpl == 2) sdot += kreg[j][1] * y_s[lane * cpl + 1];
+        }
+        if (HS == 1) {
+          sdot = wave_sum(sdot);
+          if (lane == 0) e_s[l] = sdot;
+        } else {                                                   // lanes_used == 64, lph a power of two
+          for (int o = 1; o < lph; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
+          if ((lane & (lph - 1)) == 0) e_s[(lane / lph) * 128 + l] = sdot;
+        }
+      }
+    }
+    rf_sync();
+    RF_STAMP(4 + 8 * b);
+    if (wave < HS) {                                              // masked softmax of my head `wave` over the window
+      float ev[2], xv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int l = lane + 64 * j;
+        float en = -INFINITY;
+        if (l < L) {
+          en = e_s[wave * 128 + l];
+          if (mask_s[l] == 0) en = -1e20f;                        // fill BEFORE the scale (transformer.py:66, :69)
+          en = en / p.sqrt_d;
+        }
+        ev[j] = en;
+      }
+      const float m = wave_max(fmaxf(ev[0], ev[1]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xv[j] = (lane + 64 * j < L) ? expf(ev[j] - m) : 0.f;
+      const float denom = wave_sum(xv[0] + xv[1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int l = lane + 64 * j;
+        if (l < L) e_s[wave * 128 + l] = xv[j] / denom;
+      }
+    }
+    rf_sync();
+    // ctx of my columns: the row groups split the window rows
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float *arow = e_s + ((vc4 * 4) / hd) * 128;          // hd % 4 == 0: the 4 columns share a head
+#pragma unroll
+      for (int j = 0; j < VR; ++j) {
+        const int l = vg + j * vgroups;
+        if (vg < vgroups && l < L) acc += arow[l] * vreg[j];
+      }
+      if (vg < vgroups) *reinterpret_cast<f32x4 *>(&part_s[vg * DS + vc4 * 4]) = acc;
+      rf_sync();
+      if (tid < DS) {
+        float sacc = 0.f;
+        for (int gg = 0; gg < vgroups; ++gg) sacc += part_s[gg * DS + tid];
+        y_s[d0 + tid] = sacc;                                     // ctx, at its position in the full row
+      }
+      rf_sync();
+    }
+    RF_STAMP(5 + 8 * b);
+    // Ea: fc_out as a K-split: my rows of Wo^T (my ctx columns) x all D outputs -> partial row; the members' partial rows are
+    // summed in member order; x = LayerNorm1(sum + bo + h)
+    gemv_finish<GR>(wr, B.wo_t, D, y_s, part_s, d0, d0 + DS, D, 0, D);
+    gemv_issue<GR>(wr, B.wfc_t, D, 0, D, d0, DS, 0);
+    rf_sync();
+    float v = 0.f, mean, rstd;
+    if (tid < D) t_s[tid] = gemv_sum(part_s, D, tid);
+    rf_sync();
+    RF_STAMP(6 + 8 * b);
+    if (P > 1) {
+      team_publish(team, ex, t_s, D);
+      for (int m = 0; m < P; ++m)                                 // the partners' partial rows -> part_s[m][D] (part_s is free now)
+        if (m != me) team_collect(team, ex, m, part_s + m * D, D, 0);
+      rf_sync();
+      if (tid < D) {
+        for (int m = 0; m < P; ++m) v += (m == me) ? t_s[tid] : part_s[m * D + tid];   // member order: the same sum in every member
+        v += bo_r + x_s[tid];
+      }
+      ++ex;
+      rf_sync();
+      if (tid < D) t_s[tid] = v;
+    } else {
+      if (tid < D) { v = t_s[tid] + bo_r + x_s[tid]; }
+      rf_sync();
+      if (tid < D) t_s[tid] = v;
+    }
+    rf_sync();
+    RF_STAMP(7 + 8 * b);
+    row_stats(t_s, D, p.eps, mean, rstd);
+    if (tid < D) y_s[tid] = (v - mean) * rstd * g1_r + b1_r;      // x (full row)
+    rf_sync();
+    RF_STAMP(8 + 8 * b);
+    // Eb: f = relu(Wfc x + bfc), my columns; h = LayerNorm2(f + x)
+    gemv_finish<GR>(wr, B.wfc_t, D, y_s, part_s, 0, D, D, d0, DS);
+    if (b + 1 < p.nb) gemv_issue<GR>(wr, p.blk[b + 1].wq_t, D, 0, D, d0, DS, 0);
+    else gemv_issue<GR>(wr, p.wh_t, D, 0, OUTH, o0, OS, 0);
+    rf_sync();
+    if (tid < DS) t_s[tid] = fmaxf(gemv_sum(part_s, DS, tid) + bfc_r, 0.f);
+    rf_sync();
+    RF_STAMP(9 + 8 * b);
+    if (P > 1) {
+      team_publish(team, ex, t_s, DS);
+      if (tid < DS) part_s[d0 + tid] = t_s[tid];                  // f (full row) -> part_s[0 .. D)
+      for (int m = 0; m < P; ++m)
+        if (m != me) team_collect(team, ex, m, part_s + m * DS, DS, 64 * (m - (m > me)));
+      ++ex;
+    } else {
+      if (tid < D) part_s[tid] = t_s[tid];
+    }
+    rf_sync();
+    v = 0.f;
+    if (tid < D) v = part_s[tid] + y_s[tid];
+    rf_sync();
+    if (tid < D) t_s[tid] = v;
+    rf_sync();
+    row_stats(t_s, D, p.eps, mean, rstd);
+    if (tid < D) x_s[tid] = (v - mean) * rstd * g2_r + b2_r;
+    rf_sync();
+    RF_STAMP(10 + 8 * b);
+  }
+
+  // Ez: hidden heads [lin_policy ; lin_value] + ReLU (model.py:104-107), my columns of the 2 hid outputs, then the partial dot
+  // products of the A + 1 output heads over my columns (model.py:108-110)
+  const float bh_r = (tid < OS) ? p.bh[o0 + tid] : 0.f;
+  float hw[4] = {0.f, 0.f, 0.f, 0.f};                              // my columns of output head `wave` (the first A + 1 <= 8 outputs)
+  {
+    const int o = wave;
+    if (o < p.A + 1) {
+      const int hoff = (o < p.A) ? 0 : p.hid;
+      const float *wt = (o < p.A) ? p.wp + (long long)o * p.hid : p.wv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j, col = o0 + c - hoff;
+        if (c < OS && col >= 0 && col < p.hid) hw[j] = wt[col];
+      }
+    }
+  }
+  const float bout_r = (me == 0 && tid < p.A + 1) ? (tid < p.A ? p.bp[tid] : p.bv[0]) : 0.f;
+  gemv_finish<GR>(wr, p.wh_t, D, x_s, part_s, 0, D, OUTH, o0, OS);
+  rf_sync();
+  if (tid < OS) y_s[tid] = fmaxf(gemv_sum(part_s, OS, tid) + bh_r, 0.f);
+  rf_sync();
+  for (int o = wave; o < p.A + 1; o += RF_WAVES) {                // one wave per output
+    float s = 0.f;
+    if (o < RF_WAVES) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int c = lane + 64 * j; if (c < OS) s += y_s[c] * hw[j]; }
+    } else {
+      const int hoff = (o < p.A) ? 0 : p.hid;                     // the output reads hidden columns [hoff, hoff + hid)
+      const float *wt = (o < p.A) ? p.wp + (long long)o * p.hid : p.wv;
+      for (int c = lane; c < OS; c += 64) {
+        const int col = o0 + c - hoff;                            // position inside the output's hidden half
+        if (col >= 0 && col < p.hid) s += y_s[c] * wt[col];
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0) t_s[o] = s;
+  }
+  rf_sync();
+  RF_STAMP(40);
+  if (P > 1) {
+    if (me != 0) team_publish(team, ex, t_s, p.A + 1);
+    if (me == 0) {
+      for (int m = 1; m < P; ++m) team_collect(team, ex, m, part_s + m * 64, p.A + 1, 64 * (m - 1));
+      rf_sync();
+      if (tid < p.A + 1) {
+        float s = t_s[tid];
+        for (int m = 1; m < P; ++m) s += part_s[m * 64 + tid];
+        out_s[tid] = s + bout_r;
+      }
+    }
+    ++ex;
+  } else {
+    if (tid < p.A + 1) out_s[tid] = t_s[tid] + bout_r;
+  }
+  rf_sync();
+  RF_STAMP(41);
+  if (tid == 0) {
+    if (me == 0) {                                                // sampling + staging + hand-over: as rollout_policy_kernel
+      const long long t = t_now;
+      const int A = p.A;
+      const float *lg = out_s;
+      float mx = -INFINITY;
+      for (int j = 0; j < A; ++j) mx = fmaxf(mx, lg[j]);
+      float se = 0.f;
+      for (int j = 0; j < A; ++j) se += expf(lg[j] - mx);
+      const float lse = mx + logf(se);
+      int a = a_forced;
+      if (a < 0) {
+        float c = 0.f;
+        a = A - 1;
+        for (int j = 0; j < A; ++j) {
+          c += expf(lg[j] - lse);
+          if (u_draw < c) { a = j; break; }
+        }
+      }
+      p.actions[w] = a;
+      if (p.host_actions) p.host_actions[w] = a;
+      p.st_actions[t * p.stage_W + w] = a;
+      p.st_logp[t * p.stage_W + w] = lg[a] - lse;
+      p.st_values[t * p.stage_W + w] = lg[A];
+    }
+    RF_STAMP(42);
+    __threadfence();                                              // this worker's rows are visible before the arrival below
+    if (atomicAdd(p.sync_counter, 1) == p.W * P - 1) {            // last workgroup of the step (every member of every team arrived)
+      *p.sync_counter = 0;
+      const long long t = *p.t_dev;
+      p.ctl[0] += 1;                                              // launch counter: the next launch's sequence numbers
+      *p.t_dev = t + 1;
+      if (p.host_flag) {
+        __threadfence_system();
+        __hip_atomic_store(p.host_flag, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+}  // namespace
+
+#ifdef ETM_RF_STAMPS
+extern "C" int etm_diag_rollout_trxl_stamps(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rf_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int etm_rollout_trxl_team(int H) { return (H % 4 == 0) ? 4 : ((H % 2 == 0) ? 2 : 1); }
+
+// 1 when etm_rollout_trxl handles the shape (16-byte pieces, a member's columns on <= 64 lanes x 2 per window row and >= 16 row
+// groups in the context phase, full rows on the 512 threads, everything in the static LDS buffers), else 0 (the caller keeps the
+// multi-launch path).
+extern "C" int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, int nb) {
+  if (D <= 0 || H <= 0 || L <= 0 || hid <= 0 || A <= 0 || nb <= 0 || D % H != 0) return 0;
+  const int P = etm_rollout_trxl_team(H);
+  if (nb > RF_MAXB || D % (4 * P) != 0 || D > RF_T || H > 8 || L > 128 || (2 * hid) % (4 * P) != 0 || A + 1 > 64 || (D / H) % 4 != 0) return 0;
+  const int DS = D / P, OS = 2 * hid / P, cpl = (DS + 63) / 64, HS = H / P;
+  if (DS > 128 || DS % cpl != 0 || OS > 256 || (HS > 1 && (DS / cpl != 64 || (HS & (HS - 1)) != 0))) return 0;
+  return 1;
+}
+extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
+  if (W <= 0 || D <= 0 || H <= 0 || nb <= 0) return 0;
+  const int P = etm_rollout_trxl_team(H);
+  const int64_t slots = 2 * (int64_t)nb + 2;
+  return 64 + (int64_t)W * slots * P * 2 * D * (int64_t)sizeof(float);
+}
+
+// One launch per worker group and rollout step.  blocks: nb structs of 9 device pointers each, in the order
+// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous).
+// scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes, ZEROED once by the caller before the first launch and then left alone
+// (int64 launch counter, int64 error word -- non-zero = a team member timed out --, then the exchange slots).
+extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, const float *kv,
+                                int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
+                                const float *wh_t, const float *bh, const float *wp, const float *bp, const float *wv, const float *bv,
+                                const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
+                                float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
+                                float ln_eps, void *scratch, int64_t scratch_bytes, int W, int D, int H, int L, int hid, int A, int stage_W,
+                                void *stream) {
+  (void)hipGetLastError();
+  if (!h_in || !wemb_t || !bemb || !blocks || !kv || !win || !mask || !items || !wh_t || !bh || !wp || !bp || !wv || !bv || !uniforms ||
+      !t_dev || !actions || !st_actions || !st_logp || !st_values || !sync_counter || !scratch)
+    return ETM_EINVAL;
+  if (W <= 0 || nb <= 0 || D <= 0 || H <= 0 || L <= 0 || hid <= 0 || A <= 0 || stage_W < W || D % H != 0) return ETM_EINVAL;
+  if (host_flag && !host_actions) return ETM_EINVAL;
+  const int P = etm_rollout_trxl_team(H);
+  if (!etm_rollout_trxl_supported(D, H, L, hid, A, nb) || (W + 7) / 8 * 8 * P > 256) return ETM_EUNSUPPORTED;   // all teams resident
+  if (scratch_bytes < etm_rollout_trxl_scratch_bytes(W, D, H, nb)) return ETM_EWORKSPACE;
+  RfParams p{};
+  p.h_in = h_in; p.wemb_t = wemb_t; p.bemb = bemb; p.nb = nb;
+  for (int b = 0; b < nb; ++b) {
+    const float *const *q = reinterpret_cast<const float *const *>(blocks) + 9 * b;
+    for (int k = 0; k < 9; ++k) if (!q[k]) return ETM_EINVAL;
+    p.blk[b] = RfBlock{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+  }
+  p.kv = kv; p.kv_w_stride = kv_worker_stride; p.kv_row_stride = kv_row_stride;
+  p.win = (const long long *)win; p.mask = mask; p.items = items; p.wh_t = wh_t; p.bh = bh; p.wp = wp; p.bp = bp; p.wv = wv; p.bv = bv;
+  p.uniforms = uniforms; p.forced = (const long long *)forced; p.t_dev = (long long *)t_dev; p.actions = (long long *)actions;
+  p.st_actions = (long long *)st_actions; p.st_logp = st_logp; p.st_values = st_values; p.host_actions = (long long *)host_actions;
+  p.host_flag = (long long *)host_flag; p.sync_counter = (int *)sync_counter;
+  p.n_slots = 2 * nb + 2;
+  p.ctl = (long long *)scratch;
+  p.xbuf = reinterpret_cast<float *>((char *)scratch + 64);
+  p.W = W; p.D = D; p.H = H; p.L = L; p.hid = hid; p.A = A; p.stage_W = stage_W; p.P = P;
+  p.eps = ln_eps; p.sqrt_d = (float)sqrt((double)D);
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_ROLLOUT_FUSED, st);
+  // block b -> XCD b % 8 (observed), team slot b / 8: worker (slot / P) * 8 + xcd, member slot % P
+  const int teams_per_xcd = (W + 7) / 8;
+  const dim3 grid((unsigned)(8 * teams_per_xcd * P)), block(RF_T);
+  // rows per thread of the per-block product slices: 20 registers x 4 are enough at D = 384, 32 at D = 512
+  const int DS = D / P;
+  const int rows_q = (D + RF_T / (DS / 4) - 1) / (RF_T / (DS / 4)), rows_o = (DS + RF_T / (D / 4) - 1) / (RF_T / (D / 4));
+  const bool small = rows_q <= 20 && rows_o <= 20;
+  if (L <= 64) {
+    if (small) hipLaunchKernelGGL((rollout_trxl_kernel<20, 64>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((rollout_trxl_kernel<32, 64>), grid, block, 0, st, p);
+  } else {
+    if (small) hipLaunchKernelGGL((rollout_trxl_kernel<20, 128>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((rollout_trxl_kernel<32, 128>), grid, block, 0, st, p);
+  }
+  return etm_launch_status();
+}

@@ -386,6 +386,50 @@ def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions
                "etm_rollout_policy")
 
 
+def rollout_trxl_scratch(W, D, H, nb, device):
+    """Zeroed scratch of one worker group for ``rollout_trxl`` (launch counter, error word, exchange slots)."""
+    lib = _lib.load()
+    nbytes = lib.etm_rollout_trxl_scratch_bytes(W, D, H, nb)
+    return torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+
+def rollout_trxl_error(scratch):
+    """Non-zero if a team member of the last launches timed out waiting for a partner (device scalar; no synchronisation)."""
+    return scratch[1]
+
+
+def rollout_trxl_supported(D, H, L, hid, A, nb):
+    """Does ``rollout_trxl`` handle these shapes (etm_rollout_trxl_supported)?"""
+    return bool(_lib.load().etm_rollout_trxl_supported(D, H, L, hid, A, nb))
+
+
+def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp,
+                 st_values, scratch, host_actions=None, host_flag=None, w_off=0):
+    """Transformer + hidden / output heads + sampling of one rollout step of a worker group in one launch (etm_rollout_trxl).
+    ``fused``: the transposed fixed-address weight copies of ``ActorCriticModel.refresh_rollout_weights`` (dict with the host
+    pointer table ``blocks``); ``kv`` the group's K | V cache [W, T, blocks, 2D]; ``scratch`` from ``rollout_trxl_scratch``; the
+    staging arguments as in ``rollout_policy``."""
+    lib = _lib.load()
+    h_in = _f32c(h_in, "h_in")
+    W, D = h_in.shape
+    L = win_t.shape[1]
+    A, hid = policy_head.weight.shape
+    sync = _policy_sync.get(t_dev.data_ptr())
+    if sync is None:
+        sync = _policy_sync[t_dev.data_ptr()] = torch.zeros(1, dtype=torch.int32, device=h_in.device)
+    stage_w = st_values.shape[1]
+    off = lambda t: None if t is None else t.data_ptr() + w_off * t.element_size()
+    ha = 0 if host_actions is None else host_actions.data_ptr()
+    hf = 0 if host_flag is None else host_flag.data_ptr()
+    _lib.check(lib.etm_rollout_trxl(_ptr(h_in), _ptr(fused["emb_t"]), _ptr(fused["emb_b"]), fused["blocks"], fused["nb"], _ptr(kv), kv.stride(0),
+                                    kv.stride(1), _ptr(win_t), _ptr(mask_t), _ptr(items), _ptr(fused["heads_t"]), _ptr(fused["heads_b"]),
+                                    _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight), _ptr(value_head.bias),
+                                    off(uniforms), off(forced), _ptr(t_dev), _ptr(actions), off(st_actions), off(st_logp), off(st_values),
+                                    ha, hf, _ptr(sync), float(fused["eps"]), _ptr(scratch), scratch.numel() * 8, W, D, fused["H"], L, hid, A,
+                                    stage_w, _stream()),
+               "etm_rollout_trxl")
+
+
 def rollout_heads(h2, branch, value_head):
     """logits [W,A] and value [W] from h2 = [relu(lin_policy(h)) | relu(lin_value(h))] ([W, 2*hid]); no-grad path."""
     lib = _lib.load()

@@ -27,6 +27,8 @@ class ActorCriticModel(nn.Module):
         self.channels_last = bool(config.get("encoder_channels_last", True))
         self.fused_encoder = bool(config.get("fused_rollout_encoder", True))
         self.train_encoder = bool(config.get("fused_train_encoder", True))     # False: library convolutions in the optimisation phase
+        self.fused_rollout_block = bool(config.get("fused_rollout_block", True))   # False: one launch per GEMM / LayerNorm / attention
+        self._rf = None
         self._train_encoder_ok = None
         if self.visual:
             c = self.observation_space_shape[0]
@@ -81,6 +83,7 @@ class ActorCriticModel(nn.Module):
             else:
                 self._w_heads.copy_(w)
                 self._b_heads.copy_(b)
+        self._refresh_fused_block_weights()
         if not self.visual:
             return
         with torch.no_grad():
@@ -95,6 +98,49 @@ class ActorCriticModel(nn.Module):
                 else:
                     buf.copy_(perm)
             self._wver = (self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
+
+    def rollout_block_fusable(self):
+        """Post-LN blocks without gates, one action branch, shapes inside etm_rollout_trxl's support: the trainer may run the
+        transformer, the heads and the sampling of a rollout step as one kernel."""
+        t = self.transformer
+        blk = t.transformer_blocks[0]
+        d = t.embed_dim
+        if not (self.fused_rollout_block and blk.layer_norm == "post" and not blk.use_gtrxl and len(self.policy_branches) == 1
+                and t.linear_embedding.in_features == d):
+            return False
+        return ops.rollout_trxl_supported(d, t.num_heads, t.config["memory_length"], self.hidden_size,
+                                          self.policy_branches[0].out_features, t.num_blocks)
+
+    def _refresh_fused_block_weights(self):
+        """Transposed ([in, out]) fixed-address copies of the matrices etm_rollout_trxl walks, and the host table of their
+        device pointers (built once: the buffers keep their addresses, so captured graphs stay valid)."""
+        if not self.lin_policy.weight.is_cuda or not self.rollout_block_fusable():
+            self._rf = None
+            return
+        import ctypes
+        t = self.transformer
+        with torch.no_grad():
+            fresh = {"emb_t": t.linear_embedding.weight.t(), "heads_t": torch.cat((self.lin_policy.weight, self.lin_value.weight), dim=0).t()}
+            for i, blk in enumerate(t.transformer_blocks):
+                fresh[f"wq_t{i}"] = blk.attention.queries.weight.t()
+                fresh[f"wo_t{i}"] = blk.attention.fc_out.weight.t()
+                fresh[f"wfc_t{i}"] = blk.fc[0].weight.t()
+            rf = getattr(self, "_rf", None)
+            if rf is None or rf["emb_t"].device != self.lin_policy.weight.device:
+                rf = {k: v.contiguous() for k, v in fresh.items()}
+                rf["emb_b"], rf["heads_b"] = t.linear_embedding.bias, None
+                ptrs = []
+                for i, blk in enumerate(t.transformer_blocks):
+                    ptrs += [rf[f"wq_t{i}"], rf[f"wo_t{i}"], blk.attention.fc_out.bias, blk.norm1.weight, blk.norm1.bias,
+                             rf[f"wfc_t{i}"], blk.fc[0].bias, blk.norm2.weight, blk.norm2.bias]
+                rf["_keep"] = ptrs
+                rf["blocks"] = (ctypes.c_void_p * len(ptrs))(*[p.data_ptr() for p in ptrs])
+                rf["nb"], rf["H"], rf["eps"] = t.num_blocks, t.num_heads, t.transformer_blocks[0].norm1.eps
+                self._rf = rf
+            else:
+                for k, v in fresh.items():
+                    rf[k].copy_(v)
+            self._rf["heads_b"] = self._b_heads          # concatenated hidden-head bias (refreshed above)
 
     def _encode_fused(self, obs, obs_index=None, obs_rows=None):
         if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()

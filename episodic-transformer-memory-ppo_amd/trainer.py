@@ -296,7 +296,7 @@ class PPOTrainer:
         """Device / pinned state of the workers [lo, hi) for one rollout step (see ``rollout_groups``)."""
         from types import SimpleNamespace
         dev, Wg, B = self.device, hi - lo, len(self.action_space_shape)
-        g = SimpleNamespace(lo=lo, hi=hi, W=Wg, env=env, full=full, graphs=None)
+        g = SimpleNamespace(lo=lo, hi=hi, W=Wg, env=env, full=full, graphs=None, rf_scratch=None)
         g.obs_pin, g.act_pin = self._obs_pin[lo:hi], self._act_pin[lo:hi]
         g.obs_np = self.obs[lo:hi]
         acts = g.act_pin.numpy()
@@ -457,6 +457,10 @@ class PPOTrainer:
                     t_launch += time.perf_counter() - tl
         for st_ in side_streams:
             main.wait_stream(st_)
+        t_ = self.model.transformer
+        for g in groups + [self._group_all]:
+            if g.rf_scratch is not None and int(ops.rollout_trxl_error(g.rf_scratch).item()) != 0:
+                raise RuntimeError("fused rollout step: a team member timed out waiting for its partners (set fused_rollout_block: false)")
         if forced_actions is not None:
             self._forced_tab.fill_(-1)
         # time-major staging -> the buffer's [W, S, ...] fields (one strided copy per field)
@@ -499,7 +503,20 @@ class PPOTrainer:
         fused_policy = False
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(g.kv, None, win_t, None, mask_t)
-            if single and self.model.rollout_heads_fusable():
+            if single and getattr(self.model, "_rf", None) is not None and self.model.rollout_heads_fusable():
+                # post-LN blocks without gates: the transformer, the heads and the sampling are ONE launch -- one workgroup per
+                # worker walks the whole chain as matrix-vector products over the L2-resident weights (csrc/rollout_fused.hip);
+                # the step is then encoder (4 launches) + window lookup + this kernel instead of 26 dependent launches
+                h_in = self.model._encode(obs, obs_index, rows)
+                if getattr(g, "rf_scratch", None) is None:
+                    t_ = self.model.transformer
+                    g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device)
+                ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
+                                 self._uniforms, self._forced_tab, g.t_dev, g.act_dev, st["actions"], st["log_probs"], st["values"],
+                                 g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo)
+                item = g.item
+                fused_policy = True
+            elif single and self.model.rollout_heads_fusable():
                 # hidden heads -> ONE launch for output heads, sampling, staging, t += 1; the kernel stores the actions straight
                 # into the pinned host buffer (no copy launch): they are visible to the host when the step's event (or, with
                 # host_flag_actions, the flag) says the launch is done

@@ -265,6 +265,32 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
                        float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                        int W, int A, int hid, int stage_W, void *stream);
 
+/* The transformer, the hidden / output heads and the sampling of one rollout step of a worker group as ONE launch (post-LN
+ * blocks without gates; trainer.py:163-186 -> model.py:96-112 -> transformer.py:222-253), csrc/rollout_fused.hip: a TEAM of
+ * P = etm_rollout_trxl_team(H) workgroups per worker (4 at H % 4 == 0) walks the whole chain as matrix-vector products, every
+ * member owning D / P columns of each product and H / P heads, the members exchanging their pieces through memory (16-byte
+ * packets that carry their own sequence number, bounded polling) -- instead of 6 dependent launches per block.
+ *   h_in [W, D]: transformer input (model.py:96-100); wemb_t [D, D], bemb [D]: linear_embedding (weight TRANSPOSED, [in, out]);
+ *   blocks: HOST array of nb x 9 device pointers (wq_t, wo_t, bo, norm1 gain, norm1 bias, wfc_t, bfc, norm2 gain, norm2 bias), *_t
+ *           transposed [D, D];   kv / strides / win / mask: the K | V cache rows as in etm_attn_cached (rows of all blocks: the
+ *           kernel adds b * 2D);   items [nb, W, D]: receives every block's input = the new memory items (block-major);
+ *   wh_t [D, 2 hid], bh [2 hid]: [lin_policy ; lin_value] transposed;  wp / bp / wv / bv and everything from `uniforms` to
+ *   `sync_counter`: as in etm_rollout_policy;
+ *   scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes that the caller ZEROES ONCE and then leaves to the kernel
+ *           (int64 launch counter, int64 error word -- non-zero after a launch = a team member timed out --, 48 bytes of padding,
+ *           then the exchange slots).
+ * Shape support: etm_rollout_trxl_supported(D, H, L, hid, A, nb) == 1 (D % (4 P) == 0, D <= 512, D / P <= 128, 2 hid / P <= 256,
+ * H <= 8, L <= 128, nb <= 8, A < 64) and at most 256 workgroups (8 ceil(W / 8) P); ETM_EUNSUPPORTED otherwise. */
+int etm_rollout_trxl_team(int H);
+int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, int nb);
+int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb);
+int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, const float *kv,
+                     int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
+                     const float *wh_t, const float *bh, const float *wp, const float *bp, const float *wv, const float *bv,
+                     const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
+                     float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter, float ln_eps,
+                     void *scratch, int64_t scratch_bytes, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
  * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C]; with
  * in_index non-NULL the input is in + (*in_index) * in_index_stride floats (a row of a staging array chosen on the device);

@@ -372,10 +372,12 @@ _ROLLOUT_PATHS = {
     "event_handover": {"host_flag_actions": False},          # head graph, event, tail graph instead of one graph + pinned flag
     "eager_train": {"hip_graph_train": False},
     "library_convs": {"fused_train_encoder": False},          # optimisation phase on the library convolutions
+    "multi_launch_blocks": {"fused_rollout_block": False},    # rollout: one launch per GEMM / attention / LayerNorm instead of one per step
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
-             ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs")]
+             ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs"),
+             ("img32", "multi_launch_blocks"), ("vec", "multi_launch_blocks")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -452,6 +454,7 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         assert tr._step_graph is not None and tr._stream_obs and len(tr._groups) == 2 and tr._train_graph is not None, \
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
         assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
+        assert tr.model._rf is not None, "img32/default: transformer + heads + sampling of a rollout step are one launch"
     if path == "groups4":
         assert len(tr._groups) == 4
     if path == "event_handover":
@@ -676,6 +679,48 @@ def test_rollout_group_counts_agree():
     """One, two and four pipelined worker groups (and the host-flag hand-over) against the shipped defaults at 32 workers."""
     _rollout_variants_agree([dict(), dict(rollout_groups=4), dict(rollout_groups=1), dict(rollout_groups=4, host_flag_actions=False)],
                             n_workers=32)
+
+
+def test_fused_rollout_step_kernel_vs_multi_launch_path():
+    """etm_rollout_trxl (transformer + heads + sampling of a rollout step in one launch) against the multi-launch path
+    (library GEMMs, cached attention, residual + LayerNorm and policy kernels) on the same weights, cache and observations:
+    memory items, values, log-probs and -- for every worker whose uniform is not within 1e-5 of a CDF boundary -- actions."""
+    from trainer import PPOTrainer
+    dev = _dev()
+    # teams of 4 / 2 / 1 workgroups; two heads per member with a window beyond 64 rows; D = 512 (the 32-row register slices)
+    for (D, H, L, nb, hid, A, W) in ((384, 4, 64, 3, 384, 3, 16), (64, 2, 8, 2, 64, 4, 5), (128, 1, 32, 4, 128, 2, 32),
+                                     (256, 8, 96, 2, 256, 5, 9), (512, 4, 33, 2, 512, 3, 8)):
+        cfg = dict(environment=dict(type="Synthetic", obs_shape=[7], num_actions=A, max_episode_steps=L + 5, seed=3, p_done=0.1, pool=4),
+                   gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=W, worker_steps=L + 12, n_mini_batch=1, value_loss_coefficient=0.5,
+                   hidden_layer_size=hid, max_grad_norm=0.5, rollout_groups=1,
+                   transformer=dict(num_blocks=nb, embed_dim=D, num_heads=H, memory_length=L, positional_encoding="relative",
+                                    layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
+                   learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
+                   beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
+                   clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
+        snaps = []
+        for fused in (True, False):
+            c = json.loads(json.dumps(cfg))
+            c["fused_rollout_block"] = fused
+            torch.manual_seed(17)
+            tr = PPOTrainer(c, run_id="fusedstep", device=dev, tensorboard=False)
+            with torch.no_grad():
+                for prm in tr.model.parameters():          # non-trivial LayerNorm gains / biases
+                    if prm.dim() == 1:
+                        prm.add_(0.1 * torch.randn_like(prm))
+            tr._sample_training_data()
+            assert (tr.model._rf is not None) == fused
+            tr.buffer.prepare_batch_dict()
+            b = tr.buffer
+            snaps.append({k: getattr(b, k).clone() for k in ("actions", "values", "log_probs", "memory_index")} | {"mem": b.memories.clone()})
+            tr.close()
+        a, m = snaps
+        assert torch.equal(a["memory_index"], m["memory_index"])
+        same = (a["actions"] == m["actions"]).float().mean().item()
+        assert same > 0.999, same                            # a different action only where a uniform sits on a CDF boundary
+        if same == 1.0:
+            for k in ("values", "log_probs", "mem"):
+                assert torch.allclose(a[k], m[k], atol=2e-5, rtol=1e-4), (D, k, (a[k] - m[k]).abs().max())
 
 
 def test_rollout_glue_riders_and_fused_policy():
