@@ -1,0 +1,109 @@
+// Host-side helper of the in-process environment front-ends: a multi-threaded memcpy into the pinned observation rows.
+//
+// The reference steps its environments in one process per worker (/root/reference worker.py:5-45, trainer.py:163-186), so the
+// observations of a step are produced -- and copied -- by n_workers cores at once.  The MI355X trainer steps a batched
+// environment in-process; at 3x84x84 float32 a worker group's observations are 1.35 MB per step and a single core's memcpy
+// (~25 GB/s = 55 us per group and step) was the largest item of the rollout's host time.  The copier keeps `threads - 1` helper
+// threads that spin for a short while after a job (a rollout issues one every ~100 us) and sleep on a condition variable
+// otherwise (the whole optimisation phase).  No device code in this file.
+#include "etm_common.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <immintrin.h>
+
+namespace {
+struct Copier {
+  int n = 1;                                  // participants (helpers + the caller)
+  std::vector<std::thread> helpers;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> pending{0};
+  std::atomic<bool> stop{false};
+  std::atomic<int> sleepers{0};
+  std::mutex m;
+  std::condition_variable cv;
+  char *dst = nullptr;
+  const char *src = nullptr;
+  size_t bytes = 0;
+};
+constexpr int SPIN_PAUSES = 40000;            // ~1 ms of _mm_pause before a helper goes to sleep
+
+inline void chunk_of(const Copier &c, int i, size_t &lo, size_t &hi) {
+  const size_t per = ((c.bytes + (size_t)c.n - 1) / (size_t)c.n + 63) & ~(size_t)63;   // cache-line multiples
+  lo = per * (size_t)i < c.bytes ? per * (size_t)i : c.bytes;
+  hi = lo + per < c.bytes ? lo + per : c.bytes;
+}
+void helper_main(Copier *c, int i) {
+  uint64_t last = 0;
+  for (;;) {
+    int spins = 0;
+    while (c->gen.load(std::memory_order_acquire) == last && !c->stop.load(std::memory_order_relaxed)) {
+      if (++spins < SPIN_PAUSES) { _mm_pause(); continue; }
+      std::unique_lock<std::mutex> lk(c->m);
+      c->sleepers.fetch_add(1);
+      c->cv.wait(lk, [&] { return c->gen.load(std::memory_order_acquire) != last || c->stop.load(); });
+      c->sleepers.fetch_sub(1);
+      spins = 0;
+    }
+    if (c->stop.load()) return;
+    last = c->gen.load(std::memory_order_acquire);
+    size_t lo, hi;
+    chunk_of(*c, i, lo, hi);
+    if (hi > lo) std::memcpy(c->dst + lo, c->src + lo, hi - lo);
+    c->pending.fetch_sub(1, std::memory_order_release);
+  }
+}
+}  // namespace
+
+extern "C" void *etm_host_copier_create(int threads) {
+  if (threads < 1 || threads > 64) return nullptr;
+  Copier *c = new (std::nothrow) Copier();
+  if (!c) return nullptr;
+  c->n = threads;
+  try {
+    for (int i = 1; i < threads; ++i) c->helpers.emplace_back(helper_main, c, i);
+  } catch (...) {
+    c->n = (int)c->helpers.size() + 1;        // fewer helpers than asked for: still correct
+  }
+  return c;
+}
+
+extern "C" void etm_host_copier_destroy(void *copier) {
+  Copier *c = static_cast<Copier *>(copier);
+  if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(c->m);
+    c->stop.store(true);
+  }
+  c->cv.notify_all();
+  for (auto &t : c->helpers) t.join();
+  delete c;
+}
+
+// dst[0 .. bytes) = src[0 .. bytes) (non-overlapping), split over the copier's threads; returns when every byte is written.
+// One job at a time per copier (the caller's thread takes part; calls from two threads at once are not supported).
+extern "C" int etm_host_copy(void *copier, void *dst, const void *src, int64_t bytes) {
+  Copier *c = static_cast<Copier *>(copier);
+  if (!c || bytes < 0 || (bytes > 0 && (!dst || !src))) return ETM_EINVAL;
+  if (bytes == 0) return ETM_OK;
+  if (c->n == 1 || bytes < (64 << 10)) {      // not worth a hand-over
+    std::memcpy(dst, src, (size_t)bytes);
+    return ETM_OK;
+  }
+  c->dst = static_cast<char *>(dst); c->src = static_cast<const char *>(src); c->bytes = (size_t)bytes;
+  c->pending.store(c->n - 1, std::memory_order_relaxed);
+  c->gen.fetch_add(1, std::memory_order_release);
+  if (c->sleepers.load() > 0) {
+    { std::lock_guard<std::mutex> lk(c->m); }
+    c->cv.notify_all();
+  }
+  size_t lo, hi;
+  chunk_of(*c, 0, lo, hi);
+  if (hi > lo) std::memcpy(c->dst + lo, c->src + lo, hi - lo);
+  while (c->pending.load(std::memory_order_acquire) != 0) _mm_pause();
+  return ETM_OK;
+}

@@ -63,6 +63,13 @@ struct RfParams {
   float *xbuf;                       // exchange slots [W][n_slots][P][2 D]
   long long *ctl;                    // launch counter [1], error word [1]
   int n_slots;
+  // tail (optional, wkv != nullptr): the new memory items into the bank, their K | V projection into the cache
+  const float *wkv;                  // [nb, D, 2D]: per block [Wk ; Wv]^T
+  const float *pos;                  // [T, D] positional rows added to the items before the projection, or nullptr
+  const long long *step_l, *slot_l;  // [W] episode step / memory slot of this step (the latch of etm_rollout_window)
+  float *kv_out;                     // = kv (written at row step_l[w])
+  float *bank;                       // [slots, T, nb, D]
+  long long bank_slot_stride, bank_row_stride;
   int W, D, H, L, hid, A, stage_W, P;
   float eps, sqrt_d;
 };
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   __shared__ long long off_s[128];
   __shared__ unsigned char mask_s[128];
   __shared__ float out_s[64];
+  __shared__ float items_s[RF_MAXB * RF_T];                       // every block's input (the new memory items), for the tail
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = p.D, L = p.L, H = p.H, hd = D / H, P = p.P;
   // block -> (worker, member): the members of a team get the same b % 8, i.e. (as observed) the same XCD and L2
@@ -235,6 +243,12 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     mask_s[tid] = p.mask[(long long)w * L + tid];
   }
   const float bemb_r = (tid < DS) ? p.bemb[d0 + tid] : 0.f;
+  long long step_w = 0, slot_w = 0;
+  float pos_r = 0.f;                                               // positional row of this step, my element
+  if (p.wkv) {
+    step_w = p.step_l[w]; slot_w = p.slot_l[w];
+    if (p.pos && tid < D) pos_r = p.pos[step_w * D + tid];
+  }
   rf_sync();
   // E0: linear_embedding + ReLU, my columns; collect the full row
   gemv_finish<GR>(wr, p.wemb_t, D, x_s, part_s, 0, D, D, d0, DS);
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     const RfBlock &B = p.blk[b];
     const float *kvb = p.kv + (long long)b * 2 * D;                // this block's K | V columns of a cache row
     if (me == 0 && tid < D) p.items[((long long)b * p.W + w) * D + tid] = x_s[tid];   // the block's input is the new memory item
+    if (tid < D) items_s[b * D + tid] = x_s[tid];
     // K and V of my columns: in flight now, used two and three phases later
     float kreg[KR][2];
     f32x4 vreg[VR];
@@ -500,18 +515,42 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       p.st_actions[t * p.stage_W + w] = a;
       p.st_logp[t * p.stage_W + w] = lg[a] - lse;
       p.st_values[t * p.stage_W + w] = lg[A];
-    }
-    RF_STAMP(42);
-    __threadfence();                                              // this worker's rows are visible before the arrival below
-    if (atomicAdd(p.sync_counter, 1) == p.W * P - 1) {            // last workgroup of the step (every member of every team arrived)
-      *p.sync_counter = 0;
-      const long long t = *p.t_dev;
-      p.ctl[0] += 1;                                              // launch counter: the next launch's sequence numbers
-      *p.t_dev = t + 1;
-      if (p.host_flag) {
-        __threadfence_system();
-        __hip_atomic_store(p.host_flag, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      RF_STAMP(42);
+      __threadfence();                                            // this worker's rows are visible before the arrival below
+      // the last SAMPLER of the step: every team has finished its exchanges, i.e. every workgroup of the launch has read the
+      // launch counter and (the samplers) the step counter -- both may move on, and the host may have its actions
+      if (atomicAdd(p.sync_counter, 1) == p.W - 1) {
+        *p.sync_counter = 0;
+        p.ctl[0] += 1;                                            // launch counter: the next launch's sequence numbers
+        *p.t_dev = t + 1;
+        if (p.host_flag) {
+          __threadfence_system();
+          __hip_atomic_store(p.host_flag, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
+    }
+  }
+  // ---- tail, after the hand-over (the host is stepping the environments now): bank[slot, step, b] = item_b (member 0) and
+  // cache[w, step, b] = (item_b + pos[step]) [Wk ; Wv]^T, my 2D / P columns (transformer.py:236-237 applied to one new row;
+  // the rows of this step are not part of any window of this launch that is still being read: a member gets here only after
+  // its last exchange, i.e. after every partner's last attention phase).
+  if (p.wkv) {
+    const int OUTK = 2 * D, KS = OUTK / P, k0c = me * KS;
+    gemv_issue<GR>(wr, p.wkv, D, 0, OUTK, k0c, KS, 0);
+    for (int b = 0; b < p.nb; ++b) {
+      if (tid < D) {
+        const float it = items_s[b * D + tid];
+        if (me == 0) p.bank[slot_w * p.bank_slot_stride + step_w * p.bank_row_stride + (long long)b * D + tid] = it;
+        t_s[tid] = it + pos_r;
+      }
+      rf_sync();
+      const float *wb = p.wkv + (long long)b * D * OUTK;
+      gemv_finish<GR>(wr, wb, D, t_s, part_s, 0, D, OUTK, k0c, KS);
+      if (b + 1 < p.nb) gemv_issue<GR>(wr, wb + (long long)D * OUTK, D, 0, OUTK, k0c, KS, 0);
+      rf_sync();
+      if (tid < KS)
+        p.kv_out[(long long)w * p.kv_w_stride + step_w * p.kv_row_stride + (long long)b * OUTK + k0c + tid] = gemv_sum(part_s, KS, tid);
+      rf_sync();
     }
   }
 }
@@ -547,19 +586,24 @@ extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
 // (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous).
 // scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes, ZEROED once by the caller before the first launch and then left alone
 // (int64 launch counter, int64 error word -- non-zero = a team member timed out --, then the exchange slots).
-extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, const float *kv,
+// Tail (wkv != NULL): after the action hand-over the same launch writes the new memory items into bank[slot_l[w], step_l[w]] and
+// their K | V projection (items + pos[step_l[w]]) wkv[b] into kv[w, step_l[w]] -- what the multi-launch path does with five more
+// launches while the host steps the environments.
+extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, float *kv,
                                 int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
                                 const float *wh_t, const float *bh, const float *wp, const float *bp, const float *wv, const float *bv,
                                 const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                                 float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
-                                float ln_eps, void *scratch, int64_t scratch_bytes, int W, int D, int H, int L, int hid, int A, int stage_W,
-                                void *stream) {
+                                float ln_eps, void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
+                                const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int W, int D, int H,
+                                int L, int hid, int A, int stage_W, void *stream) {
   (void)hipGetLastError();
   if (!h_in || !wemb_t || !bemb || !blocks || !kv || !win || !mask || !items || !wh_t || !bh || !wp || !bp || !wv || !bv || !uniforms ||
       !t_dev || !actions || !st_actions || !st_logp || !st_values || !sync_counter || !scratch)
     return ETM_EINVAL;
   if (W <= 0 || nb <= 0 || D <= 0 || H <= 0 || L <= 0 || hid <= 0 || A <= 0 || stage_W < W || D % H != 0) return ETM_EINVAL;
   if (host_flag && !host_actions) return ETM_EINVAL;
+  if (wkv && (!step_l || !slot_l || !bank)) return ETM_EINVAL;
   const int P = etm_rollout_trxl_team(H);
   if (!etm_rollout_trxl_supported(D, H, L, hid, A, nb) || (W + 7) / 8 * 8 * P > 256) return ETM_EUNSUPPORTED;   // all teams resident
   if (scratch_bytes < etm_rollout_trxl_scratch_bytes(W, D, H, nb)) return ETM_EWORKSPACE;
@@ -576,6 +620,8 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   p.st_actions = (long long *)st_actions; p.st_logp = st_logp; p.st_values = st_values; p.host_actions = (long long *)host_actions;
   p.host_flag = (long long *)host_flag; p.sync_counter = (int *)sync_counter;
   p.n_slots = 2 * nb + 2;
+  p.wkv = wkv; p.pos = pos; p.step_l = (const long long *)step_l; p.slot_l = (const long long *)slot_l; p.kv_out = kv; p.bank = bank;
+  p.bank_slot_stride = bank_slot_stride; p.bank_row_stride = bank_row_stride;
   p.ctl = (long long *)scratch;
   p.xbuf = reinterpret_cast<float *>((char *)scratch + 64);
   p.W = W; p.D = D; p.H = H; p.L = L; p.hid = hid; p.A = A; p.stage_W = stage_W; p.P = P;

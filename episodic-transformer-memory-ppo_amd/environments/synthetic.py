@@ -25,6 +25,19 @@ from types import SimpleNamespace
 import numpy as np
 
 _CHUNK = 4096
+_copiers = {}   # threads -> (library, copier handle): one pool of helper threads per process, shared by all front-ends
+
+
+def _copier(threads):
+    """The process-wide multi-threaded copier of the kernel library (etm_host_copier_create); created on first use."""
+    if threads not in _copiers:
+        from etm import lib as etm_lib
+        lib = etm_lib.load()
+        handle = lib.etm_host_copier_create(int(threads))
+        if not handle:
+            raise RuntimeError(f"etm_host_copier_create({threads}) failed")
+        _copiers[threads] = (lib, handle)
+    return _copiers[threads]
 
 
 class _WorkerStream:
@@ -101,8 +114,12 @@ class SyntheticVecEnv:
     """Batched form of ``num_envs`` ``SyntheticEnv`` instances (same streams, auto-reset on done)."""
 
     def __init__(self, num_envs, obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=0,
-                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0):
+                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1):
+        """``copy_threads`` > 1: the observation rows of a step are written by that many threads (the kernel library's host
+        copier; the reference's workers write theirs in n_workers processes) instead of one numpy copy."""
         self.num_envs = int(num_envs)
+        self._copy_threads = int(copy_threads)
+        self._row_bytes = int(np.prod(obs_shape)) * 4
         self.observation_space_shape = tuple(obs_shape)
         self.num_actions = int(num_actions)
         self.max_episode_steps = int(max_episode_steps)
@@ -132,6 +149,15 @@ class SyntheticVecEnv:
             return out
         chunks = self.ROW_CHUNKS if self.num_envs >= self.MIN_CHUNKED_ENVS else 1
         step = max(1, -(-self.num_envs // chunks))
+        if self._copy_threads > 1 and out.flags.c_contiguous and out.dtype == np.float32:
+            lib, handle = _copier(self._copy_threads)
+            dst, src = out.ctypes.data, frame.ctypes.data
+            for lo in range(0, self.num_envs, step):
+                hi = min(lo + step, self.num_envs)
+                if lib.etm_host_copy(handle, dst + lo * self._row_bytes, src + lo * self._row_bytes, (hi - lo) * self._row_bytes) != 0:
+                    raise RuntimeError("etm_host_copy failed")
+                on_rows(lo, hi)
+            return out
         for lo in range(0, self.num_envs, step):       # rows are handed over as soon as they are written
             hi = min(lo + step, self.num_envs)
             np.copyto(out[lo:hi], frame[lo:hi])

@@ -511,9 +511,15 @@ class PPOTrainer:
                 if getattr(g, "rf_scratch", None) is None:
                     t_ = self.model.transformer
                     g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device)
+                # ... and, after the action hand-over, the memory-bank write and the K | V projection of the new items (the tail)
+                tail = None
+                if self.config.get("fused_rollout_tail", True) and self._kv_weights[1] is None:
+                    tail = (self._kv_weights[0], self.model.transformer._pos(), g.step_l, g.slot_l, buf.bank)
+                g.tail_in_kernel = tail is not None
                 ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
                                  self._uniforms, self._forced_tab, g.t_dev, g.act_dev, st["actions"], st["log_probs"], st["values"],
-                                 g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo)
+                                 g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo,
+                                 tail=tail)
                 item = g.item
                 fused_policy = True
             elif single and self.model.rollout_heads_fusable():
@@ -569,6 +575,10 @@ class PPOTrainer:
         """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
         K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
         buf, st = self.buffer, self._stage
+        if getattr(g, "tail_in_kernel", False):      # etm_rollout_trxl has written the bank and cache rows itself
+            if not stream_obs:
+                st["obs"][:, g.lo:g.hi].index_copy_(0, g.t_row.view(1), g.obs_dev.unsqueeze(0))
+            return
         item = item.transpose(0, 1)                  # block-major staging -> [Wg, blocks, D]
         buf.bank[g.slot_l, g.step_l] = item           # (step, slot) as latched by this step's head, see _make_group
         if self._use_kv_cache:

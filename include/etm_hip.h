@@ -279,17 +279,33 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *   scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes that the caller ZEROES ONCE and then leaves to the kernel
  *           (int64 launch counter, int64 error word -- non-zero after a launch = a team member timed out --, 48 bytes of padding,
  *           then the exchange slots).
+ *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
+ *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
+ *           pos[step_l[w]]) wkv[b]  (wkv [nb, D, 2D] = per block [Wk ; Wv]^T, pos [T, D] or NULL; transformer.py:236-237 for the
+ *           one new row) -- the memory-bank write and K | V projection of trainer.py:174.
  * Shape support: etm_rollout_trxl_supported(D, H, L, hid, A, nb) == 1 (D % (4 P) == 0, D <= 512, D / P <= 128, 2 hid / P <= 256,
  * H <= 8, L <= 128, nb <= 8, A < 64) and at most 256 workgroups (8 ceil(W / 8) P); ETM_EUNSUPPORTED otherwise. */
 int etm_rollout_trxl_team(int H);
 int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, int nb);
 int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb);
-int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, const float *kv,
+int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, float *kv,
                      int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
                      const float *wh_t, const float *bh, const float *wp, const float *bp, const float *wv, const float *bv,
                      const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                      float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter, float ln_eps,
-                     void *scratch, int64_t scratch_bytes, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+                     void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
+                     const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int W, int D, int H, int L,
+                     int hid, int A, int stage_W, void *stream);
+
+/* Host-side helper of the in-process environment front-ends (no device work): a memcpy split over `threads` threads (the
+ * caller + threads - 1 helpers that spin briefly after a job and sleep otherwise).  The reference produces the observations of a
+ * step in n_workers processes at once (worker.py:5-45); here one process writes a worker group's rows into the pinned staging
+ * buffer, and a single core's memcpy was the largest host item of a rollout step.  csrc/host_copy.hip.
+ *   etm_host_copier_create: 1 <= threads <= 64, NULL on failure;  etm_host_copy: dst / src non-overlapping, returns when all
+ *   bytes are written; one job at a time per copier. */
+void *etm_host_copier_create(int threads);
+void etm_host_copier_destroy(void *copier);
+int etm_host_copy(void *copier, void *dst, const void *src, int64_t bytes);
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):
  * implicit GEMM on fp32 MFMA, no padding/dilation/groups.  in: NCHW [N,C,H,W] (in_nhwc = 0) or NHWC [N,H,W,C]; with

@@ -336,3 +336,42 @@ def test_library_collective_plumbing_without_a_device():
     if not torch.cuda.is_available():
         rc = lib.etm_comm_init(bytes(buf.raw), 0, 1, ctypes.byref(comm))
         assert rc >= 100000 and b"RCCL" in lib.etm_error_string(rc)
+
+
+def test_host_copier_and_threaded_environment_rows():
+    """etm_host_copy (the multi-threaded memcpy behind ``copy_threads``): exact for sizes around its thresholds and chunk edges,
+    from one to five threads, and a SyntheticVecEnv that uses it emits the same rows / rewards / dones as the numpy one."""
+    import ctypes
+    from etm import lib as etm_lib
+    from environments.synthetic import SyntheticVecEnv
+    lib = etm_lib.load()
+    rng = np.random.default_rng(0)
+    assert not lib.etm_host_copier_create(0) and not lib.etm_host_copier_create(65)
+    for threads in (1, 2, 3, 5):
+        h = lib.etm_host_copier_create(threads)
+        assert h
+        for n in (0, 1, 63, 65535, 65536, 65537, 300001, 1354752, 4 * 1354752 + 7):
+            src = rng.integers(0, 256, size=n + 16, dtype=np.uint8)
+            dst = np.full(n + 16, 7, dtype=np.uint8)
+            assert lib.etm_host_copy(h, dst.ctypes.data + 3, src.ctypes.data + 5, n) == 0
+            assert np.array_equal(dst[3:3 + n], src[5:5 + n]) and (dst[:3] == 7).all() and (dst[3 + n:] == 7).all()
+        for rep in range(200):                      # back-to-back jobs (helpers still spinning)
+            src = rng.integers(0, 256, size=200000, dtype=np.uint8)
+            dst = np.empty_like(src)
+            assert lib.etm_host_copy(h, dst.ctypes.data, src.ctypes.data, src.size) == 0
+            assert np.array_equal(dst, src)
+        assert lib.etm_host_copy(h, None, None, 8) != 0 and lib.etm_host_copy(None, None, None, 0) != 0
+        lib.etm_host_copier_destroy(h)
+    logs = []
+    for ct in (1, 3):
+        env = SyntheticVecEnv(6, (3, 84, 84), 3, 9, seed=4, pool=5, p_done=0.2, copy_threads=ct)
+        out = np.empty((6, 3, 84, 84), np.float32)
+        env.reset(out)
+        log = [out.copy()]
+        seen = []
+        for t in range(20):
+            _, r, d, info = env.step(np.zeros(6, np.int64), out=out, on_rows=lambda lo, hi: seen.append((lo, hi)))
+            log += [out.copy(), r.copy(), d.copy()]
+        logs.append(log)
+        assert seen and seen[-1][1] == 6
+    assert all(np.array_equal(a, b) for a, b in zip(*logs))
