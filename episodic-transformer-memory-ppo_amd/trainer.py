@@ -659,8 +659,11 @@ class PPOTrainer:
             else:
                 with torch.no_grad(), torch.cuda.graph(head, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
                     self._rollout_step_head(g, so, hf)
-                with torch.no_grad(), torch.cuda.graph(tail, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
-                    self._rollout_step_tail(g, g.item, so)
+                if getattr(g, "tail_in_kernel", False) and so:
+                    tail = None                       # nothing left to launch after the hand-over
+                else:
+                    with torch.no_grad(), torch.cuda.graph(tail, pool=pool, stream=g.stream, capture_error_mode="thread_local"):
+                        self._rollout_step_tail(g, g.item, so)
                 g.graphs = (head, tail)
             g.t_dev.zero_()
         with torch.no_grad():
