@@ -65,6 +65,9 @@ constexpr int CG_WAVES = 4;
 #ifndef ETM_CONV_MT64
 #define ETM_CONV_MT64 2
 #endif
+#ifndef CG_DIAG   // diagnostic builds only (tools/conv_layer_time.py): 1 = A operands loaded for the first groups only, 2 = B likewise, 4 = no stores
+#define CG_DIAG 0
+#endif
 
 template <int MT, int NT, bool DGRAD>
 __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel(const ConvG p) {
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
     const float *abase = p.src + koff;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if ((CG_DIAG & 1) && g >= 3) break;
       if (!DGRAD) {
         a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + loff[mt]);
       } else {
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
     }
     const float *bb = wbase + (long long)g * NT * 256;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + t * 256 + wl);
+    for (int t = 0; t < NT; ++t)
+      if (!(CG_DIAG & 2) || g < 3) b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + t * 256 + wl);
   };
   auto mfma_group = [&](int buf) {
 #pragma unroll
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
         float v = acc[mt][t][r];
         if (!DGRAD) v = fmaxf(v + bv[t], 0.f);
         else if (p.ymask) v = (mk[r] > 0.f) ? v : 0.f;
-        if (okr[r]) p.out[o_pix[r] + co] = v;
+        if (okr[r] && (!(CG_DIAG & 4) || v == 12345.678f)) p.out[o_pix[r] + co] = v;
       }
     }
   }
@@ -354,21 +359,70 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
   }
 }
 
-// out[e] = sum over the pixel slices, fixed order
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int splits, long long elems,
-                                                                float *__restrict__ out) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= elems) return;
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-  int s = 0;
-  for (; s + 4 <= splits; s += 4) {
-    t0 += partial[(long long)s * elems + e];
-    t1 += partial[(long long)(s + 1) * elems + e];
-    t2 += partial[(long long)(s + 2) * elems + e];
-    t3 += partial[(long long)(s + 3) * elems + e];
+// out[e] = sum over the pixel slices in a fixed order: a workgroup owns 64 consecutive elements, its 16 waves take the slices
+// w, w + 16, ... (eight loads in flight each) and wave 0 adds the 16 wave sums in wave order.  The weight part is written in
+// the native [Cout, C, KH, KW] layout of the parameter (k = (ky, kx, c) in the workspace), the bias part follows it.
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int splits, long long elems,
+                                                                 float *__restrict__ out, int Cout, int C, int KH, int KW) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + lane;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (e < elems) {
+    for (int s0 = wave; s0 < splits; s0 += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s0 + 16 * u;
+        if (sl < splits) acc[u] += partial[(long long)sl * elems + e];
+      }
+    }
   }
-  for (; s < splits; ++s) t0 += partial[(long long)s * elems + e];
-  out[e] = (t0 + t1) + (t2 + t3);
+  red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && e < elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    const long long KC = (long long)KH * KW * C * Cout;
+    long long o = e;                                     // bias gradient: after the weights
+    if (e < KC) {
+      const int co = (int)(e % Cout), k = (int)(e / Cout);
+      const int c = k % C, kx = (k / C) % KW, ky = k / (C * KW);
+      o = (((long long)co * C + c) * KH + ky) * KW + kx;
+    }
+    out[o] = t;
+  }
+}
+
+// Weight re-packing of one layer in ONE launch (the weights change every optimiser step): w [Cout, C, KH, KW] ->
+//   fwd   [K / 8][Cout / 32][2][32][4]: the fragment order of etm_conv_train_fwd, k = (ky, kx, c)
+//   dgrad [S * S][Kd / 8][C / 32][2][32][4]: per stride-parity class (py, px) the matrix Wd[c][(a T + j) Cout + co] =
+//         w[co][c][py + S a][px + S (T - 1 - j)], T = KH / S, in the same fragment order (rows = c): etm_conv_train_dgrad
+// (either may be NULL).  One thread per packed element.
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ w, float *__restrict__ fwd, float *__restrict__ dgrad,
+                                                        int Cout, int C, int KH, int KW, int S) {
+  const int total = Cout * C * KH * KW;
+  const int e = (int)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = e & 3, col = (e >> 2) & 31, half = (e >> 7) & 1;
+  if (fwd) {
+    const int NT = Cout >> 5;
+    const int gt = e >> 8, t = gt % NT, g = gt / NT;
+    const int co = t * 32 + col, k = g * 8 + half * 4 + j;
+    const int c = k % C, kx = (k / C) % KW, ky = k / (C * KW);
+    fwd[e] = w[((co * C + c) * KH + ky) * KW + kx];
+  }
+  if (dgrad) {
+    const int T = KH / S, Kd = T * T * Cout, per_class = C * Kd, NT = C >> 5;
+    const int cls = e / per_class, el = e - cls * per_class;
+    const int py = cls / S, px = cls - py * S;
+    const int gt = el >> 8, t = gt % NT, g = gt / NT;
+    const int c = t * 32 + col, kd = g * 8 + half * 4 + j;
+    const int co = kd % Cout, jx = (kd / Cout) % T, a = kd / (Cout * T);
+    dgrad[e] = w[((co * C + c) * KH + (py + S * a)) * KW + (px + S * (T - 1 - jx))];
+  }
 }
 
 // out = g * (y > 0): the ReLU backward of the last encoder layer (everything NHWC), 16 bytes per thread
@@ -463,7 +517,7 @@ extern "C" int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int
   return (int64_t)wgrad_splits(N * Ho * Wo, wgrad_k_ranges(Cout, (int)K)) * (K * Cout + Cout) * (int64_t)sizeof(float);
 }
 
-// dw_kc [K, Cout] (k ordered (ky, kx, c)) followed by dbias [Cout], in one buffer of K * Cout + Cout floats.
+// dw [Cout, C, KH, KW] (the parameter's own layout) followed by dbias [Cout], in one buffer of K * Cout + Cout floats.
 extern "C" int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N,
                                     int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
@@ -503,7 +557,19 @@ extern "C" int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_k
   }
   EtmProfScope prof(ETM_K_CONV_TRAIN_WGRAD, st);
   const long long elems = (long long)p.K * Cout + Cout;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, workspace, splits_used, elems, dw_kc_dbias);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, workspace, splits_used, elems, dw_kc_dbias,
+                     Cout, C, KH, KW);
+  return etm_launch_status();
+}
+
+// See conv_pack_kernel.  fwd: K * Cout floats, dgrad: K * Cout floats (S * S classes of C * (KH / S) * (KW / S) * Cout), either NULL.
+extern "C" int etm_conv_pack_weights(const float *w, float *fwd, float *dgrad, int Cout, int C, int KH, int KW, int S, void *stream) {
+  (void)hipGetLastError();
+  if (!w || (!fwd && !dgrad) || Cout <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
+  if (Cout % 32 != 0 || (KH * KW * C) % 8 != 0) return ETM_EUNSUPPORTED;
+  if (dgrad && (C % 32 != 0 || KH % S != 0 || KW % S != 0 || KH != KW || ((KH / S) * (KW / S) * Cout) % 8 != 0)) return ETM_EUNSUPPORTED;
+  const int total = Cout * C * KH * KW;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd, dgrad, Cout, C, KH, KW, S);
   return etm_launch_status();
 }
 

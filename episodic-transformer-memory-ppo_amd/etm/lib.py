@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 
@@ -39,6 +39,7 @@ SIGNATURES = {
     "etm_allreduce_f32": (_I, [_P, _P, _P, _L, _P]),
     "etm_comm_destroy": (_I, [_P]),
     "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "etm_conv_pack_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "etm_host_copier_create": (_P, [_I]),
     "etm_host_copier_destroy": (None, [_P]),
     "etm_host_copy": (_I, [_P, _P, _P, _L]),

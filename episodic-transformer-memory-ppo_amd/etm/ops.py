@@ -673,12 +673,18 @@ class _EncoderFn(torch.autograd.Function):
         _need_dev(x_nhwc, w1, b1, w2, b2, w3, b3)
         x = _f32c(x_nhwc, "obs")
         st = _stream()
-        acts, shapes = [x], []
+        acts, shapes, dgrad_packs = [x], [], []
         n, h, w, c = x.shape
         for i, (wt, bs, s) in enumerate(((w1, b1, strides[0]), (w2, b2, strides[1]), (w3, b3, strides[2]))):
             cout, _, kh, kw = wt.shape
             ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
-            packed = conv_pack_weights(wt.detach().permute(0, 2, 3, 1).reshape(cout, -1))
+            # both packings of the layer's weights in one launch; the backward-data one rides in the context
+            wt_c = _f32c(wt.detach(), "conv weight")
+            packed = torch.empty(wt_c.numel(), dtype=torch.float32, device=x.device)
+            pd = torch.empty(wt_c.numel(), dtype=torch.float32, device=x.device) if i > 0 else None
+            _lib.check(lib.etm_conv_pack_weights(_ptr(wt_c), _ptr(packed), 0 if pd is None else _ptr(pd), cout, c, kh, kw, s, st),
+                       "etm_conv_pack_weights")
+            dgrad_packs.append(pd)
             y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
             _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(packed), _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s,
                                               0, st), "etm_conv_train_fwd")
@@ -686,13 +692,13 @@ class _EncoderFn(torch.autograd.Function):
             acts.append(y)
             h, w, c = ho, wo, cout
         ctx.shapes = shapes
-        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], w2, w3)
+        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2])
         return acts[3].view(n, -1)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x0, y1, y2, y3, w2, w3 = ctx.saved_tensors
+        x0, y1, y2, y3, pd2, pd3 = ctx.saved_tensors
         st = _stream()
         dev = x0.device
         n = x0.shape[0]
@@ -702,7 +708,7 @@ class _EncoderFn(torch.autograd.Function):
         _lib.check(lib.etm_relu_mask(_ptr(g), _ptr(y3), _ptr(dy), dy.numel(), st), "etm_relu_mask")
         grads = [None] * 6
         inputs = (x0, y1, y2)
-        weights = (None, w2, w3)
+        dgrad_packs = (None, pd2, pd3)
         for i in (2, 1, 0):
             c, h, w, cout, kh, kw, s, ho, wo = ctx.shapes[i]
             K = kh * kw * c
@@ -711,12 +717,11 @@ class _EncoderFn(torch.autograd.Function):
             ws = workspace(nbytes, dev, "conv_wgrad")
             _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w, cout, kh, kw, s, st),
                        "etm_conv_train_wgrad")
-            grads[2 * i] = buf[: K * cout].view(kh, kw, c, cout).permute(3, 2, 0, 1)       # -> [Cout, C, KH, KW]
+            grads[2 * i] = buf[: K * cout].view(cout, c, kh, kw)
             grads[2 * i + 1] = buf[K * cout:]
             if i > 0:
-                packed = conv_pack_dgrad_weights(weights[i].detach(), s)
                 dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
-                _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(packed), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
+                _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
                            "etm_conv_train_dgrad")
                 dy = dx
         return (None, *grads, None)

@@ -333,14 +333,19 @@ int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_str
  *                         C in {32, 64}.  w_packed: S*S blocks, one per stride-parity class (py, px) of the input pixels, each the
  *                         fragment-order packing of Wd[c][(a*T + j)*Cout + co] = w[co][c][py + S a][px + S (T-1-j)], T = KH / S
  *                         (etm.ops.conv_pack_dgrad_weights).
- *   etm_conv_train_wgrad: dw_kc_dbias[k*Cout + co] = sum over pixels of x-window[k] * dy[co] (k ordered (ky, kx, c)), followed by
- *                         dbias[Cout] = column sums of dy, in one buffer of KH*KW*C*Cout + Cout floats.  Pixel slices are summed
- *                         in a fixed order through `workspace` (etm_conv_train_wgrad_workspace_bytes): deterministic.
- *   etm_relu_mask       : out = g * (y > 0) over n floats (n % 4 == 0, 16-byte aligned): the ReLU backward of the last layer. */
+ *   etm_conv_train_wgrad: dw[co][c][ky][kx] = sum over pixels of x-window[(ky, kx, c)] * dy[co] in the parameter's own layout
+ *                         [Cout, C, KH, KW], followed by dbias[Cout] = column sums of dy, in one buffer `dw_kc_dbias` of
+ *                         KH*KW*C*Cout + Cout floats.  Pixel slices are summed in a fixed order through `workspace`
+ *                         (etm_conv_train_wgrad_workspace_bytes): deterministic.
+ *   etm_relu_mask       : out = g * (y > 0) over n floats (n % 4 == 0, 16-byte aligned): the ReLU backward of the last layer.
+ *   etm_conv_pack_weights: w [Cout, C, KH, KW] -> `fwd` (the w_packed of etm_conv_train_fwd) and / or `dgrad` (the w_packed of
+ *                         etm_conv_train_dgrad, all S*S classes), KH*KW*C*Cout floats each, either may be NULL; one launch
+ *                         (the weights change every optimiser step). */
 int etm_conv_train_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W, int Cout, int KH,
                        int KW, int S, int out_nchw, void *stream);
 int etm_conv_train_dgrad(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
                          int KH, int KW, int S, void *stream);
+int etm_conv_pack_weights(const float *w, float *fwd, float *dgrad, int Cout, int C, int KH, int KW, int S, void *stream);
 int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
 int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N, int C,
                          int H, int W, int Cout, int KH, int KW, int S, void *stream);

@@ -1180,6 +1180,25 @@ def test_flat_adamw_with_clipping_vs_torch():
     assert int(opt.step_dev) == 5
 
 
+@pytest.mark.gpu
+def test_conv_pack_kernel_matches_the_tensor_formulation():
+    """etm_conv_pack_weights (both packings of a layer in one launch) == conv_pack_weights / conv_pack_dgrad_weights, bit-exact."""
+    from etm import ops, lib as etm_lib
+    lib = etm_lib.load()
+    dev = _dev()
+    torch.manual_seed(5)
+    for (cout, c, k, s) in ((32, 3, 8, 4), (64, 32, 4, 2), (64, 64, 3, 1), (32, 64, 6, 3)):
+        w = torch.randn((cout, c, k, k), device=dev)
+        fwd = torch.empty(w.numel(), device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        dg = torch.empty(w.numel(), device=dev) if c % 32 == 0 else None
+        etm_lib.check(lib.etm_conv_pack_weights(w.data_ptr(), fwd.data_ptr(), 0 if dg is None else dg.data_ptr(), cout, c, k, k, s, st), "pack")
+        assert torch.equal(fwd, ops.conv_pack_weights(w.permute(0, 2, 3, 1).reshape(cout, -1)).reshape(-1))
+        if dg is not None:
+            assert torch.equal(dg, ops.conv_pack_dgrad_weights(w, s).reshape(-1))
+
+
+
 @pytest.mark.parametrize("N,hw", [(5, 84), (64, 84), (7, 36), (33, 36)])
 def test_train_encoder_fwd_bwd_vs_float64_convs(N, hw):
     """Training-side encoder kernels (fp32-MFMA implicit GEMMs with fused bias / ReLU / mask / bias gradient) against the

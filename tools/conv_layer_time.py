@@ -1,0 +1,47 @@
+"""Training-side encoder kernels one by one (N = 2048, 3 x 84 x 84): HIP-event time and TFLOP/s of forward / backward-data /
+backward-weight of every layer through the C ABI.  ETM_DIAG_LIB selects another build of the library (CG_DIAG variants).
+python tools/conv_layer_time.py [N]"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
+import torch
+from etm import lib as etm_lib
+from etm import ops
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+dev = torch.device("cuda", 0); torch.manual_seed(0)
+lib = etm_lib.load()
+st = torch.cuda.current_stream().cuda_stream
+P = lambda t: t.data_ptr()
+layers = [(3, 84, 84, 32, 8, 4), (32, 20, 20, 64, 4, 2), (64, 9, 9, 64, 3, 1)]
+def timed(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+tot = 0.0
+for li, (c, h, w, cout, k, s) in enumerate(layers):
+    ho, wo = (h - k) // s + 1, (w - k) // s + 1
+    x = torch.rand((N, h, w, c), device=dev)
+    wt = torch.randn((cout, c, k, k), device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
+    y = torch.empty((N, ho, wo, cout), device=dev)
+    dy = torch.randn((N, ho, wo, cout), device=dev)
+    packed = ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+    fl = 2.0 * N * ho * wo * cout * k * k * c
+    t = timed(lambda: etm_lib.check(lib.etm_conv_train_fwd(P(x), P(packed), P(b), P(y), N, c, h, w, cout, k, k, s, 0, st), "fwd"))
+    print(f"conv{li + 1} forward   {t:8.1f} us  {fl / t / 1e6:6.1f} TFLOP/s ({fl / t / 1e6 / 157.3:.2f} of peak)"); tot += t
+    if li > 0:
+        pd = ops.conv_pack_dgrad_weights(wt, s)
+        dx = torch.empty((N, h, w, c), device=dev)
+        t = timed(lambda: etm_lib.check(lib.etm_conv_train_dgrad(P(dy), P(pd), P(x), P(dx), N, c, h, w, cout, k, k, s, st), "dgrad"))
+        print(f"conv{li + 1} bwd-data  {t:8.1f} us  {fl / t / 1e6:6.1f} TFLOP/s ({fl / t / 1e6 / 157.3:.2f} of peak)"); tot += t
+    K = k * k * c
+    buf = torch.empty(K * cout + cout, device=dev)
+    nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, h, w, cout, k, k, s)
+    ws = torch.empty(max(nbytes, 8) // 4, device=dev)
+    t = timed(lambda: etm_lib.check(lib.etm_conv_train_wgrad(P(x), P(dy), P(buf), P(ws), nbytes, N, c, h, w, cout, k, k, s, st), "wgrad"))
+    print(f"conv{li + 1} bwd-weight {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s ({fl / t / 1e6 / 157.3:.2f} of peak)  (incl. slice reduction)"); tot += t
+print(f"sum {tot:8.1f} us")
