@@ -121,7 +121,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
     for (int mt = 0; mt < MT; ++mt) {
       if ((CG_DIAG & 1) && g >= 3) break;
       if (!DGRAD) {
-        a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + loff[mt]);
+        a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + ((CG_DIAG & 8) ? (loff[mt] & ~0xfff) + lane * 4 : loff[mt]));
       } else {
         const int sy = vy0[mt] - seg, sx = vx0[mt] + gi / gpp;
         const bool ok = sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW;

@@ -170,6 +170,9 @@ class SyntheticVecEnv:
         return self._emit(out)
 
     def step(self, actions, out=None, on_rows=None):
+        # the frame a worker shows next does not depend on its done flag (a finished worker's next frame IS its reset observation),
+        # so the rows go out first: their upload overlaps the bookkeeping below
+        obs = self._emit(out, on_rows)
         if self._upos >= _CHUNK:
             for w, rng in enumerate(self._rngs):
                 self._u[w] = rng.random((_CHUNK, 2))
@@ -186,7 +189,6 @@ class SyntheticVecEnv:
                 infos[w] = {"reward": float(self._ret[w]), "length": int(self._t[w])}
             self._t[dones] = 0
             self._ret[dones] = 0.0
-        obs = self._emit(out, on_rows)  # for finished workers this frame *is* the reset observation
         return obs, rewards, dones, infos
 
     def close(self):

@@ -216,6 +216,7 @@ class PPOTrainer:
         self._flag_np = self._flag_pin.numpy()
         self._host_flag = False      # decided when the step graph is captured
         self._up_stream = torch.cuda.Stream(device=device)
+        self._state_zero_copy = bool(config.get("state_zero_copy", True))
         self._up_done = torch.cuda.Event()
         self._stream_obs = False     # decided when the step graph is captured
         self._t_row = torch.zeros((), dtype=torch.int64, device=device)
@@ -374,10 +375,21 @@ class PPOTrainer:
         if stream_obs:
             self._up_stream.wait_stream(main)      # the staging array may still be read by the previous update
 
+        # With a stream per group (the pipelined default) the observation rows of a group go to the device on the GROUP's stream
+        # -- stream order alone puts them before the step that reads them -- and the step's window kernel reads the
+        # (episode step, slot) block straight from pinned host memory: no upload of that block, no event between an upload
+        # stream and the step (each of those was a few us on the critical path of every step).
+        own_stream = stream_obs and self._state_zero_copy and all(g.stream is not None for g in groups)
+
+        def obs_stream(g):
+            return g.stream.cuda_stream if own_stream else up
+
         def upload_state(g):
-            """(episode step, slot) of the group's workers -> device, after the host bookkeeping of the step."""
+            """(episode step, slot) of the group's workers -> where the device finds them, after the host bookkeeping of the step."""
             if not g.full:
                 g.ss_np[:] = ss_global[:, g.lo:g.hi]
+            if own_stream:
+                return
             lib.etm_upload(g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8, up)
             g.up_done.record(self._up_stream)
 
@@ -387,7 +399,7 @@ class PPOTrainer:
                 if g.stream is not None:
                     torch.cuda.set_stream(g.stream)
                 cur = g.stream if g.stream is not None else main
-                if stream_obs:
+                if stream_obs and not own_stream:
                     cur.wait_event(g.up_done)        # observation rows and (step, slot) of step t are on the device
                 elif not g.full:
                     g.ss_np[:] = ss_global[:, g.lo:g.hi]
@@ -406,7 +418,7 @@ class PPOTrainer:
 
         if stream_obs:
             for g in groups:                       # observation 0 -> staging row 0
-                lib.etm_upload(stage_base + g.lo * row_bytes, src_base + g.lo * row_bytes, g.W * row_bytes, up)
+                lib.etm_upload(stage_base + g.lo * row_bytes, src_base + g.lo * row_bytes, g.W * row_bytes, obs_stream(g))
                 upload_state(g)
         for g in groups:
             launch(g, 0)
@@ -429,16 +441,15 @@ class PPOTrainer:
                 if stream_obs and t + 1 < S:
                     dst_base = stage_base + ((t + 1) * W + lo) * row_bytes
                     src_g = src_base + lo * row_bytes
+                    up_g = obs_stream(g)
 
                     def rows_ready(a, b):
-                        lib.etm_upload(dst_base + a * row_bytes, src_g + a * row_bytes, (b - a) * row_bytes, up)
+                        lib.etm_upload(dst_base + a * row_bytes, src_g + a * row_bytes, (b - a) * row_bytes, up_g)
 
                     _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np, on_rows=rows_ready)
                 else:
                     _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np)
                 t_env += time.perf_counter() - te
-                buf.rewards[lo:hi, t] = rewards
-                buf.dones[lo:hi, t] = dones
                 self.worker_current_episode_step[lo:hi] += 1
                 if dones.any():
                     for wl in np.flatnonzero(dones):
@@ -455,6 +466,8 @@ class PPOTrainer:
                         upload_state(g)              # bookkeeping of this step is final: (step, slot) follow the observation rows
                     launch(g, t + 1)
                     t_launch += time.perf_counter() - tl
+                buf.rewards[lo:hi, t] = rewards    # (after the launch: nothing on the device waits for these)
+                buf.dones[lo:hi, t] = dones
         for st_ in side_streams:
             main.wait_stream(st_)
         t_ = self.model.transformer
@@ -496,10 +509,12 @@ class PPOTrainer:
         # window lookup + staging; the same launch records the staging row of this step for the tail (t_dev is incremented by
         # the sampling kernel) and resets the K/V cache of workers at episode step 0 (they start from the projection of an
         # empty memory)
-        ops.rollout_window(g.step_dev, self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
+        # streamed + pipelined mode: the (step, slot) block is read from pinned host memory (see _sample_training_data)
+        ss_src = g.ss_pin if (stream_obs and self._state_zero_copy and g.stream is not None) else g.ss_dev
+        ops.rollout_window(ss_src[0], self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
                            st["memory_mask"], st["memory_indices"], t_row=g.t_row,
                            reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo,
-                           latch=(g.ss_dev, g.ss_latch))
+                           latch=(ss_src, g.ss_latch))
         fused_policy = False
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(g.kv, None, win_t, None, mask_t)

@@ -51,3 +51,18 @@ if tr._step_graph is not None:
     e2.record(); torch.cuda.synchronize()
     print(f"step graphs of one group ({g0.W} workers) back-to-back: head {e0.elapsed_time(e1) / n * 1e3:.1f} us, "
           f"tail {e1.elapsed_time(e2) / n * 1e3:.1f} us  (host_flag={tr._host_flag})")
+    # do the step graphs of DIFFERENT groups overlap on the device?  every group replays n times on its own stream, no host waits
+    if len(tr._groups) > 1 and all(g.graphs is not None and g.stream is not None for g in tr._groups):
+        for g in tr._groups:
+            g.t_dev.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            for g in tr._groups:
+                with torch.cuda.stream(g.stream):
+                    g.graphs[0].replay()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{len(tr._groups)} groups replaying concurrently on their streams: {dt / n * 1e6:.1f} us per round of {len(tr._groups)} graphs "
+              f"(host launch time {t_host / n * 1e6:.1f} us per round)")
