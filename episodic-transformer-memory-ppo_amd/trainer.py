@@ -217,6 +217,7 @@ class PPOTrainer:
         self._host_flag = False      # decided when the step graph is captured
         self._up_stream = torch.cuda.Stream(device=device)
         self._state_zero_copy = bool(config.get("state_zero_copy", True))
+        self._chain_log = None       # tools/rollout_profile.py: per-step host timestamps of the first group
         self._up_done = torch.cuda.Event()
         self._stream_obs = False     # decided when the step graph is captured
         self._t_row = torch.zeros((), dtype=torch.int64, device=device)
@@ -466,6 +467,8 @@ class PPOTrainer:
                         upload_state(g)              # bookkeeping of this step is final: (step, slot) follow the observation rows
                     launch(g, t + 1)
                     t_launch += time.perf_counter() - tl
+                    if self._chain_log is not None and g is groups[0]:
+                        self._chain_log.append((tw, te, tl, time.perf_counter()))
                 buf.rewards[lo:hi, t] = rewards    # (after the launch: nothing on the device waits for these)
                 buf.dones[lo:hi, t] = dones
         for st_ in side_streams:

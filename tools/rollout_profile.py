@@ -26,6 +26,7 @@ torch.cuda.synchronize()
 
 S = cfg["worker_steps"]
 for rep in range(2):
+    tr._chain_log = [] if rep == 1 else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr._sample_training_data()
@@ -35,6 +36,15 @@ for rep in range(2):
     print(f"rollout: {dt * 1e3:.1f} ms = {dt / S * 1e6:.0f} us per step (host: env.step {lt['env_s'] / S * 1e6:.0f}, waiting for actions "
           f"{lt['wait_s'] / S * 1e6:.0f}, upload + launch {lt['launch_s'] / S * 1e6:.0f} us per step)  stream_observations={tr._stream_obs} "
           f"groups={len(tr._groups)}")
+
+if tr._chain_log:
+    import numpy as _np
+    c = _np.array(tr._chain_log[8:-2])          # (wait start, flag seen, env.step + bookkeeping done, launch done)
+    cyc = _np.diff(c[:, 1])
+    print(f"first group, per step: flag seen -> env.step done {(c[:, 2] - c[:, 1]).mean() * 1e6:.1f} us, -> launch done "
+          f"{(c[:, 3] - c[:, 2]).mean() * 1e6:.1f} us, launch done -> next flag seen {(c[1:, 1] - c[:-1, 3]).mean() * 1e6:.1f} us "
+          f"(of which spinning {(c[1:, 1] - c[1:, 0]).mean() * 1e6:.1f} us); cycle {cyc.mean() * 1e6:.1f} us")
+tr._chain_log = None
 
 # device time of the step graphs alone (no host work in between): head = critical path of a step, tail = under env.step
 if tr._step_graph is not None:
