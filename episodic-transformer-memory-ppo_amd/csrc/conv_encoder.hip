@@ -24,6 +24,7 @@ struct ConvParams {
   int N, C, H, W, Cout, KH, KW, S, Ho, Wo;
   int in_nhwc, out_nchw;
   int seg_len, n_seg, groups;  // K = n_seg * seg_len, groups = K / 8
+  int nt_total;                // channel tiles of the layer (Cout / 32); a workgroup covers NT of them from blockIdx.y * NT
 };
 
 constexpr int CONV_NW = 8;   // waves per workgroup = K slices
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
 
   // weights arrive packed in fragment order (etm_hip.h): the B fragment of (k-group g, tile t) is 64 lanes x 4 floats,
   // contiguous -- one fully coalesced 1 KB load per wave instead of 64 different cache lines
-  const float *wlane = p.w + lane * 4;
+  const int t_first = (int)blockIdx.y * NT;
+  const float *wlane = p.w + lane * 4 + (long long)t_first * 256;
 
   auto a_ptr = [&](int k0) -> const float * {
     const int seg = k0 / p.seg_len, off = k0 - seg * p.seg_len;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
     const int g_ = (g0_) + u * NW;                                                                \
     const int gc_ = g_ < p.groups ? g_ : last;                                                    \
     dst_a[u] = *reinterpret_cast<const f32x4 *>(a_ptr(gc_ * 8));                                  \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) dst_b[u][t] = *reinterpret_cast<const f32x4 *>(wlane + ((long long)gc_ * NT + t) * 256); \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) dst_b[u][t] = *reinterpret_cast<const f32x4 *>(wlane + ((long long)gc_ * p.nt_total + t) * 256); \
   }
   for (int g0 = wave; g0 < p.groups; g0 += GB * NW) {
     ETM_CONV_LOAD(a_cur, b_cur, g0)
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv_relu_kernel(const ConvParam
     const int row = mfma32_row(r, lane);
     const int mm = (int)blockIdx.x * 32 + row;
     if (mm < M) {
-      const int co = t * 32 + col;
+      const int co = (t_first + t) * 32 + col;
       v = fmaxf(v + p.bias[co], 0.f);
       if (p.out_nchw) {
         const int nn = mm / (p.Ho * p.Wo);
@@ -135,6 +137,7 @@ extern "C" int etm_conv_relu(const float *in, const int64_t *in_index, int64_t i
   const bool aligned = in_nhwc ? (C % 4 == 0) : (W % 4 == 0 && S % 4 == 0);
   if (p.seg_len % 8 != 0 || K % 8 != 0 || !aligned || (Cout != 32 && Cout != 64)) return ETM_EUNSUPPORTED;
   p.groups = K / 8;
+  p.nt_total = Cout / 32;
   const int M = N * p.Ho * p.Wo;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_CONV_RELU, st);
@@ -144,6 +147,12 @@ extern "C" int etm_conv_relu(const float *in, const int64_t *in_index, int64_t i
   if (Cout == 32) {
     if (gpw <= 4) hipLaunchKernelGGL((conv_relu_kernel<1, 4>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_relu_kernel<1, 12>), grid, block, 0, st, p);
+  } else if (2 * grid.x <= 256) {
+    // few pixel tiles (a worker group of a rollout step): one channel tile per workgroup -- twice the CUs, half the MFMA chain
+    // and half the operand requests per wave; the A fragments are fetched twice, which is nothing at this size
+    const dim3 grid2(grid.x, 2);
+    if (gpw <= 4) hipLaunchKernelGGL((conv_relu_kernel<1, 4>), grid2, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_relu_kernel<1, 12>), grid2, block, 0, st, p);
   } else {
     if (gpw <= 4) hipLaunchKernelGGL((conv_relu_kernel<2, 4>), grid, block, 0, st, p);
     else if (gpw <= 8) hipLaunchKernelGGL((conv_relu_kernel<2, 8>), grid, block, 0, st, p);

@@ -1041,7 +1041,7 @@ def test_fused_rollout_encoder_vs_library_convs():
     cfg = dict(hidden_layer_size=64, transformer=dict(num_blocks=1, embed_dim=64, num_heads=2, memory_length=8,
                                                       positional_encoding="", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))
     torch.manual_seed(2)
-    for shape, n in (((3, 84, 84), 32), ((3, 84, 84), 5), ((4, 64, 64), 3)):
+    for shape, n in (((3, 84, 84), 32), ((3, 84, 84), 5), ((4, 64, 64), 3), ((3, 84, 84), 200)):   # 200: both channel tiles in one workgroup
         m = ActorCriticModel(cfg, SimpleNamespace(shape=shape), (3,), 8).to(dev)
         obs = torch.rand((n,) + shape, device=dev)
         with torch.no_grad():
