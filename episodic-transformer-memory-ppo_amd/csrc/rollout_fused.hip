@@ -37,13 +37,16 @@ namespace {
 constexpr int RF_T = 512;                  // 8 waves, up to 256 VGPRs each: room for a whole product slice in flight
 constexpr int RF_WAVES = RF_T / 64;
 constexpr int RF_MAXB = 8;
+constexpr int RF_MAXSPLIT = 16;            // K slices of the lin_hidden product in front of the kernel
 constexpr int RF_SPIN_LIMIT = 1 << 22;     // ~1 s of polling: a partner that never ran
 
 struct RfBlock {
   const float *wq_t, *wo_t, *bo, *g1, *b1, *wfc_t, *bfc, *g2, *b2;
 };
 struct RfParams {
-  const float *h_in;                 // [W, D] input of the transformer (model.py:96-100 output)
+  const float *h_in;                 // [W, D] input of the transformer (model.py:96-100 output), or, with h_splits > 0, the
+  const float *h_bias;               // [h_splits, W, D] K-slice sums of etm_rollout_hidden_partial: input = relu(sum + h_bias)
+  int h_splits;
   const float *wemb_t, *bemb;        // [D, D] transposed, [D]
   RfBlock blk[RF_MAXB];
   int nb;
@@ -237,7 +240,21 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     if (p.forced) a_forced = (int)p.forced[t_now * p.stage_W + w];
     u_draw = p.uniforms[t_now * p.stage_W + w];
   }
-  if (tid < D) x_s[tid] = p.h_in[(long long)w * D + tid];
+  if (tid < D) {
+    float v;
+    if (p.h_splits > 0) {                                          // lin_hidden arrives as K-slice sums: add them in slice order
+      float part[RF_MAXSPLIT];
+#pragma unroll
+      for (int s = 0; s < RF_MAXSPLIT; ++s) part[s] = (s < p.h_splits) ? p.h_in[((long long)s * p.W + w) * D + tid] : 0.f;
+      v = 0.f;
+#pragma unroll
+      for (int s = 0; s < RF_MAXSPLIT; ++s) v += part[s];
+      v = fmaxf(v + p.h_bias[tid], 0.f);
+    } else {
+      v = p.h_in[(long long)w * D + tid];
+    }
+    x_s[tid] = v;
+  }
   if (tid < L) {                                                   // the window rows of this worker in the K | V cache (block 0's offsets)
     off_s[tid] = (long long)w * p.kv_w_stride + p.win[(long long)w * L + tid] * p.kv_row_stride;
     mask_s[tid] = p.mask[(long long)w * L + tid];
@@ -556,6 +573,64 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
 }
 }  // namespace
 
+// ---- lin_hidden of a rollout step as K-slice partial sums (model.py:94-100 without the bias / ReLU, which the consumer adds).
+// At 16 rows the [rows, F] x [F, D] product (F = 3136: 4.8 MB of weights) is a latency problem: the library kernel walks K in
+// 49 dependent steps on 24 workgroups (13 us).  Here a workgroup owns 32 columns x one of `splits` K slices: all of its weights
+// (25 KB) and its slice of the features are requested at once -- one memory round trip on 12 x splits workgroups.
+// Thread = (k lane kq of 32, column quad c4 of 8): its weights (16 bytes per owned k row) are all requested up front; rows in
+// chunks of 16.  The 32 k lanes are summed in a fixed order: lanes 8 apart inside a 16-lane row by a DPP rotate, the remaining
+// 16 partial sums (4 row groups x 4 waves) through LDS.
+constexpr int HP_ROWS = 16, HP_KMAX = 256;
+__global__ __launch_bounds__(256) void hidden_partial_kernel(const float *__restrict__ x, const float *__restrict__ wt, float *__restrict__ part,
+                                                             int W, int F, int D, int kslice) {
+  __shared__ float xs[HP_ROWS][HP_KMAX];
+  __shared__ __attribute__((aligned(16))) float red[16][HP_ROWS][32];
+  const int tid = threadIdx.x, c4 = tid & 7, kq = tid >> 3, lane = tid & 63, wave = tid >> 6;
+  const int col0 = (int)blockIdx.x * 32, s = (int)blockIdx.y;
+  const int k0 = s * kslice, kn = min(kslice, F - k0);              // this slice: rows k0 .. k0 + kn of the [F, D] matrix
+  constexpr int KI = HP_KMAX / 32;
+  f32x4 wreg[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int kk = kq + 32 * i;
+    wreg[i] = (kk < kn) ? *reinterpret_cast<const f32x4 *>(wt + (long long)(k0 + kk) * D + col0 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int r0 = 0; r0 < W; r0 += HP_ROWS) {
+    const int rows = min(HP_ROWS, W - r0);
+    __syncthreads();
+    for (int i = tid; i < HP_ROWS * HP_KMAX; i += 256) {
+      const int r = i / HP_KMAX, kk = i - r * HP_KMAX;
+      xs[r][kk] = (r < rows && kk < kn) ? x[(long long)(r0 + r) * F + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[HP_ROWS];
+#pragma unroll
+    for (int r = 0; r < HP_ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int kk = kq + 32 * i;
+#pragma unroll
+      for (int r = 0; r < HP_ROWS; ++r) acc[r] += xs[r][kk] * wreg[i];
+    }
+    const int rg = wave * 4 + (lane >> 4);                         // 16-lane row group: 2 k lanes x 8 column quads
+#pragma unroll
+    for (int r = 0; r < HP_ROWS; ++r) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)                                  // + the lane 8 further in the row (row_ror:8): the other k lane
+        acc[r][j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r][j]), 0x128, 0xf, 0xf, false));
+      if ((lane & 8) == 0) *reinterpret_cast<f32x4 *>(&red[rg][r][c4 * 4]) = acc[r];
+    }
+    __syncthreads();
+    for (int o = tid; o < HP_ROWS * 32; o += 256) {
+      const int r = o >> 5, c = o & 31;
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][r][c];
+      if (r < rows) part[((long long)s * W + r0 + r) * D + col0 + c] = t;
+    }
+  }
+}
+
 #ifdef ETM_RF_STAMPS
 extern "C" int etm_diag_rollout_trxl_stamps(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rf_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
@@ -582,6 +657,24 @@ extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
   return 64 + (int64_t)W * slots * P * 2 * D * (int64_t)sizeof(float);
 }
 
+// part [splits, W, D] = K-slice sums of x [W, F] @ wt [F, D] (wt = the layer's weight TRANSPOSED); splits = etm_rollout_hidden_splits(F).
+extern "C" int etm_rollout_hidden_splits(int F) {
+  if (F <= 0) return 0;
+  int s = (F + HP_KMAX - 1) / HP_KMAX;            // slices of at most HP_KMAX rows ...
+  if (s < RF_MAXSPLIT && F >= 32 * RF_MAXSPLIT) s = RF_MAXSPLIT;   // ... and as many as the consumer adds when K is long
+  return s <= RF_MAXSPLIT ? s : 0;
+}
+extern "C" int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int W, int F, int D, void *stream) {
+  (void)hipGetLastError();
+  if (!x || !wt || !part || W <= 0 || F <= 0 || D <= 0) return ETM_EINVAL;
+  const int splits = etm_rollout_hidden_splits(F);
+  if (splits == 0 || D % 32 != 0 || ((uintptr_t)wt % 16) != 0) return ETM_EUNSUPPORTED;
+  const int kslice = (F + splits - 1) / splits;
+  if (kslice > HP_KMAX) return ETM_EUNSUPPORTED;
+  hipLaunchKernelGGL(hidden_partial_kernel, dim3((unsigned)(D / 32), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, x, wt, part, W, F, D, kslice);
+  return etm_launch_status();
+}
+
 // One launch per worker group and rollout step.  blocks: nb structs of 9 device pointers each, in the order
 // (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous).
 // scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes, ZEROED once by the caller before the first launch and then left alone
@@ -589,14 +682,15 @@ extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
 // Tail (wkv != NULL): after the action hand-over the same launch writes the new memory items into bank[slot_l[w], step_l[w]] and
 // their K | V projection (items + pos[step_l[w]]) wkv[b] into kv[w, step_l[w]] -- what the multi-launch path does with five more
 // launches while the host steps the environments.
+// h_splits > 0: h_in is the [h_splits, W, D] output of etm_rollout_hidden_partial and the transformer input is relu(sum + h_bias).
 extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, float *kv,
                                 int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
                                 const float *wh_t, const float *bh, const float *wp, const float *bp, const float *wv, const float *bv,
                                 const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                                 float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                                 float ln_eps, void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
-                                const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int W, int D, int H,
-                                int L, int hid, int A, int stage_W, void *stream) {
+                                const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
+                                int h_splits, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
   (void)hipGetLastError();
   if (!h_in || !wemb_t || !bemb || !blocks || !kv || !win || !mask || !items || !wh_t || !bh || !wp || !bp || !wv || !bv || !uniforms ||
       !t_dev || !actions || !st_actions || !st_logp || !st_values || !sync_counter || !scratch)
@@ -604,11 +698,12 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   if (W <= 0 || nb <= 0 || D <= 0 || H <= 0 || L <= 0 || hid <= 0 || A <= 0 || stage_W < W || D % H != 0) return ETM_EINVAL;
   if (host_flag && !host_actions) return ETM_EINVAL;
   if (wkv && (!step_l || !slot_l || !bank)) return ETM_EINVAL;
+  if (h_splits < 0 || h_splits > RF_MAXSPLIT || (h_splits > 0 && !h_bias)) return ETM_EINVAL;
   const int P = etm_rollout_trxl_team(H);
   if (!etm_rollout_trxl_supported(D, H, L, hid, A, nb) || (W + 7) / 8 * 8 * P > 256) return ETM_EUNSUPPORTED;   // all teams resident
   if (scratch_bytes < etm_rollout_trxl_scratch_bytes(W, D, H, nb)) return ETM_EWORKSPACE;
   RfParams p{};
-  p.h_in = h_in; p.wemb_t = wemb_t; p.bemb = bemb; p.nb = nb;
+  p.h_in = h_in; p.h_bias = h_bias; p.h_splits = h_splits; p.wemb_t = wemb_t; p.bemb = bemb; p.nb = nb;
   for (int b = 0; b < nb; ++b) {
     const float *const *q = reinterpret_cast<const float *const *>(blocks) + 9 * b;
     for (int k = 0; k < 9; ++k) if (!q[k]) return ETM_EINVAL;

@@ -404,7 +404,7 @@ def rollout_trxl_supported(D, H, L, hid, A, nb):
 
 
 def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp,
-                 st_values, scratch, host_actions=None, host_flag=None, w_off=0, tail=None):
+                 st_values, scratch, host_actions=None, host_flag=None, w_off=0, tail=None, h_bias=None):
     """Transformer + hidden / output heads + sampling of one rollout step of a worker group in one launch (etm_rollout_trxl).
     ``fused``: the transposed fixed-address weight copies of ``ActorCriticModel.refresh_rollout_weights`` (dict with the host
     pointer table ``blocks``); ``kv`` the group's K | V cache [W, T, blocks, 2D]; ``scratch`` from ``rollout_trxl_scratch``; the
@@ -413,13 +413,19 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
     ``bank[slot_l, step_l]`` and their K | V projection into ``kv[w, step_l]``."""
     lib = _lib.load()
     h_in = _f32c(h_in, "h_in")
+    h_splits = 0
+    if h_bias is not None:        # h_in = [splits, W, D] slice sums of rollout_hidden_partial
+        h_splits = h_in.shape[0]
+        h_in_shape = h_in.shape[1:]
+    else:
+        h_in_shape = h_in.shape
     t_args = (0, 0, 0, 0, 0, 0, 0)
     if tail is not None:
         wkv, pos, step_l, slot_l, bank = tail
         if not (wkv.is_contiguous() and bank.stride(3) == 1 and bank.stride(2) == bank.shape[3] and (pos is None or pos.is_contiguous())):
             raise ValueError("rollout_trxl tail: wkv / pos contiguous and bank rows [blocks, D] contiguous expected")
         t_args = (_ptr(wkv), 0 if pos is None else _ptr(pos), _ptr(step_l), _ptr(slot_l), _ptr(bank), bank.stride(0), bank.stride(1))
-    W, D = h_in.shape
+    W, D = h_in_shape
     L = win_t.shape[1]
     A, hid = policy_head.weight.shape
     sync = _policy_sync.get(t_dev.data_ptr())
@@ -433,9 +439,25 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
                                     kv.stride(1), _ptr(win_t), _ptr(mask_t), _ptr(items), _ptr(fused["heads_t"]), _ptr(fused["heads_b"]),
                                     _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight), _ptr(value_head.bias),
                                     off(uniforms), off(forced), _ptr(t_dev), _ptr(actions), off(st_actions), off(st_logp), off(st_values),
-                                    ha, hf, _ptr(sync), float(fused["eps"]), _ptr(scratch), scratch.numel() * 8, *t_args, W, D, fused["H"], L,
-                                    hid, A, stage_w, _stream()),
+                                    ha, hf, _ptr(sync), float(fused["eps"]), _ptr(scratch), scratch.numel() * 8, *t_args,
+                                    0 if h_bias is None else _ptr(h_bias), h_splits, W, D, fused["H"], L, hid, A, stage_w, _stream()),
                "etm_rollout_trxl")
+
+
+def rollout_hidden_partial(x, wt, out=None):
+    """K-slice partial sums of ``x [W, F] @ wt [F, D]`` (etm_rollout_hidden_partial): [splits, W, D]; the consumer
+    (``rollout_trxl(h_bias=...)``) adds the slices, the bias and the ReLU."""
+    lib = _lib.load()
+    x = _f32c(x, "features")
+    W, F = x.shape
+    D = wt.shape[1]
+    splits = lib.etm_rollout_hidden_splits(F)
+    if splits <= 0:
+        raise ValueError(f"rollout_hidden_partial: unsupported feature size {F}")
+    if out is None:
+        out = torch.empty((splits, W, D), dtype=torch.float32, device=x.device)
+    _lib.check(lib.etm_rollout_hidden_partial(_ptr(x), _ptr(wt), _ptr(out), W, F, D, _stream()), "etm_rollout_hidden_partial")
+    return out
 
 
 def rollout_heads(h2, branch, value_head):

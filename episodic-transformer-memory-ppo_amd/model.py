@@ -125,6 +125,8 @@ class ActorCriticModel(nn.Module):
                 fresh[f"wq_t{i}"] = blk.attention.queries.weight.t()
                 fresh[f"wo_t{i}"] = blk.attention.fc_out.weight.t()
                 fresh[f"wfc_t{i}"] = blk.fc[0].weight.t()
+            if self.visual and self.lin_hidden.weight.shape[0] % 32 == 0:
+                fresh["hid_t"] = self.lin_hidden.weight.t()     # [features, D]: etm_rollout_hidden_partial
             rf = getattr(self, "_rf", None)
             if rf is None or rf["emb_t"].device != self.lin_policy.weight.device:
                 rf = {k: v.contiguous() for k, v in fresh.items()}
@@ -142,7 +144,7 @@ class ActorCriticModel(nn.Module):
                     rf[k].copy_(v)
             self._rf["heads_b"] = self._b_heads          # concatenated hidden-head bias (refreshed above)
 
-    def _encode_fused(self, obs, obs_index=None, obs_rows=None):
+    def _encode_fused(self, obs, obs_index=None, obs_rows=None, features_only=False):
         if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()
                                                      and self._wver != (self.conv1.weight._version, self.conv2.weight._version,
                                                                         self.conv3.weight._version)):
@@ -155,6 +157,8 @@ class ActorCriticModel(nn.Module):
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)
         h2, w2 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w3p, self.conv3.bias, 64, h2, w2, 3, 3, 1, True, True)                                # -> NCHW
+        if features_only:
+            return x.reshape(n, -1)
         return ops.linear_relu(self.lin_hidden, x.reshape(n, -1))
 
     def _encode(self, obs, obs_index=None, obs_rows=None):

@@ -525,7 +525,17 @@ class PPOTrainer:
                 # post-LN blocks without gates: the transformer, the heads and the sampling are ONE launch -- one workgroup per
                 # worker walks the whole chain as matrix-vector products over the L2-resident weights (csrc/rollout_fused.hip);
                 # the step is then encoder (4 launches) + window lookup + this kernel instead of 26 dependent launches
-                h_in = self.model._encode(obs, obs_index, rows)
+                rf = self.model._rf
+                h_bias = None
+                if obs_index is not None and "hid_t" in rf and self.config.get("split_hidden_product", True):
+                    # lin_hidden as K-slice partial sums on 12 x 16 workgroups; the step kernel adds slices + bias + ReLU
+                    feats = self.model._encode_fused(obs, obs_index, rows, features_only=True)
+                    if getattr(g, "h_part", None) is None:
+                        g.h_part = ops.rollout_hidden_partial(feats, rf["hid_t"])
+                    h_in = ops.rollout_hidden_partial(feats, rf["hid_t"], out=g.h_part)
+                    h_bias = self.model.lin_hidden.bias
+                else:
+                    h_in = self.model._encode(obs, obs_index, rows)
                 if getattr(g, "rf_scratch", None) is None:
                     t_ = self.model.transformer
                     g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device)
@@ -537,7 +547,7 @@ class PPOTrainer:
                 ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
                                  self._uniforms, self._forced_tab, g.t_dev, g.act_dev, st["actions"], st["log_probs"], st["values"],
                                  g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo,
-                                 tail=tail)
+                                 tail=tail, h_bias=h_bias)
                 item = g.item
                 fused_policy = True
             elif single and self.model.rollout_heads_fusable():

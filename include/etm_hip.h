@@ -279,6 +279,7 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *   scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes that the caller ZEROES ONCE and then leaves to the kernel
  *           (int64 launch counter, int64 error word -- non-zero after a launch = a team member timed out --, 48 bytes of padding,
  *           then the exchange slots).
+ *   h_splits > 0: h_in is [h_splits, W, D] from etm_rollout_hidden_partial and the input is relu(sum over slices + h_bias [D]);
  *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
  *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
  *           pos[step_l[w]]) wkv[b]  (wkv [nb, D, 2D] = per block [Wk ; Wv]^T, pos [T, D] or NULL; transformer.py:236-237 for the
@@ -294,8 +295,14 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                      float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter, float ln_eps,
                      void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
-                     const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int W, int D, int H, int L,
-                     int hid, int A, int stage_W, void *stream);
+                     const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
+                     int h_splits, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+/* lin_hidden of a rollout step (model.py:94-100) as K-slice partial sums: part [splits, W, D], splits =
+ * etm_rollout_hidden_splits(F) (<= 16), = the slice sums of x [W, F] @ wt [F, D] (wt = the weight TRANSPOSED, 16-byte aligned,
+ * D % 32 == 0).  etm_rollout_trxl(h_in = part, h_bias = the layer's bias, h_splits = splits) adds the slices in slice order,
+ * the bias and the ReLU: one memory round trip on 12 x splits workgroups instead of a 49-step K walk on 24. */
+int etm_rollout_hidden_splits(int F);
+int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int W, int F, int D, void *stream);
 
 /* Host-side helper of the in-process environment front-ends (no device work): a memcpy split over `threads` threads (the
  * caller + threads - 1 helpers that spin briefly after a job and sleep otherwise).  The reference produces the observations of a

@@ -374,13 +374,14 @@ _ROLLOUT_PATHS = {
     "library_convs": {"fused_train_encoder": False},          # optimisation phase on the library convolutions
     "multi_launch_blocks": {"fused_rollout_block": False},    # rollout: one launch per GEMM / attention / LayerNorm instead of one per step
     "launched_tail": {"fused_rollout_tail": False},           # bank write + K/V projection of the new items as separate launches
+    "library_hidden": {"split_hidden_product": False},        # lin_hidden of a rollout step by the library GEMM, not as K-slice sums
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
              ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs"),
              ("img32", "multi_launch_blocks"), ("vec", "multi_launch_blocks"), ("img32", "launched_tail"), ("vec", "launched_tail"),
-             ("img32", "state_uploaded")]
+             ("img32", "state_uploaded"), ("img32", "library_hidden")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -1030,6 +1031,20 @@ def test_train_cli_and_checkpoint_format(tmp_path):
                           capture_output=True, text=True, timeout=300)
     assert play.returncode == 0, play.stderr[-2000:]
     assert "Episode length:" in play.stdout and "Episode reward:" in play.stdout
+
+
+def test_rollout_hidden_partial_sums_vs_matmul():
+    """etm_rollout_hidden_partial: the K-slice sums add up to x @ W^T (float64 reference) for group sizes around the 16-row
+    chunk and feature sizes with a ragged last slice."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(21)
+    for (W, F, D) in ((16, 3136, 384), (5, 3136, 384), (32, 1024, 64), (17, 777, 96), (1, 40, 32)):
+        x = torch.randn((W, F), device=dev)
+        wt = (torch.randn((D, F), device=dev) / F ** 0.5).t().contiguous()
+        part = ops.rollout_hidden_partial(x, wt)
+        want = (x.double() @ wt.double()).cpu().numpy()
+        close(part.sum(dim=0), want, atol=2e-5, rtol=1e-5, what=f"hidden partial sums {(W, F, D)}")
 
 
 def test_fused_rollout_encoder_vs_library_convs():
