@@ -115,8 +115,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the kernel micro-benchmarks after the timed region")
     ap.add_argument("--dist-backend", default=None, help="testing only: torch.distributed backend instead of nccl (= RCCL), e.g. gloo")
-    ap.add_argument("--dp-collective", choices=("torch", "etm"), default="torch",
-                    help="gradient all-reduce through torch.distributed (RCCL backend) or through the library's own RCCL communicator")
+    ap.add_argument("--dp-collective", choices=("torch", "etm"), default=None,
+                    help="gradient all-reduce through the library's own RCCL communicator (etm, the default: created and self-tested "
+                         "at start-up, torch.distributed takes over if that fails) or through torch.distributed (RCCL backend)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="testing only: every rank uses this device index (exercises the multi-process path on a 1-GPU box)")
     ap.add_argument("--plumbing-check", action="store_true",

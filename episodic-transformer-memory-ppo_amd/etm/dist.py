@@ -73,22 +73,32 @@ class DataParallel:
     def _start_etm_comm(self):
         """Create the library communicator now (not inside the first optimisation step, which may be under graph capture) and
         check it with a one-element all-reduce; any failure selects the torch collective."""
-        why = None
-        try:
-            if self.device is None or torch.device(self.device).type != "cuda" or dist.get_backend() != "nccl":
-                why = "needs HIP device tensors and the nccl (RCCL) backend"
-            else:
+        import threading
+        out = {"why": "did not finish"}
+
+        def create_and_probe():
+            try:
+                if self.device is None or torch.device(self.device).type != "cuda" or dist.get_backend() != "nccl":
+                    out["why"] = "needs HIP device tensors and the nccl (RCCL) backend"
+                    return
                 from . import lib as _lib
-                comm = self._etm_comm()
                 dev = torch.device(self.device)
-                probe = torch.ones(4, dtype=torch.float32, device=dev)
-                rc = _lib.load().etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream)
-                _lib.check(rc, "etm_allreduce_f32")
-                torch.cuda.synchronize(dev)
-                if probe.tolist() != [float(self.world)] * 4:
-                    why = f"self-test all-reduce returned {probe.tolist()}"
-        except Exception as exc:           # noqa: BLE001 -- any failure: use the framework's collective
-            why = repr(exc)
+                with torch.cuda.device(dev):
+                    comm = self._etm_comm()
+                    probe = torch.ones(4, dtype=torch.float32, device=dev)
+                    rc = _lib.load().etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream)
+                    _lib.check(rc, "etm_allreduce_f32")
+                    torch.cuda.synchronize(dev)
+                out["why"] = None if probe.tolist() == [float(self.world)] * 4 else f"self-test all-reduce returned {probe.tolist()}"
+            except Exception as exc:       # noqa: BLE001 -- any failure: use the framework's collective
+                out["why"] = repr(exc)
+
+        # bounded: a rendezvous that never completes on some node must not stall the job -- the torch collective takes over
+        limit = float(os.environ.get("ETM_COMM_TIMEOUT_S", "120"))
+        th = threading.Thread(target=create_and_probe, daemon=True)
+        th.start()
+        th.join(limit)
+        why = f"not ready after {limit:.0f} s" if th.is_alive() else out["why"]
         # all ranks must agree on the transport
         flag = torch.tensor([0 if why is None else 1], dtype=torch.int32,
                             device=self.device if dist.get_backend() == "nccl" else "cpu")
