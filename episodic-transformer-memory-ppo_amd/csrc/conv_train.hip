@@ -48,7 +48,8 @@ struct ConvG {
   int T;                 // backward-data: taps per dimension (K / S); forward: unused
   int n_seg, seg_len, groups;   // K = n_seg * seg_len, groups = K / 8
   int cH, cW;            // pixels per image and class (forward: oH, oW; backward-data: oH / S, oW / S)
-  int Mc;                // pixels per class = N * cH * cW (< 2^24)
+  int Mc;                // pixels per class = N * cH * cW (< 2^24); backward-data: cH * cW * Npad (position-major order)
+  int Npad;              // backward-data: N rounded up to a multiple of 32 * MT (the MT tiles of a wave share ONE pixel position)
   int out_nchw;
   float inv_chw, inv_cw; // 1 / (cH * cW), 1 / cW
 };
@@ -69,70 +70,83 @@ constexpr int CG_WAVES = 4;
 #define CG_DIAG 0
 #endif
 
-template <int MT, int NT, bool DGRAD>
-__global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel(const ConvG p) {
+// CLS (backward-data): stride-parity classes handled by ONE workgroup.  The classes of a class-grid pixel (cy, cx) read the SAME
+// T x T gradient taps -- only their weights differ -- so with CLS = S * S the classes are just more channel tiles of one GEMM:
+// an A fragment feeds 4 NT CLS MFMAs instead of 4 NT (the vector-memory instructions per MFMA are what bounds these kernels).
+template <int MT, int NT, bool DGRAD, int CLS = 1>
+__global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MINW)) void conv_gemm_kernel(const ConvG p) {
+  constexpr int NTT = NT * CLS;                     // accumulator tiles per pixel tile: (class, channel tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
-  const int cls = blockIdx.y;                       // parity class (backward-data), 0 for forward
-  const int py = DGRAD ? cls / p.S : 0, px = DGRAD ? cls - py * p.S : 0;
+  const int cls0 = (int)blockIdx.y * CLS;           // first parity class of this workgroup (backward-data), 0 for forward
   const int tile0 = ((int)blockIdx.x * CG_WAVES + wave) * MT;
   if (tile0 * 32 >= p.Mc) return;                   // whole wave; no barriers in this kernel
+  const int gps = p.seg_len / 8;                    // groups per segment
+  const int gpp = DGRAD ? p.sC / 8 : gps;           // groups per source pixel (backward-data)
+  // Backward-data walks the pixels POSITION-major: a tile is 32 images at one input pixel (cy, cx) of the class, and the MT
+  // tiles of a wave share that pixel.  The taps that fall outside the gradient image are then the same for the whole wave and
+  // are skipped as a k RANGE (wave-uniform) instead of being multiplied as zeros: the image-major order spent 1.23x (stride 2,
+  // 4 x 4) to 1.65x (stride 1, 3 x 3) the algorithmic MFMAs on border pixels, plus the per-lane validity tests in the loop.
+  int pos_cy = 0, pos_cx = 0, n0 = 0, seg_lo = 0, seg_hi = p.n_seg - 1, gi_lo = 0, gi_hi = gps;
+  if (DGRAD) {
+    const int pos = (tile0 * 32) / p.Npad;
+    n0 = tile0 * 32 - pos * p.Npad;
+    pos_cy = pos / p.cW;
+    pos_cx = pos - pos_cy * p.cW;
+    // tap (a, j) reads the gradient pixel (cy - a, cx - (T - 1) + j)
+    seg_lo = max(0, pos_cy - (p.sH - 1));
+    seg_hi = min(p.T - 1, pos_cy);
+    gi_lo = max(0, (p.T - 1) - pos_cx) * gpp;
+    gi_hi = (min(p.T - 1, p.sW - 1 + (p.T - 1) - pos_cx) + 1) * gpp;
+  }
+  const int n_groups = (seg_hi - seg_lo + 1) * (gi_hi - gi_lo);
 
   // per pixel tile: this lane's pixel as a 32-bit ELEMENT offset from the source tensor (the k walk below adds wave-uniform
   // offsets to the base pointer, so a load is `base(SGPR) + offset(VGPR)`: no per-lane address arithmetic inside the loop),
   // and (backward-data) the source row / column of the lane's first tap for the validity tests
-  int loff[MT], vy0[MT], vx0[MT];
+  int loff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = min((tile0 + mt) * 32 + col, p.Mc - 1);
-    const int n = fast_div(m, p.cH * p.cW, p.inv_chw);
-    const int rem = m - n * (p.cH * p.cW);
-    const int cy = fast_div(rem, p.cW, p.inv_cw), cx = rem - cy * p.cW;
     if (!DGRAD) {
+      const int m = min((tile0 + mt) * 32 + col, p.Mc - 1);
+      const int n = fast_div(m, p.cH * p.cW, p.inv_chw);
+      const int rem = m - n * (p.cH * p.cW);
+      const int cy = fast_div(rem, p.cW, p.inv_cw), cx = rem - cy * p.cW;
       loff[mt] = ((n * p.sH + cy * p.S) * p.sW + cx * p.S) * p.sC + half * 4;
-      vy0[mt] = vx0[mt] = 0;
     } else {
-      // input pixel (iy, ix) = (S cy + py, S cx + px); tap (a, j): source pixel (cy - a, cx - (T - 1) + j)
-      vy0[mt] = cy;
-      vx0[mt] = cx - (p.T - 1);
-      loff[mt] = ((n * p.sH + cy) * p.sW + (cx - (p.T - 1))) * p.sC + half * 4;      // may point before a row start: only used when valid
+      // input pixel (iy, ix) = (S cy + py, S cx + px) of image n; tap (a, j): source pixel (cy - a, cx - (T - 1) + j); only
+      // the valid (a, j) are walked, so the offset is only ever used inside the gradient image
+      const int n = min(n0 + mt * 32 + col, p.N - 1);
+      loff[mt] = ((n * p.sH + pos_cy) * p.sW + (pos_cx - (p.T - 1))) * p.sC + half * 4;
     }
   }
-  f32x16 acc[MT][NT];
+  f32x16 acc[MT][NTT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
 
-  const float *wbase = p.wp + (long long)cls * p.groups * NT * 256;
+  const long long wcls = (long long)p.groups * NT * 256;   // floats per class block
+  const float *wbase = p.wp + (long long)cls0 * wcls;
   const int wl = lane * 4;
   const int row_elems = p.sW * p.sC;
-  // the k walk: segment `seg` (a kernel row), then 8-float groups inside it; backward-data additionally tracks the tap column
-  // (sC / 8 groups per source pixel) for the validity of the lane's taps.  All of it is wave-uniform.
-  const int gps = p.seg_len / 8;                    // groups per segment
-  const int gpp = DGRAD ? p.sC / 8 : gps;           // groups per source pixel (backward-data)
+  // the k walk: segment `seg` (a kernel row), then 8-float groups inside it (backward-data: the valid rows / tap columns only).
+  // All of it is wave-uniform.
 
-  f32x4 a_reg[3][MT], b_reg[3][NT];               // three k-groups in flight: the loads of group g + 2 are issued before the MFMAs of group g
+  f32x4 a_reg[3][MT], b_reg[3][NTT];              // three k-groups in flight: the loads of group g + 2 are issued before the MFMAs of group g
   auto load_group = [&](int seg, int gi, int g, int buf) {
     const int koff = (DGRAD ? -seg : seg) * row_elems + gi * 8;      // uniform
     const float *abase = p.src + koff;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if ((CG_DIAG & 1) && g >= 3) break;
-      if (!DGRAD) {
-        a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + ((CG_DIAG & 8) ? (loff[mt] & ~0xfff) + lane * 4 : loff[mt]));
-      } else {
-        const int sy = vy0[mt] - seg, sx = vx0[mt] + gi / gpp;
-        const bool ok = sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? abase + loff[mt] : p.src + half * 4);
-        a_reg[buf][mt] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + ((CG_DIAG & 8) ? (loff[mt] & ~0xfff) + lane * 4 : loff[mt]));
     }
     const float *bb = wbase + (long long)g * NT * 256;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (!(CG_DIAG & 2) || g < 3) b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + t * 256 + wl);
+    for (int t = 0; t < NTT; ++t)
+      if (!(CG_DIAG & 2) || g < 3) b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + (t / NT) * wcls + (t % NT) * 256 + wl);
   };
   auto mfma_group = [&](int buf) {
 #pragma unroll
@@ -140,29 +154,29 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NTT; ++t)
           acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_reg[buf][mt][j], b_reg[buf][t][j], acc[mt][t], 0, 0, 0);
   };
 
   // software pipeline over the groups (seg-major), prefetch distance 2: a load has two MFMA bursts of this wave (and those of the
   // other waves of the SIMD) to arrive.  Three k-groups per iteration: the buffers rotate without copies.
-  int seg_n = 0, gi_n = 0, g_n = 0;                 // coordinates of the NEXT group to load
+  int seg_n = seg_lo, gi_n = gi_lo, left_n = n_groups;   // coordinates of the NEXT group to load, groups still to load
   auto load_next = [&](int buf) {
-    if (g_n < p.groups) {
-      load_group(seg_n, gi_n, g_n, buf);
-      ++g_n;
-      if (++gi_n == gps) { gi_n = 0; ++seg_n; }
+    if (left_n > 0) {
+      load_group(seg_n, gi_n, seg_n * gps + gi_n, buf);
+      --left_n;
+      if (++gi_n == gi_hi) { gi_n = gi_lo; ++seg_n; }
     }
   };
   load_next(0);
   load_next(1);
-  for (int g = 0; g < p.groups; g += 3) {
+  for (int g = 0; g < n_groups; g += 3) {
     load_next(2);
     mfma_group(0);
     load_next(0);
-    if (g + 1 < p.groups) mfma_group(1);
+    if (g + 1 < n_groups) mfma_group(1);
     load_next(1);
-    if (g + 2 < p.groups) mfma_group(2);
+    if (g + 2 < n_groups) mfma_group(2);
   }
 
   // epilogue: bias / mask operands are requested up front (no wait per row), rows past the end are clamped and not stored
@@ -170,26 +184,29 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
 #pragma unroll
   for (int t = 0; t < NT; ++t) bv[t] = DGRAD ? 0.f : p.bias[t * 32 + col];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+   for (int c = 0; c < CLS; ++c) {
+    const int cls = cls0 + c;
+    const int py = DGRAD ? cls / p.S : 0, px = DGRAD ? cls - py * p.S : 0;
     long long o_pix[16];
     bool okr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int mraw = (tile0 + mt) * 32 + mfma32_row(r, lane);
-      okr[r] = mraw < p.Mc;
-      const int mm = okr[r] ? mraw : p.Mc - 1;
-      // forward: the pixel index IS the NHWC row; backward-data decodes the class-local pixel (float-reciprocal division)
-      o_pix[r] = (long long)mm * p.oC;
-      if (DGRAD) {
-        const int n = fast_div(mm, p.cH * p.cW, p.inv_chw);
-        const int rem = mm - n * (p.cH * p.cW);
-        const int cy = fast_div(rem, p.cW, p.inv_cw), cx = rem - cy * p.cW;
-        o_pix[r] = (((long long)n * p.oH + cy * p.S + py) * p.oW + cx * p.S + px) * p.oC;
+      if (!DGRAD) {                                    // forward: the pixel index IS the NHWC row
+        const int mraw = (tile0 + mt) * 32 + mfma32_row(r, lane);
+        okr[r] = mraw < p.Mc;
+        o_pix[r] = (long long)(okr[r] ? mraw : p.Mc - 1) * p.oC;
+      } else {                                         // backward-data: row = image, the input pixel is the wave's
+        const int n = n0 + mt * 32 + mfma32_row(r, lane);
+        okr[r] = n < p.N;
+        o_pix[r] = (((long long)(okr[r] ? n : p.N - 1) * p.oH + pos_cy * p.S + py) * p.oW + pos_cx * p.S + px) * p.oC;
       }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int co = t * 32 + col;
+    for (int tl = 0; tl < NT; ++tl) {
+      const int t = c * NT + tl;
+      const int co = tl * 32 + col;
       float mk[16];
       if (DGRAD && p.ymask) {
 #pragma unroll
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, ETM_CONV_MINW) void conv_gemm_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[mt][t][r];
-        if (!DGRAD) v = fmaxf(v + bv[t], 0.f);
+        if (!DGRAD) v = fmaxf(v + bv[tl], 0.f);
         else if (p.ymask) v = (mk[r] > 0.f) ? v : 0.f;
         if (okr[r] && (!(CG_DIAG & 4) || v == 12345.678f)) p.out[o_pix[r] + co] = v;
       }
@@ -483,15 +500,22 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   p.sH = Ho; p.sW = Wo; p.sC = Cout;
   p.oH = H; p.oW = W; p.oC = C;
   p.S = S; p.T = KH / S; p.n_seg = p.T; p.seg_len = p.T * Cout; p.groups = p.T * p.T * Cout / 8;
-  p.cH = H / S; p.cW = W / S; p.Mc = N * p.cH * p.cW; p.out_nchw = 0;
-  if (p.Mc >= (1 << 24)) return ETM_EUNSUPPORTED;
+  p.cH = H / S; p.cW = W / S; p.out_nchw = 0;
+  const bool merged = (C == 32 && S == 2);                                  // all four parity classes in one workgroup
+  const int unit = 32 * (merged ? 2 : (C == 32 ? ETM_CONV_MT32 : ETM_CONV_MT64));   // images per wave (all at one pixel position)
+  p.Npad = (N + unit - 1) / unit * unit;
+  if ((long long)p.cH * p.cW * p.Npad >= (1 << 24)) return ETM_EUNSUPPORTED;
+  p.Mc = p.cH * p.cW * p.Npad;
   p.inv_chw = 1.0f / (float)(p.cH * p.cW); p.inv_cw = 1.0f / (float)p.cW;
   if ((p.T * p.T * Cout) % 8 != 0) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_CONV_TRAIN_DGRAD, st);
   const int tiles = (p.Mc + 31) / 32;
   const unsigned classes = (unsigned)(S * S);
-  if (C == 32) {
+  if (merged) {
+    constexpr int MT = 2;
+    hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, true, 4>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), 1), dim3(CG_WAVES * 64), 0, st, p);
+  } else if (C == 32) {
     constexpr int MT = ETM_CONV_MT32;
     hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, true>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64), 0, st, p);
   } else {
