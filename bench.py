@@ -69,9 +69,16 @@ def pmc_traffic(kernel):
     symbol = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel"}.get(kernel, kernel)
     try:
         with open(path) as f:
-            k = json.load(f)[symbol]
+            doc = json.load(f)
+        target = ""
+        if symbol not in doc:         # round-2 layout: {target: {kernel symbol incl. template arguments: counters}}
+            target = "window_train" if symbol == "window_pass_kernel" else next(t for t in doc if any(n.startswith(symbol) for n in doc[t]))
+            doc = doc[target]
+            symbol = next(n for n in doc if n.startswith(symbol))
+        k = doc[symbol]
         return {"bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"]["mean"] + 1024 * k["WRITE_SIZE"]["mean"],
-                "source": f"profiles/{os.path.basename(path)}, kernel symbol {symbol} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "source": f"profiles/{os.path.basename(path)}, {('target ' + target + ', ') if target else ''}kernel symbol {symbol} "
+                          "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                           "N=2048 L=64 D=384 H=4; forward and backward launches of the window pass averaged)",
                 "mfma_busy_fraction_pmc": k.get("derived", {}).get("mfma_busy_fraction")}
     except Exception:
@@ -93,6 +100,19 @@ def cpu_baseline(cfg, seed=0):
         env = make_vec_env(c["environment"], c["n_workers"])
         torch.manual_seed(seed)
         tr = OracleTrainer(c, env, seed=seed)
+        # the rollout is 64 x (a few dozen tiny ops on 32 samples): more threads only add hand-over cost there, the optimisation
+        # phase (convolutions on 2048 images) uses all of them
+        roll_threads = min(threads, 8)
+        sample = tr.sample
+
+        def sample_few_threads(forced_actions=None):
+            torch.set_num_threads(roll_threads)
+            try:
+                return sample(forced_actions)
+            finally:
+                torch.set_num_threads(threads)
+
+        tr.sample = sample_few_threads
         t0 = time.perf_counter()
         _, _, split = tr.update(0)
         dt = time.perf_counter() - t0
@@ -102,8 +122,8 @@ def cpu_baseline(cfg, seed=0):
     return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"1 update of {c['n_workers']} workers x {c['worker_steps']} steps (= {steps} env steps) with {c['epochs']} epochs x 1 "
                       f"minibatch of {steps} samples: same per-env-step work as the full config (minibatch 2048, 5 epochs); "
-                      f"{dt:.1f} s (rollout {split['rollout_s']:.1f} s, train {split['train_s']:.1f} s) on {threads} torch threads "
-                      f"of {cores} host cores"}
+                      f"{dt:.1f} s (rollout {split['rollout_s']:.1f} s on {roll_threads} torch threads, train {split['train_s']:.1f} s on "
+                      f"{threads}) of {cores} host cores"}
 
 
 def main():

@@ -179,7 +179,13 @@ __global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MI
     if (g + 2 < n_groups) mfma_group(2);
   }
 
-  // epilogue: bias / mask operands are requested up front (no wait per row), rows past the end are clamped and not stored
+  // epilogue.  The accumulator layout (lane = channel, register = pixel row) would store 4 bytes per lane and instruction: 16
+  // store (and 16 mask-load) instructions per tile, as many vector-memory instructions as the k loop of a short-K layer
+  // issues.  Each tile goes through a per-wave LDS buffer instead and leaves as 16 bytes per lane: 8 lanes cover the 32
+  // channels of a pixel row, 4 stores (and 4 mask loads) per tile.
+  __shared__ __attribute__((aligned(16))) float ep_s[CG_WAVES][32][36];
+  float(*tile)[36] = ep_s[wave];
+  const int er = lane >> 3, ec = (lane & 7) * 4;     // this lane's row (+ 8 i) and first channel in the transposed tile
   float bv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bv[t] = DGRAD ? 0.f : p.bias[t * 32 + col];
@@ -189,35 +195,43 @@ __global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MI
    for (int c = 0; c < CLS; ++c) {
     const int cls = cls0 + c;
     const int py = DGRAD ? cls / p.S : 0, px = DGRAD ? cls - py * p.S : 0;
-    long long o_pix[16];
-    bool okr[16];
+    long long o_pix[4];
+    bool okr[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int i = 0; i < 4; ++i) {
+      const int row = er + 8 * i;
       if (!DGRAD) {                                    // forward: the pixel index IS the NHWC row
-        const int mraw = (tile0 + mt) * 32 + mfma32_row(r, lane);
-        okr[r] = mraw < p.Mc;
-        o_pix[r] = (long long)(okr[r] ? mraw : p.Mc - 1) * p.oC;
+        const int mraw = (tile0 + mt) * 32 + row;
+        okr[i] = mraw < p.Mc;
+        o_pix[i] = (long long)(okr[i] ? mraw : p.Mc - 1) * p.oC;
       } else {                                         // backward-data: row = image, the input pixel is the wave's
-        const int n = n0 + mt * 32 + mfma32_row(r, lane);
-        okr[r] = n < p.N;
-        o_pix[r] = (((long long)(okr[r] ? n : p.N - 1) * p.oH + pos_cy * p.S + py) * p.oW + pos_cx * p.S + px) * p.oC;
+        const int n = n0 + mt * 32 + row;
+        okr[i] = n < p.N;
+        o_pix[i] = (((long long)(okr[i] ? n : p.N - 1) * p.oH + pos_cy * p.S + py) * p.oW + pos_cx * p.S + px) * p.oC;
       }
     }
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
       const int t = c * NT + tl;
-      const int co = tl * 32 + col;
-      float mk[16];
+      f32x4 mk[4];
       if (DGRAD && p.ymask) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = p.ymask[o_pix[r] + co];
+        for (int i = 0; i < 4; ++i) mk[i] = *reinterpret_cast<const f32x4 *>(p.ymask + o_pix[i] + tl * 32 + ec);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[mt][t][r];
         if (!DGRAD) v = fmaxf(v + bv[tl], 0.f);
-        else if (p.ymask) v = (mk[r] > 0.f) ? v : 0.f;
-        if (okr[r] && (!(CG_DIAG & 4) || v == 12345.678f)) p.out[o_pix[r] + co] = v;
+        tile[mfma32_row(r, lane)][col] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&tile[er + 8 * i][ec]);
+        if (DGRAD && p.ymask) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = (mk[i][q] > 0.f) ? v[q] : 0.f;
+        }
+        if (okr[i] && (!(CG_DIAG & 4) || v[0] == 12345.678f)) *reinterpret_cast<f32x4 *>(p.out + o_pix[i] + tl * 32 + ec) = v;
       }
     }
   }
