@@ -40,6 +40,7 @@ struct ConvG {
   const float *wp;       // packed weights (fragment order), one block of `groups * NT * 256` floats per parity class
   const float *bias;     // forward only
   const float *ymask;    // backward-data: output of the layer below (NHWC, same shape as the result); NULL: no mask
+  const long long *img_index;   // forward, optional: image n of the batch is src image img_index[n] (the minibatch gather, fused)
   float *out;
   int N;
   int sH, sW, sC;        // source tensor dims (rows, cols, channels)
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MI
       const int n = fast_div(m, p.cH * p.cW, p.inv_chw);
       const int rem = m - n * (p.cH * p.cW);
       const int cy = fast_div(rem, p.cW, p.inv_cw), cx = rem - cy * p.cW;
-      loff[mt] = ((n * p.sH + cy * p.S) * p.sW + cx * p.S) * p.sC + half * 4;
+      const int ns = p.img_index ? (int)p.img_index[n] : n;        // source image (fused minibatch gather)
+      loff[mt] = ((ns * p.sH + cy * p.S) * p.sW + cx * p.S) * p.sC + half * 4;
     } else {
       // input pixel (iy, ix) = (S cy + py, S cx + px) of image n; tap (a, j): source pixel (cy - a, cx - (T - 1) + j); only
       // the valid (a, j) are walked, so the offset is only ever used inside the gradient image
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MI
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvW {
   const float *x;        // layer input NHWC [N,H,W,C]
+  const long long *img_index;   // optional: image n of the batch is x image img_index[n]
   const float *dy;       // pre-activation gradient of the layer output, NHWC [N,Ho,Wo,Cout]
   float *partial;        // [splits][K * Cout + Cout]: dW in (k, co) order, then the column sums of dy
   int N, H, W, C, Cout, S, Ho, Wo;
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
     const int n = fast_div(mc, p.Ho * p.Wo, p.inv_hw);
     const int rem = mc - n * (p.Ho * p.Wo);
     const int oy = fast_div(rem, p.Wo, p.inv_w), ox = rem - oy * p.Wo;
-    const float *xrow = p.x + (((long long)n * p.H + oy * p.S) * p.W + ox * p.S) * p.C;
+    const long long ns = p.img_index ? p.img_index[n] : n;
+    const float *xrow = p.x + ((ns * p.H + oy * p.S) * p.W + ox * p.S) * p.C;
     const float *drow = p.dy + (long long)mc * p.Cout;
 #pragma unroll
     for (int j = 0; j < A_J; ++j) {
@@ -475,13 +479,16 @@ static int conv_geometry_ok(int C, int Cout, int KH, int KW, int S, int W) {
   return 1;
 }
 
-extern "C" int etm_conv_train_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W, int Cout,
+extern "C" int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_t x_images, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W, int Cout,
                                   int KH, int KW, int S, int out_nchw, void *stream) {
   (void)hipGetLastError();
   if (!x || !w_packed || !bias || !y || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   if (!conv_geometry_ok(C, Cout, KH, KW, S, W)) return ETM_EUNSUPPORTED;
   ConvG p{};
   p.src = x; p.wp = w_packed; p.bias = bias; p.ymask = nullptr; p.out = y; p.N = N;
+  p.img_index = (const long long *)x_index;
+  // the kernel addresses the source with 32-bit element offsets
+  if ((x_index ? x_images : (int64_t)N) * H * W * C >= ((int64_t)1 << 31) || (x_index && x_images <= 0)) return ETM_EUNSUPPORTED;
   p.sH = H; p.sW = W; p.sC = C;
   p.oH = (H - KH) / S + 1; p.oW = (W - KW) / S + 1; p.oC = Cout;
   p.S = S; p.T = 0; p.n_seg = KH; p.seg_len = KW * C; p.groups = KH * KW * C / 8;
@@ -556,14 +563,14 @@ extern "C" int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int
 }
 
 // dw [Cout, C, KH, KW] (the parameter's own layout) followed by dbias [Cout], in one buffer of K * Cout + Cout floats.
-extern "C" int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N,
+extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N,
                                     int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
   if (!x || !dy || !dw_kc_dbias || !workspace || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   if (!conv_geometry_ok(C, Cout, KH, KW, S, W)) return ETM_EUNSUPPORTED;
   if (workspace_bytes < etm_conv_train_wgrad_workspace_bytes(N, C, H, W, Cout, KH, KW, S)) return ETM_EWORKSPACE;
   ConvW p{};
-  p.x = x; p.dy = dy; p.partial = workspace; p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.S = S;
+  p.x = x; p.img_index = (const long long *)x_index; p.dy = dy; p.partial = workspace; p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.S = S;
   p.Ho = (H - KH) / S + 1; p.Wo = (W - KW) / S + 1;
   p.seg_len = KW * C; p.n_seg = KH; p.K = KH * KW * C;
   p.M = N * p.Ho * p.Wo;

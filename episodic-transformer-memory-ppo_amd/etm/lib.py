@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "etm_comm_destroy": (_I, [_P]),
     "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_conv_pack_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "etm_gather_rows": (_I, [_P, _P, _P, _I, _P, _L, _L, _P]),
     "etm_host_copier_create": (_P, [_I]),
     "etm_host_copier_destroy": (None, [_P]),
     "etm_host_copy": (_I, [_P, _P, _P, _L]),
@@ -61,10 +62,10 @@ SIGNATURES = {
     "etm_gate_train_bwd_workspace_bytes": (_L, [_I, _I]),
     "etm_gate_train_bwd1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_gate_train_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "etm_conv_train_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_train_fwd": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_train_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_train_wgrad_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
-    "etm_conv_train_wgrad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_train_wgrad": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_relu_mask": (_I, [_P, _P, _P, _L, _P]),
     "etm_grad_sqnorm": (_I, [_P, _L, _P, _I, _P, _P]),
     "etm_adamw_clip": (_I, [_P, _P, _P, _P, _L, _P, _I, _P, _P, _D, _D, _D, _D, _F, _P, _P]),

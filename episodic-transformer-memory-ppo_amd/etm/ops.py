@@ -444,6 +444,30 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
                "etm_rollout_trxl")
 
 
+def gather_rows(fields, idx):
+    """``[t.index_select(0, idx) for t in fields]`` in one launch (etm_gather_rows): the per-sample fields of a minibatch.
+    Tensors whose rows are not a multiple of 4 bytes (or not contiguous) go through index_select."""
+    import ctypes
+    lib = _lib.load()
+    n = idx.numel()
+    outs = [None] * len(fields)
+    sel = []
+    for k, t in enumerate(fields):
+        row = t[0].numel() * t.element_size() if t.shape[0] > 0 else 0
+        if t.is_contiguous() and 0 < row <= 4096 and row % 4 == 0 and t.shape[0] == fields[0].shape[0] and len(sel) < 16:
+            outs[k] = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            sel.append((k, row))
+        else:
+            outs[k] = t.index_select(0, idx)
+    if sel:
+        m = len(sel)
+        src = (ctypes.c_void_p * m)(*[fields[k].data_ptr() for k, _ in sel])
+        dst = (ctypes.c_void_p * m)(*[outs[k].data_ptr() for k, _ in sel])
+        rb = (ctypes.c_int64 * m)(*[r for _, r in sel])
+        _lib.check(lib.etm_gather_rows(src, dst, rb, m, _ptr(idx), n, fields[sel[0][0]].shape[0], _stream()), "etm_gather_rows")
+    return outs
+
+
 def rollout_hidden_partial(x, wt, out=None):
     """K-slice partial sums of ``x [W, F] @ wt [F, D]`` (etm_rollout_hidden_partial): [splits, W, D]; the consumer
     (``rollout_trxl(h_bias=...)``) adds the slices, the bias and the ReLU."""
@@ -690,13 +714,16 @@ class _EncoderFn(torch.autograd.Function):
     flatten order (model.py:94) and back."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, w1, b1, w2, b2, w3, b3, strides):
+    def forward(ctx, x_nhwc, w1, b1, w2, b2, w3, b3, strides, index=None):
         lib = _lib.load()
         _need_dev(x_nhwc, w1, b1, w2, b2, w3, b3)
         x = _f32c(x_nhwc, "obs")
         st = _stream()
         acts, shapes, dgrad_packs = [x], [], []
         n, h, w, c = x.shape
+        x_images = n
+        if index is not None:          # batch image i = x[index[i]]: the minibatch gather rides in the first layer's loads
+            n = index.numel()
         for i, (wt, bs, s) in enumerate(((w1, b1, strides[0]), (w2, b2, strides[1]), (w3, b3, strides[2]))):
             cout, _, kh, kw = wt.shape
             ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
@@ -708,22 +735,22 @@ class _EncoderFn(torch.autograd.Function):
                        "etm_conv_pack_weights")
             dgrad_packs.append(pd)
             y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-            _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(packed), _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s,
-                                              0, st), "etm_conv_train_fwd")
+            _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, x_images, _ptr(packed),
+                                              _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s, 0, st), "etm_conv_train_fwd")
             shapes.append((c, h, w, cout, kh, kw, s, ho, wo))
             acts.append(y)
             h, w, c = ho, wo, cout
         ctx.shapes = shapes
-        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2])
+        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2], index)
         return acts[3].view(n, -1)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x0, y1, y2, y3, pd2, pd3 = ctx.saved_tensors
+        x0, y1, y2, y3, pd2, pd3, index = ctx.saved_tensors
         st = _stream()
         dev = x0.device
-        n = x0.shape[0]
+        n = y1.shape[0]
         g = _f32c(g, "d_features")
         c3, h3, w3_, cout3, _, _, _, ho3, wo3 = ctx.shapes[2]
         dy = torch.empty((n, ho3, wo3, cout3), dtype=torch.float32, device=dev)
@@ -737,8 +764,8 @@ class _EncoderFn(torch.autograd.Function):
             buf = torch.empty(K * cout + cout, dtype=torch.float32, device=dev)
             nbytes = lib.etm_conv_train_wgrad_workspace_bytes(n, c, h, w, cout, kh, kw, s)
             ws = workspace(nbytes, dev, "conv_wgrad")
-            _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w, cout, kh, kw, s, st),
-                       "etm_conv_train_wgrad")
+            _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w,
+                                                cout, kh, kw, s, st), "etm_conv_train_wgrad")
             grads[2 * i] = buf[: K * cout].view(cout, c, kh, kw)
             grads[2 * i + 1] = buf[K * cout:]
             if i > 0:
@@ -746,15 +773,16 @@ class _EncoderFn(torch.autograd.Function):
                 _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
                            "etm_conv_train_dgrad")
                 dy = dx
-        return (None, *grads, None)
+        return (None, *grads, None, None)
 
 
-def encoder_train(obs_nhwc, conv1, conv2, conv3):
-    """Differentiable encoder forward on an NHWC observation batch [N, H, W, C]: features [N, Ho * Wo * Cout], NHWC-flattened
+def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None):
+    """Differentiable encoder forward on an NHWC observation batch [N, H, W, C] -- or, with ``index`` (int64 [n]), on the images
+    ``obs_nhwc[index]`` without gathering them first: features [N, Ho * Wo * Cout], NHWC-flattened
     (``nhwc_columns`` gives the matching column order of the following linear layer's weight).  Gradients flow to the
     convolution weights and biases (observations need none)."""
     return _EncoderFn.apply(obs_nhwc, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias,
-                            (conv1.stride[0], conv2.stride[0], conv3.stride[0]))
+                            (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index)
 
 
 def nhwc_columns(weight, channels):

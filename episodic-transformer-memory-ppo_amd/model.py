@@ -16,6 +16,14 @@ from etm.ops import WindowSpec
 from transformer import Transformer
 
 
+class IndexedObservations:
+    """A minibatch of visual observations as (all observations of the update in NHWC memory order [n, H, W, C], int64 row
+    indices): what ``buffer.samples_flat["obs"][mini_batch_indices]`` (buffer.py:84-91) denotes, without materialising it."""
+
+    def __init__(self, bank_nhwc, index):
+        self.bank, self.index = bank_nhwc, index
+
+
 class ActorCriticModel(nn.Module):
     def __init__(self, config, observation_space, action_space_shape, max_episode_length):
         super().__init__()
@@ -163,7 +171,17 @@ class ActorCriticModel(nn.Module):
 
     def _encode(self, obs, obs_index=None, obs_rows=None):
         """Observation encoder.  ``obs_index`` (int64 device scalar, fused rollout encoder only): ``obs`` is a time-major
-        stack [S, N, C, H, W] and row obs[obs_index] is encoded (the row is selected on the device)."""
+        stack [S, N, C, H, W] and row obs[obs_index] is encoded (the row is selected on the device).  ``obs`` may be an
+        ``IndexedObservations(bank_nhwc, index)``: the minibatch = bank_nhwc[index], gathered inside the first encoder layer."""
+        if isinstance(obs, IndexedObservations):
+            if self.visual and self.train_encoder and torch.is_grad_enabled():
+                if self._train_encoder_ok is None:
+                    self._train_encoder_ok = ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3))
+                if self._train_encoder_ok:
+                    feats = ops.encoder_train(obs.bank, self.conv1, self.conv2, self.conv3, index=obs.index)
+                    w_nhwc = ops.nhwc_columns(self.lin_hidden.weight, self.conv3.out_channels)
+                    return torch.relu(F.linear(feats, w_nhwc, self.lin_hidden.bias))
+            obs = obs.bank.index_select(0, obs.index).permute(0, 3, 1, 2)      # NCHW view of the gathered NHWC rows
         if obs_index is not None:
             if not self._fused_encoder_ok(obs[0]):
                 raise RuntimeError("obs_index needs the fused rollout encoder (visual observations, no grad)")

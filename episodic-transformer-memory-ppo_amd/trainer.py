@@ -32,7 +32,7 @@ from etm import lib as etm_lib
 from etm import ops
 from etm.ops import WindowSpec
 from etm.optim import FlatAdamW
-from model import ActorCriticModel
+from model import ActorCriticModel, IndexedObservations
 from utils import polynomial_decay, process_episode_info
 
 
@@ -830,15 +830,16 @@ class PPOTrainer:
         advantages (data-parallel runs merge them over ranks before this graph); None: computed here.  Returns stats[6]."""
         buf = self.buffer
         skip = ("obs",) if self._obs_train is not None else ()
-        mb = {k: v.index_select(0, idx) for k, v in buf.samples_flat.items() if k not in skip}
+        keys = [k for k in buf.samples_flat if k not in skip]
+        mb = dict(zip(keys, ops.gather_rows([buf.samples_flat[k] for k in keys], idx)))    # one launch for the small fields
         if self._bank_pos is not None:
             spec = WindowSpec.from_bank(self._bank_pos_buf, mb["memory_index"], mb["memory_indices"], None, mb["memory_mask"])
             spec.pos_included = True
         else:
             spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
         obs = mb.get("obs")
-        if self._obs_train is not None:     # gather NHWC rows; the NCHW view of them is already channels_last
-            obs = self._obs_train.index_select(0, idx).permute(0, 3, 1, 2)
+        if self._obs_train is not None:     # NHWC rows of the minibatch: gathered by the first encoder layer itself
+            obs = IndexedObservations(self._obs_train, idx)
         logits, value, _ = self.model.forward_logits(obs, spec, want_items=False)
         if stats3 is None:
             stats3 = ops.adv_stats(mb["advantages"])

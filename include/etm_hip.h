@@ -304,6 +304,12 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
 int etm_rollout_hidden_splits(int F);
 int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int W, int F, int D, void *stream);
 
+/* Minibatch gather of the per-sample fields in one launch (buffer.py:84-91 `samples_flat[key][mini_batch_indices]`):
+ * dst[f][i, :] = src[f][idx[i], :] for f < n_fields (<= 16) and i < n.  src / dst / row_bytes: HOST arrays of n_fields device
+ * pointers / byte counts; rows are contiguous, row_bytes % 4 == 0; every src[f] has src_rows rows.  Bit-exact data movement. */
+int etm_gather_rows(const void *const *src, void *const *dst, const int64_t *row_bytes, int n_fields, const int64_t *idx, int64_t n,
+                    int64_t src_rows, void *stream);
+
 /* Host-side helper of the in-process environment front-ends (no device work): a memcpy split over `threads` threads (the
  * caller + threads - 1 helpers that spin briefly after a job and sleep otherwise).  The reference produces the observations of a
  * step in n_workers processes at once (worker.py:5-45); here one process writes a worker group's rows into the pinned staging
@@ -333,6 +339,9 @@ int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_str
  *   etm_conv_train_fwd  : y = relu(conv(x) + bias).  x NHWC [N,H,W,C]; w_packed = the [Cout, KH*KW*C] matrix (k ordered
  *                         (ky, kx, c)) in the fragment order of etm_conv_relu; y NHWC [N,Ho,Wo,Cout] (out_nchw must be 0: the
  *                         consumer of the last layer permutes its weight columns instead of the features, model.py:94).
+ *                         x_index (device int64 [N], or NULL): image n of the batch is image x_index[n] of x (x then holds
+ *                         x_images images) -- the minibatch gather of the observations fused into the first layer's loads; the
+ *                         same argument of etm_conv_train_wgrad.
  *   etm_conv_train_dgrad: dx = conv_transpose(dy) * (y_below > 0): gradient wrt the layer INPUT x [N,H,W,C], multiplied by the
  *                         ReLU mask of the layer below (y_below = x itself, the post-ReLU output of that layer; NULL: no mask),
  *                         i.e. the pre-activation gradient the next etm_conv_train_wgrad / _dgrad call consumes.  dy NHWC
@@ -348,14 +357,14 @@ int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_str
  *   etm_conv_pack_weights: w [Cout, C, KH, KW] -> `fwd` (the w_packed of etm_conv_train_fwd) and / or `dgrad` (the w_packed of
  *                         etm_conv_train_dgrad, all S*S classes), KH*KW*C*Cout floats each, either may be NULL; one launch
  *                         (the weights change every optimiser step). */
-int etm_conv_train_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W, int Cout, int KH,
-                       int KW, int S, int out_nchw, void *stream);
+int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_t x_images, const float *w_packed, const float *bias, float *y, int N,
+                       int C, int H, int W, int Cout, int KH, int KW, int S, int out_nchw, void *stream);
 int etm_conv_train_dgrad(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
                          int KH, int KW, int S, void *stream);
 int etm_conv_pack_weights(const float *w, float *fwd, float *dgrad, int Cout, int C, int KH, int KW, int S, void *stream);
 int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
-int etm_conv_train_wgrad(const float *x, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N, int C,
-                         int H, int W, int Cout, int KH, int KW, int S, void *stream);
+int etm_conv_train_wgrad(const float *x, const int64_t *x_index, const float *dy, float *dw_kc_dbias, float *workspace,
+                         int64_t workspace_bytes, int N, int C, int H, int W, int Cout, int KH, int KW, int S, void *stream);
 int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *stream);
 
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major

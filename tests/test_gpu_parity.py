@@ -1033,6 +1033,31 @@ def test_train_cli_and_checkpoint_format(tmp_path):
     assert "Episode length:" in play.stdout and "Episode reward:" in play.stdout
 
 
+def test_gather_rows_and_indexed_encoder_input():
+    """etm_gather_rows == index_select per field (bit-exact, mixed dtypes / row sizes); the encoder kernels reading images through
+    an index == the same kernels on the gathered batch (bit-exact forward and gradients)."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(33)
+    n_src, n = 300, 77
+    fields = [torch.randint(0, 9, (n_src, 1), device=dev), torch.randn(n_src, device=dev), torch.randn((n_src, 1), device=dev),
+              torch.rand((n_src, 64), device=dev) > 0.5, torch.randint(0, 50, (n_src, 64), device=dev), torch.randint(0, 5, (n_src,), device=dev),
+              torch.randn((n_src, 7), device=dev), torch.rand((n_src, 3), device=dev) > 0.5]       # the last one: 3-byte rows -> index_select
+    idx = torch.randint(0, n_src, (n,), device=dev)
+    for got, t in zip(ops.gather_rows(fields, idx), fields):
+        assert got.dtype == t.dtype and torch.equal(got, t.index_select(0, idx))
+    convs = [torch.nn.Conv2d(3, 32, 8, 4).to(dev), torch.nn.Conv2d(32, 64, 4, 2).to(dev), torch.nn.Conv2d(64, 64, 3, 1).to(dev)]
+    params = [p for c in convs for p in (c.weight, c.bias)]
+    bank = torch.rand((40, 84, 84, 3), device=dev)
+    pick = torch.randint(0, 40, (9,), device=dev)
+    go = torch.randn((9, 64 * 7 * 7), device=dev)
+    f_idx = ops.encoder_train(bank, *convs, index=pick)
+    g_idx = torch.autograd.grad(f_idx, params, go)
+    f_ref = ops.encoder_train(bank.index_select(0, pick), *convs)
+    g_ref = torch.autograd.grad(f_ref, params, go)
+    assert torch.equal(f_idx, f_ref) and all(torch.equal(a, b) for a, b in zip(g_idx, g_ref))
+
+
 def test_rollout_hidden_partial_sums_vs_matmul():
     """etm_rollout_hidden_partial: the K-slice sums add up to x @ W^T (float64 reference) for group sizes around the 16-row
     chunk and feature sizes with a ragged last slice."""

@@ -31,7 +31,7 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
     dy = torch.randn((N, ho, wo, cout), device=dev)
     packed = ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1))
     fl = 2.0 * N * ho * wo * cout * k * k * c
-    t = timed(lambda: etm_lib.check(lib.etm_conv_train_fwd(P(x), P(packed), P(b), P(y), N, c, h, w, cout, k, k, s, 0, st), "fwd"))
+    t = timed(lambda: etm_lib.check(lib.etm_conv_train_fwd(P(x), None, N, P(packed), P(b), P(y), N, c, h, w, cout, k, k, s, 0, st), "fwd"))
     print(f"conv{li + 1} forward   {t:8.1f} us  {fl / t / 1e6:6.1f} TFLOP/s ({fl / t / 1e6 / 157.3:.2f} of peak)"); tot += t
     if li > 0:
         pd = ops.conv_pack_dgrad_weights(wt, s)
@@ -42,6 +42,6 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
     buf = torch.empty(K * cout + cout, device=dev)
     nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, h, w, cout, k, k, s)
     ws = torch.empty(max(nbytes, 8) // 4, device=dev)
-    t = timed(lambda: etm_lib.check(lib.etm_conv_train_wgrad(P(x), P(dy), P(buf), P(ws), nbytes, N, c, h, w, cout, k, k, s, st), "wgrad"))
+    t = timed(lambda: etm_lib.check(lib.etm_conv_train_wgrad(P(x), None, P(dy), P(buf), P(ws), nbytes, N, c, h, w, cout, k, k, s, st), "wgrad"))
     print(f"conv{li + 1} bwd-weight {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s ({fl / t / 1e6 / 157.3:.2f} of peak)  (incl. slice reduction)"); tot += t
 print(f"sum {tot:8.1f} us")
