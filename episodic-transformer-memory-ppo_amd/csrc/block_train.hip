@@ -167,6 +167,38 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
   if (wave == 0 && c < C) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
+// ---- backward of relu(x W^T + b) up to the GEMMs (model.py:94-107, transformer.py:232): gm = g * (y > 0) and the column sums of
+// gm (= the bias gradient) in one pass; 64 columns x 64 rows per workgroup (wave w takes the rows w, w + 4, ...), partial sums
+// per row chunk, colsum_reduce_kernel adds the chunks in a fixed order.  y == nullptr: no mask (plain linear layer).
+__global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float *__restrict__ g, const float *__restrict__ y, float *__restrict__ gm,
+                                                              float *__restrict__ partial, int N, int C) {
+  __shared__ float sm[TR_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * 64;
+  float acc = 0.f;
+  if (c < C) {
+    float gv[16], yv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + wave + 4 * k;
+      const bool ok = r < N;
+      gv[k] = ok ? g[(long long)r * C + c] : 0.f;
+      yv[k] = (ok && y) ? y[(long long)r * C + c] : 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + wave + 4 * k;
+      const float v = yv[k] > 0.f ? gv[k] : 0.f;
+      if (r < N && gm) gm[(long long)r * C + c] = v;
+      acc += v;
+    }
+  }
+  sm[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) partial[(long long)blockIdx.y * C + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+}
+
 // ---- GRU gate (transformer.py:287-298) with A = y [Wr;Wz;Wg]^T [N,3D], B = x [Ur;Uz]^T [N,2D], C = (r x) Ug^T [N,D]
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -300,6 +332,30 @@ extern "C" int etm_ln_train_bwd(const float *dy, const float *s, const float *st
   if (rc) return rc;
   EtmProfScope prof(ETM_K_COLSUM, st);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((3 * D + 63) / 64)), dim3(256), 0, st, workspace, P, 3 * D, dgamma_dbeta_dbias);
+  return etm_launch_status();
+}
+
+// gm [N, C] = g * (y > 0) (y NULL: gm = g, and gm itself may then be NULL), db [C] = column sums of gm.
+// workspace: ceil(N / 64) * C floats.
+extern "C" int64_t etm_relu_bwd_colsum_workspace_bytes(int N, int C) {
+  if (N <= 0 || C <= 0) return 0;
+  return (int64_t)((N + 63) / 64) * C * (int64_t)sizeof(float);
+}
+extern "C" int etm_relu_bwd_colsum(const float *g, const float *y, float *gm, float *db, float *workspace, int64_t workspace_bytes, int N, int C,
+                                   void *stream) {
+  (void)hipGetLastError();
+  if (!g || !db || !workspace || N <= 0 || C <= 0 || (y && !gm)) return ETM_EINVAL;
+  if (workspace_bytes < etm_relu_bwd_colsum_workspace_bytes(N, C)) return ETM_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = (N + 63) / 64;
+  {
+    EtmProfScope prof(ETM_K_COLSUM, st);
+    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, st, g, y, gm, workspace, N, C);
+    int rc = etm_launch_status();
+    if (rc) return rc;
+  }
+  EtmProfScope prof(ETM_K_COLSUM, st);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, workspace, P, C, db);
   return etm_launch_status();
 }
 

@@ -83,7 +83,51 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_clip_kernel(float4 *__restr
     p[i] = pv; g[i] = gv; m[i] = mv; v[i] = vv;
   }
 }
+// Monitored gradient norms (model.py:128-151: one norm per module group, taken after clipping): partial[s] = sum of squares of
+// segment s (a run of <= 4096 floats inside ONE parameter tensor), then out[g] = sqrt(sum_s member[g][s] * partial[s]) -- two
+// launches whatever the number of tensors and groups, every sum in a fixed order.
+__global__ __launch_bounds__(OPT_THREADS) void segment_sqsum_kernel(const float *__restrict__ g, const long long *__restrict__ seg_start,
+                                                                    const int *__restrict__ seg_len, float *__restrict__ partial) {
+  __shared__ float sm[4];
+  const int s = blockIdx.x;
+  const float *src = g + seg_start[s];
+  const int len = seg_len[s];
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = (int)threadIdx.x + k * OPT_THREADS;
+    v[k] = i < len ? src[i] : 0.f;
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc += v[k] * v[k];
+  const float t = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) partial[s] = t;
+}
+__global__ __launch_bounds__(OPT_THREADS) void group_norm_kernel(const float *__restrict__ member, const float *__restrict__ partial, int n_segs,
+                                                                 float *__restrict__ out) {
+  __shared__ float sm[4];
+  const int gidx = blockIdx.x;
+  float acc = 0.f;
+  for (int s = threadIdx.x; s < n_segs; s += OPT_THREADS) acc += member[(long long)gidx * n_segs + s] * partial[s];
+  const float t = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) out[gidx] = sqrtf(t);
+}
 }  // namespace
+
+// out[g] = sqrt(sum over segments of member[g][s] * ||flat[seg_start[s] .. + seg_len[s])||^2); seg_len <= 4096; partial: n_segs floats.
+extern "C" int etm_group_norms(const float *flat, const int64_t *seg_start, const int32_t *seg_len, int n_segs, const float *member, int n_groups,
+                               float *partial, float *out, void *stream) {
+  (void)hipGetLastError();
+  if (!flat || !seg_start || !seg_len || !member || !partial || !out || n_segs <= 0 || n_groups <= 0) return ETM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_OPTIM, st);
+  hipLaunchKernelGGL(segment_sqsum_kernel, dim3((unsigned)n_segs), dim3(OPT_THREADS), 0, st, flat, (const long long *)seg_start, seg_len, partial);
+  int rc = etm_launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(group_norm_kernel, dim3((unsigned)n_groups), dim3(OPT_THREADS), 0, st, member, partial, n_segs, out);
+  return etm_launch_status();
+}
 
 extern "C" int etm_grad_sqnorm(const float *g, int64_t n, float *partial, int n_partial, int64_t *step, void *stream) {
   (void)hipGetLastError();

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 21
 
 _lib = None
 
@@ -41,6 +41,9 @@ SIGNATURES = {
     "etm_rollout_policy": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_conv_pack_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "etm_gather_rows": (_I, [_P, _P, _P, _I, _P, _L, _L, _P]),
+    "etm_group_norms": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "etm_relu_bwd_colsum_workspace_bytes": (_L, [_I, _I]),
+    "etm_relu_bwd_colsum": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_host_copier_create": (_P, [_I]),
     "etm_host_copier_destroy": (None, [_P]),
     "etm_host_copy": (_I, [_P, _P, _P, _L]),

@@ -804,6 +804,38 @@ def upload(dst, src_pinned, stream):
 _fused_linear_relu = None  # None: untested, True/False after the first call
 
 
+class _LinearReluFn(torch.autograd.Function):
+    """y = relu(x W^T + b) with the element-wise part of the backward in two launches (etm_relu_bwd_colsum: ReLU mask and
+    bias gradient in one pass + the fixed-order column-sum reduction) instead of a mask multiply and a framework reduction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch.addmm(bias, x, weight.t())
+        torch.relu_(y)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        lib = _lib.load()
+        g = _f32c(g, "grad")
+        n, c = g.shape
+        gm = torch.empty_like(g)
+        db = torch.empty(c, dtype=torch.float32, device=g.device)
+        nbytes = lib.etm_relu_bwd_colsum_workspace_bytes(n, c)
+        ws = workspace(nbytes, g.device, "relu_bwd")
+        _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), _ptr(db), _ptr(ws), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+        dx = gm.mm(weight) if ctx.needs_input_grad[0] else None
+        dw = gm.t().mm(x) if ctx.needs_input_grad[1] else None
+        return dx, dw, db
+
+
+def linear_relu_train(x, weight, bias):
+    """relu(F.linear(x, weight, bias)) for 2-D fp32 device tensors under autograd (see _LinearReluFn)."""
+    return _LinearReluFn.apply(x, weight, bias)
+
+
 def linear_relu(lin, x, out=None):
     """relu(lin(x)).  In the no-grad rollout path the ReLU rides in the GEMM epilogue (hipBLASLt through
     ``torch._addmm_activation``), saving one launch per layer; with autograd enabled it is the plain two-op form.
@@ -811,6 +843,9 @@ def linear_relu(lin, x, out=None):
     global _fused_linear_relu
 
     def plain():
+        if (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and lin.bias is not None and out is None
+                and x.is_contiguous()):
+            return _LinearReluFn.apply(x, lin.weight, lin.bias)
         y = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
         return y if out is None else out.copy_(y)
 

@@ -927,8 +927,28 @@ class PPOTrainer:
                 for p in m.parameters():
                     member[g, index[id(p)]] += 1.0   # upstream concatenates, so a parameter listed twice counts twice
         self._grad_member = member.to(self.device)
+        # segments of the flat gradient arena (<= 4096 floats, inside one tensor) for etm_group_norms
+        base = self.flat_grads.data_ptr()
+        starts, lens, owner = [], [], []
+        for i, p in enumerate(self.params):
+            off = (self._grad_views[i].data_ptr() - base) // 4
+            for s in range(0, p.numel(), 4096):
+                starts.append(off + s)
+                lens.append(min(4096, p.numel() - s))
+                owner.append(i)
+        self._seg_start = torch.tensor(starts, dtype=torch.int64, device=self.device)
+        self._seg_len = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        self._seg_member = member[:, owner].contiguous().to(self.device)
+        self._seg_partial = torch.empty(len(starts), dtype=torch.float32, device=self.device)
 
     def _grad_group_norms(self):
+        if self.flat_grads.is_cuda and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params[:2], self._grad_views[:2])):
+            out = torch.empty(len(self._grad_keys), dtype=torch.float32, device=self.device)
+            etm_lib.check(etm_lib.load().etm_group_norms(self.flat_grads.data_ptr(), self._seg_start.data_ptr(), self._seg_len.data_ptr(),
+                                                         self._seg_start.numel(), self._seg_member.data_ptr(), len(self._grad_keys),
+                                                         self._seg_partial.data_ptr(), out.data_ptr(),
+                                                         torch.cuda.current_stream(self.device).cuda_stream), "etm_group_norms")
+            return out
         sq = torch.stack(torch._foreach_norm([p.grad for p in self.params])) ** 2
         return torch.sqrt(self._grad_member @ sq)
 

@@ -304,6 +304,20 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
 int etm_rollout_hidden_splits(int F);
 int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int W, int F, int D, void *stream);
 
+/* Backward of y = relu(x W^T + b) (model.py:94-107, transformer.py:232) up to its two GEMMs, in two launches: gm [N, C] =
+ * g * (y > 0) and db [C] = column sums of gm (fixed summation order).  y NULL: plain linear layer (gm = g; gm may be NULL, only
+ * db is produced).  workspace: etm_relu_bwd_colsum_workspace_bytes(N, C). */
+int64_t etm_relu_bwd_colsum_workspace_bytes(int N, int C);
+int etm_relu_bwd_colsum(const float *g, const float *y, float *gm, float *db, float *workspace, int64_t workspace_bytes, int N, int C,
+                        void *stream);
+
+/* Monitored gradient norms of the module groups (model.py:128-151) from the flat gradient arena in two launches:
+ * out[g] = sqrt(sum_s member[g][s] * ||flat[seg_start[s] .. seg_start[s] + seg_len[s])||^2).  Segments: runs of <= 4096 floats, each
+ * inside one parameter tensor (device arrays seg_start int64 [n_segs], seg_len int32 [n_segs]); member [n_groups, n_segs] float
+ * (how often the group lists the segment's tensor); partial: n_segs floats of scratch. */
+int etm_group_norms(const float *flat, const int64_t *seg_start, const int32_t *seg_len, int n_segs, const float *member, int n_groups,
+                    float *partial, float *out, void *stream);
+
 /* Minibatch gather of the per-sample fields in one launch (buffer.py:84-91 `samples_flat[key][mini_batch_indices]`):
  * dst[f][i, :] = src[f][idx[i], :] for f < n_fields (<= 16) and i < n.  src / dst / row_bytes: HOST arrays of n_fields device
  * pointers / byte counts; rows are contiguous, row_bytes % 4 == 0; every src[f] has src_rows rows.  Bit-exact data movement. */

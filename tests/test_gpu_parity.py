@@ -1033,6 +1033,26 @@ def test_train_cli_and_checkpoint_format(tmp_path):
     assert "Episode length:" in play.stdout and "Episode reward:" in play.stdout
 
 
+def test_linear_relu_backward_kernels_vs_autograd():
+    """_LinearReluFn (mask + bias gradient in one pass, fixed-order column sums) against torch's relu(linear) in float64."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(41)
+    for (n, k, c) in ((2048, 384, 384), (100, 3136, 384), (7, 20, 70), (65, 33, 3)):
+        x = torch.randn((n, k), device=dev, requires_grad=True)
+        w = (torch.randn((c, k), device=dev) / k ** 0.5).requires_grad_()
+        b = torch.randn(c, device=dev, requires_grad=True)
+        go = torch.randn((n, c), device=dev)
+        y = ops.linear_relu_train(x, w, b)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+        xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+        yd = torch.relu(torch.nn.functional.linear(xd, wd, bd))
+        rx, rw, rb = torch.autograd.grad(yd, (xd, wd, bd), go.double())
+        close(y, yd.detach().cpu().numpy(), atol=2e-5, rtol=1e-5, what="linear_relu forward")
+        for got, ref, what in ((gx, rx, "dx"), (gw, rw, "dw"), (gb, rb, "db")):
+            close(got, ref.cpu().numpy(), atol=2e-4 if what != "dx" else 2e-5, rtol=1e-4, what=f"linear_relu {what} {(n, k, c)}")
+
+
 def test_gather_rows_and_indexed_encoder_input():
     """etm_gather_rows == index_select per field (bit-exact, mixed dtypes / row sizes); the encoder kernels reading images through
     an index == the same kernels on the gathered batch (bit-exact forward and gradients)."""
