@@ -521,7 +521,10 @@ class PPOTrainer:
         fused_policy = False
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(g.kv, None, win_t, None, mask_t)
-            if single and getattr(self.model, "_rf", None) is not None and self.model.rollout_heads_fusable():
+            rf_ = getattr(self.model, "_rf", None)
+            # (every team of the step kernel must be resident at once: at most 256 workgroups per launch, else the multi-launch path)
+            if (single and rf_ is not None and self.model.rollout_heads_fusable()
+                    and (g.W + 7) // 8 * 8 * etm_lib.load().etm_rollout_trxl_team(rf_["H"]) <= 256):
                 # post-LN blocks without gates: the transformer, the heads and the sampling are ONE launch -- one workgroup per
                 # worker walks the whole chain as matrix-vector products over the L2-resident weights (csrc/rollout_fused.hip);
                 # the step is then encoder (4 launches) + window lookup + this kernel instead of 26 dependent launches
