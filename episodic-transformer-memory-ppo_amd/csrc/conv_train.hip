@@ -56,16 +56,10 @@ struct ConvG {
 };
 
 constexpr int CG_WAVES = 4;
-// pixel tiles per wave (x NT channel tiles = accumulator tiles): 4 accumulator tiles keep a wave at 64 AGPRs + ~90 VGPRs, i.e.
-// three waves per SIMD -- the operand loads come straight from L2 / HBM and need that occupancy to hide their latency
-#ifndef ETM_CONV_MT32
-#define ETM_CONV_MT32 4
-#endif
+// pixel tiles per wave MT (x NT channel tiles = accumulator tiles) are picked per launch (conv_pick_mt); up to 4 accumulator
+// tiles a wave stays at ~140 registers, i.e. three waves per SIMD
 #ifndef ETM_CONV_MINW
-#define ETM_CONV_MINW 3      // waves per SIMD the register allocation must leave room for
-#endif
-#ifndef ETM_CONV_MT64
-#define ETM_CONV_MT64 2
+#define ETM_CONV_MINW 3      // waves per SIMD the register allocation must leave room for (up to 4 accumulator tiles)
 #endif
 #ifndef CG_DIAG   // diagnostic builds only (tools/conv_layer_time.py): 1 = A operands loaded for the first groups only, 2 = B likewise, 4 = no stores
 #define CG_DIAG 0
@@ -473,6 +467,28 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4 *__restrict_
 }
 }  // namespace
 
+// Pixel tiles per wave.  A wave's work grows with MT (and the operand loads per MFMA fall), but the chip finishes in
+// ceil(workgroups / 256 CUs) rounds of roughly MT units each as long as few workgroups share a CU -- 324 workgroups cost two
+// rounds, 196 one.  Measured at N = 2048 (tools/conv_layer_time.py with -DETM_CONV_MT32/64 builds): forward layer 1: MT 2 / 4 =
+// 137 / 165 us; layer 2: MT 1 / 2 / 4 = 147 / 152 / 202; layer 3: 106 / 98 / 90; backward-data layer 3: 98 / 107 / 125.
+// Rule: minimise rounds x MT; on a tie the forward takes the largest MT (fewer weight loads per MFMA), backward-data the smallest.
+static int conv_pick_mt(long long tiles, const int *cands, int n_cands, bool prefer_large) {
+  int best = cands[0];
+  long long best_cost = -1;
+  for (int i = 0; i < n_cands; ++i) {
+    const int mt = cands[i];
+    const long long wgs = (tiles + (long long)CG_WAVES * mt - 1) / ((long long)CG_WAVES * mt);
+    const long long cost = ((wgs + 255) / 256) * mt;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && (prefer_large ? mt > best : mt < best))) { best = mt; best_cost = cost; }
+  }
+  return best;
+}
+template <int MT, int NT, bool DGRAD, int CLS = 1>
+static void conv_launch(const ConvG &p, long long tiles, unsigned classes, hipStream_t st) {
+  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, DGRAD, CLS>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64),
+                     0, st, p);
+}
+
 static int conv_geometry_ok(int C, int Cout, int KH, int KW, int S, int W) {
   if (Cout != 32 && Cout != 64) return 0;
   if ((KW * C) % 8 != 0 || (W * C) % 4 != 0 || (S * C) % 4 != 0) return 0;
@@ -500,11 +516,15 @@ extern "C" int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_
   EtmProfScope prof(ETM_K_CONV_TRAIN_FWD, st);
   const int tiles = (p.Mc + 31) / 32;
   if (Cout == 32) {
-    constexpr int MT = ETM_CONV_MT32;
-    hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, false>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), 1), dim3(CG_WAVES * 64), 0, st, p);
+    const int cands[] = {2, 4};
+    if (conv_pick_mt(tiles, cands, 2, true) == 2) conv_launch<2, 1, false>(p, tiles, 1, st);
+    else conv_launch<4, 1, false>(p, tiles, 1, st);
   } else {
-    constexpr int MT = ETM_CONV_MT64;
-    hipLaunchKernelGGL((conv_gemm_kernel<MT, 2, false>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), 1), dim3(CG_WAVES * 64), 0, st, p);
+    const int cands[] = {1, 2, 4};
+    const int mt = conv_pick_mt(tiles, cands, 3, true);
+    if (mt == 1) conv_launch<1, 2, false>(p, tiles, 1, st);
+    else if (mt == 2) conv_launch<2, 2, false>(p, tiles, 1, st);
+    else conv_launch<4, 2, false>(p, tiles, 1, st);
   }
   return etm_launch_status();
 }
@@ -523,7 +543,19 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   p.S = S; p.T = KH / S; p.n_seg = p.T; p.seg_len = p.T * Cout; p.groups = p.T * p.T * Cout / 8;
   p.cH = H / S; p.cW = W / S; p.out_nchw = 0;
   const bool merged = (C == 32 && S == 2);                                  // all four parity classes in one workgroup
-  const int unit = 32 * (merged ? 2 : (C == 32 ? ETM_CONV_MT32 : ETM_CONV_MT64));   // images per wave (all at one pixel position)
+  int mt = 2;
+  if (!merged) {
+    const int c32[] = {2, 4}, c64[] = {1, 2, 4};
+    long long best = -1;
+    for (int i = 0; i < (C == 32 ? 2 : 3); ++i) {                             // the tile count depends on MT (images padded to a wave's unit)
+      const int m = C == 32 ? c32[i] : c64[i];
+      const long long t = (long long)(H / S) * (W / S) * ((N + 32 * m - 1) / (32 * m)) * m;
+      const long long wgs = (t + (long long)CG_WAVES * m - 1) / ((long long)CG_WAVES * m);
+      const long long cost = ((wgs + 255) / 256) * m;
+      if (best < 0 || cost < best) { best = cost; mt = m; }                   // ties: the smallest MT (candidates ascend)
+    }
+  }
+  const int unit = 32 * mt;                                                   // images per wave (all at one pixel position)
   p.Npad = (N + unit - 1) / unit * unit;
   if ((long long)p.cH * p.cW * p.Npad >= (1 << 24)) return ETM_EUNSUPPORTED;
   p.Mc = p.cH * p.cW * p.Npad;
@@ -533,16 +565,11 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   EtmProfScope prof(ETM_K_CONV_TRAIN_DGRAD, st);
   const int tiles = (p.Mc + 31) / 32;
   const unsigned classes = (unsigned)(S * S);
-  if (merged) {
-    constexpr int MT = 2;
-    hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, true, 4>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), 1), dim3(CG_WAVES * 64), 0, st, p);
-  } else if (C == 32) {
-    constexpr int MT = ETM_CONV_MT32;
-    hipLaunchKernelGGL((conv_gemm_kernel<MT, 1, true>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64), 0, st, p);
-  } else {
-    constexpr int MT = ETM_CONV_MT64;
-    hipLaunchKernelGGL((conv_gemm_kernel<MT, 2, true>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64), 0, st, p);
-  }
+  if (merged) conv_launch<2, 1, true, 4>(p, tiles, 1, st);
+  else if (C == 32) { if (mt == 2) conv_launch<2, 1, true>(p, tiles, classes, st); else conv_launch<4, 1, true>(p, tiles, classes, st); }
+  else if (mt == 1) conv_launch<1, 2, true>(p, tiles, classes, st);
+  else if (mt == 2) conv_launch<2, 2, true>(p, tiles, classes, st);
+  else conv_launch<4, 2, true>(p, tiles, classes, st);
   return etm_launch_status();
 }
 
