@@ -573,8 +573,13 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   return etm_launch_status();
 }
 
+// Workgroups of a weight-gradient launch over all k-ranges: two are resident per CU (65 KB of LDS each), so 512 is exactly one
+// round of the 256 CUs -- 768 (1.5 rounds) cost 175 / 135 us on layers 2 / 3 where 512 cost 133 / 101, 1024: 150 / 115 (measured).
+#ifndef ETM_WGRAD_TARGET
+#define ETM_WGRAD_TARGET 512
+#endif
 static int wgrad_splits(int M, int k_ranges) {
-  int s = 768 / k_ranges;             // ~3 workgroups per CU over all k-ranges
+  int s = ETM_WGRAD_TARGET / k_ranges;
   const int cap = (M + 255) / 256;    // at least 256 pixels per slice
   if (s > cap) s = cap;
   if (s > 512) s = 512;
