@@ -275,6 +275,61 @@ def folded_supported(D, L, num_heads):
     return D % 32 == 0 and hd % 2 == 0 and ((D <= 512 and L <= 128) or (D <= 1024 and L <= 64))
 
 
+class _HeadFoldFn(torch.autograd.Function):
+    """u[h] = q_h Wk_h ([N, hd] x [hd, D] per head): q [N, D], wk [D, D] -> u [H, N, D].  The batched library GEMMs read q and write
+    dq through per-head strided views (batch stride hd, row stride D), so no head-major copy of q / dq is ever made."""
+
+    @staticmethod
+    def forward(ctx, q, wk, H):
+        N, D = q.shape
+        hd = D // H
+        ctx.save_for_backward(q, wk)
+        ctx.H = H
+        return torch.bmm(q.view(N, H, hd).transpose(0, 1), wk.view(H, hd, D))
+
+    @staticmethod
+    def backward(ctx, du):
+        q, wk = ctx.saved_tensors
+        H = ctx.H
+        N, D = q.shape
+        hd = D // H
+        du = du.contiguous()
+        dq = dwk = None
+        if ctx.needs_input_grad[0]:
+            dq = torch.empty_like(q)
+            torch.bmm(du, wk.view(H, hd, D).transpose(1, 2), out=dq.view(N, H, hd).transpose(0, 1))
+        if ctx.needs_input_grad[1]:
+            dwk = torch.bmm(q.view(N, H, hd).permute(1, 2, 0), du).view(D, D)
+        return dq, dwk, None
+
+
+class _HeadUnfoldFn(torch.autograd.Function):
+    """ctx[:, h] = z_h Wv_h^T ([N, D] x [D, hd] per head): z [H, N, D], wv [D, D] -> ctx [N, D], written straight into its
+    [N, H * hd] layout through a strided view (no transpose copy forward or backward)."""
+
+    @staticmethod
+    def forward(ctx, z, wv, H):
+        _, N, D = z.shape
+        hd = D // H
+        ctx.save_for_backward(z, wv)
+        ctx.H = H
+        out = torch.empty((N, D), dtype=z.dtype, device=z.device)
+        torch.bmm(z, wv.view(H, hd, D).transpose(1, 2), out=out.view(N, H, hd).transpose(0, 1))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, wv = ctx.saved_tensors
+        H = ctx.H
+        _, N, D = z.shape
+        hd = D // H
+        g = g.contiguous()
+        gh = g.view(N, H, hd).transpose(0, 1)                      # [H, N, hd], strided
+        dz = torch.bmm(gh, wv.view(H, hd, D)) if ctx.needs_input_grad[0] else None
+        dwv = torch.bmm(gh.transpose(1, 2), z).view(D, D) if ctx.needs_input_grad[1] else None
+        return dz, dwv, None
+
+
 def mha(q, wk, wv, spec, block, num_heads, ln_g=None, ln_b=None, pos=None, ln_eps=1e-5, impl=None):
     """Window attention of one block.  q [N,D] projected queries -> (ctx [N,D] before fc_out, attention [N,H,L])."""
     impl = _default_impl if impl is None else impl
@@ -286,6 +341,10 @@ def mha(q, wk, wv, spec, block, num_heads, ln_g=None, ln_b=None, pos=None, ln_ep
         return _MhaFn.apply(q, wk, wv, ln_g, ln_b, pos, spec, block, num_heads, ln_eps)
     hd = D // H
     # u[h] = q_h Wk_h and ctx_h = z_h Wv_h^T: [N,hd] x [hd,D] per head (library GEMMs; autograd supplies d q, d Wk, d Wv)
+    if q.is_cuda and q.is_contiguous() and wk.is_contiguous() and wv.is_contiguous():
+        u = _HeadFoldFn.apply(q, wk, H)
+        z, att = _WindowFn.apply(u, ln_g, ln_b, pos, spec, block, ln_eps)
+        return _HeadUnfoldFn.apply(z, wv, H), att
     u = torch.bmm(q.view(N, H, hd).transpose(0, 1), wk.view(H, hd, D))
     z, att = _WindowFn.apply(u, ln_g, ln_b, pos, spec, block, ln_eps)
     ctx = torch.bmm(z, wv.view(H, hd, D).transpose(1, 2)).transpose(0, 1).reshape(N, D)
