@@ -23,6 +23,7 @@
 //   gradient) are accumulated by the threads that stage dY.
 #include "etm_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -68,13 +69,16 @@ constexpr int CG_WAVES = 4;
 // CLS (backward-data): stride-parity classes handled by ONE workgroup.  The classes of a class-grid pixel (cy, cx) read the SAME
 // T x T gradient taps -- only their weights differ -- so with CLS = S * S the classes are just more channel tiles of one GEMM:
 // an A fragment feeds 4 NT CLS MFMAs instead of 4 NT (the vector-memory instructions per MFMA are what bounds these kernels).
-template <int MT, int NT, bool DGRAD, int CLS = 1>
-__global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MINW)) void conv_gemm_kernel(const ConvG p) {
+// BLDS: weight fragments through LDS, shared by the four waves of a workgroup (false: every wave loads its own)
+template <int MT, int NT, bool DGRAD, int CLS = 1, bool BLDS = true>
+__global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT * (NT * CLS == 1 ? 4 : 2) > 8)) ? 2 : ETM_CONV_MINW)) void conv_gemm_kernel(const ConvG p) {
   constexpr int NTT = NT * CLS;                     // accumulator tiles per pixel tile: (class, channel tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int cls0 = (int)blockIdx.y * CLS;           // first parity class of this workgroup (backward-data), 0 for forward
   const int tile0 = ((int)blockIdx.x * CG_WAVES + wave) * MT;
-  if (tile0 * 32 >= p.Mc) return;                   // whole wave; no barriers in this kernel
+  // (with the shared weight fragments every wave of the workgroup takes part in the barriers: a wave past the last pixel tile
+  // works on clamped pixels and stores nothing)
+  if (!BLDS && tile0 * 32 >= p.Mc) return;
   const int gps = p.seg_len / 8;                    // groups per segment
   const int gpp = DGRAD ? p.sC / 8 : gps;           // groups per source pixel (backward-data)
   // Backward-data walks the pixels POSITION-major: a tile is 32 images at one input pixel (cy, cx) of the class, and the MT
@@ -130,6 +134,76 @@ __global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MI
   // the k walk: segment `seg` (a kernel row), then 8-float groups inside it (backward-data: the valid rows / tap columns only).
   // All of it is wave-uniform.
 
+  if constexpr (BLDS) {
+    // The weight fragments of a k-group are the same for the four waves of the workgroup (forward: all waves walk all groups;
+    // backward-data: the waves of a workgroup share the pixel position, hence the k range), and every vector-memory
+    // instruction costs MFMA issue time.  So a CHUNK of CH groups x NTT fragments (1 KB each) is fetched once per workgroup --
+    // wave w loads the fragments w, w + 4, ... -- and handed over through LDS (double-buffered, one barrier per chunk that does
+    // not drain the loads in flight); each wave reads all fragments back with ds_read_b128.  NT = 1: 0.25 instead of 1 weight
+    // load per wave and group, four merged classes: 1 instead of 4.
+    constexpr int CH = NTT == 1 ? 4 : 2;              // groups per chunk: CH * NTT is a multiple of the 4 waves
+    constexpr int TPW = CH * NTT / CG_WAVES;          // fragments this wave fetches per chunk
+    __shared__ __attribute__((aligned(16))) float bt_s[2][CH * NTT][256];
+    f32x4 a_reg[2][CH][MT], b_st[TPW];
+    const int gw = gi_hi - gi_lo;
+    const int n_chunks = (n_groups + CH - 1) / CH;
+    int seg_n = seg_lo, gi_n = gi_lo, i_n = 0;        // the next group to fetch (clamped to the last valid one past the end)
+    auto fetch_chunk = [&](auto abuf) {
+      constexpr int AB = decltype(abuf)::value;
+      int koff[CH], gidx[CH];
+#pragma unroll
+      for (int cg = 0; cg < CH; ++cg) {
+        koff[cg] = (DGRAD ? -seg_n : seg_n) * row_elems + gi_n * 8;
+        gidx[cg] = seg_n * gps + gi_n;
+        if (i_n + 1 < n_groups) {                     // uniform
+          ++i_n;
+          if (++gi_n == gi_hi) { gi_n = gi_lo; ++seg_n; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {                 // my weight fragments first: their wait must not include the A loads below
+        const int jt = wave + k * CG_WAVES, cg = jt / NTT, t = jt - cg * NTT;
+        b_st[k] = *reinterpret_cast<const f32x4 *>(wbase + (long long)gidx[cg] * NT * 256 + (t / NT) * wcls + (t % NT) * 256 + wl);
+      }
+#pragma unroll
+      for (int cg = 0; cg < CH; ++cg)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_reg[AB][cg][mt] = *reinterpret_cast<const f32x4 *>(p.src + koff[cg] + loff[mt]);
+    };
+    auto stash_b = [&](auto bbuf) {
+      constexpr int BB = decltype(bbuf)::value;
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) *reinterpret_cast<f32x4 *>(&bt_s[BB][wave + k * CG_WAVES][wl]) = b_st[k];
+    };
+    auto chunk = [&](int c, auto bufc) {
+      constexpr int B = decltype(bufc)::value;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // chunk c's fragments are in bt_s[B]; bt_s[1 - B] is free
+      if (c + 1 < n_chunks) fetch_chunk(std::integral_constant<int, 1 - B>{});
+#pragma unroll
+      for (int cg = 0; cg < CH; ++cg) {
+        if (c * CH + cg < n_groups) {                  // uniform
+          f32x4 bf[NTT];
+#pragma unroll
+          for (int t = 0; t < NTT; ++t) bf[t] = *reinterpret_cast<const f32x4 *>(&bt_s[B][cg * NTT + t][wl]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int t = 0; t < NTT; ++t)
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_reg[B][cg][mt][j], bf[t][j], acc[mt][t], 0, 0, 0);
+        }
+      }
+      if (c + 1 < n_chunks) stash_b(std::integral_constant<int, 1 - B>{});
+    };
+    (void)gw;
+    fetch_chunk(std::integral_constant<int, 0>{});
+    stash_b(std::integral_constant<int, 0>{});
+    for (int c = 0; c < n_chunks; c += 2) {
+      chunk(c, std::integral_constant<int, 0>{});
+      if (c + 1 < n_chunks) chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
   f32x4 a_reg[3][MT], b_reg[3][NTT];              // three k-groups in flight: the loads of group g + 2 are issued before the MFMAs of group g
   auto load_group = [&](int seg, int gi, int g, int buf) {
     const int koff = (DGRAD ? -seg : seg) * row_elems + gi * 8;      // uniform
@@ -173,6 +247,8 @@ __global__ __launch_bounds__(CG_WAVES * 64, (MT * NT * CLS > 4 ? 2 : ETM_CONV_MI
     if (g + 1 < n_groups) mfma_group(1);
     load_next(1);
     if (g + 2 < n_groups) mfma_group(2);
+  }
+
   }
 
   // epilogue.  The accumulator layout (lane = channel, register = pixel row) would store 4 bytes per lane and instruction: 16
@@ -471,8 +547,15 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4 *__restrict_
 // ceil(workgroups / 256 CUs) rounds of roughly MT units each as long as few workgroups share a CU -- 324 workgroups cost two
 // rounds, 196 one.  Measured at N = 2048 (tools/conv_layer_time.py with -DETM_CONV_MT32/64 builds): forward layer 1: MT 2 / 4 =
 // 137 / 165 us; layer 2: MT 1 / 2 / 4 = 147 / 152 / 202; layer 3: 106 / 98 / 90; backward-data layer 3: 98 / 107 / 125.
-// Rule: minimise rounds x MT; on a tie the forward takes the largest MT (fewer weight loads per MFMA), backward-data the smallest.
+// Rule: minimise rounds x MT, ties to the smallest MT.  With the weight fragments shared through LDS (second sweep): forward
+// layer 1: MT 2 / 4 = 125 / 140 us, layer 2: MT 1 / 2 / 4 = 136 / 134 / 180, layer 3: 96 / 97 / 108 -- except that a 64-channel
+// layer whose MT = 4 launch is a single round of at most one workgroup per CU (layer 3: 196 workgroups) does best with
+// private fragments and no barriers (89 us).
 static int conv_pick_mt(long long tiles, const int *cands, int n_cands, bool prefer_large) {
+  if (const char *e = getenv("ETM_DIAG_CONV_MT")) {     // diagnostic override (tools/conv_layer_time.py sweeps)
+    const int v = atoi(e);
+    for (int i = 0; i < n_cands; ++i) if (cands[i] == v) return v;
+  }
   int best = cands[0];
   long long best_cost = -1;
   for (int i = 0; i < n_cands; ++i) {
@@ -483,9 +566,9 @@ static int conv_pick_mt(long long tiles, const int *cands, int n_cands, bool pre
   }
   return best;
 }
-template <int MT, int NT, bool DGRAD, int CLS = 1>
+template <int MT, int NT, bool DGRAD, int CLS = 1, bool BLDS = true>
 static void conv_launch(const ConvG &p, long long tiles, unsigned classes, hipStream_t st) {
-  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, DGRAD, CLS>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64),
+  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, DGRAD, CLS, BLDS>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64),
                      0, st, p);
 }
 
@@ -517,11 +600,13 @@ extern "C" int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_
   const int tiles = (p.Mc + 31) / 32;
   if (Cout == 32) {
     const int cands[] = {2, 4};
-    if (conv_pick_mt(tiles, cands, 2, true) == 2) conv_launch<2, 1, false>(p, tiles, 1, st);
+    if (conv_pick_mt(tiles, cands, 2, false) == 2) conv_launch<2, 1, false>(p, tiles, 1, st);
     else conv_launch<4, 1, false>(p, tiles, 1, st);
+  } else if ((tiles + CG_WAVES * 4 - 1) / (CG_WAVES * 4) <= 256 && !getenv("ETM_DIAG_CONV_MT")) {
+    conv_launch<4, 2, false, 1, false>(p, tiles, 1, st);
   } else {
-    const int cands[] = {1, 2, 4};
-    const int mt = conv_pick_mt(tiles, cands, 3, true);
+    const int cands[] = {2, 1, 4};
+    const int mt = conv_pick_mt(tiles, cands, 3, false);
     if (mt == 1) conv_launch<1, 2, false>(p, tiles, 1, st);
     else if (mt == 2) conv_launch<2, 2, false>(p, tiles, 1, st);
     else conv_launch<4, 2, false>(p, tiles, 1, st);
@@ -549,13 +634,15 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
     long long best = -1;
     for (int i = 0; i < (C == 32 ? 2 : 3); ++i) {                             // the tile count depends on MT (images padded to a wave's unit)
       const int m = C == 32 ? c32[i] : c64[i];
-      const long long t = (long long)(H / S) * (W / S) * ((N + 32 * m - 1) / (32 * m)) * m;
+      const int wu = 32 * m * CG_WAVES;                                    // images of a workgroup: they share one pixel position
+      const long long t = (long long)(H / S) * (W / S) * ((N + wu - 1) / wu) * (wu / 32);
       const long long wgs = (t + (long long)CG_WAVES * m - 1) / ((long long)CG_WAVES * m);
       const long long cost = ((wgs + 255) / 256) * m;
       if (best < 0 || cost < best) { best = cost; mt = m; }                   // ties: the smallest MT (candidates ascend)
     }
   }
-  const int unit = 32 * mt;                                                   // images per wave (all at one pixel position)
+  // images that share one pixel position: a whole workgroup's (its waves share the weight fragments of that position's k range)
+  const int unit = 32 * mt * CG_WAVES;
   p.Npad = (N + unit - 1) / unit * unit;
   if ((long long)p.cH * p.cW * p.Npad >= (1 << 24)) return ETM_EUNSUPPORTED;
   p.Mc = p.cH * p.cW * p.Npad;
