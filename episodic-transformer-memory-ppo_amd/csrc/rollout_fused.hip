@@ -47,6 +47,14 @@ struct RfParams {
   const float *h_in;                 // [W, D] input of the transformer (model.py:96-100 output), or, with h_splits > 0, the
   const float *h_bias;               // [h_splits, W, D] K-slice sums of etm_rollout_hidden_partial: input = relu(sum + h_bias)
   int h_splits;
+  // window lookup of the step inside this launch (optional, ss != nullptr; replaces etm_rollout_window in front of it)
+  const long long *ss;               // [2, W] (episode step, slot) of the workers: device memory or pinned host memory
+  const unsigned char *mask_table;   // [L, L]
+  const long long *index_table;      // [T, L]
+  unsigned char *st_mask, *mask_t;   // staging rows [S, stage_W, L] (at this group's first worker), the group's current mask [W, L]
+  long long *st_idx, *win_t, *latch, *t_row;
+  const float *kv_init;              // [T, nb, 2D]: cache rows of an episode that has not written them yet
+  int T;
   const float *wemb_t, *bemb;        // [D, D] transposed, [D]
   RfBlock blk[RF_MAXB];
   int nb;
@@ -255,17 +263,54 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     }
     x_s[tid] = v;
   }
+  long long step_w = 0, slot_w = 0;
+  if (p.ss) { step_w = p.ss[w]; slot_w = p.ss[p.W + w]; }          // read in place (possibly from pinned host memory)
+  else if (p.wkv) { step_w = p.step_l[w]; slot_w = p.slot_l[w]; }
   if (tid < L) {                                                   // the window rows of this worker in the K | V cache (block 0's offsets)
-    off_s[tid] = (long long)w * p.kv_w_stride + p.win[(long long)w * L + tid] * p.kv_row_stride;
-    mask_s[tid] = p.mask[(long long)w * L + tid];
+    long long idx;
+    unsigned char m;
+    if (p.ss) {                                                    // the lookup of trainer.py:165-169 (rollout_window_kernel's job)
+      const long long r = step_w < 0 ? 0 : (step_w > L - 1 ? L - 1 : step_w);
+      m = p.mask_table[r * L + tid];
+      idx = p.index_table[step_w * L + tid];
+      if (me == 0) {                                               // ... with its staging: the step's buffer rows, the group's current rows
+        const long long t = *p.t_dev;
+        p.mask_t[(long long)w * L + tid] = m;
+        p.win_t[(long long)w * L + tid] = idx;
+        p.st_mask[(t * p.stage_W + w) * L + tid] = m;
+        p.st_idx[(t * p.stage_W + w) * L + tid] = idx;
+        if (tid == 0) {
+          p.latch[w] = step_w;
+          p.latch[p.W + w] = slot_w;
+          if (w == 0 && p.t_row) *p.t_row = t;
+        }
+      }
+    } else {
+      idx = p.win[(long long)w * L + tid];
+      m = p.mask[(long long)w * L + tid];
+    }
+    off_s[tid] = (long long)w * p.kv_w_stride + idx * p.kv_row_stride;
+    mask_s[tid] = m;
+  }
+  if (p.ss && p.kv_init && step_w == 0) {
+    // a new episode: its cache rows hold the projection of an empty memory (trainer.py:208-213 in cache form).  Every member
+    // resets exactly the K and V columns it reads, so no member depends on another one's stores.
+    const int q4 = DS >> 2;
+    const long long rowf = (long long)p.nb * 2 * D;                // floats per cache row of kv_init
+    for (long long i = tid; i < (long long)p.T * p.nb * 2 * q4; i += RF_T) {
+      const int c4 = (int)(i % q4);
+      const long long rest = i / q4;
+      const int kvh = (int)(rest & 1), b = (int)((rest >> 1) % p.nb);
+      const long long r = (rest >> 1) / p.nb;
+      const long long col = (long long)b * 2 * D + kvh * D + d0 + c4 * 4;
+      *reinterpret_cast<f32x4 *>(p.kv_out + (long long)w * p.kv_w_stride + r * p.kv_row_stride + col) =
+          *reinterpret_cast<const f32x4 *>(p.kv_init + r * rowf + col);
+    }
+    __syncthreads();                                               // stores complete and visible to the whole workgroup
   }
   const float bemb_r = (tid < DS) ? p.bemb[d0 + tid] : 0.f;
-  long long step_w = 0, slot_w = 0;
   float pos_r = 0.f;                                               // positional row of this step, my element
-  if (p.wkv) {
-    step_w = p.step_l[w]; slot_w = p.slot_l[w];
-    if (p.pos && tid < D) pos_r = p.pos[step_w * D + tid];
-  }
+  if (p.wkv && p.pos && tid < D) pos_r = p.pos[step_w * D + tid];
   rf_sync();
   // E0: linear_embedding + ReLU, my columns; collect the full row
   gemv_finish<GR>(wr, p.wemb_t, D, x_s, part_s, 0, D, D, d0, DS);
@@ -690,9 +735,13 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
                                 float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                                 float ln_eps, void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
                                 const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
-                                int h_splits, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
+                                int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
+                                int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
+                                int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
   (void)hipGetLastError();
-  if (!h_in || !wemb_t || !bemb || !blocks || !kv || !win || !mask || !items || !wh_t || !bh || !wp || !bp || !wv || !bv || !uniforms ||
+  if (ss && (!mask_table || !index_table || !st_mask || !st_idx || !latch || !mask_t || !win_t || T <= 0)) return ETM_EINVAL;
+  if (!ss && (!win || !mask)) return ETM_EINVAL;
+  if (!h_in || !wemb_t || !bemb || !blocks || !kv || !items || !wh_t || !bh || !wp || !bp || !wv || !bv || !uniforms ||
       !t_dev || !actions || !st_actions || !st_logp || !st_values || !sync_counter || !scratch)
     return ETM_EINVAL;
   if (W <= 0 || nb <= 0 || D <= 0 || H <= 0 || L <= 0 || hid <= 0 || A <= 0 || stage_W < W || D % H != 0) return ETM_EINVAL;
@@ -703,6 +752,9 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   if (!etm_rollout_trxl_supported(D, H, L, hid, A, nb) || (W + 7) / 8 * 8 * P > 256) return ETM_EUNSUPPORTED;   // all teams resident
   if (scratch_bytes < etm_rollout_trxl_scratch_bytes(W, D, H, nb)) return ETM_EWORKSPACE;
   RfParams p{};
+  p.ss = (const long long *)ss; p.mask_table = mask_table; p.index_table = (const long long *)index_table; p.st_mask = st_mask;
+  p.st_idx = (long long *)st_idx; p.latch = (long long *)latch; p.t_row = (long long *)t_row; p.mask_t = mask_t; p.win_t = (long long *)win_t;
+  p.kv_init = kv_init; p.T = T;
   p.h_in = h_in; p.h_bias = h_bias; p.h_splits = h_splits; p.wemb_t = wemb_t; p.bemb = bemb; p.nb = nb;
   for (int b = 0; b < nb; ++b) {
     const float *const *q = reinterpret_cast<const float *const *>(blocks) + 9 * b;

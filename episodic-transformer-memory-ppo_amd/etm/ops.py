@@ -463,11 +463,13 @@ def rollout_trxl_supported(D, H, L, hid, A, nb):
 
 
 def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head, uniforms, forced, t_dev, actions, st_actions, st_logp,
-                 st_values, scratch, host_actions=None, host_flag=None, w_off=0, tail=None, h_bias=None):
+                 st_values, scratch, host_actions=None, host_flag=None, w_off=0, tail=None, h_bias=None, window=None):
     """Transformer + hidden / output heads + sampling of one rollout step of a worker group in one launch (etm_rollout_trxl).
     ``fused``: the transposed fixed-address weight copies of ``ActorCriticModel.refresh_rollout_weights`` (dict with the host
     pointer table ``blocks``); ``kv`` the group's K | V cache [W, T, blocks, 2D]; ``scratch`` from ``rollout_trxl_scratch``; the
-    staging arguments as in ``rollout_policy``.  ``tail`` = (wkv [blocks, D, 2D], pos [T, D] or None, step_l [W], slot_l [W],
+    staging arguments as in ``rollout_policy``.  ``window`` = (ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init):
+    the launch does the step's window lookup (and the cache reset of workers at episode step 0) itself -- no ``rollout_window``
+    in front of it.  ``tail`` = (wkv [blocks, D, 2D], pos [T, D] or None, step_l [W], slot_l [W],
     bank [slots, T, blocks, D]): after the action hand-over the same launch writes the new memory items into
     ``bank[slot_l, step_l]`` and their K | V projection into ``kv[w, step_l]``."""
     lib = _lib.load()
@@ -478,6 +480,13 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
         h_in_shape = h_in.shape[1:]
     else:
         h_in_shape = h_in.shape
+    w_args = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    if window is not None:        # (ss [2, W], mask_table, index_table, st_mask, st_idx, latch [2, W], t_row, kv_init or None)
+        ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init = window
+        Lw = win_t.shape[1]
+        w_args = (_ptr(ss), _ptr(mask_table), _ptr(index_table), st_mask.data_ptr() + w_off * Lw * st_mask.element_size(),
+                  st_idx.data_ptr() + w_off * Lw * st_idx.element_size(), _ptr(latch), _ptr(t_row), _ptr(mask_t), _ptr(win_t),
+                  0 if kv_init is None else _ptr(kv_init), index_table.shape[0])
     t_args = (0, 0, 0, 0, 0, 0, 0)
     if tail is not None:
         wkv, pos, step_l, slot_l, bank = tail
@@ -499,7 +508,7 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
                                     _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight), _ptr(value_head.bias),
                                     off(uniforms), off(forced), _ptr(t_dev), _ptr(actions), off(st_actions), off(st_logp), off(st_values),
                                     ha, hf, _ptr(sync), float(fused["eps"]), _ptr(scratch), scratch.numel() * 8, *t_args,
-                                    0 if h_bias is None else _ptr(h_bias), h_splits, W, D, fused["H"], L, hid, A, stage_w, _stream()),
+                                    0 if h_bias is None else _ptr(h_bias), h_splits, *w_args, W, D, fused["H"], L, hid, A, stage_w, _stream()),
                "etm_rollout_trxl")
 
 

@@ -514,17 +514,21 @@ class PPOTrainer:
         # empty memory)
         # streamed + pipelined mode: the (step, slot) block is read from pinned host memory (see _sample_training_data)
         ss_src = g.ss_pin if (stream_obs and self._state_zero_copy and g.stream is not None) else g.ss_dev
-        ops.rollout_window(ss_src[0], self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
-                           st["memory_mask"], st["memory_indices"], t_row=g.t_row,
-                           reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo,
-                           latch=(ss_src, g.ss_latch))
+        rf_ = getattr(self.model, "_rf", None) if self._use_kv_cache else None
+        # (every team of the step kernel must be resident at once: at most 256 workgroups per launch, else the multi-launch path)
+        fused_step = (single and rf_ is not None and self.model.rollout_heads_fusable()
+                      and (g.W + 7) // 8 * 8 * etm_lib.load().etm_rollout_trxl_team(rf_["H"]) <= 256)
+        # the fused step kernel does the window lookup (and the cache reset of new episodes) itself: one launch fewer in the chain
+        window_in_step = fused_step and self.config.get("window_in_step_kernel", True)
+        if not window_in_step:
+            ops.rollout_window(ss_src[0], self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
+                               st["memory_mask"], st["memory_indices"], t_row=g.t_row,
+                               reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo,
+                               latch=(ss_src, g.ss_latch))
         fused_policy = False
         if self._use_kv_cache:
             kv_spec = WindowSpec.from_bank(g.kv, None, win_t, None, mask_t)
-            rf_ = getattr(self.model, "_rf", None)
-            # (every team of the step kernel must be resident at once: at most 256 workgroups per launch, else the multi-launch path)
-            if (single and rf_ is not None and self.model.rollout_heads_fusable()
-                    and (g.W + 7) // 8 * 8 * etm_lib.load().etm_rollout_trxl_team(rf_["H"]) <= 256):
+            if fused_step:
                 # post-LN blocks without gates: the transformer, the heads and the sampling are ONE launch -- one workgroup per
                 # worker walks the whole chain as matrix-vector products over the L2-resident weights (csrc/rollout_fused.hip);
                 # the step is then encoder (4 launches) + window lookup + this kernel instead of 26 dependent launches
@@ -550,7 +554,9 @@ class PPOTrainer:
                 ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
                                  self._uniforms, self._forced_tab, g.t_dev, g.act_dev, st["actions"], st["log_probs"], st["values"],
                                  g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo,
-                                 tail=tail, h_bias=h_bias)
+                                 tail=tail, h_bias=h_bias,
+                                 window=(ss_src, self._mask_table, self._index_table, st["memory_mask"], st["memory_indices"],
+                                         g.ss_latch, g.t_row, self._kv_init) if window_in_step else None)
                 item = g.item
                 fused_policy = True
             elif single and self.model.rollout_heads_fusable():

@@ -279,6 +279,11 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *   scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes that the caller ZEROES ONCE and then leaves to the kernel
  *           (int64 launch counter, int64 error word -- non-zero after a launch = a team member timed out --, 48 bytes of padding,
  *           then the exchange slots).
+ *   window lookup inside the launch (ss non-NULL; then win / mask may be NULL and no etm_rollout_window is needed in front): ss [2, W]
+ *           = (episode step, slot) of the workers (device or pinned host memory, read in place); every team looks its window rows /
+ *           mask up in index_table [T, L] / mask_table [L, L] (trainer.py:165-169), member 0 also writes them to win_t / mask_t [W, L]
+ *           and to row *t_dev of the staging arrays st_idx / st_mask [S, stage_W, L], latches ss into latch [2, W] and *t_dev into
+ *           t_row; a worker at episode step 0 first gets its cache rows reset to kv_init [T, nb, 2D] (NULL: no reset);
  *   h_splits > 0: h_in is [h_splits, W, D] from etm_rollout_hidden_partial and the input is relu(sum over slices + h_bias [D]);
  *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
  *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
@@ -296,7 +301,9 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter, float ln_eps,
                      void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
                      const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
-                     int h_splits, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+                     int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
+                     int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
+                     int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
 /* lin_hidden of a rollout step (model.py:94-100) as K-slice partial sums: part [splits, W, D], splits =
  * etm_rollout_hidden_splits(F) (<= 16), = the slice sums of x [W, F] @ wt [F, D] (wt = the weight TRANSPOSED, 16-byte aligned,
  * D % 32 == 0).  etm_rollout_trxl(h_in = part, h_bias = the layer's bias, h_splits = splits) adds the slices in slice order,

@@ -375,13 +375,14 @@ _ROLLOUT_PATHS = {
     "multi_launch_blocks": {"fused_rollout_block": False},    # rollout: one launch per GEMM / attention / LayerNorm instead of one per step
     "launched_tail": {"fused_rollout_tail": False},           # bank write + K/V projection of the new items as separate launches
     "library_hidden": {"split_hidden_product": False},        # lin_hidden of a rollout step by the library GEMM, not as K-slice sums
+    "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
              ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs"),
              ("img32", "multi_launch_blocks"), ("vec", "multi_launch_blocks"), ("img32", "launched_tail"), ("vec", "launched_tail"),
-             ("img32", "state_uploaded"), ("img32", "library_hidden")]
+             ("img32", "state_uploaded"), ("img32", "library_hidden"), ("img32", "window_launch")]
 
 
 def movement_error(sd, z, tag, keys, prev):
