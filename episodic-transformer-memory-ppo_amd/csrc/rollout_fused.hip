@@ -40,9 +40,15 @@ constexpr int RF_MAXB = 8;
 constexpr int RF_MAXSPLIT = 16;            // K slices of the lin_hidden product in front of the kernel
 constexpr int RF_SPIN_LIMIT = 1 << 22;     // ~1 s of polling: a partner that never ran
 
+struct RfGate {                      // GRU gate (transformer.py:255-298): the six maps transposed ([in, out]) and the bias bg
+  const float *wry, *wzy, *wgy, *urx, *uzx, *ugx, *bg;
+};
 struct RfBlock {
   const float *wq_t, *wo_t, *bo, *g1, *b1, *wfc_t, *bfc, *g2, *b2;
+  RfGate gate1, gate2;               // GTrXL only
+  const float *nkv_g, *nkv_b;        // pre-LN only: norm_kv of the memory rows (applied by the tail before the K | V projection)
 };
+constexpr int RF_BLOCK_PTRS = 25;
 struct RfParams {
   const float *h_in;                 // [W, D] input of the transformer (model.py:96-100 output), or, with h_splits > 0, the
   const float *h_bias;               // [h_splits, W, D] K-slice sums of etm_rollout_hidden_partial: input = relu(sum + h_bias)
@@ -74,6 +80,7 @@ struct RfParams {
   float *xbuf;                       // exchange slots [W][n_slots][P][2 D]
   long long *ctl;                    // launch counter [1], error word [1]
   int n_slots;
+  int pre_ln, gtrxl;                 // block layout: LayerNorm before (pre) or after (post) the sub-layers; GRU gates instead of residuals
   // tail (optional, wkv != nullptr): the new memory items into the bank, their K | V projection into the cache
   const float *wkv;                  // [nb, D, 2D]: per block [Wk ; Wv]^T
   const float *pos;                  // [T, D] positional rows added to the items before the projection, or nullptr
@@ -207,7 +214,9 @@ __device__ __forceinline__ void team_collect(const Team &t, int ex, int m, float
 }
 
 // GR: rows of a product slice in registers per thread; LMAX: window rows the K / V registers are sized for.
-template <int GR, int LMAX>
+// GEN: the general block layout (pre-LN and / or GRU gates) is compiled in; the post-LN layout without gates (the headline
+// configuration) gets a kernel without that code, which keeps its register allocation free of spills.
+template <int GR, int LMAX, bool GEN>
 __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   constexpr int KR = LMAX / RF_WAVES;                             // window rows per wave (energies)
   constexpr int VR = LMAX / 16;                                   // window rows per thread (context): >= 16 row groups (D / P <= 128)
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   __shared__ unsigned char mask_s[128];
   __shared__ float out_s[64];
   __shared__ float items_s[RF_MAXB * RF_T];                       // every block's input (the new memory items), for the tail
+  __shared__ float a_s[RF_T], h1_s[RF_T], g_s[RF_T], n_s[RF_T], pub_s[RF_T];   // gated / pre-LN layouts: full rows between the sub-layers
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = p.D, L = p.L, H = p.H, hd = D / H, P = p.P;
   // block -> (worker, member): the members of a team get the same b % 8, i.e. (as observed) the same XCD and L2
@@ -365,8 +375,16 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     float bo_r = 0.f, g1_r = 0.f, b1_r = 0.f, g2_r = 0.f, b2_r = 0.f, bfc_r = 0.f;
     if (tid < D) { bo_r = B.bo[tid]; g1_r = B.g1[tid]; b1_r = B.b1[tid]; g2_r = B.g2[tid]; b2_r = B.b2[tid]; }
     if (tid < DS) bfc_r = B.bfc[d0 + tid];
-    // q (my columns = my heads)
-    gemv_finish<GR>(wr, B.wq_t, D, x_s, part_s, 0, D, D, d0, DS);
+    // q (my columns = my heads); pre-LN: from LayerNorm1(h) (transformer.py:128-131)
+    const float *qsrc = x_s;
+    if (GEN && p.pre_ln) {
+      float mq, rq;
+      row_stats(x_s, D, p.eps, mq, rq);
+      if (tid < D) n_s[tid] = (x_s[tid] - mq) * rq * g1_r + b1_r;
+      rf_sync();
+      qsrc = n_s;
+    }
+    gemv_finish<GR>(wr, B.wq_t, D, qsrc, part_s, 0, D, D, d0, DS);
     gemv_issue<GR>(wr, B.wo_t, D, d0, D, 0, D, 0);
     rf_sync();
     if (tid < DS) y_s[tid] = gemv_sum(part_s, DS, tid);
@@ -436,6 +454,109 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       rf_sync();
     }
     RF_STAMP(5 + 8 * b);
+    if constexpr (GEN) {
+      // ---- general layout (transformer.py:117-172): attention -> gate1 or residual -> (post: norm1) -> (pre: norm2) -> fc ->
+      // gate2 or residual -> (post: norm2).  Same machinery: every product's slice is requested when the previous product has
+      // consumed the registers; full rows are assembled by exchanges.
+      struct Nxt { const float *w; int k0, OUT, o0, OUTS; };
+      const Nxt after_block = (b + 1 < p.nb) ? Nxt{p.blk[b + 1].wq_t, 0, D, d0, DS} : Nxt{p.wh_t, 0, OUTH, o0, OS};
+      auto col_prod = [&](const float *wt, const float *src_s, const Nxt &nx) -> float {     // my DS columns of wt^T src
+        gemv_finish<GR>(wr, wt, D, src_s, part_s, 0, D, D, d0, DS);
+        gemv_issue<GR>(wr, nx.w, D, nx.k0, nx.OUT, nx.o0, nx.OUTS, 0);
+        rf_sync();
+        const float r = (tid < DS) ? gemv_sum(part_s, DS, tid) : 0.f;
+        rf_sync();
+        return r;
+      };
+      auto gather_full = [&](float mine, float *dst_s) {           // every member's DS values -> the full row in dst_s
+        if (tid < DS) pub_s[tid] = mine;
+        rf_sync();
+        if (P > 1) {
+          team_publish(team, ex, pub_s, DS);
+          if (tid < DS) dst_s[d0 + tid] = pub_s[tid];
+          for (int m = 0; m < P; ++m)
+            if (m != me) team_collect(team, ex, m, dst_s + m * DS, DS, 64 * (m - (m > me)));
+          ++ex;
+        } else {
+          if (tid < D) dst_s[tid] = pub_s[tid];
+        }
+        rf_sync();
+      };
+      auto gate = [&](const RfGate &G, const float *xs, const float *ys, float *dst_s, const Nxt &nx) {   // dst = GRUGate(x, y)
+        const Nxt col{nullptr, 0, D, d0, DS};
+        const float ar = col_prod(G.wry, ys, Nxt{G.wzy, col.k0, col.OUT, col.o0, col.OUTS});
+        const float az = col_prod(G.wzy, ys, Nxt{G.wgy, col.k0, col.OUT, col.o0, col.OUTS});
+        const float ag = col_prod(G.wgy, ys, Nxt{G.urx, col.k0, col.OUT, col.o0, col.OUTS});
+        const float br = col_prod(G.urx, xs, Nxt{G.uzx, col.k0, col.OUT, col.o0, col.OUTS});
+        const float bz = col_prod(G.uzx, xs, Nxt{G.ugx, col.k0, col.OUT, col.o0, col.OUTS});
+        float xm = 0.f, r = 0.f, z = 0.f;
+        if (tid < DS) {
+          xm = xs[d0 + tid];
+          r = 1.0f / (1.0f + expf(-(ar + br)));
+          z = 1.0f / (1.0f + expf(-(az + bz - G.bg[d0 + tid])));
+        }
+        gather_full(r * xm, g_s);                                  // r * x, full row, for Ug
+        const float c = col_prod(G.ugx, g_s, nx);
+        const float hh = tanhf(ag + c);
+        gather_full((1.0f - z) * xm + z * hh, dst_s);
+      };
+      // fc_out as a K-split (as below): partial rows summed in member order, + bias
+      gemv_finish<GR>(wr, B.wo_t, D, y_s, part_s, d0, d0 + DS, D, 0, D);
+      if (p.gtrxl) gemv_issue<GR>(wr, B.gate1.wry, D, 0, D, d0, DS, 0);
+      else gemv_issue<GR>(wr, B.wfc_t, D, 0, D, d0, DS, 0);
+      rf_sync();
+      if (tid < D) t_s[tid] = gemv_sum(part_s, D, tid);
+      rf_sync();
+      float av = 0.f;
+      if (P > 1) {
+        team_publish(team, ex, t_s, D);
+        for (int m = 0; m < P; ++m)
+          if (m != me) team_collect(team, ex, m, part_s + m * D, D, 0);
+        rf_sync();
+        if (tid < D)
+          for (int m = 0; m < P; ++m) av += (m == me) ? t_s[tid] : part_s[m * D + tid];
+        ++ex;
+      } else if (tid < D) {
+        av = t_s[tid];
+      }
+      av += bo_r;
+      rf_sync();
+      float mean2, rstd2;
+      // h1 = gate1(h, attention) or attention + h; post-LN: norm1 of it
+      if (p.gtrxl) {
+        if (tid < D) a_s[tid] = av;
+        rf_sync();
+        gate(B.gate1, x_s, a_s, p.pre_ln ? h1_s : t_s, Nxt{B.wfc_t, 0, D, d0, DS});
+      } else {
+        if (tid < D) (p.pre_ln ? h1_s : t_s)[tid] = av + x_s[tid];
+        rf_sync();
+      }
+      if (!p.pre_ln) {
+        row_stats(t_s, D, p.eps, mean2, rstd2);
+        if (tid < D) h1_s[tid] = (t_s[tid] - mean2) * rstd2 * g1_r + b1_r;
+        rf_sync();
+      }
+      const float *fsrc = h1_s;
+      if (p.pre_ln) {                                              // pre-LN: the projection reads norm2(h1)
+        row_stats(h1_s, D, p.eps, mean2, rstd2);
+        if (tid < D) n_s[tid] = (h1_s[tid] - mean2) * rstd2 * g2_r + b2_r;
+        rf_sync();
+        fsrc = n_s;
+      }
+      const float f = fmaxf(col_prod(B.wfc_t, fsrc, p.gtrxl ? Nxt{B.gate2.wry, 0, D, d0, DS} : after_block) + bfc_r, 0.f);
+      gather_full(f, a_s);                                         // fc output, full row
+      if (p.gtrxl) {
+        gate(B.gate2, h1_s, a_s, p.pre_ln ? x_s : t_s, after_block);
+      } else {
+        if (tid < D) (p.pre_ln ? x_s : t_s)[tid] = a_s[tid] + h1_s[tid];
+        rf_sync();
+      }
+      if (!p.pre_ln) {
+        row_stats(t_s, D, p.eps, mean2, rstd2);
+        if (tid < D) x_s[tid] = (t_s[tid] - mean2) * rstd2 * g2_r + b2_r;
+        rf_sync();
+      }
+    } else {
     // Ea: fc_out as a K-split: my rows of Wo^T (my ctx columns) x all D outputs -> partial row; the members' partial rows are
     // summed in member order; x = LayerNorm1(sum + bo + h)
     gemv_finish<GR>(wr, B.wo_t, D, y_s, part_s, d0, d0 + DS, D, 0, D);
@@ -495,6 +616,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     if (tid < D) x_s[tid] = (v - mean) * rstd * g2_r + b2_r;
     rf_sync();
     RF_STAMP(10 + 8 * b);
+    }
   }
 
   // Ez: hidden heads [lin_policy ; lin_value] + ReLU (model.py:104-107), my columns of the 2 hid outputs, then the partial dot
@@ -600,12 +722,20 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     const int OUTK = 2 * D, KS = OUTK / P, k0c = me * KS;
     gemv_issue<GR>(wr, p.wkv, D, 0, OUTK, k0c, KS, 0);
     for (int b = 0; b < p.nb; ++b) {
+      float xin = 0.f;
       if (tid < D) {
         const float it = items_s[b * D + tid];
         if (me == 0) p.bank[slot_w * p.bank_slot_stride + step_w * p.bank_row_stride + (long long)b * D + tid] = it;
-        t_s[tid] = it + pos_r;
+        xin = it + pos_r;
+        ((GEN && p.blk[b].nkv_g) ? n_s : t_s)[tid] = xin;
       }
       rf_sync();
+      if (GEN && p.blk[b].nkv_g) {                                 // pre-LN: the cache holds projections of norm_kv(memory) (transformer.py:128-131)
+        float mk, rk;
+        row_stats(n_s, D, p.eps, mk, rk);
+        if (tid < D) t_s[tid] = (xin - mk) * rk * p.blk[b].nkv_g[tid] + p.blk[b].nkv_b[tid];
+        rf_sync();
+      }
       const float *wb = p.wkv + (long long)b * D * OUTK;
       gemv_finish<GR>(wr, wb, D, t_s, part_s, 0, D, OUTK, k0c, KS);
       if (b + 1 < p.nb) gemv_issue<GR>(wr, wb + (long long)D * OUTK, D, 0, OUTK, k0c, KS, 0);
@@ -698,7 +828,7 @@ extern "C" int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, i
 extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
   if (W <= 0 || D <= 0 || H <= 0 || nb <= 0) return 0;
   const int P = etm_rollout_trxl_team(H);
-  const int64_t slots = 2 * (int64_t)nb + 2;
+  const int64_t slots = 6 * (int64_t)nb + 2;                       // exchanges per launch: up to 6 per block (gated layout) + 2
   return 64 + (int64_t)W * slots * P * 2 * D * (int64_t)sizeof(float);
 }
 
@@ -720,8 +850,11 @@ extern "C" int etm_rollout_hidden_partial(const float *x, const float *wt, float
   return etm_launch_status();
 }
 
-// One launch per worker group and rollout step.  blocks: nb structs of 9 device pointers each, in the order
-// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous).
+// One launch per worker group and rollout step.  blocks: nb structs of 25 device pointers each, in the order
+// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias,  gate1: wr_t, wz_t, wg_t, ur_t, uz_t, ug_t, bg,  gate2: the same
+// seven,  norm_kv gain, norm_kv bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous).  The gate entries are read with
+// gtrxl != 0 only, the norm_kv entries (both or neither) by the tail of a pre-LN model; pre_ln / gtrxl select the block layout of
+// transformer.py:117-172.
 // scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes, ZEROED once by the caller before the first launch and then left alone
 // (int64 launch counter, int64 error word -- non-zero = a team member timed out --, then the exchange slots).
 // Tail (wkv != NULL): after the action hand-over the same launch writes the new memory items into bank[slot_l[w], step_l[w]] and
@@ -737,7 +870,7 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
                                 const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
                                 int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                                 int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                                int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
+                                int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
   (void)hipGetLastError();
   if (ss && (!mask_table || !index_table || !st_mask || !st_idx || !latch || !mask_t || !win_t || T <= 0)) return ETM_EINVAL;
   if (!ss && (!win || !mask)) return ETM_EINVAL;
@@ -757,16 +890,20 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   p.kv_init = kv_init; p.T = T;
   p.h_in = h_in; p.h_bias = h_bias; p.h_splits = h_splits; p.wemb_t = wemb_t; p.bemb = bemb; p.nb = nb;
   for (int b = 0; b < nb; ++b) {
-    const float *const *q = reinterpret_cast<const float *const *>(blocks) + 9 * b;
+    const float *const *q = reinterpret_cast<const float *const *>(blocks) + RF_BLOCK_PTRS * b;
     for (int k = 0; k < 9; ++k) if (!q[k]) return ETM_EINVAL;
-    p.blk[b] = RfBlock{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+    if (gtrxl) for (int k = 9; k < 23; ++k) if (!q[k]) return ETM_EINVAL;
+    if ((q[23] == nullptr) != (q[24] == nullptr)) return ETM_EINVAL;
+    p.blk[b] = RfBlock{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8],
+                       RfGate{q[9], q[10], q[11], q[12], q[13], q[14], q[15]}, RfGate{q[16], q[17], q[18], q[19], q[20], q[21], q[22]}, q[23], q[24]};
   }
+  p.pre_ln = pre_ln; p.gtrxl = gtrxl;
   p.kv = kv; p.kv_w_stride = kv_worker_stride; p.kv_row_stride = kv_row_stride;
   p.win = (const long long *)win; p.mask = mask; p.items = items; p.wh_t = wh_t; p.bh = bh; p.wp = wp; p.bp = bp; p.wv = wv; p.bv = bv;
   p.uniforms = uniforms; p.forced = (const long long *)forced; p.t_dev = (long long *)t_dev; p.actions = (long long *)actions;
   p.st_actions = (long long *)st_actions; p.st_logp = st_logp; p.st_values = st_values; p.host_actions = (long long *)host_actions;
   p.host_flag = (long long *)host_flag; p.sync_counter = (int *)sync_counter;
-  p.n_slots = 2 * nb + 2;
+  p.n_slots = 6 * nb + 2;
   p.wkv = wkv; p.pos = pos; p.step_l = (const long long *)step_l; p.slot_l = (const long long *)slot_l; p.kv_out = kv; p.bank = bank;
   p.bank_slot_stride = bank_slot_stride; p.bank_row_stride = bank_row_stride;
   p.ctl = (long long *)scratch;
@@ -782,12 +919,19 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   const int DS = D / P;
   const int rows_q = (D + RF_T / (DS / 4) - 1) / (RF_T / (DS / 4)), rows_o = (DS + RF_T / (D / 4) - 1) / (RF_T / (D / 4));
   const bool small = rows_q <= 20 && rows_o <= 20;
+  const bool gen = pre_ln || gtrxl;
+#define RF_LAUNCH(GR_, LM_)                                                                                      \
+  do {                                                                                                           \
+    if (gen) hipLaunchKernelGGL((rollout_trxl_kernel<GR_, LM_, true>), grid, block, 0, st, p);                   \
+    else hipLaunchKernelGGL((rollout_trxl_kernel<GR_, LM_, false>), grid, block, 0, st, p);                      \
+  } while (0)
   if (L <= 64) {
-    if (small) hipLaunchKernelGGL((rollout_trxl_kernel<20, 64>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((rollout_trxl_kernel<32, 64>), grid, block, 0, st, p);
+    if (small) RF_LAUNCH(20, 64);
+    else RF_LAUNCH(32, 64);
   } else {
-    if (small) hipLaunchKernelGGL((rollout_trxl_kernel<20, 128>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((rollout_trxl_kernel<32, 128>), grid, block, 0, st, p);
+    if (small) RF_LAUNCH(20, 128);
+    else RF_LAUNCH(32, 128);
   }
+#undef RF_LAUNCH
   return etm_launch_status();
 }

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 
@@ -52,7 +52,7 @@ SIGNATURES = {
     "etm_rollout_trxl_scratch_bytes": (_L, [_I, _I, _I, _I]),
     "etm_rollout_trxl": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                               _P, _L, _P, _P, _P, _P, _P, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
-                              _I, _I, _I, _I, _I, _I, _I, _P]),
+                              _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_rollout_hidden_splits": (_I, [_I]),
     "etm_rollout_hidden_partial": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

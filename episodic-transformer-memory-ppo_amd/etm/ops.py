@@ -508,7 +508,8 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
                                     _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight), _ptr(value_head.bias),
                                     off(uniforms), off(forced), _ptr(t_dev), _ptr(actions), off(st_actions), off(st_logp), off(st_values),
                                     ha, hf, _ptr(sync), float(fused["eps"]), _ptr(scratch), scratch.numel() * 8, *t_args,
-                                    0 if h_bias is None else _ptr(h_bias), h_splits, *w_args, W, D, fused["H"], L, hid, A, stage_w, _stream()),
+                                    0 if h_bias is None else _ptr(h_bias), h_splits, *w_args, int(fused.get("pre_ln", 0)),
+                                    int(fused.get("gtrxl", 0)), W, D, fused["H"], L, hid, A, stage_w, _stream()),
                "etm_rollout_trxl")
 
 

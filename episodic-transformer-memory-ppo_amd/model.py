@@ -113,7 +113,7 @@ class ActorCriticModel(nn.Module):
         t = self.transformer
         blk = t.transformer_blocks[0]
         d = t.embed_dim
-        if not (self.fused_rollout_block and blk.layer_norm == "post" and not blk.use_gtrxl and len(self.policy_branches) == 1
+        if not (self.fused_rollout_block and blk.layer_norm in ("post", "pre") and len(self.policy_branches) == 1
                 and t.linear_embedding.in_features == d):
             return False
         return ops.rollout_trxl_supported(d, t.num_heads, t.config["memory_length"], self.hidden_size,
@@ -133,6 +133,10 @@ class ActorCriticModel(nn.Module):
                 fresh[f"wq_t{i}"] = blk.attention.queries.weight.t()
                 fresh[f"wo_t{i}"] = blk.attention.fc_out.weight.t()
                 fresh[f"wfc_t{i}"] = blk.fc[0].weight.t()
+                if blk.use_gtrxl:                                   # GRU gates: the six maps of both gates, transposed
+                    for gi, gate in ((1, blk.gate1), (2, blk.gate2)):
+                        for name in ("Wr", "Wz", "Wg", "Ur", "Uz", "Ug"):
+                            fresh[f"g{gi}{name}_t{i}"] = getattr(gate, name).weight.t()
             if self.visual and self.lin_hidden.weight.shape[0] % 32 == 0:
                 fresh["hid_t"] = self.lin_hidden.weight.t()     # [features, D]: etm_rollout_hidden_partial
             rf = getattr(self, "_rf", None)
@@ -140,12 +144,19 @@ class ActorCriticModel(nn.Module):
                 rf = {k: v.contiguous() for k, v in fresh.items()}
                 rf["emb_b"], rf["heads_b"] = t.linear_embedding.bias, None
                 ptrs = []
-                for i, blk in enumerate(t.transformer_blocks):
+                for i, blk in enumerate(t.transformer_blocks):       # 25 pointers per block (include/etm_hip.h, etm_rollout_trxl)
                     ptrs += [rf[f"wq_t{i}"], rf[f"wo_t{i}"], blk.attention.fc_out.bias, blk.norm1.weight, blk.norm1.bias,
                              rf[f"wfc_t{i}"], blk.fc[0].bias, blk.norm2.weight, blk.norm2.bias]
+                    for gi, gname in ((1, "gate1"), (2, "gate2")):
+                        if blk.use_gtrxl:
+                            ptrs += [rf[f"g{gi}{name}_t{i}"] for name in ("Wr", "Wz", "Wg", "Ur", "Uz", "Ug")] + [getattr(blk, gname).bg]
+                        else:
+                            ptrs += [None] * 7
+                    ptrs += [blk.norm_kv.weight, blk.norm_kv.bias] if blk.layer_norm == "pre" else [None, None]
                 rf["_keep"] = ptrs
-                rf["blocks"] = (ctypes.c_void_p * len(ptrs))(*[p.data_ptr() for p in ptrs])
+                rf["blocks"] = (ctypes.c_void_p * len(ptrs))(*[None if p is None else p.data_ptr() for p in ptrs])
                 rf["nb"], rf["H"], rf["eps"] = t.num_blocks, t.num_heads, t.transformer_blocks[0].norm1.eps
+                rf["pre_ln"], rf["gtrxl"] = int(t.transformer_blocks[0].layer_norm == "pre"), int(t.transformer_blocks[0].use_gtrxl)
                 self._rf = rf
             else:
                 for k, v in fresh.items():

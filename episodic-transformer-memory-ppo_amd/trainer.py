@@ -548,7 +548,7 @@ class PPOTrainer:
                     g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device)
                 # ... and, after the action hand-over, the memory-bank write and the K | V projection of the new items (the tail)
                 tail = None
-                if self.config.get("fused_rollout_tail", True) and self._kv_weights[1] is None:
+                if self.config.get("fused_rollout_tail", True):      # (pre-LN: the kernel applies norm_kv before projecting)
                     tail = (self._kv_weights[0], self.model.transformer._pos(), g.step_l, g.slot_l, buf.bank)
                 g.tail_in_kernel = tail is not None
                 ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,

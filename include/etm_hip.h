@@ -271,8 +271,10 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  * member owning D / P columns of each product and H / P heads, the members exchanging their pieces through memory (16-byte
  * packets that carry their own sequence number, bounded polling) -- instead of 6 dependent launches per block.
  *   h_in [W, D]: transformer input (model.py:96-100); wemb_t [D, D], bemb [D]: linear_embedding (weight TRANSPOSED, [in, out]);
- *   blocks: HOST array of nb x 9 device pointers (wq_t, wo_t, bo, norm1 gain, norm1 bias, wfc_t, bfc, norm2 gain, norm2 bias), *_t
- *           transposed [D, D];   kv / strides / win / mask: the K | V cache rows as in etm_attn_cached (rows of all blocks: the
+ *   blocks: HOST array of nb x 25 device pointers (wq_t, wo_t, bo, norm1 gain, norm1 bias, wfc_t, bfc, norm2 gain, norm2 bias; gate1:
+ *           wr_t, wz_t, wg_t, ur_t, uz_t, ug_t, bg; gate2: the same seven; norm_kv gain, norm_kv bias), *_t transposed [D, D]; the
+ *           gate pointers are read with gtrxl != 0 (GRU gates instead of residuals, transformer.py:255-298), the norm_kv pair by the
+ *           tail of a pre-LN model (pre_ln != 0: LayerNorm in front of the sub-layers, transformer.py:128-150);   kv / strides / win / mask: the K | V cache rows as in etm_attn_cached (rows of all blocks: the
  *           kernel adds b * 2D);   items [nb, W, D]: receives every block's input = the new memory items (block-major);
  *   wh_t [D, 2 hid], bh [2 hid]: [lin_policy ; lin_value] transposed;  wp / bp / wv / bv and everything from `uniforms` to
  *   `sync_counter`: as in etm_rollout_policy;
@@ -303,7 +305,7 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
                      int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                      int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                     int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+                     int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
 /* lin_hidden of a rollout step (model.py:94-100) as K-slice partial sums: part [splits, W, D], splits =
  * etm_rollout_hidden_splits(F) (<= 16), = the slice sums of x [W, F] @ wt [F, D] (wt = the weight TRANSPOSED, 16-byte aligned,
  * D % 32 == 0).  etm_rollout_trxl(h_in = part, h_bias = the layer's bias, h_splits = splits) adds the slices in slice order,

@@ -693,13 +693,17 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
     from trainer import PPOTrainer
     dev = _dev()
     # teams of 4 / 2 / 1 workgroups; two heads per member with a window beyond 64 rows; D = 512 (the 32-row register slices)
-    for (D, H, L, nb, hid, A, W) in ((384, 4, 64, 3, 384, 3, 16), (64, 2, 8, 2, 64, 4, 5), (128, 1, 32, 4, 128, 2, 32),
-                                     (256, 8, 96, 2, 256, 5, 9), (512, 4, 33, 2, 512, 3, 8)):
+    # ... and the general block layouts of transformer.py:117-172: pre-LN and / or GRU gates (BASELINE configs 2 and 5 are pre-LN GTrXL)
+    for (D, H, L, nb, hid, A, W, ln, gtrxl) in ((384, 4, 64, 3, 384, 3, 16, "post", False), (64, 2, 8, 2, 64, 4, 5, "post", False),
+                                                (128, 1, 32, 4, 128, 2, 32, "post", False), (256, 8, 96, 2, 256, 5, 9, "post", False),
+                                                (512, 4, 33, 2, 512, 3, 8, "post", False),
+                                                (384, 4, 128, 2, 384, 3, 16, "pre", True), (128, 1, 32, 4, 128, 2, 8, "pre", True),
+                                                (64, 2, 8, 2, 64, 4, 5, "post", True), (256, 8, 96, 2, 256, 5, 9, "pre", False)):
         cfg = dict(environment=dict(type="Synthetic", obs_shape=[7], num_actions=A, max_episode_steps=L + 5, seed=3, p_done=0.1, pool=4),
                    gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=W, worker_steps=L + 12, n_mini_batch=1, value_loss_coefficient=0.5,
                    hidden_layer_size=hid, max_grad_norm=0.5, rollout_groups=1,
                    transformer=dict(num_blocks=nb, embed_dim=D, num_heads=H, memory_length=L, positional_encoding="relative",
-                                    layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
+                                    layer_norm=ln, gtrxl=gtrxl, gtrxl_bias=1.0 if gtrxl else 0.0),
                    learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
                    beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
                    clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
@@ -725,7 +729,7 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
         assert same > 0.999, same                            # a different action only where a uniform sits on a CDF boundary
         if same == 1.0:
             for k in ("values", "log_probs", "mem"):
-                assert torch.allclose(a[k], m[k], atol=2e-5, rtol=1e-4), (D, k, (a[k] - m[k]).abs().max())
+                assert torch.allclose(a[k], m[k], atol=2e-5, rtol=1e-4), (D, ln, gtrxl, k, (a[k] - m[k]).abs().max())
 
 
 def test_rollout_glue_riders_and_fused_policy():

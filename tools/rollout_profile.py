@@ -9,7 +9,8 @@ if os.environ.get("ETM_DIAG_LIB"):
 from yaml_parser import YamlParser
 from trainer import PPOTrainer
 
-cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", "synthetic_minigrid.yaml")).get_config()
+cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs",
+                              os.environ.get("ETM_PROFILE_CONFIG", "synthetic_minigrid") + ".yaml")).get_config()   # BASELINE config 3 by default
 for k in sys.argv[1:]:
     name, val = k.split("=")
     tgt = cfg
