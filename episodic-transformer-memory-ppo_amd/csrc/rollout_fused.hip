@@ -40,15 +40,17 @@ constexpr int RF_MAXB = 8;
 constexpr int RF_MAXSPLIT = 16;            // K slices of the lin_hidden product in front of the kernel
 constexpr int RF_SPIN_LIMIT = 1 << 22;     // ~1 s of polling: a partner that never ran
 
-struct RfGate {                      // GRU gate (transformer.py:255-298): the six maps transposed ([in, out]) and the bias bg
-  const float *wry, *wzy, *wgy, *urx, *uzx, *ugx, *bg;
+struct RfGate {                      // GRU gate (transformer.py:255-298), maps transposed ([in, out]):
+  const float *wy;                   // [D, 3D]: [Wr | Wz | Wg] applied to y, columns member-major: member m owns m * 3 DS + {r, z, g} * DS + c
+  const float *ux;                   // [D, 2D]: [Ur | Uz] applied to x, member-major likewise
+  const float *ugx, *bg;             // [D, D] Ug, [D] bias
 };
 struct RfBlock {
   const float *wq_t, *wo_t, *bo, *g1, *b1, *wfc_t, *bfc, *g2, *b2;
   RfGate gate1, gate2;               // GTrXL only
   const float *nkv_g, *nkv_b;        // pre-LN only: norm_kv of the memory rows (applied by the tail before the K | V projection)
 };
-constexpr int RF_BLOCK_PTRS = 25;
+constexpr int RF_BLOCK_PTRS = 19;
 struct RfParams {
   const float *h_in;                 // [W, D] input of the transformer (model.py:96-100 output), or, with h_splits > 0, the
   const float *h_bias;               // [h_splits, W, D] K-slice sums of etm_rollout_hidden_partial: input = relu(sum + h_bias)
@@ -80,6 +82,7 @@ struct RfParams {
   float *xbuf;                       // exchange slots [W][n_slots][P][2 D]
   long long *ctl;                    // launch counter [1], error word [1]
   int n_slots;
+  int merge_gate;                    // GRU gates: the maps of y / of x as one product each (small D) or as separate column blocks
   int pre_ln, gtrxl;                 // block layout: LayerNorm before (pre) or after (post) the sub-layers; GRU gates instead of residuals
   // tail (optional, wkv != nullptr): the new memory items into the bank, their K | V projection into the cache
   const float *wkv;                  // [nb, D, 2D]: per block [Wk ; Wv]^T
@@ -239,6 +242,11 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   const int DS = D / P, d0 = me * DS;                              // my columns of every D-wide product
   const int HS = H / P;                                            // my heads: me * HS ...
   const int OUTH = 2 * p.hid, OS = OUTH / P, o0 = me * OS;         // my columns of the hidden heads
+  // Column-split matrices arrive MEMBER-BLOCKED: [P][K][columns of the member], so a member's slice of a product is one contiguous
+  // run (147 KB at D = 384) instead of 384-byte pieces at the row stride of the whole matrix -- the K-split fc_out product, whose
+  // slice always was contiguous, was the fastest product of the timeline.
+  const long long mcol = (long long)me * D * DS;                   // my block of a [D, D] matrix split by columns
+  const long long mhead = (long long)me * D * OS;                  // my block of the [D, 2 hid] hidden heads
   Team team;
   team.P = P; team.me = me; team.D = D;
   team.slots = p.xbuf + (long long)w * p.n_slots * P * 2 * D;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
 
   RF_STAMP(0);
   f32x4 wr[GR];                                                    // the product slice in flight
-  gemv_issue<GR>(wr, p.wemb_t, D, 0, D, d0, DS, 0);
+  gemv_issue<GR>(wr, p.wemb_t + mcol, D, 0, DS, 0, DS, 0);
   // inputs of the sampling at the very end (thread 0 of member 0)
   long long t_now = 0;
   int a_forced = -1;
@@ -323,8 +331,8 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   if (p.wkv && p.pos && tid < D) pos_r = p.pos[step_w * D + tid];
   rf_sync();
   // E0: linear_embedding + ReLU, my columns; collect the full row
-  gemv_finish<GR>(wr, p.wemb_t, D, x_s, part_s, 0, D, D, d0, DS);
-  gemv_issue<GR>(wr, p.blk[0].wq_t, D, 0, D, d0, DS, 0);
+  gemv_finish<GR>(wr, p.wemb_t + mcol, D, x_s, part_s, 0, D, DS, 0, DS);
+  gemv_issue<GR>(wr, p.blk[0].wq_t + mcol, D, 0, DS, 0, DS, 0);
   rf_sync();
   if (tid < DS) t_s[tid] = fmaxf(gemv_sum(part_s, DS, tid) + bemb_r, 0.f);
   rf_sync();
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       rf_sync();
       qsrc = n_s;
     }
-    gemv_finish<GR>(wr, B.wq_t, D, qsrc, part_s, 0, D, D, d0, DS);
+    gemv_finish<GR>(wr, B.wq_t + mcol, D, qsrc, part_s, 0, D, DS, 0, DS);
     gemv_issue<GR>(wr, B.wo_t, D, d0, D, 0, D, 0);
     rf_sync();
     if (tid < DS) y_s[tid] = gemv_sum(part_s, DS, tid);
@@ -459,9 +467,18 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       // gate2 or residual -> (post: norm2).  Same machinery: every product's slice is requested when the previous product has
       // consumed the registers; full rows are assembled by exchanges.
       struct Nxt { const float *w; int k0, OUT, o0, OUTS; };
-      const Nxt after_block = (b + 1 < p.nb) ? Nxt{p.blk[b + 1].wq_t, 0, D, d0, DS} : Nxt{p.wh_t, 0, OUTH, o0, OS};
-      auto col_prod = [&](const float *wt, const float *src_s, const Nxt &nx) -> float {     // my DS columns of wt^T src
-        gemv_finish<GR>(wr, wt, D, src_s, part_s, 0, D, D, d0, DS);
+      const bool merge_gate = p.merge_gate != 0;                   // etm_rollout_trxl_gate_merged(D, H): the caller packed the gates accordingly
+      const Nxt after_block = (b + 1 < p.nb) ? Nxt{p.blk[b + 1].wq_t + mcol, 0, DS, 0, DS} : Nxt{p.wh_t + mhead, 0, OS, 0, OS};
+      auto slice_prod = [&](const float *wt, const float *src_s, const Nxt &nx) -> float {   // a contiguous [D, DS] block
+        gemv_finish<GR>(wr, wt, D, src_s, part_s, 0, D, DS, 0, DS);
+        gemv_issue<GR>(wr, nx.w, D, nx.k0, nx.OUT, nx.o0, nx.OUTS, 0);
+        rf_sync();
+        const float r = (tid < DS) ? gemv_sum(part_s, DS, tid) : 0.f;
+        rf_sync();
+        return r;
+      };
+      auto col_prod = [&](const float *wt, const float *src_s, const Nxt &nx) -> float {     // my DS columns of wt^T src (member-blocked wt)
+        gemv_finish<GR>(wr, wt + mcol, D, src_s, part_s, 0, D, DS, 0, DS);
         gemv_issue<GR>(wr, nx.w, D, nx.k0, nx.OUT, nx.o0, nx.OUTS, 0);
         rf_sync();
         const float r = (tid < DS) ? gemv_sum(part_s, DS, tid) : 0.f;
@@ -483,12 +500,34 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
         rf_sync();
       };
       auto gate = [&](const RfGate &G, const float *xs, const float *ys, float *dst_s, const Nxt &nx) {   // dst = GRUGate(x, y)
-        const Nxt col{nullptr, 0, D, d0, DS};
-        const float ar = col_prod(G.wry, ys, Nxt{G.wzy, col.k0, col.OUT, col.o0, col.OUTS});
-        const float az = col_prod(G.wzy, ys, Nxt{G.wgy, col.k0, col.OUT, col.o0, col.OUTS});
-        const float ag = col_prod(G.wgy, ys, Nxt{G.urx, col.k0, col.OUT, col.o0, col.OUTS});
-        const float br = col_prod(G.urx, xs, Nxt{G.uzx, col.k0, col.OUT, col.o0, col.OUTS});
-        const float bz = col_prod(G.uzx, xs, Nxt{G.ugx, col.k0, col.OUT, col.o0, col.OUTS});
+        // the three maps of y are ONE product over my 3 DS columns of [Wr | Wz | Wg]^T, the two maps of x one over 2 DS columns
+        // of [Ur | Uz]^T: two phases instead of five (a phase costs a round trip whatever its size)
+        // -- when the merged product still fits two register batches (small D: phases are pure latency); at D = 384 a merged
+        // product is three batches, two of them exposed round trips, and five pre-requested slices are faster (measured:
+        // config 2 step graph 209 -> 183 us merged, config 5 312 -> 356 us merged).
+        float ar = 0.f, az = 0.f, ag = 0.f, br = 0.f, bz = 0.f;
+        // my block of [Wr | Wz | Wg]^T / [Ur | Uz]^T: merged form [P][D][j DS] (one product over j DS columns), else [P][j][D][DS]
+        // (j contiguous [D, DS] blocks)
+        const float *wy = G.wy + (long long)me * 3 * D * DS, *ux = G.ux + (long long)me * 2 * D * DS;
+        const long long blk = (long long)D * DS;
+        if (merge_gate) {
+          gemv_finish<GR>(wr, wy, D, ys, part_s, 0, D, 3 * DS, 0, 3 * DS);
+          gemv_issue<GR>(wr, ux, D, 0, 2 * DS, 0, 2 * DS, 0);
+          rf_sync();
+          if (tid < DS) { ar = gemv_sum(part_s, 3 * DS, tid); az = gemv_sum(part_s, 3 * DS, DS + tid); ag = gemv_sum(part_s, 3 * DS, 2 * DS + tid); }
+          rf_sync();
+          gemv_finish<GR>(wr, ux, D, xs, part_s, 0, D, 2 * DS, 0, 2 * DS);
+          gemv_issue<GR>(wr, G.ugx + mcol, D, 0, DS, 0, DS, 0);
+          rf_sync();
+          if (tid < DS) { br = gemv_sum(part_s, 2 * DS, tid); bz = gemv_sum(part_s, 2 * DS, DS + tid); }
+          rf_sync();
+        } else {
+          ar = slice_prod(wy, ys, Nxt{wy + blk, 0, DS, 0, DS});
+          az = slice_prod(wy + blk, ys, Nxt{wy + 2 * blk, 0, DS, 0, DS});
+          ag = slice_prod(wy + 2 * blk, ys, Nxt{ux, 0, DS, 0, DS});
+          br = slice_prod(ux, xs, Nxt{ux + blk, 0, DS, 0, DS});
+          bz = slice_prod(ux + blk, xs, Nxt{G.ugx + mcol, 0, DS, 0, DS});
+        }
         float xm = 0.f, r = 0.f, z = 0.f;
         if (tid < DS) {
           xm = xs[d0 + tid];
@@ -502,8 +541,12 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       };
       // fc_out as a K-split (as below): partial rows summed in member order, + bias
       gemv_finish<GR>(wr, B.wo_t, D, y_s, part_s, d0, d0 + DS, D, 0, D);
-      if (p.gtrxl) gemv_issue<GR>(wr, B.gate1.wry, D, 0, D, d0, DS, 0);
-      else gemv_issue<GR>(wr, B.wfc_t, D, 0, D, d0, DS, 0);
+      if (p.gtrxl) {
+        const int ow = merge_gate ? 3 * DS : DS;
+        gemv_issue<GR>(wr, B.gate1.wy + (long long)me * 3 * D * DS, D, 0, ow, 0, ow, 0);
+      } else {
+        gemv_issue<GR>(wr, B.wfc_t + mcol, D, 0, DS, 0, DS, 0);
+      }
       rf_sync();
       if (tid < D) t_s[tid] = gemv_sum(part_s, D, tid);
       rf_sync();
@@ -526,7 +569,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       if (p.gtrxl) {
         if (tid < D) a_s[tid] = av;
         rf_sync();
-        gate(B.gate1, x_s, a_s, p.pre_ln ? h1_s : t_s, Nxt{B.wfc_t, 0, D, d0, DS});
+        gate(B.gate1, x_s, a_s, p.pre_ln ? h1_s : t_s, Nxt{B.wfc_t + mcol, 0, DS, 0, DS});
       } else {
         if (tid < D) (p.pre_ln ? h1_s : t_s)[tid] = av + x_s[tid];
         rf_sync();
@@ -543,7 +586,8 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
         rf_sync();
         fsrc = n_s;
       }
-      const float f = fmaxf(col_prod(B.wfc_t, fsrc, p.gtrxl ? Nxt{B.gate2.wry, 0, D, d0, DS} : after_block) + bfc_r, 0.f);
+      const int ow2 = merge_gate ? 3 * DS : DS;
+      const float f = fmaxf(col_prod(B.wfc_t, fsrc, p.gtrxl ? Nxt{B.gate2.wy + (long long)me * 3 * D * DS, 0, ow2, 0, ow2} : after_block) + bfc_r, 0.f);
       gather_full(f, a_s);                                         // fc output, full row
       if (p.gtrxl) {
         gate(B.gate2, h1_s, a_s, p.pre_ln ? x_s : t_s, after_block);
@@ -560,7 +604,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     // Ea: fc_out as a K-split: my rows of Wo^T (my ctx columns) x all D outputs -> partial row; the members' partial rows are
     // summed in member order; x = LayerNorm1(sum + bo + h)
     gemv_finish<GR>(wr, B.wo_t, D, y_s, part_s, d0, d0 + DS, D, 0, D);
-    gemv_issue<GR>(wr, B.wfc_t, D, 0, D, d0, DS, 0);
+    gemv_issue<GR>(wr, B.wfc_t + mcol, D, 0, DS, 0, DS, 0);
     rf_sync();
     float v = 0.f, mean, rstd;
     if (tid < D) t_s[tid] = gemv_sum(part_s, D, tid);
@@ -590,9 +634,9 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     rf_sync();
     RF_STAMP(8 + 8 * b);
     // Eb: f = relu(Wfc x + bfc), my columns; h = LayerNorm2(f + x)
-    gemv_finish<GR>(wr, B.wfc_t, D, y_s, part_s, 0, D, D, d0, DS);
-    if (b + 1 < p.nb) gemv_issue<GR>(wr, p.blk[b + 1].wq_t, D, 0, D, d0, DS, 0);
-    else gemv_issue<GR>(wr, p.wh_t, D, 0, OUTH, o0, OS, 0);
+    gemv_finish<GR>(wr, B.wfc_t + mcol, D, y_s, part_s, 0, D, DS, 0, DS);
+    if (b + 1 < p.nb) gemv_issue<GR>(wr, p.blk[b + 1].wq_t + mcol, D, 0, DS, 0, DS, 0);
+    else gemv_issue<GR>(wr, p.wh_t + mhead, D, 0, OS, 0, OS, 0);
     rf_sync();
     if (tid < DS) t_s[tid] = fmaxf(gemv_sum(part_s, DS, tid) + bfc_r, 0.f);
     rf_sync();
@@ -636,7 +680,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     }
   }
   const float bout_r = (me == 0 && tid < p.A + 1) ? (tid < p.A ? p.bp[tid] : p.bv[0]) : 0.f;
-  gemv_finish<GR>(wr, p.wh_t, D, x_s, part_s, 0, D, OUTH, o0, OS);
+  gemv_finish<GR>(wr, p.wh_t + mhead, D, x_s, part_s, 0, D, OS, 0, OS);
   rf_sync();
   if (tid < OS) y_s[tid] = fmaxf(gemv_sum(part_s, OS, tid) + bh_r, 0.f);
   rf_sync();
@@ -720,7 +764,9 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   // its last exchange, i.e. after every partner's last attention phase).
   if (p.wkv) {
     const int OUTK = 2 * D, KS = OUTK / P, k0c = me * KS;
-    gemv_issue<GR>(wr, p.wkv, D, 0, OUTK, k0c, KS, 0);
+    const float *wkv_m = p.wkv + (long long)me * D * KS;            // [nb][P][D][KS]: my contiguous block of block 0
+    const long long wkv_b = (long long)P * D * KS;
+    gemv_issue<GR>(wr, wkv_m, D, 0, KS, 0, KS, 0);
     for (int b = 0; b < p.nb; ++b) {
       float xin = 0.f;
       if (tid < D) {
@@ -736,9 +782,9 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
         if (tid < D) t_s[tid] = (xin - mk) * rk * p.blk[b].nkv_g[tid] + p.blk[b].nkv_b[tid];
         rf_sync();
       }
-      const float *wb = p.wkv + (long long)b * D * OUTK;
-      gemv_finish<GR>(wr, wb, D, t_s, part_s, 0, D, OUTK, k0c, KS);
-      if (b + 1 < p.nb) gemv_issue<GR>(wr, wb + (long long)D * OUTK, D, 0, OUTK, k0c, KS, 0);
+      const float *wb = wkv_m + b * wkv_b;
+      gemv_finish<GR>(wr, wb, D, t_s, part_s, 0, D, KS, 0, KS);
+      if (b + 1 < p.nb) gemv_issue<GR>(wr, wb + wkv_b, D, 0, KS, 0, KS, 0);
       rf_sync();
       if (tid < KS)
         p.kv_out[(long long)w * p.kv_w_stride + step_w * p.kv_row_stride + (long long)b * OUTK + k0c + tid] = gemv_sum(part_s, KS, tid);
@@ -825,6 +871,24 @@ extern "C" int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, i
   if (DS > 128 || DS % cpl != 0 || OS > 256 || (HS > 1 && (DS / cpl != 64 || (HS & (HS - 1)) != 0))) return 0;
   return 1;
 }
+// Register rows per product slice (20 at D = 384, 32 at D = 512) and the GRU-gate packing that goes with a shape.
+static int rf_rows(int D, int H) {
+  const int P = etm_rollout_trxl_team(H), DS = D / P;
+  const int rows_q = (D + RF_T / (DS / 4) - 1) / (RF_T / (DS / 4)), rows_o = (DS + RF_T / (D / 4) - 1) / (RF_T / (D / 4));
+  return (rows_q <= 20 && rows_o <= 20) ? 20 : 32;
+}
+// 1: a gate's maps of y ([Wr | Wz | Wg]^T) and of x ([Ur | Uz]^T) are ONE product each over the member's 3 DS / 2 DS columns --
+// pack them member-blocked as [P][D][3 DS] / [P][D][2 DS]; 0: five separate column blocks -- pack [P][3][D][DS] / [P][2][D][DS].
+// Merged when the merged product still fits two register batches (phases are pure latency at small D; at D = 384 the merged
+// product would be three batches with two exposed round trips).
+extern "C" int etm_rollout_trxl_gate_merged(int D, int H) {
+  if (D <= 0 || H <= 0 || D % H != 0) return 0;
+  const int P = etm_rollout_trxl_team(H);
+  if (D % (4 * P) != 0) return 0;
+  const int DS = D / P, kch = RF_T / (3 * DS / 4);
+  if (kch <= 0) return 0;
+  return (D + kch - 1) / kch <= 2 * rf_rows(D, H) ? 1 : 0;
+}
 extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
   if (W <= 0 || D <= 0 || H <= 0 || nb <= 0) return 0;
   const int P = etm_rollout_trxl_team(H);
@@ -850,9 +914,10 @@ extern "C" int etm_rollout_hidden_partial(const float *x, const float *wt, float
   return etm_launch_status();
 }
 
-// One launch per worker group and rollout step.  blocks: nb structs of 25 device pointers each, in the order
-// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias,  gate1: wr_t, wz_t, wg_t, ur_t, uz_t, ug_t, bg,  gate2: the same
-// seven,  norm_kv gain, norm_kv bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous).  The gate entries are read with
+// One launch per worker group and rollout step.  blocks: nb structs of 19 device pointers each, in the order
+// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias,  gate1: wy_t [D, 3D], ux_t [D, 2D], ug_t, bg,  gate2: the same four,
+// norm_kv gain, norm_kv bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous); wy_t = [Wr | Wz | Wg]^T and ux_t = [Ur | Uz]^T
+// with MEMBER-MAJOR columns: member m of the P = etm_rollout_trxl_team(H) owns the columns m * 3 DS + {r, z, g} * DS + c (DS = D / P).  The gate entries are read with
 // gtrxl != 0 only, the norm_kv entries (both or neither) by the tail of a pre-LN model; pre_ln / gtrxl select the block layout of
 // transformer.py:117-172.
 // scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes, ZEROED once by the caller before the first launch and then left alone
@@ -892,12 +957,12 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   for (int b = 0; b < nb; ++b) {
     const float *const *q = reinterpret_cast<const float *const *>(blocks) + RF_BLOCK_PTRS * b;
     for (int k = 0; k < 9; ++k) if (!q[k]) return ETM_EINVAL;
-    if (gtrxl) for (int k = 9; k < 23; ++k) if (!q[k]) return ETM_EINVAL;
-    if ((q[23] == nullptr) != (q[24] == nullptr)) return ETM_EINVAL;
+    if (gtrxl) for (int k = 9; k < 17; ++k) if (!q[k]) return ETM_EINVAL;
+    if ((q[17] == nullptr) != (q[18] == nullptr)) return ETM_EINVAL;
     p.blk[b] = RfBlock{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8],
-                       RfGate{q[9], q[10], q[11], q[12], q[13], q[14], q[15]}, RfGate{q[16], q[17], q[18], q[19], q[20], q[21], q[22]}, q[23], q[24]};
+                       RfGate{q[9], q[10], q[11], q[12]}, RfGate{q[13], q[14], q[15], q[16]}, q[17], q[18]};
   }
-  p.pre_ln = pre_ln; p.gtrxl = gtrxl;
+  p.pre_ln = pre_ln; p.gtrxl = gtrxl; p.merge_gate = etm_rollout_trxl_gate_merged(D, H);
   p.kv = kv; p.kv_w_stride = kv_worker_stride; p.kv_row_stride = kv_row_stride;
   p.win = (const long long *)win; p.mask = mask; p.items = items; p.wh_t = wh_t; p.bh = bh; p.wp = wp; p.bp = bp; p.wv = wv; p.bv = bv;
   p.uniforms = uniforms; p.forced = (const long long *)forced; p.t_dev = (long long *)t_dev; p.actions = (long long *)actions;
@@ -916,9 +981,7 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   const int teams_per_xcd = (W + 7) / 8;
   const dim3 grid((unsigned)(8 * teams_per_xcd * P)), block(RF_T);
   // rows per thread of the per-block product slices: 20 registers x 4 are enough at D = 384, 32 at D = 512
-  const int DS = D / P;
-  const int rows_q = (D + RF_T / (DS / 4) - 1) / (RF_T / (DS / 4)), rows_o = (DS + RF_T / (D / 4) - 1) / (RF_T / (D / 4));
-  const bool small = rows_q <= 20 && rows_o <= 20;
+  const bool small = rf_rows(D, H) == 20;
   const bool gen = pre_ln || gtrxl;
 #define RF_LAUNCH(GR_, LM_)                                                                                      \
   do {                                                                                                           \

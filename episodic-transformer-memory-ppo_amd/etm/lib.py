@@ -49,6 +49,7 @@ SIGNATURES = {
     "etm_host_copy": (_I, [_P, _P, _P, _L]),
     "etm_rollout_trxl_team": (_I, [_I]),
     "etm_rollout_trxl_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "etm_rollout_trxl_gate_merged": (_I, [_I, _I]),
     "etm_rollout_trxl_scratch_bytes": (_L, [_I, _I, _I, _I]),
     "etm_rollout_trxl": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                               _P, _L, _P, _P, _P, _P, _P, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,

@@ -12,6 +12,7 @@ from torch.distributions import Categorical
 from torch.nn import functional as F
 
 from etm import ops
+from etm import lib as etm_lib
 from etm.ops import WindowSpec
 from transformer import Transformer
 
@@ -127,16 +128,28 @@ class ActorCriticModel(nn.Module):
             return
         import ctypes
         t = self.transformer
+        d = t.embed_dim
+        team = etm_lib.load().etm_rollout_trxl_team(t.num_heads)
+        merged = bool(etm_lib.load().etm_rollout_trxl_gate_merged(d, t.num_heads))
+
+        def blocked(w_t):
+            """[K, OUT] (transposed weight) -> member-blocked [P, K, OUT / P]: a team member's columns as one contiguous run."""
+            k, out = w_t.shape
+            return w_t.reshape(k, team, out // team).permute(1, 0, 2)
+
         with torch.no_grad():
-            fresh = {"emb_t": t.linear_embedding.weight.t(), "heads_t": torch.cat((self.lin_policy.weight, self.lin_value.weight), dim=0).t()}
+            fresh = {"emb_t": blocked(t.linear_embedding.weight.t()),
+                     "heads_t": blocked(torch.cat((self.lin_policy.weight, self.lin_value.weight), dim=0).t())}
             for i, blk in enumerate(t.transformer_blocks):
-                fresh[f"wq_t{i}"] = blk.attention.queries.weight.t()
-                fresh[f"wo_t{i}"] = blk.attention.fc_out.weight.t()
-                fresh[f"wfc_t{i}"] = blk.fc[0].weight.t()
-                if blk.use_gtrxl:                                   # GRU gates: the six maps of both gates, transposed
+                fresh[f"wq_t{i}"] = blocked(blk.attention.queries.weight.t())
+                fresh[f"wo_t{i}"] = blk.attention.fc_out.weight.t()          # K-split product: rows of a member are contiguous as they are
+                fresh[f"wfc_t{i}"] = blocked(blk.fc[0].weight.t())
+                if blk.use_gtrxl:    # GRU gates: [Wr | Wz | Wg]^T and [Ur | Uz]^T member-blocked, packed as the kernel expects for this shape
                     for gi, gate in ((1, blk.gate1), (2, blk.gate2)):
-                        for name in ("Wr", "Wz", "Wg", "Ur", "Uz", "Ug"):
-                            fresh[f"g{gi}{name}_t{i}"] = getattr(gate, name).weight.t()
+                        for key, names in (("wy", ("Wr", "Wz", "Wg")), ("ux", ("Ur", "Uz"))):
+                            parts = torch.stack([blocked(getattr(gate, n).weight.t()) for n in names], dim=1)     # [P, j, D, DS]
+                            fresh[f"g{gi}{key}_t{i}"] = parts.permute(0, 2, 1, 3) if merged else parts            # merged: [P, D, j, DS]
+                        fresh[f"g{gi}ug_t{i}"] = blocked(gate.Ug.weight.t())
             if self.visual and self.lin_hidden.weight.shape[0] % 32 == 0:
                 fresh["hid_t"] = self.lin_hidden.weight.t()     # [features, D]: etm_rollout_hidden_partial
             rf = getattr(self, "_rf", None)
@@ -144,14 +157,14 @@ class ActorCriticModel(nn.Module):
                 rf = {k: v.contiguous() for k, v in fresh.items()}
                 rf["emb_b"], rf["heads_b"] = t.linear_embedding.bias, None
                 ptrs = []
-                for i, blk in enumerate(t.transformer_blocks):       # 25 pointers per block (include/etm_hip.h, etm_rollout_trxl)
+                for i, blk in enumerate(t.transformer_blocks):       # 19 pointers per block (include/etm_hip.h, etm_rollout_trxl)
                     ptrs += [rf[f"wq_t{i}"], rf[f"wo_t{i}"], blk.attention.fc_out.bias, blk.norm1.weight, blk.norm1.bias,
                              rf[f"wfc_t{i}"], blk.fc[0].bias, blk.norm2.weight, blk.norm2.bias]
                     for gi, gname in ((1, "gate1"), (2, "gate2")):
                         if blk.use_gtrxl:
-                            ptrs += [rf[f"g{gi}{name}_t{i}"] for name in ("Wr", "Wz", "Wg", "Ur", "Uz", "Ug")] + [getattr(blk, gname).bg]
+                            ptrs += [rf[f"g{gi}wy_t{i}"], rf[f"g{gi}ux_t{i}"], rf[f"g{gi}ug_t{i}"], getattr(blk, gname).bg]
                         else:
-                            ptrs += [None] * 7
+                            ptrs += [None] * 4
                     ptrs += [blk.norm_kv.weight, blk.norm_kv.bias] if blk.layer_norm == "pre" else [None, None]
                 rf["_keep"] = ptrs
                 rf["blocks"] = (ctypes.c_void_p * len(ptrs))(*[None if p is None else p.data_ptr() for p in ptrs])

@@ -548,8 +548,8 @@ class PPOTrainer:
                     g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device)
                 # ... and, after the action hand-over, the memory-bank write and the K | V projection of the new items (the tail)
                 tail = None
-                if self.config.get("fused_rollout_tail", True):      # (pre-LN: the kernel applies norm_kv before projecting)
-                    tail = (self._kv_weights[0], self.model.transformer._pos(), g.step_l, g.slot_l, buf.bank)
+                if self.config.get("fused_rollout_tail", True) and getattr(self, "_kv_w_blocked", None) is not None:   # (pre-LN: the kernel applies norm_kv)
+                    tail = (self._kv_w_blocked, self.model.transformer._pos(), g.step_l, g.slot_l, buf.bank)
                 g.tail_in_kernel = tail is not None
                 ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
                                  self._uniforms, self._forced_tab, g.t_dev, g.act_dev, st["actions"], st["log_probs"], st["values"],
@@ -640,6 +640,16 @@ class PPOTrainer:
                 for dst, src in zip(self._kv_weights, fresh):
                     if torch.is_tensor(dst):
                         dst.copy_(src)
+            if self.device.type == "cuda":
+                # the step kernel's tail reads the projection weights member-blocked: [blocks, P, D, 2D / P] (fixed address)
+                team = etm_lib.load().etm_rollout_trxl_team(tr.num_heads)
+                w = self._kv_weights[0]
+                if w.shape[2] % team == 0:
+                    wb = w.reshape(w.shape[0], w.shape[1], team, w.shape[2] // team).permute(0, 2, 1, 3)
+                    if getattr(self, "_kv_w_blocked", None) is None:
+                        self._kv_w_blocked = wb.contiguous()
+                    else:
+                        self._kv_w_blocked.copy_(wb)
             pos = tr._pos()
             live = self.buffer.bank[:W].reshape(W * T, self.num_blocks, self.embed_dim)
             pos_all = pos.repeat(W, 1) if pos is not None else None

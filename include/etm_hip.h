@@ -270,13 +270,17 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  * P = etm_rollout_trxl_team(H) workgroups per worker (4 at H % 4 == 0) walks the whole chain as matrix-vector products, every
  * member owning D / P columns of each product and H / P heads, the members exchanging their pieces through memory (16-byte
  * packets that carry their own sequence number, bounded polling) -- instead of 6 dependent launches per block.
- *   h_in [W, D]: transformer input (model.py:96-100); wemb_t [D, D], bemb [D]: linear_embedding (weight TRANSPOSED, [in, out]);
- *   blocks: HOST array of nb x 25 device pointers (wq_t, wo_t, bo, norm1 gain, norm1 bias, wfc_t, bfc, norm2 gain, norm2 bias; gate1:
- *           wr_t, wz_t, wg_t, ur_t, uz_t, ug_t, bg; gate2: the same seven; norm_kv gain, norm_kv bias), *_t transposed [D, D]; the
+ *   h_in [W, D]: transformer input (model.py:96-100); wemb_t [P][D][D / P], bemb [D]: linear_embedding (transposed, member-blocked);
+ *   blocks: HOST array of nb x 19 device pointers (wq_t, wo_t, bo, norm1 gain, norm1 bias, wfc_t, bfc, norm2 gain, norm2 bias; gate1:
+ *           wy_t = [Wr | Wz | Wg]^T, ux_t = [Ur | Uz]^T, ug_t, bg; gate2: the same four; norm_kv gain, norm_kv bias).  Layouts: *_t =
+ *           the weight TRANSPOSED ([in, out]); every matrix that is split by COLUMNS over the team (wemb_t, wq_t, wfc_t, ug_t, wh_t and
+ *           wkv per block) is MEMBER-BLOCKED: [P][in][out / P], member m's columns m * out / P ... as one contiguous block (wo_t is
+ *           split by rows and stays [D, D]); wy_t / ux_t are [P][D][j * D / P] (j = 3 / 2 maps side by side per member) if
+ *           etm_rollout_trxl_gate_merged(D, H) and [P][j][D][D / P] otherwise; the
  *           gate pointers are read with gtrxl != 0 (GRU gates instead of residuals, transformer.py:255-298), the norm_kv pair by the
  *           tail of a pre-LN model (pre_ln != 0: LayerNorm in front of the sub-layers, transformer.py:128-150);   kv / strides / win / mask: the K | V cache rows as in etm_attn_cached (rows of all blocks: the
  *           kernel adds b * 2D);   items [nb, W, D]: receives every block's input = the new memory items (block-major);
- *   wh_t [D, 2 hid], bh [2 hid]: [lin_policy ; lin_value] transposed;  wp / bp / wv / bv and everything from `uniforms` to
+ *   wh_t [P][D][2 hid / P] (member-blocked), bh [2 hid]: [lin_policy ; lin_value] transposed;  wp / bp / wv / bv and everything from `uniforms` to
  *   `sync_counter`: as in etm_rollout_policy;
  *   scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes that the caller ZEROES ONCE and then leaves to the kernel
  *           (int64 launch counter, int64 error word -- non-zero after a launch = a team member timed out --, 48 bytes of padding,
@@ -289,12 +293,13 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *   h_splits > 0: h_in is [h_splits, W, D] from etm_rollout_hidden_partial and the input is relu(sum over slices + h_bias [D]);
  *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
  *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
- *           pos[step_l[w]]) wkv[b]  (wkv [nb, D, 2D] = per block [Wk ; Wv]^T, pos [T, D] or NULL; transformer.py:236-237 for the
+ *           pos[step_l[w]]) wkv[b]  (wkv [nb][P][D][2D / P] = per block [Wk ; Wv]^T member-blocked, pos [T, D] or NULL; transformer.py:236-237 for the
  *           one new row) -- the memory-bank write and K | V projection of trainer.py:174.
  * Shape support: etm_rollout_trxl_supported(D, H, L, hid, A, nb) == 1 (D % (4 P) == 0, D <= 512, D / P <= 128, 2 hid / P <= 256,
  * H <= 8, L <= 128, nb <= 8, A < 64) and at most 256 workgroups (8 ceil(W / 8) P); ETM_EUNSUPPORTED otherwise. */
 int etm_rollout_trxl_team(int H);
 int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, int nb);
+int etm_rollout_trxl_gate_merged(int D, int H);   /* packing of the GRU-gate matrices that the kernel expects for this shape, see below */
 int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb);
 int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, float *kv,
                      int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
