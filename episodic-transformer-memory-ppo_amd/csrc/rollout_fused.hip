@@ -40,10 +40,10 @@ constexpr int RF_MAXB = 8;
 constexpr int RF_MAXSPLIT = 16;            // K slices of the lin_hidden product in front of the kernel
 constexpr int RF_SPIN_LIMIT = 1 << 22;     // ~1 s of polling: a partner that never ran
 
-struct RfGate {                      // GRU gate (transformer.py:255-298), maps transposed ([in, out]):
-  const float *wy;                   // [D, 3D]: [Wr | Wz | Wg] applied to y, columns member-major: member m owns m * 3 DS + {r, z, g} * DS + c
-  const float *ux;                   // [D, 2D]: [Ur | Uz] applied to x, member-major likewise
-  const float *ugx, *bg;             // [D, D] Ug, [D] bias
+struct RfGate {                      // GRU gate (transformer.py:255-298), maps transposed ([in, out]) and member-blocked:
+  const float *wy;                   // [Wr | Wz | Wg] applied to y: [P][D][3 DS] (merged) or [P][3][D][DS]
+  const float *ux;                   // [Ur | Uz] applied to x: [P][D][2 DS] or [P][2][D][DS]
+  const float *ugx, *bg;             // Ug [P][D][DS], bias [D]
 };
 struct RfBlock {
   const float *wq_t, *wo_t, *bo, *g1, *b1, *wfc_t, *bfc, *g2, *b2;
@@ -915,9 +915,10 @@ extern "C" int etm_rollout_hidden_partial(const float *x, const float *wt, float
 }
 
 // One launch per worker group and rollout step.  blocks: nb structs of 19 device pointers each, in the order
-// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias,  gate1: wy_t [D, 3D], ux_t [D, 2D], ug_t, bg,  gate2: the same four,
-// norm_kv gain, norm_kv bias); *_t = the nn.Linear weight TRANSPOSED ([in, out], contiguous); wy_t = [Wr | Wz | Wg]^T and ux_t = [Ur | Uz]^T
-// with MEMBER-MAJOR columns: member m of the P = etm_rollout_trxl_team(H) owns the columns m * 3 DS + {r, z, g} * DS + c (DS = D / P).  The gate entries are read with
+// (wq_t, wo_t, bo, ln1_gain, ln1_bias, wfc_t, bfc, ln2_gain, ln2_bias,  gate1: wy_t, ux_t, ug_t, bg,  gate2: the same four,  norm_kv gain,
+// norm_kv bias); *_t = the nn.Linear weight TRANSPOSED ([in, out]).  Every matrix that is split by columns over the P =
+// etm_rollout_trxl_team(H) members (wemb_t, wq_t, wfc_t, ug_t, wh_t, wkv) is MEMBER-BLOCKED [P][in][out / P]; wo_t (split by rows) stays
+// [D, D]; wy_t = [Wr | Wz | Wg]^T and ux_t = [Ur | Uz]^T are [P][D][j DS] if etm_rollout_trxl_gate_merged(D, H), else [P][j][D][DS] (DS = D / P).  The gate entries are read with
 // gtrxl != 0 only, the norm_kv entries (both or neither) by the tail of a pre-LN model; pre_ln / gtrxl select the block layout of
 // transformer.py:117-172.
 // scratch: etm_rollout_trxl_scratch_bytes(W, D, H, nb) bytes, ZEROED once by the caller before the first launch and then left alone
