@@ -114,11 +114,13 @@ class SyntheticVecEnv:
     """Batched form of ``num_envs`` ``SyntheticEnv`` instances (same streams, auto-reset on done)."""
 
     def __init__(self, num_envs, obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=0,
-                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1):
+                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1, row_chunks=None):
         """``copy_threads`` > 1: the observation rows of a step are written by that many threads (the kernel library's host
         copier; the reference's workers write theirs in n_workers processes) instead of one numpy copy."""
         self.num_envs = int(num_envs)
         self._copy_threads = int(copy_threads)
+        if row_chunks is not None:
+            self.ROW_CHUNKS = int(row_chunks)          # instance override of the on_rows granularity
         self._row_bytes = int(np.prod(obs_shape)) * 4
         self.observation_space_shape = tuple(obs_shape)
         self.num_actions = int(num_actions)
