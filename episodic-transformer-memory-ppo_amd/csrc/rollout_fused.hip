@@ -284,6 +284,28 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   long long step_w = 0, slot_w = 0;
   if (p.ss) { step_w = p.ss[w]; slot_w = p.ss[p.W + w]; }          // read in place (possibly from pinned host memory)
   else if (p.wkv) { step_w = p.step_l[w]; slot_w = p.slot_l[w]; }
+  const float bemb_r = (tid < DS) ? p.bemb[d0 + tid] : 0.f;
+  rf_sync();
+  // E0: linear_embedding + ReLU, my columns; collect the full row
+  gemv_finish<GR>(wr, p.wemb_t + mcol, D, x_s, part_s, 0, D, DS, 0, DS);
+  gemv_issue<GR>(wr, p.blk[0].wq_t + mcol, D, 0, DS, 0, DS, 0);
+  rf_sync();
+  if (tid < DS) t_s[tid] = fmaxf(gemv_sum(part_s, DS, tid) + bemb_r, 0.f);
+  rf_sync();
+  RF_STAMP(1);
+  if (P > 1) {
+    team_publish(team, ex, t_s, DS);
+    if (tid < DS) x_s[d0 + tid] = t_s[tid];
+    for (int m = 0; m < P; ++m)
+      if (m != me) team_collect(team, ex, m, x_s + m * DS, DS, 64 * (m - (m > me)));   // one wave per partner
+    ++ex;
+  } else {
+    if (tid < D) x_s[tid] = t_s[tid];
+  }
+  rf_sync();
+  RF_STAMP(2);
+  // The step's window lookup (and a new episode's cache reset) is done HERE, after the first exchange: the (step, slot) words were
+  // requested at kernel start (possibly from pinned host memory, ~2 us) and are consumed only now.
   if (tid < L) {                                                   // the window rows of this worker in the K | V cache (block 0's offsets)
     long long idx;
     unsigned char m;
@@ -326,28 +348,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     }
     __syncthreads();                                               // stores complete and visible to the whole workgroup
   }
-  const float bemb_r = (tid < DS) ? p.bemb[d0 + tid] : 0.f;
-  float pos_r = 0.f;                                               // positional row of this step, my element
-  if (p.wkv && p.pos && tid < D) pos_r = p.pos[step_w * D + tid];
   rf_sync();
-  // E0: linear_embedding + ReLU, my columns; collect the full row
-  gemv_finish<GR>(wr, p.wemb_t + mcol, D, x_s, part_s, 0, D, DS, 0, DS);
-  gemv_issue<GR>(wr, p.blk[0].wq_t + mcol, D, 0, DS, 0, DS, 0);
-  rf_sync();
-  if (tid < DS) t_s[tid] = fmaxf(gemv_sum(part_s, DS, tid) + bemb_r, 0.f);
-  rf_sync();
-  RF_STAMP(1);
-  if (P > 1) {
-    team_publish(team, ex, t_s, DS);
-    if (tid < DS) x_s[d0 + tid] = t_s[tid];
-    for (int m = 0; m < P; ++m)
-      if (m != me) team_collect(team, ex, m, x_s + m * DS, DS, 64 * (m - (m > me)));   // one wave per partner
-    ++ex;
-  } else {
-    if (tid < D) x_s[tid] = t_s[tid];
-  }
-  rf_sync();
-  RF_STAMP(2);
 
   // mappings of the attention phases
   const int cpl = (DS + 63) / 64;                                  // energies: my columns per lane (DS = 96 -> 2 on 48 lanes)
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   // the rows of this step are not part of any window of this launch that is still being read: a member gets here only after
   // its last exchange, i.e. after every partner's last attention phase).
   if (p.wkv) {
+    const float pos_r = (p.pos && tid < D) ? p.pos[step_w * D + tid] : 0.f;   // positional row of this step, my element
     const int OUTK = 2 * D, KS = OUTK / P, k0c = me * KS;
     const float *wkv_m = p.wkv + (long long)me * D * KS;            // [nb][P][D][KS]: my contiguous block of block 0
     const long long wkv_b = (long long)P * D * KS;
