@@ -1,0 +1,20 @@
+import os, sys, time, math
+sys.path.insert(0, "episodic-transformer-memory-ppo_amd")
+import torch
+from yaml_parser import YamlParser
+from trainer import PPOTrainer
+for name, n in (("synthetic_minigrid", 60), ("synthetic_mortar_gtrxl", 20), ("synthetic_cartpole", 60)):
+    cfg = YamlParser(f"episodic-transformer-memory-ppo_amd/configs/{name}.yaml").get_config()
+    torch.manual_seed(0)
+    tr = PPOTrainer(cfg, run_id="soak", device=torch.device("cuda", 0), tensorboard=False)
+    t0 = time.time(); bad = 0
+    for u in range(n):
+        lr, beta, clip = tr.schedules(u)
+        tr._sample_training_data(); tr.buffer.prepare_batch_dict()
+        stats, norms = tr._train_epochs(lr, clip, beta)
+        s = torch.stack([torch.as_tensor(r) for r in stats]).float()
+        if not torch.isfinite(s).all(): bad += 1
+    torch.cuda.synchronize()
+    p = torch.cat([q.detach().reshape(-1) for q in tr.model.parameters()])
+    print(f"{name}: {n} updates in {time.time()-t0:.1f} s, non-finite stat rows in {bad} updates, params finite: {bool(torch.isfinite(p).all())}, last loss {float(s[-1][2]):.4f}", flush=True)
+    tr.close()
