@@ -326,7 +326,7 @@ constexpr int WG_MC = 32;      // pixels per staged chunk
 template <int KT, int CT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
   constexpr int KW_ = KT * 32, CW_ = CT * 32;          // k-range and channels of this workgroup
-  constexpr int A_LD = KW_ + 32, D_LD = CT == 1 ? 32 : 96;   // LDS row strides = 32 mod 64 floats: the two pixel rows of a k-step hit disjoint banks
+  constexpr int A_LD = KW_ + (KW_ % 64 == 0 ? 32 : 64), D_LD = CT == 1 ? 32 : 96;   // LDS row strides = 32 mod 64 floats: the two pixel rows of a k-step hit disjoint banks
   constexpr int A_J = KW_ / 32, D_J = CW_ / 32;        // float4s per thread and chunk (8 threads per pixel row)
   constexpr int A_SZ = WG_MC * A_LD, D_SZ = WG_MC * D_LD;
   extern __shared__ __attribute__((aligned(16))) float wg_lds[];   // [2][A_SZ] then [2][D_SZ]: two chunks in flight
@@ -673,7 +673,13 @@ static int wgrad_splits(int M, int k_ranges) {
   if (s < 1) s = 1;
   return s;
 }
-static int wgrad_k_ranges(int Cout, int K) { const int kw = (Cout == 32 ? 6 : 4) * 32; return (K + kw - 1) / kw; }
+// k tiles (of 32) per workgroup: 6 at Cout = 32 (all of the first layer's K = 192); at Cout = 64 four, or three when that divides K
+// without a partly empty last range (K = 576: 6 ranges of 96 instead of 5 of 128 with 10 % of the MFMAs on zero tiles)
+static int wgrad_kt(int Cout, int K) {
+  if (Cout == 32) return 6;
+  return (K % 128 != 0 && K % 96 == 0) ? 3 : 4;
+}
+static int wgrad_k_ranges(int Cout, int K) { const int kw = wgrad_kt(Cout, K) * 32; return (K + kw - 1) / kw; }
 
 extern "C" int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cout, int KH, int KW, int S) {
   const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1;
@@ -706,6 +712,13 @@ extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, cons
       if (p.K % 32 != 0) return ETM_EUNSUPPORTED;
       constexpr size_t lds = 2 * (size_t)WG_MC * ((KT * 32 + 32) + 32) * sizeof(float);
       auto kern = conv_wgrad_kernel<KT, 1>;
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3((unsigned)splits_used, (unsigned)((p.K + KT * 32 - 1) / (KT * 32))), dim3(256), lds, st, p);
+    } else if (wgrad_kt(Cout, p.K) == 3) {
+      constexpr int KT = 3;            // 96 k per workgroup
+      if (p.K % 32 != 0) return ETM_EUNSUPPORTED;
+      constexpr size_t lds = 2 * (size_t)WG_MC * ((KT * 32 + 64) + 96) * sizeof(float);
+      auto kern = conv_wgrad_kernel<KT, 2>;
       (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, dim3((unsigned)splits_used, (unsigned)((p.K + KT * 32 - 1) / (KT * 32))), dim3(256), lds, st, p);
     } else {
