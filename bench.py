@@ -27,6 +27,10 @@ import os
 import sys
 import time
 
+# the host driver shares device memory between the ranks of a node through dmabuf handles only (RCCL, multi-process runs);
+# must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "episodic-transformer-memory-ppo_amd")
 for _p in (REPO, PKG, os.path.join(REPO, "tools")):

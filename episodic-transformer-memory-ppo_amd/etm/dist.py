@@ -33,6 +33,7 @@ class DataParallel:
         if self.world > 1 and not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (the only form this host driver has)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {}
