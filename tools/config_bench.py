@@ -1,5 +1,5 @@
 """Time full PPO updates for any config of configs/ (whole-path env-steps/s, phases).
-python tools/config_bench.py NAME [updates] [key=value ...]   (config keys: 0/1 -> bool, other integers as they are; ETM_DIAG_LIB=... selects
+python tools/config_bench.py NAME [updates] [key=value ...]   (config keys, dotted for a section: 0/1 -> bool unless the key holds an integer, integers otherwise; ETM_DIAG_LIB=... selects
 another build of the library)"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,13 @@ n_upd = int(rest[0]) if rest else 3
 cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", name + ".yaml")).get_config()
 for kv in (a for a in sys.argv[2:] if "=" in a):
     key, val = kv.split("=")
-    cfg[key] = (val == "1") if val in ("0", "1") else int(val)
+    node = cfg
+    *path, key = key.split(".")                       # environment.copy_threads=8 reaches into a section
+    for part in path:
+        node = node[part]
+    old = node.get(key)
+    as_int = isinstance(old, int) and not isinstance(old, bool)       # an integer key stays one (copy_threads=1)
+    node[key] = (val == "1") if val in ("0", "1") and not as_int else int(val)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="cfgbench", device=dev, tensorboard=False)
