@@ -76,7 +76,9 @@ def pmc_traffic(kernel):
             doc = json.load(f)
         target = ""
         if symbol not in doc:         # round-2 layout: {target: {kernel symbol incl. template arguments: counters}}
-            target = "window_train" if symbol == "window_pass_kernel" else next(t for t in doc if any(n.startswith(symbol) for n in doc[t]))
+            # the timed region hands the window pass SORTED minibatches: that target if it was collected
+            target = (("window_sorted" if "window_sorted" in doc else "window_train") if symbol == "window_pass_kernel"
+                      else next(t for t in doc if any(n.startswith(symbol) for n in doc[t])))
             doc = doc[target]
             symbol = next(n for n in doc if n.startswith(symbol))
         k = doc[symbol]
@@ -311,9 +313,10 @@ def main():
             if kind == "hbm":
                 roofline["extra_bytes_per_launch"] = N * 4.0 * (2 * H * D + H * L * (2 if dom.endswith("bwd_kernel") else 1))
                 roofline["note"] = ("bytes_per_launch = N*L*D*4, the un-deduplicated window read of SURVEY 8d; minibatches are sorted by "
-                                    "(worker, step) and every XCD takes a contiguous chunk of the samples, so part of that stream is "
-                                    "served by L2 / Infinity Cache (unique window rows per block <= 61 MB): see rooflines.window.cold_hbm "
-                                    "for the same kernel with every byte coming from HBM")
+                                    "(worker, step) and every XCD takes a contiguous chunk of the samples, so most of that stream is "
+                                    "served by the XCD's L2 (unique window rows per block <= 61 MB; `traffic` = the PMC passes of "
+                                    "the sorted pattern: about a third of bytes_per_launch crosses the fabric): see "
+                                    "rooflines.window.cold_hbm for the same kernel with every byte coming from HBM")
         rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
         out = {
             "metric": "env-steps/sec (whole node) MinigridMemory 3x84x84",

@@ -1,7 +1,7 @@
 """Kernel micro-benchmarks behind the roofline fractions of SURVEY.md section 8d (imported by bench.py, runnable on its own
 for rocprofv3 passes):
 
-    python tools/kernel_rooflines.py [window_cold|window_train|mfma3|mfma5|gae|ppo|all] [launches]
+    python tools/kernel_rooflines.py [window_cold|window_train|window_sorted|mfma3|mfma5|gae|ppo|all] [launches]
 
 Every figure is algorithmic work per launch (stated below) / average launch duration from the library's per-launch HIP
 events (etm_profile_*: an event pair on the launch stream around each kernel), against the MI355X peaks of
@@ -13,6 +13,8 @@ events (etm_profile_*: an event pair on the launch stream around each kernel), a
                 blocks of the bank (604 MB between two reads of a row > the 256 MB Infinity Cache): every byte comes from HBM
       train     the access pattern of the optimisation phase: N of the W * S (worker, step) pairs of a 32 x 512 rollout with
                 sliding windows -- unique rows per block <= 61 MB, so L2 / Infinity-Cache hits are part of the rate
+      sorted    the same minibatch in ascending (worker, step) order, as the trainer hands it over (sort_minibatch): every XCD
+                takes a contiguous chunk of the samples, neighbours in time share most of their rows in that XCD's L2
   dense MFMA    fp32 MFMA, forward N * 2 * (2 L D^2 + 2 L D) flop, dW N * 2 * (2 L D^2) flop per launch, config 3 and config 5 dims
   GAE           HBM, 13 bytes per (worker, step): config size (32 x 512) and 65,536 x 512
   PPO loss      HBM, 28 + 8 A bytes per sample: minibatch size (2048) and 2^24 samples
@@ -64,7 +66,7 @@ def _mfma(name, flops, avg_ms, launches, **extra):
 
 
 def window(mode, dev, launches=24, N=2048, L=64, D=384, H=4):
-    """Folded window pass, forward and backward, ``mode`` = "cold" or "train" (see the module docstring)."""
+    """Folded window pass, forward and backward, ``mode`` = "cold", "train" or "sorted" (see the module docstring)."""
     gen = torch.Generator(device="cpu").manual_seed(0)
     nb = 3
     if mode == "cold":
@@ -79,6 +81,8 @@ def window(mode, dev, launches=24, N=2048, L=64, D=384, H=4):
         E = W * (S // 40 + 1)
         bank = torch.randn((E, T, nb, D), device=dev)
         pairs = torch.randperm(W * S, generator=gen)[:N].to(dev)           # a minibatch: N of the (worker, step) pairs
+        if mode == "sorted":
+            pairs = torch.sort(pairs).values
         w, s = pairs // S, pairs % S
         ep = w * (S // 40 + 1) + s // 40                                   # episodes of 40 steps
         step = s % 40
@@ -174,7 +178,7 @@ def ppo(dev, N, A=3, launches=20):
 def all_rooflines(dev, quick=False):
     """Everything bench.py reports next to the throughput line (outside its timed region)."""
     n = 10 if quick else 24
-    out = {"window": {"cold_hbm": window("cold", dev, n), "train_like": window("train", dev, n),
+    out = {"window": {"cold_hbm": window("cold", dev, n), "train_like": window("train", dev, n), "train_sorted": window("sorted", dev, n),
                       "cold_hbm_L128": window("cold", dev, n, L=128)}}
     torch.cuda.empty_cache()
     out["mfma"] = {"config3_dims": mfma(dev, n, 2048, 64, 384, 4), "config5_dims": mfma(dev, n, 2048, 128, 384, 4)}
@@ -198,6 +202,8 @@ if __name__ == "__main__":
         res = window("cold", dev, n, L=128)
     elif what == "window_train":
         res = window("train", dev, n)
+    elif what == "window_sorted":
+        res = window("sorted", dev, n)
     elif what == "mfma3":
         res = mfma(dev, n, 2048, 64, 384, 4)
     elif what == "mfma5":
