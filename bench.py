@@ -51,6 +51,12 @@ def load_config():
 
 def kernel_work(name, N, L, D, H):
     """Algorithmic work of one launch at the training shape (DESIGN.md section 'Kernels'): ("hbm", bytes) or ("mfma", flops)."""
+    if name.startswith("conv_") and name[-1] in "123" and "layer" in name:
+        # encoder pass of one layer: 2 * N * Ho * Wo * k * k * C * Cout flop (forward, backward-data and backward-weight alike);
+        # the weight-gradient id covers two launches per pass (main kernel + slice reduction): flops per LAUNCH = half
+        import kernel_rooflines
+        fl = kernel_rooflines.encoder_flops(N)[int(name[-1]) - 1]
+        return "mfma", fl / (2.0 if "wgrad" in name else 1.0)
     if name in ("window_fwd_kernel", "window_bwd_kernel"):
         # folded attention pass: the read of the gathered window, L*D*4 B per sample and block (SURVEY.md 8d's algorithmic
         # figure; the H folded vectors in / out and the attention weights are reported separately as extra_bytes_per_launch)
@@ -62,18 +68,33 @@ def kernel_work(name, N, L, D, H):
     return None
 
 
+# profile name of this build -> kernel symbol (prefix) in the rocprofv3 counter files
+PMC_SYMBOL = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel",
+              "conv_fwd_layer1": "conv_gemm_kernel<2, 1, false", "conv_fwd_layer2": "conv_gemm_kernel<1, 2, false",
+              "conv_fwd_layer3": "conv_gemm_kernel<4, 2, false", "conv_dgrad_layer2": "conv_gemm_kernel<2, 1, true",
+              "conv_dgrad_layer3": "conv_gemm_kernel<1, 2, true", "conv_wgrad_layer1": "conv_wgrad_kernel<6, 1>",
+              "conv_wgrad_layer2": "conv_wgrad_kernel<4, 2>", "conv_wgrad_layer3": "conv_wgrad_kernel<3, 2>"}
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of ``kernel`` at the training shape from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_summary.json if present, else round 1's; produced by tools/run_pmc.sh in separate --pmc passes):
+    (the newest profiles/rNN_pmc_summary.json that holds the kernel; produced by tools/run_pmc.sh in separate --pmc passes):
     FETCH_SIZE KiB x 2 (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KiB.
     None if no profile is present."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
-    if not os.path.exists(path):
-        path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
-    symbol = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel"}.get(kernel, kernel)
+    symbol = PMC_SYMBOL.get(kernel, kernel)
     try:
-        with open(path) as f:
-            doc = json.load(f)
+        doc = path = None
+        for cand in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel
+            path = os.path.join(REPO, "profiles", cand)
+            if not os.path.exists(path):
+                continue
+            with open(path) as f:
+                d = json.load(f)
+            if symbol in d or any(isinstance(v, dict) and any(n.startswith(symbol) for n in v) for v in d.values()):
+                doc = d
+                break
+        if doc is None:
+            return None
         target = ""
         if symbol not in doc:         # round-2 layout: {target: {kernel symbol incl. template arguments: counters}}
             # the timed region hands the window pass SORTED minibatches: that target if it was collected
@@ -84,8 +105,8 @@ def pmc_traffic(kernel):
         k = doc[symbol]
         return {"bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"]["mean"] + 1024 * k["WRITE_SIZE"]["mean"],
                 "source": f"profiles/{os.path.basename(path)}, {('target ' + target + ', ') if target else ''}kernel symbol {symbol} "
-                          "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                          "N=2048 L=64 D=384 H=4; forward and backward launches of the window pass averaged)",
+                          "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at the config-3 shape"
+                          + ("; forward and backward launches of the window pass averaged)" if symbol.startswith("window") else ")"),
                 "mfma_busy_fraction_pmc": k.get("derived", {}).get("mfma_busy_fraction")}
     except Exception:
         return None
@@ -292,27 +313,68 @@ def main():
                 else:
                     entry["gbs"] = work[1] / (ms / cnt * 1e-3) / 1e9
             kernels[name] = entry
+        # ---- the kernels of a rollout step, timed eagerly AFTER the timed region (inside it they run from captured graphs, which
+        # take no per-kernel events): average launch time x the launches the timed region made = their share of GPU time
+        rollout_step = None
+        if not args.no_profile and trainer is not None:
+            try:
+                import kernel_rooflines
+                rollout_step = kernel_rooflines.rollout_step(trainer)
+            except Exception as exc:       # reporting only: never lose the throughput line over it
+                rollout_step = {"error": repr(exc)}
+        # estimated GPU time of every modelled kernel over the whole timed region: the optimisation phase is sampled (every
+        # profile_sample_every-th minibatch runs eagerly with events), the rollout step kernels are launched S x groups times per update
+        n_mb = cfg["epochs"] * cfg["n_mini_batch"] * args.steps
+        sampled = max(1, n_mb // max(1, getattr(trainer, "profile_sample_every", 1) or 1))
+        for k in kernels.values():
+            k["est_region_ms"] = k["total_ms"] * n_mb / sampled
+        est = {k: v["est_region_ms"] for k, v in kernels.items() if "bound" in v}
+        if rollout_step and "rollout_trxl_kernel" in rollout_step:
+            est["rollout_trxl_kernel"] = rollout_step["rollout_trxl_kernel"]["avg_launch_ms"] * S * len(trainer._groups) * args.steps
         roofline = None
         cand = [k for k in kernels if "bound" in kernels[k]]
+        dom_all = max(est, key=est.get) if est else None
+        if dom_all == "rollout_trxl_kernel":
+            # the kernel with the largest share of GPU time is the rollout step kernel: a dependent chain of matrix-vector products
+            # (latency-bound); its rate is reported as streamed bytes / time against the HBM peak, with what that stream really is
+            rs = rollout_step["rollout_trxl_kernel"]
+            roofline = {"kernel": "rollout_trxl_kernel", "bound": "hbm", "achieved": rs["achieved"], "peak": rs["peak"], "unit": "GB/s",
+                        "frac": rs["frac"], "traffic": None, "traffic_unit": "bytes per launch", "avg_launch_ms": rs["avg_launch_ms"],
+                        "launches": rs["launches"], "bytes_per_launch": rs["bytes_per_launch"], "dtype": "f32",
+                        "est_region_ms": est[dom_all], "us_per_dependent_phase": rs["us_per_dependent_phase"], "model": rs["model"],
+                        "note": "dominant kernel of ALL GPU time (rollout: one launch per worker group and step).  It is a dependency "
+                                "chain (products -> exchange -> LayerNorm ...), bound by round-trip latency, not by a roofline: "
+                                "bytes_per_launch = workers x every matrix of the chain (each team streams them once for ONE worker) + the "
+                                "K | V window columns, served by L2 / the Infinity Cache (unique bytes: model.unique_weight_bytes); "
+                                "timed eagerly after the timed region (graph replays take no per-kernel events).  The dominant kernel of "
+                                "the optimisation phase is in roofline_train."}
+            tr_pmc = pmc_traffic("rollout_trxl_kernel")
+            if tr_pmc:
+                roofline["traffic"], roofline["traffic_source"] = tr_pmc["bytes_per_launch"], tr_pmc["source"]
+                roofline["hbm_side_frac"] = tr_pmc["bytes_per_launch"] / (rs["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roofline_train = None
         if cand:
-            dom = max(cand, key=lambda k: kernels[k]["total_ms"])
+            dom = max(cand, key=lambda k: kernels[k]["est_region_ms"])
             kind, work = kernel_work(dom, N, L, D, H)
             if kind == "mfma":
                 ach, peak, unit, extra = kernels[dom]["tflops"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", {"flops_per_launch": work, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
             else:
                 ach, peak, unit, extra = kernels[dom]["gbs"], HBM_PEAK_GBS, "GB/s", {"bytes_per_launch": work, "dtype": "f32"}
             tr_pmc = pmc_traffic(dom)
-            roofline = {"kernel": dom, "bound": kind, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                        "traffic": tr_pmc["bytes_per_launch"] if tr_pmc else None,       # HBM-side bytes per launch (PMC)
-                        "traffic_unit": "bytes per launch", "traffic_source": tr_pmc["source"] if tr_pmc else None,
-                        "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
-                        "shape": {"N": N, "L": L, "D": D, "H": H}}
+            roofline_train = {"kernel": dom, "bound": kind, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                              "traffic": tr_pmc["bytes_per_launch"] if tr_pmc else None,       # HBM-side bytes per launch (PMC)
+                              "traffic_unit": "bytes per launch", "traffic_source": tr_pmc["source"] if tr_pmc else None,
+                              "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
+                              "est_region_ms": kernels[dom]["est_region_ms"], "shape": {"N": N, "L": L, "D": D, "H": H}}
+            if tr_pmc:
+                # what crosses the fabric per launch / time / peak: next to the algorithmic `frac`
+                roofline_train["hbm_side_frac"] = tr_pmc["bytes_per_launch"] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             if tr_pmc and kind == "mfma":
-                roofline["mfma_busy_fraction_pmc"] = tr_pmc.get("mfma_busy_fraction_pmc")
-            roofline.update(extra)
+                roofline_train["mfma_busy_fraction_pmc"] = tr_pmc.get("mfma_busy_fraction_pmc")
+            roofline_train.update(extra)
             if kind == "hbm":
-                roofline["extra_bytes_per_launch"] = N * 4.0 * (2 * H * D + H * L * (2 if dom.endswith("bwd_kernel") else 1))
-                roofline["note"] = ("bytes_per_launch = N*L*D*4, the un-deduplicated window read of SURVEY 8d; minibatches are sorted by "
+                roofline_train["extra_bytes_per_launch"] = N * 4.0 * (2 * H * D + H * L * (2 if dom.endswith("bwd_kernel") else 1))
+                roofline_train["note"] = ("bytes_per_launch = N*L*D*4, the un-deduplicated window read of SURVEY 8d; minibatches are sorted by "
                                     "(worker, step) and every XCD takes a contiguous chunk of the samples, so most of that stream is "
                                     "served by the XCD's L2 (unique window rows per block <= 61 MB; `traffic` = the PMC passes of "
                                     "the sorted pattern: about a third of bytes_per_launch crosses the fabric): see "
@@ -339,7 +401,9 @@ def main():
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
-            "roofline": roofline,
+            "roofline": roofline if roofline is not None else roofline_train,
+            "roofline_train": roofline_train,
+            "rollout_step": rollout_step,
             "allreduce": allreduce,
             "kernels_train": kernels,
             "kernels_rollout": rollout_k,
@@ -351,6 +415,7 @@ def main():
                 del trainer
                 torch.cuda.empty_cache()
                 out["rooflines"] = kernel_rooflines.all_rooflines(device)
+                out["rooflines"]["rollout_step"] = rollout_step
             except Exception as exc:       # reporting only: never lose the throughput line over it
                 out["rooflines"] = {"error": repr(exc)}
             trainer = None

@@ -596,7 +596,7 @@ extern "C" int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_
   if (p.Mc >= (1 << 24)) return ETM_EUNSUPPORTED;
   p.inv_chw = 1.0f / (float)(p.cH * p.cW); p.inv_cw = 1.0f / (float)p.cW;
   hipStream_t st = (hipStream_t)stream;
-  EtmProfScope prof(ETM_K_CONV_TRAIN_FWD, st);
+  EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
   const int tiles = (p.Mc + 31) / 32;
   if (Cout == 32) {
     const int cands[] = {2, 4};
@@ -649,7 +649,7 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   p.inv_chw = 1.0f / (float)(p.cH * p.cW); p.inv_cw = 1.0f / (float)p.cW;
   if ((p.T * p.T * Cout) % 8 != 0) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  EtmProfScope prof(ETM_K_CONV_TRAIN_DGRAD, st);
+  EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
   const int tiles = (p.Mc + 31) / 32;
   const unsigned classes = (unsigned)(S * S);
   if (merged) conv_launch<2, 1, true, 4>(p, tiles, 1, st);
@@ -706,7 +706,7 @@ extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, cons
   const int splits_used = (p.M + p.rows_per_split - 1) / p.rows_per_split;
   hipStream_t st = (hipStream_t)stream;
   {
-    EtmProfScope prof(ETM_K_CONV_TRAIN_WGRAD, st);
+    EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_WGRAD, ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, KH), st);
     if (Cout == 32) {
       constexpr int KT = 6;            // 192 k per workgroup
       if (p.K % 32 != 0) return ETM_EUNSUPPORTED;
@@ -732,7 +732,7 @@ extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, cons
     int rc = etm_launch_status();
     if (rc) return rc;
   }
-  EtmProfScope prof(ETM_K_CONV_TRAIN_WGRAD, st);
+  EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_WGRAD, ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, KH), st);
   const long long elems = (long long)p.K * Cout + Cout;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, workspace, splits_used, elems, dw_kc_dbias,
                      Cout, C, KH, KW);

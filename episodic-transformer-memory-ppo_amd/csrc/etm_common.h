@@ -82,8 +82,13 @@ enum EtmKernelId {
   ETM_K_ROLLOUT_WINDOW, ETM_K_ROLLOUT_SAMPLE, ETM_K_ADD_LN, ETM_K_CONV_RELU, ETM_K_ROLLOUT_HEADS, ETM_K_GRU_GATE, ETM_K_WINDOW_FWD, ETM_K_WINDOW_BWD,
   ETM_K_LN_TRAIN_FWD, ETM_K_LN_TRAIN_BWD, ETM_K_COLSUM, ETM_K_GATE_TRAIN, ETM_K_OPTIM,
   ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_TRAIN_DGRAD, ETM_K_CONV_TRAIN_WGRAD, ETM_K_ROLLOUT_FUSED,
+  // the encoder passes per layer (kernel size 8 / 4 / 3 = layers 1 / 2 / 3 of model.py:29-31; other geometries keep the ids above)
+  ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3,
+  ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, ETM_K_HIDDEN_PARTIAL, ETM_K_RELU_BWD_COLSUM, ETM_K_GATHER_ROWS,
   ETM_K_COUNT
 };
+// profile id of an encoder pass by layer (kernel size), falling back to the pass's generic id
+static inline int etm_conv_layer_kid(int generic, int l1, int l2, int l3, int KH) { return KH == 8 ? (l1 >= 0 ? l1 : generic) : KH == 4 ? l2 : KH == 3 ? l3 : generic; }
 // LayerNorm statistics of the gathered window rows (defined in mha_fwd.hip; shared by the dense and the folded attention).
 int etm_launch_ln_stats(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
                         const int64_t *pidx, const float *pos, float eps, float *stats, int N, int L, int D, hipStream_t st);

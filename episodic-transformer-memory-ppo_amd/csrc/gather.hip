@@ -43,6 +43,7 @@ extern "C" int etm_gather_rows(const void *const *src, void *const *dst, const i
     if (n * p.words[f] > most) most = n * p.words[f];
   }
   p.idx = (const long long *)idx; p.n = n; p.src_rows = src_rows;
+  EtmProfScope prof(ETM_K_GATHER_ROWS, (hipStream_t)stream);
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n_fields), dim3(256), 0, (hipStream_t)stream, p);
   return etm_launch_status();
 }

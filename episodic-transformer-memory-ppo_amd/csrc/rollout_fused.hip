@@ -92,6 +92,7 @@ struct RfParams {
   float *bank;                       // [slots, T, nb, D]
   long long bank_slot_stride, bank_row_stride;
   int W, D, H, L, hid, A, stage_W, P;
+  int map_mode;                      // block -> (worker, member) placement, see etm_rollout_trxl_set_placement
   float eps, sqrt_d;
 };
 
@@ -235,9 +236,16 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   __shared__ float a_s[RF_T], h1_s[RF_T], g_s[RF_T], n_s[RF_T], pub_s[RF_T];   // gated / pre-LN layouts: full rows between the sub-layers
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = p.D, L = p.L, H = p.H, hd = D / H, P = p.P;
-  // block -> (worker, member): the members of a team get the same b % 8, i.e. (as observed) the same XCD and L2
+  // block -> (worker, member).  Placement is a speed matter only (workgroup b is observed on XCD b % 8; every exchange is
+  // system-scope, i.e. correct under any placement):
+  //   0  the members of a team share b % 8: one XCD hosts whole teams -- and therefore ALL weight slices (7 MB at D = 384: more than
+  //      its 4 MB L2, so every step re-streams them from the Infinity Cache);
+  //   1  XCD x hosts member x % P of 8 / P-th of the workers: it only ever touches that member's slices (a quarter of every
+  //      matrix at P = 4), which stay L2-resident from step to step next to the workers' K | V columns of that member.
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int me = idx % P, w = (idx / P) * 8 + xcd;
+  int me, w;
+  if (p.map_mode == 0) { me = idx % P; w = (idx / P) * 8 + xcd; }
+  else { me = xcd % P; w = idx * (8 / P) + xcd / P; }
   if (w >= p.W) return;
   const int DS = D / P, d0 = me * DS;                              // my columns of every D-wide product
   const int HS = H / P;                                            // my heads: me * HS ...
@@ -862,6 +870,21 @@ extern "C" int etm_diag_rollout_trxl_stamps(long long *out) {
 
 extern "C" int etm_rollout_trxl_team(int H) { return (H % 4 == 0) ? 4 : ((H % 2 == 0) ? 2 : 1); }
 
+// Placement of a launch's workgroups (process-wide, read at launch): 0 = a team's members on one XCD, 1 = one member index per
+// XCD (its weight slices stay resident in that XCD's L2).  Results do not depend on it.
+static int g_rf_placement = 1;
+extern "C" int etm_rollout_trxl_set_placement(int mode) {
+  if (mode != 0 && mode != 1) return ETM_EINVAL;
+  g_rf_placement = mode;
+  return ETM_OK;
+}
+// workgroups of one launch for W workers under the current placement (all of them must be resident at once: <= 256)
+extern "C" int etm_rollout_trxl_grid(int W, int H) {
+  if (W <= 0 || H <= 0) return 0;
+  const int P = etm_rollout_trxl_team(H);
+  return g_rf_placement == 0 ? (W + 7) / 8 * 8 * P : 8 * ((W + 8 / P - 1) / (8 / P));
+}
+
 // 1 when etm_rollout_trxl handles the shape (16-byte pieces, a member's columns on <= 64 lanes x 2 per window row and >= 16 row
 // groups in the context phase, full rows on the 512 threads, everything in the static LDS buffers), else 0 (the caller keeps the
 // multi-launch path).
@@ -912,6 +935,7 @@ extern "C" int etm_rollout_hidden_partial(const float *x, const float *wt, float
   if (splits == 0 || D % 32 != 0 || ((uintptr_t)wt % 16) != 0) return ETM_EUNSUPPORTED;
   const int kslice = (F + splits - 1) / splits;
   if (kslice > HP_KMAX) return ETM_EUNSUPPORTED;
+  EtmProfScope prof(ETM_K_HIDDEN_PARTIAL, (hipStream_t)stream);
   hipLaunchKernelGGL(hidden_partial_kernel, dim3((unsigned)(D / 32), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, x, wt, part, W, F, D, kslice);
   return etm_launch_status();
 }
@@ -950,7 +974,7 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   if (wkv && (!step_l || !slot_l || !bank)) return ETM_EINVAL;
   if (h_splits < 0 || h_splits > RF_MAXSPLIT || (h_splits > 0 && !h_bias)) return ETM_EINVAL;
   const int P = etm_rollout_trxl_team(H);
-  if (!etm_rollout_trxl_supported(D, H, L, hid, A, nb) || (W + 7) / 8 * 8 * P > 256) return ETM_EUNSUPPORTED;   // all teams resident
+  if (!etm_rollout_trxl_supported(D, H, L, hid, A, nb) || etm_rollout_trxl_grid(W, H) > 256) return ETM_EUNSUPPORTED;   // all teams resident
   if (scratch_bytes < etm_rollout_trxl_scratch_bytes(W, D, H, nb)) return ETM_EWORKSPACE;
   RfParams p{};
   p.ss = (const long long *)ss; p.mask_table = mask_table; p.index_table = (const long long *)index_table; p.st_mask = st_mask;
@@ -980,9 +1004,8 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   p.eps = ln_eps; p.sqrt_d = (float)sqrt((double)D);
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_ROLLOUT_FUSED, st);
-  // block b -> XCD b % 8 (observed), team slot b / 8: worker (slot / P) * 8 + xcd, member slot % P
-  const int teams_per_xcd = (W + 7) / 8;
-  const dim3 grid((unsigned)(8 * teams_per_xcd * P)), block(RF_T);
+  p.map_mode = g_rf_placement;
+  const dim3 grid((unsigned)etm_rollout_trxl_grid(W, H)), block(RF_T);
   // rows per thread of the per-block product slices: 20 registers x 4 are enough at D = 384, 32 at D = 512
   const bool small = rf_rows(D, H) == 20;
   const bool gen = pre_ln || gtrxl;

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
 # tools and of the parity tests; announced on load, never the default
 LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lib = None
 
@@ -48,6 +48,8 @@ SIGNATURES = {
     "etm_host_copier_destroy": (None, [_P]),
     "etm_host_copy": (_I, [_P, _P, _P, _L]),
     "etm_rollout_trxl_team": (_I, [_I]),
+    "etm_rollout_trxl_set_placement": (_I, [_I]),
+    "etm_rollout_trxl_grid": (_I, [_I, _I]),
     "etm_rollout_trxl_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "etm_rollout_trxl_gate_merged": (_I, [_I, _I]),
     "etm_rollout_trxl_scratch_bytes": (_L, [_I, _I, _I, _I]),

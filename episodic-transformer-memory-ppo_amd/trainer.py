@@ -96,6 +96,10 @@ class PPOTrainer:
             raise RuntimeError("PPOTrainer needs an MI355X (HIP) device: this build has no CPU training path "
                                "(the CPU restatement under oracle/ is test infrastructure only)")
         etm_lib.load()  # fail loudly if the kernels are not built
+        # placement of the rollout step kernel's workgroups: "member_xcd" (default) keeps each XCD on one member's weight slices
+        # (L2-resident from step to step), "team_xcd" puts a worker's whole team on one XCD (round 2's placement)
+        placement = {"team_xcd": 0, "member_xcd": 1}[config.get("rollout_team_placement", "member_xcd")]
+        etm_lib.check(etm_lib.load().etm_rollout_trxl_set_placement(placement), "etm_rollout_trxl_set_placement")
         self.config = config
         self.device = device
         self.run_id = run_id
@@ -515,9 +519,11 @@ class PPOTrainer:
         # streamed + pipelined mode: the (step, slot) block is read from pinned host memory (see _sample_training_data)
         ss_src = g.ss_pin if (stream_obs and self._state_zero_copy and g.stream is not None) else g.ss_dev
         rf_ = getattr(self.model, "_rf", None) if self._use_kv_cache else None
-        # (every team of the step kernel must be resident at once: at most 256 workgroups per launch, else the multi-launch path)
+        # (every team of the step kernel must be resident at once, and the groups' step kernels run concurrently: the workgroups
+        # of ALL groups together must fit the 256 CUs -- one 512-thread workgroup per CU --, else the multi-launch path)
+        n_conc = len(self._groups) if not g.full else 1
         fused_step = (single and rf_ is not None and self.model.rollout_heads_fusable()
-                      and (g.W + 7) // 8 * 8 * etm_lib.load().etm_rollout_trxl_team(rf_["H"]) <= 256)
+                      and n_conc * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256)
         # the fused step kernel does the window lookup (and the cache reset of new episodes) itself: one launch fewer in the chain
         window_in_step = fused_step and self.config.get("window_in_step_kernel", True)
         if not window_in_step:

@@ -298,6 +298,12 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  * Shape support: etm_rollout_trxl_supported(D, H, L, hid, A, nb) == 1 (D % (4 P) == 0, D <= 512, D / P <= 128, 2 hid / P <= 256,
  * H <= 8, L <= 128, nb <= 8, A < 64) and at most 256 workgroups (8 ceil(W / 8) P); ETM_EUNSUPPORTED otherwise. */
 int etm_rollout_trxl_team(int H);
+/* Workgroup placement of the step kernel (process-wide; results do not depend on it): 0 = the P members of a worker's team on one
+ * XCD, 1 (default) = XCD x hosts member x % P of an 8 / P-th of the workers, so that an XCD only ever reads one member's slice of
+ * every matrix and those slices stay resident in its L2 from step to step.  etm_rollout_trxl_grid(W, H): workgroups of one launch
+ * under the current placement -- all of them must be resident at once (<= 256 on the MI355X), else ETM_EUNSUPPORTED. */
+int etm_rollout_trxl_set_placement(int mode);
+int etm_rollout_trxl_grid(int W, int H);
 int etm_rollout_trxl_supported(int D, int H, int L, int hid, int A, int nb);
 int etm_rollout_trxl_gate_merged(int D, int H);   /* packing of the GRU-gate matrices that the kernel expects for this shape, see below */
 int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb);

@@ -153,16 +153,62 @@ def test_actor_critic_vs_reference(golden_dir):
         loss.backward()
         for k, p in m.named_parameters():
             if k.startswith("conv"):
-                # ReLU-kink sensitivity: a handful of the ~85k conv activations lie within fp32 rounding of zero, so their
-                # gates can differ between the CPU reference and the device (and between MIOpen algorithm choices); with a
-                # batch of 4 one flipped gate moves the encoder gradients by several per cent.  The encoder convolutions are
-                # library (MIOpen) kernels, so they are only checked for direction and scale here.
+                # ReLU-kink sensitivity: a handful of the ~85k conv activations of THESE fixtures lie within fp32 rounding of zero,
+                # so their gates can differ between the CPU reference and the device; with a batch of 4 one flipped gate moves
+                # the encoder gradients by several per cent.  Direction and scale only here; the encoder gradients are pinned at
+                # full tolerance by test_actor_critic_gradients_away_from_the_relu_kink (a fixture without ambiguous gates) and
+                # by test_train_encoder_fwd_bwd_vs_float64_convs.
                 want = z[tag + "grad_sample/" + k].astype(np.float64)
                 got = dg.sample(p.grad.detach().cpu().numpy(), 96).astype(np.float64)
                 cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
                 assert cos > 0.98 and 0.8 < np.linalg.norm(got) / (np.linalg.norm(want) + 1e-30) < 1.25, (k, cos)
             else:
                 grad_close(p.grad, z, tag, k, 96, rel=1e-3)
+
+
+# Measured on the MI355X (round 3): see the printed line of the test; bounds are 2 x measured, rounded up.
+NOKINK_GRAD_REL = 2e-4
+
+
+def test_actor_critic_gradients_away_from_the_relu_kink(golden_dir):
+    """model_nokink.npz: the procedural case was chosen so that every ReLU input of the reference's forward pass keeps
+    |x| > 2e-5 (make_golden.py:golden_model_nokink) -- every gate is decided identically by any fp32 evaluation order, so ALL
+    gradients, the encoder's included, are compared element-wise with the reference (model.py:71-112 backward)."""
+    from types import SimpleNamespace
+    from model import ActorCriticModel
+    dev = _dev()
+    z = load(golden_dir, "model_nokink.npz")
+    case, tag = str(z["case_name"]), "case/"
+    assert float(z["relu_margin"]) > 2e-5
+    info = json.loads(str(z[tag + "cfg_json"]))
+    cfg, T, n, obs_shape = info["cfg"], info["T"], info["n"], tuple(info["obs_shape"])
+    t = cfg["transformer"]
+    keys, shapes = shapes_of(z, tag)
+    m = ActorCriticModel(cfg, SimpleNamespace(shape=obs_shape), tuple(info["act"]), T)
+    load_det(m, case, keys, shapes)
+    m.to(dev)
+    obs = torch.from_numpy(np.abs(dg.det_normal(case, "obs", (n,) + obs_shape, 0.4)).clip(0, 1)).to(dev)
+    mem = torch.from_numpy(dg.det_normal(case, "mem", (n, t["memory_length"], t["num_blocks"], t["embed_dim"]), 0.3)).to(dev)
+    mask = torch.from_numpy(dg.leading_mask(case, n, t["memory_length"])).to(dev)
+    idx = torch.from_numpy(dg.window_indices(case, n, t["memory_length"], T)).to(dev)
+    pi, value, new_mem = m(obs, mem, mask, idx)
+    close(pi[0].logits, z[tag + "log_probs_all"], atol=2e-5, what="logp")
+    close(value, z[tag + "value"], atol=2e-5, what="value")
+    close(new_mem, z[tag + "new_mem"], atol=2e-5, what="mem")
+    loss = (pi[0].logits * torch.from_numpy(dg.det_normal(case, "gl", tuple(pi[0].logits.shape))).to(dev)).sum() + \
+           (value * torch.from_numpy(dg.det_normal(case, "gv", tuple(value.shape))).to(dev)).sum()
+    loss.backward()
+    assert m._train_encoder_ok, "the hand-written encoder kernels ran"
+    worst = 0.0
+    for k, p in m.named_parameters():
+        want = z[tag + "grad_sample/" + k].astype(np.float64)
+        got = dg.sample(p.grad.detach().cpu().numpy(), 384).astype(np.float64)
+        norm = float(z[tag + "grad_norm/" + k])
+        rel = float(np.abs(got - want).max()) / max(norm, 1e-12)
+        worst = max(worst, rel)
+        assert rel <= NOKINK_GRAD_REL, (k, rel)
+        assert abs(float(np.linalg.norm(p.grad.detach().cpu().numpy().astype(np.float64))) - norm) <= 10 * NOKINK_GRAD_REL * norm, k
+    print(f"[nokink] worst element error of any gradient tensor / its norm: {worst:.2e} (bound {NOKINK_GRAD_REL:.0e})")
 
 
 # ------------------------------------------------------------------ kernel #1 vs the oracle: banked gather, LN, positions, Q5
@@ -382,7 +428,10 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
              ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs"),
              ("img32", "multi_launch_blocks"), ("vec", "multi_launch_blocks"), ("img32", "launched_tail"), ("vec", "launched_tail"),
-             ("img32", "state_uploaded"), ("img32", "library_hidden"), ("img32", "window_launch")]
+             ("img32", "state_uploaded"), ("img32", "library_hidden"), ("img32", "window_launch"),
+             # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
+             ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
+             ("cfg5", "default"), ("cfg5", "eager")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -434,9 +483,10 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         else:      # image observations: the fixture holds a subsample and the sum
             ob = b.obs.cpu().numpy()
             assert np.array_equal(dg.sample(ob, 8192), z[tag + "obs_sample"]) and np.float64(ob.astype(np.float64).sum()) == z[tag + "obs_sum"]
-        close(b.values, z[tag + "values"], atol=1e-4, what="values")
-        close(b.log_probs, z[tag + "log_probs"], atol=1e-4, what="log_probs")
-        close(b.advantages, z[tag + "advantages"], atol=5e-4, what="advantages")
+        measured = {f: float(np.abs(getattr(b, f).cpu().numpy().astype(np.float64) - z[tag + f]).max()) for f in ("values", "log_probs", "advantages")}
+        close(b.values, z[tag + "values"], atol=TF_ATOL["values"], rtol=0, what="values")
+        close(b.log_probs, z[tag + "log_probs"], atol=TF_ATOL["log_probs"], rtol=0, what="log_probs")
+        close(b.advantages, z[tag + "advantages"], atol=TF_ATOL["advantages"], rtol=0, what="advantages")
         if tag + "memories" in z:
             e_ref = z[tag + "memories"].shape[0]
             assert b.num_episodes >= e_ref
@@ -451,15 +501,35 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         lr, clip, beta = (float(x) for x in z[tag + "hp"])
         assert (lr, beta, clip) == tuple(float(x) for x in tr.schedules(upd))
         stats, _ = tr._train_epochs(lr, clip, beta, perms=z[tag + "perms"])
-        close(np.asarray(stats), z[tag + "stats"], atol=1e-4, rtol=5e-3, what="stats")
+        st_err = np.abs(np.asarray(stats, dtype=np.float64) - z[tag + "stats"])
+        measured["stats_abs"] = float(st_err.max())
+        measured["stats_rel"] = float((st_err / (np.abs(z[tag + "stats"]) + TF_STATS_ATOL / TF_STATS_RTOL)).max())
+        close(np.asarray(stats), z[tag + "stats"], atol=TF_STATS_ATOL, rtol=TF_STATS_RTOL, what="stats")
         worst, worst_key, overall = movement_error(tr.model.state_dict(), z, tag, keys, prev)
+        measured.update(move_all=overall, move_worst=worst)
         print(f"[teacher-forced {name}/{path} update {upd}] parameter-movement error: all tensors {overall:.2e}, worst tensor {worst:.2e} = {worst_key}")
+        print(f"[teacher-forced {name}/{path} update {upd}] measured: " + ", ".join(f"{k} {v:.2e}" for k, v in measured.items()))
+        if os.environ.get("ETM_TF_MEASURE_LOG"):
+            with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
+                f.write(json.dumps({"case": name, "path": path, "update": upd, **measured}) + "\n")
         assert overall <= TF_MOVE_TOL_ALL and worst <= TF_MOVE_TOL_TENSOR, (worst, worst_key, overall)
     if name == "img32" and path == "default":
         assert tr._step_graph is not None and tr._stream_obs and len(tr._groups) == 2 and tr._train_graph is not None, \
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
         assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
         assert tr.model._rf is not None, "img32/default: transformer + heads + sampling of a rollout step are one launch"
+    if name in ("cfg2", "cfg3", "cfg5") and path == "default":
+        # the benchmarked instantiations ran: captured step graphs with the one-launch step kernel (teams of etm_rollout_trxl_team(H)
+        # workgroups per worker: 4 at H = 4), captured optimisation step; visual configs: observation streaming, two worker groups,
+        # the hand-written encoder kernels
+        from etm import lib as etm_lib
+        H = cfg["transformer"]["num_heads"]
+        assert tr._step_graph is not None and tr._train_graph is not None and tr.model._rf is not None, name
+        assert all(g.rf_scratch is not None and g.tail_in_kernel for g in tr._groups), "every group's step ran etm_rollout_trxl incl. its tail"
+        assert etm_lib.load().etm_rollout_trxl_team(H) == (4 if H == 4 else 1)
+        assert tr.model._rf["pre_ln"] == int(cfg["transformer"]["layer_norm"] == "pre") and tr.model._rf["gtrxl"] == int(cfg["transformer"]["gtrxl"])
+        if name != "cfg2":
+            assert tr._stream_obs and tr._host_flag and len(tr._groups) == 2 and tr.model._train_encoder_ok, name
     if path == "groups4":
         assert len(tr._groups) == 4
     if path == "event_handover":
@@ -473,6 +543,10 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 # arithmetic of the reference's single-tensor AdamW operation by operation (csrc/optim.hip); with the framework's fused AdamW,
 # which evaluates the update in double precision, the same comparison gave 1.4e-4 / 2e-2.
 TF_MOVE_TOL_ALL, TF_MOVE_TOL_TENSOR = 1.5e-4, 2e-3
+# absolute bounds on the rollout outputs (values are O(1)) and on the six loss statistics; measured maxima over all fixtures and
+# paths are in profiles/r03/teacher_forced_measured.jsonl, the bounds are about twice those
+TF_ATOL = {"values": 1e-4, "log_probs": 1e-4, "advantages": 5e-4}
+TF_STATS_ATOL, TF_STATS_RTOL = 1e-4, 5e-3
 
 
 def test_trainer_self_consistency_and_free_run():

@@ -208,7 +208,7 @@ def test_polynomial_decay(golden_dir):
 
 
 # ------------------------------------------------------------------ teacher-forced rollout + updates
-@pytest.mark.parametrize("name", ["vec", "gtrxl", "img", "img32"])
+@pytest.mark.parametrize("name", ["vec", "gtrxl", "img", "img32", "cfg2"])
 def test_teacher_forced_rollout_and_update(golden_dir, name):
     from environments.synthetic import SyntheticVecEnv
     z = load(golden_dir, f"rollout_{name}.npz")
@@ -249,3 +249,39 @@ def test_teacher_forced_rollout_and_update(golden_dir, name):
             if k.endswith("inv_freqs"):
                 continue
             close(dg.sample(v.detach().numpy(), 64), z[tag + "sd_after_sample/" + k], atol=2e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_teacher_forced_rollout_at_baseline_model_sizes(golden_dir, name):
+    """BASELINE model sizes (config 3: D 384 / H 4 / L 64 / 3 blocks / 3x84x84 / 32 workers; config 5: pre-LN GTrXL, L 128, 4 blocks):
+    the oracle's first rollout against the reference's, teacher-forced.  Rollout only -- the optimisation step of these fixtures
+    (one minibatch of 2,400 - 2,560 samples) takes minutes on the CPU; the whole-path comparison at these sizes is the GPU
+    suite's test_trainer_teacher_forced_vs_reference[cfg3 / cfg5]."""
+    from environments.synthetic import SyntheticVecEnv
+    z = load(golden_dir, f"rollout_{name}.npz")
+    info = json.loads(str(z["cfg_json"]))
+    cfg, envk = info["cfg"], info["env"]
+    env = SyntheticVecEnv(cfg["n_workers"], **{**envk, "obs_shape": tuple(envk["obs_shape"])})
+    keys, shapes = shapes_of(z, "")
+    sd0 = {k: torch.from_numpy(v) for k, v in dg.det_state_dict("rollout_" + name, keys, shapes).items()}
+    sd0["transformer.pos_embedding.inv_freqs"] = 1e4 ** (-torch.arange(0, cfg["transformer"]["embed_dim"], 2.0) / cfg["transformer"]["embed_dim"])
+    tr = ra.OracleTrainer(cfg, env, state_dict=sd0, seed=0)
+    tag = "u0/"
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    try:
+        buf = tr.sample(forced_actions=z[tag + "actions"][:, :, 0])
+    finally:
+        torch.set_num_threads(prev)
+    for k in ("memory_mask", "memory_index", "memory_indices", "dones"):
+        assert np.array_equal(np.asarray(buf[k]), z[tag + k]), k
+    assert np.array_equal(tr.ep_step.numpy(), z[tag + "ep_step_after"]) and np.array_equal(buf["rewards"], z[tag + "rewards"])
+    assert int(z[tag + "memory_indices"].max()) >= cfg["transformer"]["memory_length"], "the fixture's windows slide past L"
+    ob = np.asarray(buf["obs"])
+    assert np.array_equal(dg.sample(ob, 8192), z[tag + "obs_sample"]) and np.float64(ob.astype(np.float64).sum()) == z[tag + "obs_sum"]
+    close(buf["values"], z[tag + "values"], atol=2e-5)
+    close(buf["log_probs"], z[tag + "log_probs"], atol=2e-5)
+    close(buf["advantages"], z[tag + "advantages"], atol=1e-4)
+    mem = np.asarray(buf["memories"])
+    assert tuple(mem.shape) == tuple(z[tag + "memories_shape"])
+    close(dg.sample(mem, 32768), z[tag + "memories_sample"], atol=2e-5)

@@ -1,7 +1,7 @@
 """Kernel micro-benchmarks behind the roofline fractions of SURVEY.md section 8d (imported by bench.py, runnable on its own
 for rocprofv3 passes):
 
-    python tools/kernel_rooflines.py [window_cold|window_train|window_sorted|mfma3|mfma5|gae|ppo|all] [launches]
+    python tools/kernel_rooflines.py [window_cold|window_train|window_sorted|mfma3|mfma5|gae|ppo|encoder|rollout_step|all] [launches]
 
 Every figure is algorithmic work per launch (stated below) / average launch duration from the library's per-launch HIP
 events (etm_profile_*: an event pair on the launch stream around each kernel), against the MI355X peaks of
@@ -18,6 +18,10 @@ events (etm_profile_*: an event pair on the launch stream around each kernel), a
   dense MFMA    fp32 MFMA, forward N * 2 * (2 L D^2 + 2 L D) flop, dW N * 2 * (2 L D^2) flop per launch, config 3 and config 5 dims
   GAE           HBM, 13 bytes per (worker, step): config size (32 x 512) and 65,536 x 512
   PPO loss      HBM, 28 + 8 A bytes per sample: minibatch size (2048) and 2^24 samples
+  encoder       fp32 MFMA, 2 * N * Ho * Wo * k * k * C * Cout flop per layer and pass (forward / backward-data / backward-weight incl.
+                its slice reduction) of the three convolutions at N = 2048, 3 x 84 x 84
+  rollout_step  the kernels of one rollout step of one worker group in their captured order; the step kernel's streamed bytes
+                (W x every matrix of the chain + the workers' K | V window columns) / time, and the length of its dependency chain
 """
 import os
 import sys
@@ -175,6 +179,110 @@ def ppo(dev, N, A=3, launches=20):
     return res
 
 
+ENCODER_LAYERS = ((3, 84, 84, 32, 8, 4), (32, 20, 20, 64, 4, 2), (64, 9, 9, 64, 3, 1))      # (C, H, W, Cout, k, stride): model.py:29-31 on 3x84x84
+
+
+def encoder_flops(N, layers=ENCODER_LAYERS):
+    """Algorithmic flops of one pass of each layer: 2 * (N * Ho * Wo) * (k * k * C) * Cout (the same for forward, backward-data
+    and backward-weight)."""
+    return [2.0 * N * ((h - k) // s + 1) * ((w - k) // s + 1) * cout * k * k * c for (c, h, w, cout, k, s) in layers]
+
+
+def encoder(dev, launches=20, N=2048):
+    """Training-side encoder kernels (csrc/conv_train.hip) layer by layer and pass by pass through the C ABI at the minibatch
+    shape, against the fp32 MFMA peak.  Weight-gradient figures include the slice reduction launch."""
+    lib = etm_lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    torch.manual_seed(0)
+    bufs = []
+    for (c, h, w, cout, k, s) in ENCODER_LAYERS:
+        ho, wo = (h - k) // s + 1, (w - k) // s + 1
+        wt = torch.randn((cout, c, k, k), device=dev) * 0.05
+        nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, h, w, cout, k, k, s)
+        bufs.append(dict(x=torch.rand((N, h, w, c), device=dev), b=torch.randn(cout, device=dev), y=torch.empty((N, ho, wo, cout), device=dev),
+                         dy=torch.randn((N, ho, wo, cout), device=dev), packed=ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1)),
+                         pd=ops.conv_pack_dgrad_weights(wt, s) if c != 3 else None, dx=torch.empty((N, h, w, c), device=dev),
+                         dw=torch.empty(k * k * c * cout + cout, device=dev), ws=torch.empty(max(nbytes, 8) // 4, device=dev), nbytes=nbytes))
+
+    def step_fn():
+        for (c, h, w, cout, k, s), b in zip(ENCODER_LAYERS, bufs):
+            etm_lib.check(lib.etm_conv_train_fwd(P(b["x"]), None, N, P(b["packed"]), P(b["b"]), P(b["y"]), N, c, h, w, cout, k, k, s, 0, st), "fwd")
+            if b["pd"] is not None:
+                etm_lib.check(lib.etm_conv_train_dgrad(P(b["dy"]), P(b["pd"]), P(b["x"]), P(b["dx"]), N, c, h, w, cout, k, k, s, st), "dgrad")
+            etm_lib.check(lib.etm_conv_train_wgrad(P(b["x"]), None, P(b["dy"]), P(b["dw"]), P(b["ws"]), b["nbytes"], N, c, h, w, cout, k, k, s, st), "wgrad")
+
+    t = _timed(step_fn, launches)
+    fl = encoder_flops(N)
+    res, tot_ms, tot_fl = {}, 0.0, 0.0
+    for li in range(3):
+        for pas in ("fwd", "dgrad", "wgrad"):
+            name = f"conv_{pas}_layer{li + 1}"
+            if name not in t:
+                continue
+            avg, cnt = t[name]
+            per_pass = avg * (2 if pas == "wgrad" else 1)          # wgrad: main kernel + slice reduction are two timed launches
+            res[name] = _mfma(name, fl[li], per_pass, cnt // (2 if pas == "wgrad" else 1), shape=dict(N=N, layer=ENCODER_LAYERS[li]))
+            tot_ms += per_pass
+            tot_fl += fl[li]
+    res["all_passes"] = dict(flops=tot_fl, ms=tot_ms, achieved=tot_fl / (tot_ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, passes=8)
+    return res
+
+
+def rollout_step_model(cfg, W, hidden_features):
+    """What one launch of the rollout step kernel (csrc/rollout_fused.hip) moves and how long its dependency chain is.
+    Every worker's team streams every matrix of the chain once (weights are shared by all workers, but a team serves ONE worker:
+    matrix-VECTOR products), plus the worker's K | V cache columns of the window; the tail streams the K | V projection."""
+    t = cfg["transformer"]
+    D, nb, L, H = t["embed_dim"], t["num_blocks"], t["memory_length"], t["num_heads"]
+    hid = cfg["hidden_layer_size"]
+    gates = 2 * 6 * D * D if t.get("gtrxl") else 0
+    w_chain = D * D + nb * (3 * D * D + gates) + D * 2 * hid              # embedding, per block q / fc_out / fc (+ gates), hidden heads
+    w_tail = nb * D * 2 * D
+    kv = nb * L * 2 * D
+    exchanges = 2 + nb * (6 if t.get("gtrxl") else 2)
+    products = 2 + nb * (15 if t.get("gtrxl") else 3)
+    return dict(weight_bytes_per_worker_to_handover=4 * w_chain, weight_bytes_per_worker_tail=4 * w_tail, kv_bytes_per_worker=4 * kv,
+                bytes_per_launch=4 * W * (w_chain + w_tail + kv), bytes_per_launch_to_handover=4 * W * (w_chain + kv),
+                unique_weight_bytes=4 * (w_chain + w_tail), dependent_products=products, team_exchanges=exchanges,
+                dependent_phases=products + exchanges + nb * 2 + 1, workers=W)
+
+
+def rollout_step(trainer, launches=40):
+    """The kernels of ONE rollout step of one worker group (conv x3, lin_hidden K-slice sums, the step kernel), launched eagerly
+    in their captured order with the library's per-launch HIP events.  Call after a rollout has run (graphs captured, weights
+    refreshed); the step counter is held at 0, the bank / cache rows it writes are not used afterwards by the caller."""
+    lib = etm_lib.load()
+    g = trainer._groups[0]
+    so, hf = trainer._stream_obs, trainer._host_flag
+
+    def step_fn():
+        g.t_dev.zero_()
+        g.flag_np[0] = 0
+        with torch.no_grad():
+            trainer._rollout_step_device(g, so, hf)
+
+    stream = g.stream if g.stream is not None else torch.cuda.current_stream()
+    with torch.cuda.stream(stream):
+        t = _timed(step_fn, launches)
+    torch.cuda.synchronize()
+    res = {"kernels": {k: dict(avg_us=v[0] * 1e3, launches_per_step=v[1] / launches) for k, v in t.items()}}
+    res["step_sum_us"] = sum(v[0] * 1e3 * v[1] / launches for v in t.values())
+    if "rollout_trxl_kernel" in t:
+        feats = trainer.model.lin_hidden.in_features
+        m = rollout_step_model(trainer.config, g.W, feats)
+        us = t["rollout_trxl_kernel"][0] * 1e3
+        gbs = m["bytes_per_launch"] / (us * 1e-6) / 1e9
+        res["rollout_trxl_kernel"] = dict(kernel="rollout_trxl_kernel", bound="latency (dependent chain of matrix-vector products; bytes are L2 / "
+                                          "Infinity-Cache streams, not HBM)", avg_launch_ms=us * 1e-3, launches=t["rollout_trxl_kernel"][1],
+                                          bytes_per_launch=m["bytes_per_launch"], achieved=gbs, unit="GB/s", peak=HBM_PEAK_GBS,
+                                          frac=gbs / HBM_PEAK_GBS, l2_aggregate_peak_gbs=34500.0, frac_of_l2_peak=gbs / 34500.0,
+                                          us_per_dependent_phase=us / m["dependent_phases"], model=m,
+                                          placement=trainer.config.get("rollout_team_placement", "member_xcd"))
+    return res
+
+
 def all_rooflines(dev, quick=False):
     """Everything bench.py reports next to the throughput line (outside its timed region)."""
     n = 10 if quick else 24
@@ -186,7 +294,25 @@ def all_rooflines(dev, quick=False):
     out["gae"] = {"config_size": gae(dev, 32, 512, n), "scaled": gae(dev, 65536, 512, n)}
     out["ppo_loss"] = {"config_size": ppo(dev, 2048, 3, n), "scaled": ppo(dev, 1 << 24, 3, n)}
     torch.cuda.empty_cache()
+    out["encoder"] = encoder(dev, n)
+    torch.cuda.empty_cache()
     return out
+
+
+def _bench_trainer(dev, overrides=()):
+    """A PPOTrainer on BASELINE config 3 that has run one rollout (graphs captured): the fixture of the rollout_step target."""
+    from yaml_parser import YamlParser
+    from trainer import PPOTrainer
+    cfg = YamlParser(os.path.join(PKG, "configs", "synthetic_minigrid.yaml")).get_config()
+    for kv in overrides:
+        k, v = kv.split("=")
+        cfg[k] = int(v) if v.lstrip("-").isdigit() else v
+    torch.manual_seed(0)
+    tr = PPOTrainer(cfg, run_id="roofline", device=dev, tensorboard=False)
+    tr._sample_training_data()
+    tr.buffer.prepare_batch_dict()
+    torch.cuda.synchronize()
+    return tr
 
 
 if __name__ == "__main__":
@@ -212,6 +338,12 @@ if __name__ == "__main__":
         res = {"config_size": gae(dev, 32, 512, n), "scaled": gae(dev, 65536, 512, n)}
     elif what == "ppo":
         res = {"config_size": ppo(dev, 2048, 3, n), "scaled": ppo(dev, 1 << 24, 3, n)}
+    elif what == "encoder":
+        res = encoder(dev, n)
+    elif what == "rollout_step":
+        tr = _bench_trainer(dev, sys.argv[3:])
+        res = rollout_step(tr, n)
+        tr.close()
     else:
         raise SystemExit(__doc__)
     print(json.dumps(res, indent=1))

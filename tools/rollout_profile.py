@@ -17,7 +17,7 @@ for k in sys.argv[1:]:
     *path, leaf = name.split(".")
     for part in path:
         tgt = tgt[part]
-    tgt[leaf] = (val == "1") if val in ("0", "1") else int(val)
+    tgt[leaf] = (val == "1") if val in ("0", "1") else (int(val) if val.lstrip("-").isdigit() else val)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="prof", device=dev, tensorboard=False)

@@ -2,13 +2,13 @@
 # rocprofv3 PMC passes of the kernel micro-benchmarks (tools/kernel_rooflines.py) and of the encoder kernels
 # (tools/conv_time.py); run on the MI355X box.  Counters are collected in separate passes with --kernel-trace only (no other
 # tracing domain), as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2).
-#   bash tools/run_pmc.sh [targets...]          default targets: window_cold window_train window_sorted window_cold128 mfma3 gae ppo conv
-# Output: gpurun_out/pmc_r02/<target>/<pass>/*counter_collection.csv  ->  python tools/pmc_summarize.py gpurun_out/pmc_r02 profiles/r02_pmc_summary.json
+#   bash tools/run_pmc.sh [targets...]          default targets: window_cold window_train window_sorted window_cold128 mfma3 gae ppo encoder rollout_step
+# Output: gpurun_out/pmc_r03/<target>/<pass>/counters.csv  ->  python tools/pmc_summarize.py gpurun_out/pmc_r03 profiles/r03_pmc_summary.json
 set -u
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/pmc_r02
-TARGETS=${@:-window_cold window_train window_sorted window_cold128 mfma3 gae ppo conv}
+OUT=$ROOT/gpurun_out/pmc_${ROUND:-r03}
+TARGETS=${@:-window_cold window_train window_sorted window_cold128 mfma3 gae ppo encoder rollout_step}
 for target in $TARGETS; do
   if [ $target = conv ]; then cmd="python $ROOT/tools/conv_time.py"; else cmd="python $ROOT/tools/kernel_rooflines.py $target 6"; fi
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
