@@ -116,7 +116,7 @@ def cpu_baseline(cfg, seed=0):
     """Oracle trainer on host cores, bounded sample: 32 workers x 64 steps, 5 epochs x 1 minibatch of 2048."""
     from environments.vec_env import make_vec_env
     from oracle.ref_algo import OracleTrainer
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) or 1
     threads = min(cores, 64)
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--plumbing-check", action="store_true",
                     help="testing only, no GPU needed: run the multi-process skeleton of this script (rank / world parsing, process "
                          "group, sharding, barrier, flat-bucket all-reduce, max over ranks, rank-0 JSON line) on CPU tensors over gloo")
+    ap.add_argument("--numa-pin", choices=("auto", "on", "off"), default="auto",
+                    help="restrict the rank (trainer thread, observation-copier helpers, torch pool) to the CPUs of its GPU's NUMA node "
+                         "before any pinned buffer is allocated; auto = on for multi-GPU runs (8 ranks share the host), off for one GPU")
     ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
                     help="kernel family of the window attention (etm.ops.set_attention_impl); folded is the product default")
     args = ap.parse_args()
@@ -210,7 +213,11 @@ def main():
         raise SystemExit("bench.py measures the MI355X path; no HIP device is visible (there is no CPU fallback)")
     device = torch.device("cuda", local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device)
     torch.cuda.set_device(device)
-    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))  # host side is a single python loop per rank
+    numa_cpus = None
+    if args.numa_pin == "on" or (args.numa_pin == "auto" and world > 1):
+        from etm.dist import pin_to_gpu_numa_node
+        numa_cpus = pin_to_gpu_numa_node(device.index)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)) // max(world, 1))))  # host side is a single python loop per rank
 
     from etm import lib as etm_lib
     from etm.dist import DataParallel
@@ -274,19 +281,19 @@ def main():
         try:
             bucket = trainer.flat_grads
             for _ in range(3):
-                dp.all_reduce_grads()
+                dp.all_reduce_grads(average=False)
             torch.cuda.synchronize(device)
             dp.barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_ar = 20
             e0.record()
             for _ in range(n_ar):
-                dp.all_reduce_grads()
+                dp.all_reduce_grads(average=False)
             e1.record()
             torch.cuda.synchronize(device)
             ar_ms = dp.max_over_ranks(e0.elapsed_time(e1) / n_ar)
             nbytes = bucket.numel() * 4
-            allreduce = {"bytes": nbytes, "avg_ms": ar_ms, "includes": "sum all-reduce + division by world size (one launch)",
+            allreduce = {"bytes": nbytes, "avg_ms": ar_ms, "includes": "sum all-reduce of the flat fp32 gradient arena (the division by the world size rides in the optimiser kernel)",
                          "bus_gbs": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9, "xgmi_link_peak_gbs": 153.0,
                          "per_update": cfg["epochs"] * cfg["n_mini_batch"]}
         except Exception as exc:       # reporting only: never lose the throughput line over it
@@ -399,7 +406,9 @@ def main():
                                    "(numpy default_rng(seed + worker id)); rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); "
                                    "environments stepped in-process on the host (part of the timed region); random-init weights",
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
-                       "attention": args.attention, "dp_collective": dp.collective if dp is not None else None},
+                       "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
+                       "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
+                       "rollout_team_placement": cfg.get("rollout_team_placement", "member_xcd")},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline if roofline is not None else roofline_train,
             "roofline_train": roofline_train,

@@ -62,9 +62,6 @@ constexpr int CG_WAVES = 4;
 #ifndef ETM_CONV_MINW
 #define ETM_CONV_MINW 3      // waves per SIMD the register allocation must leave room for (up to 4 accumulator tiles)
 #endif
-#ifndef CG_DIAG   // diagnostic builds only (tools/conv_layer_time.py): 1 = A operands loaded for the first groups only, 2 = B likewise, 4 = no stores
-#define CG_DIAG 0
-#endif
 
 // CLS (backward-data): stride-parity classes handled by ONE workgroup.  The classes of a class-grid pixel (cy, cx) read the SAME
 // T x T gradient taps -- only their weights differ -- so with CLS = S * S the classes are just more channel tiles of one GEMM:
@@ -210,13 +207,12 @@ __global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT *
     const float *abase = p.src + koff;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      if ((CG_DIAG & 1) && g >= 3) break;
-      a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + ((CG_DIAG & 8) ? (loff[mt] & ~0xfff) + lane * 4 : loff[mt]));
+      a_reg[buf][mt] = *reinterpret_cast<const f32x4 *>(abase + loff[mt]);
     }
     const float *bb = wbase + (long long)g * NT * 256;
 #pragma unroll
     for (int t = 0; t < NTT; ++t)
-      if (!(CG_DIAG & 2) || g < 3) b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + (t / NT) * wcls + (t % NT) * 256 + wl);
+      b_reg[buf][t] = *reinterpret_cast<const f32x4 *>(bb + (t / NT) * wcls + (t % NT) * 256 + wl);
   };
   auto mfma_group = [&](int buf) {
 #pragma unroll
@@ -303,7 +299,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT *
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = (mk[i][q] > 0.f) ? v[q] : 0.f;
         }
-        if (okr[i] && (!(CG_DIAG & 4) || v[0] == 12345.678f)) *reinterpret_cast<f32x4 *>(p.out + o_pix[i] + tl * 32 + ec) = v;
+        if (okr[i]) *reinterpret_cast<f32x4 *>(p.out + o_pix[i] + tl * 32 + ec) = v;
       }
     }
   }
@@ -552,10 +548,6 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4 *__restrict_
 // layer whose MT = 4 launch is a single round of at most one workgroup per CU (layer 3: 196 workgroups) does best with
 // private fragments and no barriers (89 us).
 static int conv_pick_mt(long long tiles, const int *cands, int n_cands, bool prefer_large) {
-  if (const char *e = getenv("ETM_DIAG_CONV_MT")) {     // diagnostic override (tools/conv_layer_time.py sweeps)
-    const int v = atoi(e);
-    for (int i = 0; i < n_cands; ++i) if (cands[i] == v) return v;
-  }
   int best = cands[0];
   long long best_cost = -1;
   for (int i = 0; i < n_cands; ++i) {
@@ -602,7 +594,7 @@ extern "C" int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_
     const int cands[] = {2, 4};
     if (conv_pick_mt(tiles, cands, 2, false) == 2) conv_launch<2, 1, false>(p, tiles, 1, st);
     else conv_launch<4, 1, false>(p, tiles, 1, st);
-  } else if ((tiles + CG_WAVES * 4 - 1) / (CG_WAVES * 4) <= 256 && !getenv("ETM_DIAG_CONV_MT")) {
+  } else if ((tiles + CG_WAVES * 4 - 1) / (CG_WAVES * 4) <= 256) {
     conv_launch<4, 2, false, 1, false>(p, tiles, 1, st);
   } else {
     const int cands[] = {2, 1, 4};

@@ -46,33 +46,6 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
-// ---- diagnostic builds only (tools/diag_variants.sh): per-wave s_memtime samples into a device buffer.  Never defined in
-// the product library.
-#if defined(ETM_DIAG_TRACE)
-#define ETM_TRACE_DECL(n_) unsigned long long etm_ts_[n_]
-#define ETM_TRACE_AT(i_) etm_ts_[i_] = __builtin_amdgcn_s_memtime()
-__device__ __forceinline__ unsigned long long etm_hw_ids() {
-  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
-  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
-  return ((unsigned long long)xcc << 32) | hw;
-}
-#else
-#define ETM_TRACE_DECL(n_)
-#define ETM_TRACE_AT(i_)
-#endif
-
-// Diagnostic builds only (tools/diag_variants.sh prio): wave priority for the instruction arbiter (s_setprio 0..3) inside /
-// outside the MFMA streams of the dense kernels.  The product build leaves both at 0, i.e. the macros below expand to nothing
-// (measured: priorities change nothing, an fp32 MFMA stream blocks the other wave's issue regardless).
-#ifndef ETM_PRIO_MFMA
-#define ETM_PRIO_MFMA 0
-#endif
-#ifndef ETM_PRIO_OTHER
-#define ETM_PRIO_OTHER 0
-#endif
-#define ETM_SETPRIO_MFMA() do { if (ETM_PRIO_MFMA != ETM_PRIO_OTHER) __builtin_amdgcn_s_setprio(ETM_PRIO_MFMA); } while (0)
-#define ETM_SETPRIO_OTHER() do { if (ETM_PRIO_MFMA != ETM_PRIO_OTHER) __builtin_amdgcn_s_setprio(ETM_PRIO_OTHER); } while (0)
-
 static inline int etm_launch_status() { return (int)hipGetLastError(); }
 
 // ---- optional per-kernel timing with HIP events (see etm_profile_* in include/etm_hip.h); off by default.

@@ -128,10 +128,6 @@ __global__ __launch_bounds__(256) void bwd_scores_kernel(const BwdParams p) {
 //
 // Staging is straight-line and unconditional (indices clamped, non-existent rows zeroed when stored) so that the row
 // indices two chunks ahead and the operands one chunk ahead stay in flight under the MFMAs.
-#if defined(ETM_DIAG_TRACE)
-constexpr int DW_TRACE_WGS = 256, DW_TRACE_SLOTS = 512, DW_TRACE_ITERS = 80;
-__device__ unsigned long long g_dw_trace[DW_TRACE_WGS * 8 * DW_TRACE_SLOTS];
-#endif
 
 template <bool HAS_LN, bool HAS_POS>
 __global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
@@ -244,24 +240,9 @@ __global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
   // arrivals, so waves may meet at different barrier instructions.)  A group that has run out of chunks stages zeros
   // (rvalid is false past c_end; chunk ids past the array are clamped inside ETM_ISSUE_IDX), so no branch guards the
   // loads and nothing forces the compiler to drain them early.
-#if defined(ETM_DIAG_TRACE)
-  unsigned long long *tb = g_dw_trace + ((long long)min((int)blockIdx.x, DW_TRACE_WGS - 1) * 8 + (threadIdx.x >> 6)) * DW_TRACE_SLOTS;
-  if (lane == 0) { tb[0] = etm_hw_ids(); tb[1] = __builtin_amdgcn_s_memtime(); tb[2] = (unsigned long long)n_max; }
-#endif
-  ETM_SETPRIO_OTHER();
   if (grp == 1) __syncthreads();
   for (int k = 0; k < n_max; ++k) {
-    ETM_TRACE_DECL(8);
-#if defined(ETM_DIAG_TRACE)
-    __builtin_amdgcn_sched_barrier(0);
-    ETM_TRACE_AT(6);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    ETM_TRACE_AT(0);
     // ---- staging segment: registers -> LDS, then refill the registers for this group's next chunks
-#if defined(ETM_DIAG_NO_STAGE_STORES)
-    if (k == 0)
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float sc = (d_valid[i] && o_ok) ? d_scal[i] : 0.f;
@@ -273,15 +254,9 @@ __global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
       *reinterpret_cast<f32x4 *>(&As[(rr + 8 * i) * TM + c4 * 4]) = g;
       *reinterpret_cast<f32x4 *>(&Bs[(rr + 8 * i) * TN + c4 * 4]) = v;
     }
-    ETM_TRACE_AT(1);
-#if !defined(ETM_DIAG_NO_STAGE_LOADS)
     ETM_ISSUE_DATA()                             // operands of this group's chunk k+1
     ETM_ISSUE_IDX(c_first + 2 * (k + 2))         // indices of this group's chunk k+2
-#endif
-    ETM_TRACE_AT(2);
     __syncthreads();
-    ETM_SETPRIO_MFMA();
-    ETM_TRACE_AT(3);
 
     // ---- MFMA segment; fragments of k-step s+1 are read while the MFMAs of k-step s issue
     const float *ap = As + half * TM + wm * 64 + col;
@@ -297,37 +272,21 @@ __global__ __launch_bounds__(512) void bwd_dw_kernel(const BwdParams p) {
         nb1 = bp[(2 * s + 2) * TN + 32];
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the next fragments' LDS reads ahead of this step's MFMAs
-#if defined(ETM_DIAG_SKIP_MFMA)   // diagnostic build only: everything but the matrix instructions (fragments kept alive)
-      acc[0][0][0] += a0 * b0; acc[0][1][0] += a0 * b1; acc[1][0][0] += a1 * b0; acc[1][1][0] += a1 * b1;
-#else
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-#endif
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     // Every MFMA of the segment must ISSUE before the barrier.  Left alone, the scheduler sinks the last one below it (an
     // MFMA has no memory side effect), and that lone instruction then queues behind the partner group's back-to-back
     // MFMA stream: this wave sits at it for the partner's whole segment and its staging is no longer hidden
-    // (measured with the s_memtime trace build: 4.5 k cycles lost per phase, tools/diag_run.py).
+    // (measured with round 1's s_memtime trace build: 4.5 k cycles lost per phase).
     __builtin_amdgcn_sched_barrier(0);
-    ETM_SETPRIO_OTHER();
-    ETM_TRACE_AT(4);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    ETM_TRACE_AT(5);
-#if defined(ETM_DIAG_TRACE)
-    if (lane == 0 && k < DW_TRACE_ITERS) {
-      for (int j = 0; j < 5; ++j) tb[8 + k * 6 + j] = etm_ts_[j];
-      tb[8 + k * 6 + 5] = etm_ts_[6];   // slot 5: loop top (pinned), before the waits on the previous staging's loads
-    }
-#endif
   }
   if (grp == 0) __syncthreads();
-#if defined(ETM_DIAG_TRACE)
-  if (lane == 0) tb[3] = __builtin_amdgcn_s_memtime();
-#endif
 #undef ETM_ISSUE_IDX
 #undef ETM_ISSUE_DATA
 
@@ -539,11 +498,6 @@ extern "C" int64_t etm_mha_bwd_workspace_bytes(int N, int L, int D) {
   return ((int64_t)pl.splits * 2 * D * D + (int64_t)2 * N * D * (D / 32)) * (int64_t)sizeof(float);
 }
 
-#if defined(ETM_DIAG_TRACE)
-extern "C" int etm_diag_dw_trace_read(void *dst, long long bytes) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dw_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 extern "C" int etm_mha_bwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
                            const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,

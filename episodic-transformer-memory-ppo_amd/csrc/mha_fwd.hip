@@ -80,10 +80,6 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *bank, long l
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-#if defined(ETM_DIAG_TRACE)
-constexpr int FW_TRACE_WGS = 4096, FW_TRACE_SLOTS = 64;
-__device__ unsigned long long g_fw_trace[FW_TRACE_WGS * 4 * FW_TRACE_SLOTS];
-#endif
 
 template <int HT, bool HAS_LN, bool HAS_POS>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
@@ -106,10 +102,6 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int L = p.L, Lp = p.Lp, D = p.D, N = p.N;
-#if defined(ETM_DIAG_TRACE)
-  unsigned long long *tb = g_fw_trace + ((long long)min((int)blockIdx.x, FW_TRACE_WGS - 1) * 4 + wave) * FW_TRACE_SLOTS;
-  if (lane == 0) { tb[0] = etm_hw_ids(); tb[1] = __builtin_amdgcn_s_memtime(); }
-#endif
 
   // ---- operands.  A (window rows): a window row is only ever used by ONE lane pair (lane l and l+32 of the wave that owns
   // the row), so it is loaded straight from global memory into that lane's registers in fragment order -- an LDS round trip
@@ -169,11 +161,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int nk = D / BK;
-  ETM_SETPRIO_OTHER();
   ETM_ISSUE_LOADS(0)
   for (int kb = 0; kb < nk; ++kb) {
-    ETM_TRACE_DECL(4);
-    ETM_TRACE_AT(0);
     // finish this chunk's A fragments in registers (positional add / LayerNorm / zeroing of non-existent rows)
     f32x4 af[4];
 #pragma unroll
@@ -185,20 +174,11 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
       af[kk] = v;
     }
     // weight chunk: registers -> LDS
-#if defined(ETM_DIAG_NO_STAGE_STORES)
-    if (kb == 0)
-#endif
 #pragma unroll
     for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4 *>(&Ws[(r0 + 32 * j) * LDP + c4 * 4]) = wr[j];
-#if !defined(ETM_DIAG_NO_BARRIERS)
     __syncthreads();
-#endif
-    ETM_TRACE_AT(1);
-#if !defined(ETM_DIAG_NO_STAGE_LOADS)
     ETM_ISSUE_LOADS(min(kb + 1, nk - 1))  // global loads stay in flight under the MFMAs below (last chunk re-fetched: harmless)
-#endif
 
-    ETM_SETPRIO_MFMA();
     // lane supplies A[row][k] from its registers and B[k][col'] from LDS with k = 8 kk + 4 half + j (same pairing)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -206,10 +186,6 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
       float4 bt[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) bt[t] = *reinterpret_cast<const float4 *>(&Ws[(t * 32 + col) * LDP + kk * 8 + half * 4]);
-#if defined(ETM_DIAG_SKIP_MFMA)   // diagnostic build only: everything but the matrix instructions (fragments kept alive)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][0] += a[0] * bt[t].x + a[1] * bt[t].y + a[2] * bt[t].z + a[3] * bt[t].w;
-#else
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bt[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -218,24 +194,11 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bt[t].z, acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bt[t].w, acc[t], 0, 0, 0);
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
-    ETM_SETPRIO_OTHER();
-    ETM_TRACE_AT(2);
-#if !defined(ETM_DIAG_NO_BARRIERS)
     __syncthreads();
-#endif
-    ETM_TRACE_AT(3);
-#if defined(ETM_DIAG_TRACE)
-    if (lane == 0 && kb < 12)
-      for (int j = 0; j < 4; ++j) tb[4 + kb * 4 + j] = etm_ts_[j];
-#endif
   }
 #undef ETM_ISSUE_LOADS
-#if defined(ETM_DIAG_TRACE)
-  if (lane == 0) tb[2] = __builtin_amdgcn_s_memtime();
-#endif
 
   // ---- epilogue.  All 32 rows of a wave belong to one sample (Lp is a multiple of 32).
   const int srow0 = wave * 32;
@@ -331,9 +294,6 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const FwdParams p) {
       }
     }
   }
-#if defined(ETM_DIAG_TRACE)
-  if (lane == 0) tb[3] = __builtin_amdgcn_s_memtime();
-#endif
 }
 
 template <int HT>
@@ -359,11 +319,6 @@ int etm_launch_ln_stats(const float *bank, int64_t ep_stride, int64_t row_stride
   return etm_launch_status();
 }
 
-#if defined(ETM_DIAG_TRACE)
-extern "C" int etm_diag_fw_trace_read(void *dst, long long bytes) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fw_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 extern "C" int etm_mha_fwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
                            const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,

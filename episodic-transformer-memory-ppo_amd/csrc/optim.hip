@@ -6,7 +6,8 @@
 // the whole step is two launches, whatever the number of parameters:
 //   etm_grad_sqnorm   per-workgroup partial sums of g^2 (fixed chunking => deterministic), and step += 1
 //   etm_adamw_clip    every workgroup adds the partial sums in the same order -> total norm -> clip coefficient
-//                     min(1, max_norm / (norm + 1e-6)) (the rule of clip_grad_norm_), then for its elements:
+//                     min(1, max_norm / (norm + 1e-6)) (the rule of clip_grad_norm_; data parallel: x 1 / world, the averaging of
+//                     the all-reduced sum), then for its elements:
 //                       g *= coef (written back: the monitored gradient norms of model.py:128-151 are taken after clipping)
 //                       p *= 1 - lr wd;  m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g g
 //                       p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)   (torch's single-tensor AdamW, fp32, same order)
@@ -48,14 +49,18 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_clip_kernel(float4 *__restr
                                                                  float4 *__restrict__ v, long long n4, const float *__restrict__ partial,
                                                                  int n_partial, const float *__restrict__ lr_dev,
                                                                  const long long *__restrict__ step, double beta1, double beta2, double eps,
-                                                                 double weight_decay, float max_norm, float *__restrict__ norm_out) {
+                                                                 double weight_decay, float max_norm, float grad_scale,
+                                                                 float *__restrict__ norm_out) {
   __shared__ float sm[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n_partial; i += OPT_THREADS) acc += partial[i];
-  const float total = sqrtf(block_sum_256(acc, sm));
+  // grad_scale: the arena holds grad_scale^-1 times the gradient (data parallel: the all-reduced SUM, grad_scale = 1 / world) --
+  // the division rides in the clip coefficient instead of costing a pass over the arena; 1.0f changes no bit
+  const float total = sqrtf(block_sum_256(acc, sm)) * grad_scale;
   if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  coef *= grad_scale;
   // scalars as torch.optim.AdamW forms them (python floats = doubles), then the fp32 tensor arithmetic of its single-tensor
   // path in the same order: p.mul_(1 - lr wd); m.lerp_(g, 1 - b1); v.mul_(b2).addcmul_(g, g, value = 1 - b2);
   // denom = (v.sqrt() / sqrt(1 - b2^t)).add_(eps); p.addcdiv_(m, denom, value = -lr / (1 - b1^t))
@@ -141,11 +146,11 @@ extern "C" int etm_grad_sqnorm(const float *g, int64_t n, float *partial, int n_
 }
 
 extern "C" int etm_adamw_clip(float *p, float *g, float *m, float *v, int64_t n, const float *partial, int n_partial, const float *lr_dev,
-                              const int64_t *step, double beta1, double beta2, double eps, double weight_decay, float max_norm, float *norm_out,
-                              void *stream) {
+                              const int64_t *step, double beta1, double beta2, double eps, double weight_decay, float max_norm, float grad_scale,
+                              float *norm_out, void *stream) {
   (void)hipGetLastError();
   if (!p || !g || !m || !v || !partial || !lr_dev || !step || n <= 0 || n % 4 != 0 || n_partial <= 0 || n_partial > 4096) return ETM_EINVAL;
-  if ((uintptr_t)p % 16 || (uintptr_t)g % 16 || (uintptr_t)m % 16 || (uintptr_t)v % 16) return ETM_EINVAL;
+  if ((uintptr_t)p % 16 || (uintptr_t)g % 16 || (uintptr_t)m % 16 || (uintptr_t)v % 16 || !(grad_scale > 0.f)) return ETM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_OPTIM, st);
   const long long n4 = n / 4;
@@ -153,6 +158,6 @@ extern "C" int etm_adamw_clip(float *p, float *g, float *m, float *v, int64_t n,
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_clip_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, st, (float4 *)p, (float4 *)g, (float4 *)m, (float4 *)v, n4,
-                     partial, n_partial, lr_dev, (const long long *)step, beta1, beta2, eps, weight_decay, max_norm, norm_out);
+                     partial, n_partial, lr_dev, (const long long *)step, beta1, beta2, eps, weight_decay, max_norm, grad_scale, norm_out);
   return etm_launch_status();
 }

@@ -753,7 +753,11 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       p.st_logp[t * p.stage_W + w] = lg[a] - lse;
       p.st_values[t * p.stage_W + w] = lg[A];
       RF_STAMP(42);
-      __threadfence();                                            // this worker's rows are visible before the arrival below
+      // this worker's rows are visible before the arrival below -- system scope when the action went to pinned host memory: the
+      // host reads it as soon as it sees the flag that the LAST sampler stores, so every sampler's store must have completed at
+      // system scope before its arrival (an agent-scope fence does not promise that for host memory)
+      if (p.host_actions) __threadfence_system();
+      else __threadfence();
       // the last SAMPLER of the step: every team has finished its exchanges, i.e. every workgroup of the launch has read the
       // launch counter and (the samplers) the step counter -- both may move on, and the host may have its actions
       if (atomicAdd(p.sync_counter, 1) == p.W - 1) {

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const float *__rest
     st_actions[t * stage_W + w] = a;
     st_logp[t * stage_W + w] = lg[a] - lse;
     st_values[t * stage_W + w] = lg[A];
-    __threadfence();                                     // this worker's rows are visible before the arrival below
+    if (host_actions) __threadfence_system();            // (host memory: see rollout_fused.hip) this worker's rows are visible before
+    else __threadfence();                                // the arrival below
     if (atomicAdd(sync_counter, 1) == W - 1) {           // last workgroup of the step
       *sync_counter = 0;
       *t_dev = t + 1;

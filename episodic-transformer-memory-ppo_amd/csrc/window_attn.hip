@@ -123,13 +123,7 @@ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
 constexpr int HG = 4;  // heads staged in LDS per chunk (one at a time in registers)
 
-#if defined(ETM_DIAG_TRACE)
-constexpr int WIN_TRACE_WGS = 2048, WIN_TRACE_SLOTS = 16;
-__device__ unsigned long long g_win_trace[WIN_TRACE_WGS * 8 * WIN_TRACE_SLOTS];
-#define WIN_T(i_) { if (lane == 0) tb[i_] = __builtin_amdgcn_s_memtime(); }
-#else
 #define WIN_T(i_)
-#endif
 
 template <int NJ, int RW, int NW, bool HAS_LN, bool HAS_POS, bool FULLD>
 __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p) {
@@ -143,10 +137,6 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L, D = p.D, H = p.H;
-#if defined(ETM_DIAG_TRACE)
-  unsigned long long *tb = g_win_trace + ((long long)min((int)blockIdx.x, WIN_TRACE_WGS - 1) * 8 + (wave & 7)) * WIN_TRACE_SLOTS;
-  if (lane == 0) tb[0] = etm_hw_ids();
-#endif
   WIN_T(1)
   float *a_s = sm;              // [H][LP]   logits, then attention (forward) / dE (backward)
   float *zs = sm + H * LP;      // [NW][HG][DP] per-wave partial weighted sums
@@ -236,31 +226,12 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   }
 
   f32x2 x[RW][NJ];
-#if defined(ETM_DIAG_TRACE)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  WIN_T(2)   // row bookkeeping arrived
-#endif
   // the vec rows of the first chunk arrived with the row bookkeeping (same round trip); they go to LDS before the row
   // loads are issued, so the barrier in front of pass 1 is reached while the rows are still in flight
   store_vec();
 #pragma unroll
   for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
-#if defined(ETM_DIAG_TRACE)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  WIN_T(3)   // window rows arrived
-#endif
 
-#if defined(ETM_DIAG_LOAD_ONLY)   // diagnostic build only: the gather alone (ceiling of the access pattern)
-  {
-    f32x2 acc = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < RW; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc += x[i][j];
-    if (acc[0] + acc[1] == 123.456f) p.out[0] = acc[0];
-    return;
-  }
-#endif
   // ---- pass 1: logits[h][l] = x[l] . vec[h]
   {
     for (int h0 = 0; h0 < H; h0 += HG) {
@@ -485,11 +456,6 @@ int check_common(const void *bank, const void *win, const void *mask, const void
 
 }  // namespace
 
-#if defined(ETM_DIAG_TRACE)
-extern "C" int etm_diag_win_trace_read(void *dst, long long bytes) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_win_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 extern "C" int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
                               const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,

@@ -13,6 +13,45 @@ import torch
 import torch.distributed as dist
 
 
+def gpu_numa_cpus(device_index: int):
+    """CPUs of the NUMA node the GPU hangs off (sysfs: the PCI function's numa_node -> that node's cpulist), or None if the
+    platform does not say (single-node hosts report -1)."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus or None
+    except Exception:              # noqa: BLE001 -- no sysfs entry, no permission, odd format: leave the affinity alone
+        return None
+
+
+def pin_to_gpu_numa_node(device_index: int):
+    """Restrict this process (and the threads it creates afterwards: the observation copier's helpers, torch's pool) to the CPUs
+    of the GPU's NUMA node, so that the pinned staging buffers are first-touched on that node and the rollout loop's polls /
+    uploads do not cross the socket interconnect.  Returns the CPU set, or None when nothing was changed."""
+    cpus = gpu_numa_cpus(device_index)
+    if not cpus:
+        return None
+    try:
+        allowed = os.sched_getaffinity(0)
+        cpus = cpus & allowed
+        if len(cpus) < 4:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except Exception:              # noqa: BLE001
+        return None
+
+
 class DataParallel:
     def __init__(self, device=None, backend=None, collective=None):
         """``collective``: who issues the gradient all-reduce -- "etm" (default: the library's own RCCL communicator,
@@ -33,7 +72,12 @@ class DataParallel:
         if self.world > 1 and not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (the only form this host driver has)
+            # dmabuf IPC is the only form this host driver has; the runtime reads the variable when it starts, so the entry points
+            # (train.py, bench.py) set it before their first device call -- say so if a caller did not
+            if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and backend == "nccl":
+                print("[etm.dist] HSA_ENABLE_IPC_MODE_LEGACY=0 is not in the environment: RCCL needs it set before the HIP runtime "
+                      "starts (export it, or set it before the first torch.cuda call)", flush=True)
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {}
@@ -72,87 +116,106 @@ class DataParallel:
         return self.flat
 
     def _start_etm_comm(self):
-        """Create the library communicator now (not inside the first optimisation step, which may be under graph capture) and
-        check it with a one-element all-reduce; any failure selects the torch collective."""
-        import threading
-        out = {"why": "did not finish"}
+        """Create the library communicator now (not inside the first optimisation step, which may be under graph capture), on the
+        calling thread, and check it with a four-element all-reduce.  Every step of the hand-shake is SYMMETRIC -- all ranks issue
+        the same torch.distributed collectives in the same order whatever happens locally -- so a failure on one rank (RCCL not
+        loadable, CPU tensors, gloo backend, several ranks on one device) can never leave ranks in different collectives:
 
-        def create_and_probe():
+          1. local pre-check                      -> all_reduce(MIN) of "I can try"          (everybody leaves here together if not)
+          2. rank 0 draws the rendezvous id       -> broadcast of [status byte | 128-byte id] (rank 0 ALWAYS broadcasts; a failure
+                                                                                               travels as status 1 + a zeroed id)
+          3. etm_comm_init + self-test all-reduce -> all_reduce(MIN) of "mine works"
+
+        A rendezvous that cannot complete is bounded by RCCL's own timeouts (and the process group's), not by a helper thread."""
+        from . import lib as _lib
+        on_dev = dist.get_backend() == "nccl"
+        flag_dev = self.device if on_dev else "cpu"
+
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        why = None
+        if self.device is None or torch.device(self.device).type != "cuda" or not on_dev:
+            why = "needs HIP device tensors and the nccl (RCCL) backend"
+        else:
             try:
-                if self.device is None or torch.device(self.device).type != "cuda" or dist.get_backend() != "nccl":
-                    out["why"] = "needs HIP device tensors and the nccl (RCCL) backend"
-                    return
-                from . import lib as _lib
-                dev = torch.device(self.device)
-                with torch.cuda.device(dev):
-                    comm = self._etm_comm()
-                    probe = torch.ones(4, dtype=torch.float32, device=dev)
-                    rc = _lib.load().etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream)
-                    _lib.check(rc, "etm_allreduce_f32")
-                    torch.cuda.synchronize(dev)
-                out["why"] = None if probe.tolist() == [float(self.world)] * 4 else f"self-test all-reduce returned {probe.tolist()}"
-            except Exception as exc:       # noqa: BLE001 -- any failure: use the framework's collective
-                out["why"] = repr(exc)
-
-        # bounded: a rendezvous that never completes on some node must not stall the job -- the torch collective takes over
-        limit = float(os.environ.get("ETM_COMM_TIMEOUT_S", "120"))
-        th = threading.Thread(target=create_and_probe, daemon=True)
-        th.start()
-        th.join(limit)
-        why = f"not ready after {limit:.0f} s" if th.is_alive() else out["why"]
-        # all ranks must agree on the transport
-        flag = torch.tensor([0 if why is None else 1], dtype=torch.int32,
-                            device=self.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) != 0:
-            if self.rank == 0 or why is not None:
-                print(f"[etm.dist] rank {self.rank}: library RCCL communicator not used ({why or 'another rank could not create it'}); "
-                      "gradient all-reduce goes through torch.distributed", flush=True)
-            if self._comm is not None:
-                try:
-                    from . import lib as _lib
-                    _lib.load().etm_comm_destroy(self._comm)
-                except Exception:          # noqa: BLE001
-                    pass
-                self._comm = None
-            self.collective = "torch"
-
-    def _etm_comm(self):
-        """Library-owned RCCL communicator (created on first use): rank 0 draws the rendezvous id, torch.distributed carries
-        its 128 bytes to the other ranks, every rank joins with its current device."""
-        if self._comm is None:
-            import ctypes
-            from . import lib as _lib
-            lib = _lib.load()
-            dev = torch.device(self.device)
-            if dev.type != "cuda":
-                raise RuntimeError("collective='etm' needs HIP device tensors (RCCL); use the torch collective for CPU / gloo runs")
+                _lib.load()
+            except Exception as exc:       # noqa: BLE001
+                why = repr(exc)
+        if not agree(why is None):                                        # step 1
+            return self._use_torch_collective(why)
+        import ctypes
+        lib = _lib.load()
+        dev = torch.device(self.device)
+        msg = torch.zeros(1 + 128, dtype=torch.uint8)
+        if self.rank == 0:
             buf = ctypes.create_string_buffer(128)
-            if self.rank == 0:
-                _lib.check(lib.etm_comm_unique_id(buf), "etm_comm_unique_id")
-            on_dev = dist.get_backend() == "nccl"
-            t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-            t = t.to(dev) if on_dev else t
-            dist.broadcast(t, src=0)
-            raw = bytes(t.cpu().numpy().tobytes())
-            comm = ctypes.c_void_p()
-            with torch.cuda.device(dev):
-                _lib.check(lib.etm_comm_init(raw, self.rank, self.world, ctypes.byref(comm)), "etm_comm_init")
-            self._comm = comm
-        return self._comm
+            rc = lib.etm_comm_unique_id(buf)
+            if rc == 0:
+                msg[1:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+            else:
+                msg[0] = 1
+                why = f"etm_comm_unique_id failed ({rc})"
+        msg = msg.to(dev)
+        dist.broadcast(msg, src=0)                                        # step 2 (unconditional on every rank)
+        msg = msg.cpu()
+        ok = int(msg[0]) == 0
+        if ok:
+            try:
+                comm = ctypes.c_void_p()
+                with torch.cuda.device(dev):
+                    _lib.check(lib.etm_comm_init(bytes(msg[1:].numpy().tobytes()), self.rank, self.world, ctypes.byref(comm)), "etm_comm_init")
+                    self._comm = comm
+                    probe = torch.ones(4, dtype=torch.float32, device=dev)
+                    _lib.check(lib.etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream),
+                               "etm_allreduce_f32")
+                    torch.cuda.synchronize(dev)
+                if probe.tolist() != [float(self.world)] * 4:
+                    ok, why = False, f"self-test all-reduce returned {probe.tolist()}"
+            except Exception as exc:       # noqa: BLE001 -- any failure: use the framework's collective
+                ok, why = False, repr(exc)
+        elif why is None:
+            why = "rank 0 could not draw a rendezvous id"
+        if not agree(ok):                                                 # step 3
+            return self._use_torch_collective(why)
 
-    def all_reduce_grads(self):
-        """Sum the flat gradient bucket over ranks and average (one RCCL all-reduce)."""
+    def _use_torch_collective(self, why):
+        if self.rank == 0 or why is not None:
+            print(f"[etm.dist] rank {self.rank}: library RCCL communicator not used ({why or 'another rank could not create it'}); "
+                  "gradient all-reduce goes through torch.distributed", flush=True)
+        if self._comm is not None:
+            try:
+                from . import lib as _lib
+                _lib.load().etm_comm_destroy(self._comm)
+            except Exception:          # noqa: BLE001
+                pass
+            self._comm = None
+        self.collective = "torch"
+
+    def all_reduce_grads(self, average=True):
+        """Sum the flat gradient bucket over ranks (one RCCL all-reduce).  ``average=True`` also divides by the world size (one more
+        launch over the bucket); the trainer passes False and hands ``grad_scale = 1 / world`` to the optimiser step instead, where
+        the division rides in the clip coefficient (csrc/optim.hip)."""
         if not self.active:
             return
         if self.collective == "etm":
             from . import lib as _lib
-            rc = _lib.load().etm_allreduce_f32(self._etm_comm(), self.flat.data_ptr(), self.flat.data_ptr(), self.flat.numel(),
+            if self._comm is None:
+                raise RuntimeError("library communicator missing (DataParallel creates it at construction)")
+            rc = _lib.load().etm_allreduce_f32(self._comm, self.flat.data_ptr(), self.flat.data_ptr(), self.flat.numel(),
                                                torch.cuda.current_stream(self.flat.device).cuda_stream)
             _lib.check(rc, "etm_allreduce_f32")
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(self.world)
+        if average:
+            self.flat.div_(self.world)
+
+    @property
+    def grad_scale(self):
+        """1 / world: what the optimiser step multiplies into the clip coefficient after ``all_reduce_grads(average=False)``."""
+        return 1.0 / self.world if self.active else 1.0
 
     def merge_adv_stats(self, stats3: torch.Tensor) -> torch.Tensor:
         """Merge per-rank (count, mean, M2) into global statistics (Chan et al. pairwise update).  ``stats3`` is [3] or

@@ -6,9 +6,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 #                             second HIP runtime in the process (kernels would then launch on a runtime with no device)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ETM_DIAG_LIB: another build of the same library (ablation / candidate builds of tools/diag_variants.sh), for A/B runs of the
-# tools and of the parity tests; announced on load, never the default
-LIB_PATH = os.environ.get("ETM_DIAG_LIB") or os.path.join(_HERE, "libetm_hip.so")
+LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
 ABI_VERSION = 24
 
 _lib = None
@@ -75,7 +73,7 @@ SIGNATURES = {
     "etm_conv_train_wgrad": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_relu_mask": (_I, [_P, _P, _P, _L, _P]),
     "etm_grad_sqnorm": (_I, [_P, _L, _P, _I, _P, _P]),
-    "etm_adamw_clip": (_I, [_P, _P, _P, _P, _L, _P, _I, _P, _P, _D, _D, _D, _D, _F, _P, _P]),
+    "etm_adamw_clip": (_I, [_P, _P, _P, _P, _L, _P, _I, _P, _P, _D, _D, _D, _D, _F, _F, _P, _P]),
     "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),
     "etm_adv_stats": (_I, [_P, _I, _P, _P]),
     "etm_ppo_loss_workspace_bytes": (_L, [_I]),

@@ -457,6 +457,11 @@ def rollout_trxl_error(scratch):
     return scratch[1]
 
 
+def rollout_trxl_clear_error(scratch):
+    """Reset the error word of the step kernel's scratch area (after the caller has dealt with a reported time-out)."""
+    scratch[1].zero_()
+
+
 def rollout_trxl_supported(D, H, L, hid, A, nb):
     """Does ``rollout_trxl`` handle these shapes (etm_rollout_trxl_supported)?"""
     return bool(_lib.load().etm_rollout_trxl_supported(D, H, L, hid, A, nb))
@@ -759,10 +764,18 @@ def conv_pack_dgrad_weights(weight, stride):
     return torch.stack(blocks).contiguous()
 
 
-def encoder_train_supported(obs_shape, convs):
-    """Can the hand-written training kernels run this encoder?  (model.py:40-56 geometry with 84 x 84 or similar inputs.)"""
+def encoder_train_supported(obs_shape, convs, batch=None):
+    """Can the hand-written training kernels run this encoder?  (model.py:40-56 geometry with 84 x 84 or similar inputs.)
+    ``batch``: images per call -- the kernels index output pixels with 24 bits (N * Ho * Wo < 2^24 per layer, padded to the
+    backward-data kernel's image unit of 1024) and the source with 32-bit element offsets; larger minibatches take the library path."""
     c, h, w = obs_shape
     for conv in convs:
+        if batch is not None:
+            kh, s = conv.kernel_size[0], conv.stride[0]
+            padded = (batch + 1023) // 1024 * 1024
+            if (batch * h * w * c >= 2 ** 31 or batch * ((h - kh) // s + 1) * ((w - kh) // s + 1) >= 2 ** 24      # forward / backward-weight
+                    or (conv is not convs[0] and padded * (h // s) * (w // s) >= 2 ** 24)):                      # backward-data
+                return False
         kh, kw = conv.kernel_size
         s = conv.stride[0]
         if (kh != kw or conv.stride[0] != conv.stride[1] or conv.padding != (0, 0) or conv.dilation != (1, 1) or conv.groups != 1

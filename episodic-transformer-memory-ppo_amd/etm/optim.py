@@ -54,9 +54,10 @@ class FlatAdamW:
     def zero_grad(self):
         self.flat_grads.zero_()
 
-    def step(self, max_grad_norm=0.0):
+    def step(self, max_grad_norm=0.0, grad_scale=1.0):
         """Clip the gradient arena to ``max_grad_norm`` (global L2 norm, the rule of ``clip_grad_norm_``; <= 0: no clipping) and
-        apply one AdamW update.  Two launches on the current stream."""
+        apply one AdamW update.  Two launches on the current stream.  ``grad_scale``: the arena holds gradient / grad_scale
+        (data parallel: the all-reduced sum, grad_scale = 1 / world); the scale rides in the clip coefficient."""
         lib = _lib.load()
         st = torch.cuda.current_stream(self.device).cuda_stream
         n = self.flat_params.numel()
@@ -65,4 +66,4 @@ class FlatAdamW:
         _lib.check(lib.etm_adamw_clip(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), n, self.partial.data_ptr(), self.N_PARTIAL, self.lr_dev.data_ptr(),
                                       self.step_dev.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                      float(max_grad_norm), self.total_norm.data_ptr(), st), "etm_adamw_clip")
+                                      float(max_grad_norm), float(grad_scale), self.total_norm.data_ptr(), st), "etm_adamw_clip")

@@ -201,7 +201,8 @@ class ActorCriticModel(nn.Module):
             if self.visual and self.train_encoder and torch.is_grad_enabled():
                 if self._train_encoder_ok is None:
                     self._train_encoder_ok = ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3))
-                if self._train_encoder_ok:
+                if self._train_encoder_ok and ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3),
+                                                                            batch=int(obs.index.numel())):
                     feats = ops.encoder_train(obs.bank, self.conv1, self.conv2, self.conv3, index=obs.index)
                     w_nhwc = ops.nhwc_columns(self.lin_hidden.weight, self.conv3.out_channels)
                     return ops.linear_relu_train(feats, w_nhwc, self.lin_hidden.bias)
@@ -216,7 +217,8 @@ class ActorCriticModel(nn.Module):
         if self.visual and self.train_encoder and obs.is_cuda and torch.is_grad_enabled() and obs.dim() == 4:
             if self._train_encoder_ok is None:
                 self._train_encoder_ok = ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3))
-            if self._train_encoder_ok:
+            if self._train_encoder_ok and ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3),
+                                                                        batch=int(obs.shape[0])):
                 # optimisation phase: the three relu(conv2d) layers forward and backward on the hand-written MFMA kernels
                 # (NHWC activations; the trainer hands over an NCHW view of NHWC memory, which permutes back for free)
                 feats = ops.encoder_train(obs.permute(0, 2, 3, 1), self.conv1, self.conv2, self.conv3)      # (h, w, c) flatten order

@@ -7,15 +7,19 @@ One process drives one MI355X.  For data-parallel training over the GPUs of a no
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config ...
 
 (``n_workers`` in the YAML is the number of environments PER PROCESS; gradients are all-reduced with RCCL -- through
-torch.distributed by default, through the library's own communicator with ETM_DP_COLLECTIVE=etm.)
+the library's own communicator by default, through torch.distributed with ETM_DP_COLLECTIVE=torch.)
 """
 import argparse
 import os
 
-import torch
+# the host driver shares device memory between the ranks of a node through dmabuf handles only (RCCL, multi-process runs); the HIP
+# runtime reads this when it starts, i.e. at the first device call below -- so it is set here, before anything touches the device
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from trainer import PPOTrainer
-from yaml_parser import YamlParser
+import torch  # noqa: E402
+
+from trainer import PPOTrainer  # noqa: E402
+from yaml_parser import YamlParser  # noqa: E402
 
 
 def main():
@@ -36,7 +40,8 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        from etm.dist import DataParallel
+        from etm.dist import DataParallel, pin_to_gpu_numa_node
+        pin_to_gpu_numa_node(local_rank)            # before the pinned staging buffers are allocated; no-op if the platform does not say
         dp = DataParallel(device)
         first_worker = dp.rank * config["n_workers"]
     trainer = PPOTrainer(config, run_id=args.run_id, device=device, dp=dp, first_worker_id=first_worker,

@@ -13,8 +13,9 @@ for the GPU:
 * GAE and the PPO loss (+ its backward) are single fused kernels; loss statistics stay on the device and are
   fetched once per update (upstream: 6 host syncs per minibatch, :318-323); the whole minibatch step (gather, forward,
   loss, backward, clip, AdamW) is one captured HIP graph with device-resident schedules;
-* data parallelism (absent upstream): ``dp`` all-reduces one flat gradient bucket with RCCL between ``backward()``
-  and gradient clipping (:310-311) and merges advantage statistics so normalisation is over the global minibatch.
+* data parallelism (absent upstream): ``dp`` all-reduces (sums) one flat gradient bucket with RCCL between ``backward()``
+  and gradient clipping (:310-311) -- the division by the world size rides in the clip coefficient -- and merges advantage
+  statistics so normalisation is over the global minibatch.
 
 There is no CPU path: constructing the trainer without a HIP device raises.
 """
@@ -480,7 +481,18 @@ class PPOTrainer:
         t_ = self.model.transformer
         for g in groups + [self._group_all]:
             if g.rf_scratch is not None and int(ops.rollout_trxl_error(g.rf_scratch).item()) != 0:
-                raise RuntimeError("fused rollout step: a team member timed out waiting for its partners (set fused_rollout_block: false)")
+                # a team member gave up waiting for its partners (not all workgroups were resident): this rollout's data are
+                # unusable.  Leave the trainer in a state that can continue: clear the error word, switch to the multi-launch
+                # step for the rest of the run and drop the captured graphs so that the next rollout re-captures them.
+                for gg in groups + [self._group_all]:
+                    if gg.rf_scratch is not None:
+                        ops.rollout_trxl_clear_error(gg.rf_scratch)
+                    gg.graphs = None
+                self.model.fused_rollout_block = False
+                self.model._rf = None
+                self._step_graph = None
+                raise RuntimeError("fused rollout step: a team member timed out waiting for its partners; this rollout is void. The "
+                                   "trainer has switched to the multi-launch step (fused_rollout_block: false) for the following rollouts")
         if forced_actions is not None:
             self._forced_tab.fill_(-1)
         # time-major staging -> the buffer's [W, S, ...] fields (one strided copy per field)
@@ -815,10 +827,13 @@ class PPOTrainer:
         self.flat_grads.zero_()
         loss.backward()
         if self.dp is not None:
-            self.dp.all_reduce_grads()
+            self.dp.all_reduce_grads(average=False)       # the sum; the 1 / world rides in the clip coefficient below
         # global-norm clipping (the rule of torch.nn.utils.clip_grad_norm_, upstream :311) + AdamW on the flat arenas: 2 launches
-        self.optimizer.step(self.config["max_grad_norm"])
+        self.optimizer.step(self.config["max_grad_norm"], grad_scale=self._grad_scale())
         return stats
+
+    def _grad_scale(self):
+        return self.dp.grad_scale if self.dp is not None else 1.0
 
     def _set_lr(self, learning_rate: float):
         self.optimizer.set_lr(learning_rate)
@@ -887,7 +902,7 @@ class PPOTrainer:
     def _train_body_b(self, monitor):
         """Second half: global-norm clipping (same rule as torch.nn.utils.clip_grad_norm_, upstream :311) on the flat bucket,
         fused AdamW, monitored gradient norms."""
-        self.optimizer.step(self.config["max_grad_norm"])
+        self.optimizer.step(self.config["max_grad_norm"], grad_scale=self._grad_scale())
         return self._grad_group_norms() if monitor else None
 
     def _train_step_graph(self, idx, learning_rate, clip_range, beta, monitor):
@@ -916,7 +931,7 @@ class PPOTrainer:
             self._train_warm += 1
             st = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
             if dp is not None:
-                dp.all_reduce_grads()
+                dp.all_reduce_grads(average=False)
             nm = self._train_body_b(monitor)
             return st.clone(), (nm.clone() if nm is not None else None)
         if self._train_graph is None or self._tg_key != key:
@@ -937,7 +952,7 @@ class PPOTrainer:
         ga, gb = self._train_graph
         ga.replay()
         if gb is not None:
-            dp.all_reduce_grads()
+            dp.all_reduce_grads(average=False)
             gb.replay()
         return self._tg_stats.clone(), (self._tg_norms.clone() if monitor else None)
 

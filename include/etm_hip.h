@@ -241,11 +241,14 @@ int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const 
  *                    be NULL).  Runs after the data-parallel all-reduce of g.
  *   etm_adamw_clip : total norm = sqrt(sum partial) -> coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping);
  *                    g *= coef (written back), decoupled weight decay, AdamW update with bias corrections from *step, lr read
- *                    from *lr_dev.  norm_out (optional) receives the un-clipped total norm.
+ *                    from *lr_dev.  norm_out (optional) receives the un-clipped total norm.  grad_scale > 0: the arena holds
+ *                    gradient / grad_scale (data parallel: the all-reduced SUM over `world` ranks, grad_scale = 1 / world); norm
+ *                    and written-back gradient are those of arena * grad_scale (the division rides in the clip coefficient
+ *                    instead of costing a pass over the arena); 1.0f leaves every bit as without it.
  * Device-resident lr / step make the pair replayable inside a captured HIP graph. */
 int etm_grad_sqnorm(const float *g, int64_t n, float *partial, int n_partial, int64_t *step, void *stream);
 int etm_adamw_clip(float *p, float *g, float *m, float *v, int64_t n, const float *partial, int n_partial, const float *lr_dev,
-                   const int64_t *step, double beta1, double beta2, double eps, double weight_decay, float max_norm, float *norm_out,
+                   const int64_t *step, double beta1, double beta2, double eps, double weight_decay, float max_norm, float grad_scale, float *norm_out,
                    void *stream);
 
 /* Output heads on the rollout path (model.py:108-110): h [W, 2*hid] = [relu(lin_policy) | relu(lin_value)] rows;

@@ -70,6 +70,50 @@ def test_data_parallel_world_size_2(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _worker4(rank, world, port, out_dir):
+    """World size 4 with UNEVEN per-rank sample counts: the merged advantage statistics and the summed-then-scaled gradient (the
+    trainer's all_reduce_grads(average=False) + grad_scale in the optimiser step) against the global quantities."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, PKG)
+    from etm.dist import DataParallel
+    dp = DataParallel(device=torch.device("cpu"), backend="gloo")      # collective 'etm' requested by default: must agree on torch
+    assert dp.active and dp.world == 4 and dp.collective == "torch" and abs(dp.grad_scale - 0.25) < 1e-12
+    g = torch.Generator().manual_seed(11)
+    counts = [10, 25, 40, 25]                                          # e.g. ranks whose minibatches hold different sample counts
+    adv = torch.randn((sum(counts),), generator=g) * 2 - 0.5
+    lo = sum(counts[:rank])
+    mine = adv[lo: lo + counts[rank]]
+    # k = 3 independent minibatches merged row-wise with ONE all-gather (what the trainer does per epoch)
+    rows = []
+    for k in range(3):
+        m = mine * (k + 1)
+        rows.append(torch.stack([torch.tensor(float(m.numel())), m.mean(), ((m - m.mean()) ** 2).sum()]))
+    merged = dp.merge_adv_stats(torch.stack(rows))
+    for k in range(3):
+        a = adv * (k + 1)
+        want = torch.stack([torch.tensor(float(a.numel())), a.mean(), ((a - a.mean()) ** 2).sum()])
+        assert torch.allclose(merged[k], want, rtol=1e-5, atol=1e-5), (k, merged[k], want)
+        assert abs(float(torch.sqrt(merged[k][2] / (merged[k][0] - 1))) - float(a.std())) < 1e-4      # torch.std: unbiased
+    # gradient exchange: sum over ranks, 1 / world applied by the consumer
+    dp.flat = torch.full((1000,), float(rank + 1))
+    dp.all_reduce_grads(average=False)
+    assert torch.equal(dp.flat, torch.full((1000,), 10.0))
+    assert torch.allclose(dp.flat * dp.grad_scale, torch.full((1000,), 2.5))
+    dp.flat = torch.full((7,), float(rank))
+    dp.all_reduce_grads()                                              # average=True: the stand-alone form
+    assert torch.allclose(dp.flat, torch.full((7,), 1.5))
+    assert dp.max_over_ranks(float(10 - rank)) == 10.0
+    dp.barrier()
+    dp.close()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_data_parallel_world_size_4_uneven_counts(tmp_path):
+    world, port = 4, _free_port()
+    mp.spawn(_worker4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1", "ok2", "ok3"]
+
+
 def test_single_process_is_passthrough():
     sys.path.insert(0, PKG)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):

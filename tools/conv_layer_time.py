@@ -1,5 +1,5 @@
 """Training-side encoder kernels one by one (N = 2048, 3 x 84 x 84): HIP-event time and TFLOP/s of forward / backward-data /
-backward-weight of every layer through the C ABI.  ETM_DIAG_LIB selects another build of the library (CG_DIAG variants).
+backward-weight of every layer through the C ABI (tools/kernel_rooflines.py encoder is the bench.py form of the same figures).
 python tools/conv_layer_time.py [N]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
