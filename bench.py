@@ -408,7 +408,7 @@ def main():
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
-                       "rollout_team_placement": cfg.get("rollout_team_placement", "member_xcd")},
+                       "rollout_team_placement": cfg.get("rollout_team_placement", "team_xcd")},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline if roofline is not None else roofline_train,
             "roofline_train": roofline_train,

@@ -85,7 +85,7 @@ struct RfParams {
   int merge_gate;                    // GRU gates: the maps of y / of x as one product each (small D) or as separate column blocks
   int pre_ln, gtrxl;                 // block layout: LayerNorm before (pre) or after (post) the sub-layers; GRU gates instead of residuals
   // tail (optional, wkv != nullptr): the new memory items into the bank, their K | V projection into the cache
-  const float *wkv;                  // [nb, D, 2D]: per block [Wk ; Wv]^T
+  const float *wkv;                  // [nb][P][D][2D / P]: per block and member [its columns of Wk^T | its columns of Wv^T]
   const float *pos;                  // [T, D] positional rows added to the items before the projection, or nullptr
   const long long *step_l, *slot_l;  // [W] episode step / memory slot of this step (the latch of etm_rollout_window)
   float *kv_out;                     // = kv (written at row step_l[w])
@@ -772,13 +772,13 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     }
   }
   // ---- tail, after the hand-over (the host is stepping the environments now): bank[slot, step, b] = item_b (member 0) and
-  // cache[w, step, b] = (item_b + pos[step]) [Wk ; Wv]^T, my 2D / P columns (transformer.py:236-237 applied to one new row;
+  // cache[w, step, b] = (item_b + pos[step]) [Wk ; Wv]^T, the D / P columns of K and of V that I read (transformer.py:236-237 applied to one new row;
   // the rows of this step are not part of any window of this launch that is still being read: a member gets here only after
   // its last exchange, i.e. after every partner's last attention phase).
   if (p.wkv) {
     const float pos_r = (p.pos && tid < D) ? p.pos[step_w * D + tid] : 0.f;   // positional row of this step, my element
-    const int OUTK = 2 * D, KS = OUTK / P, k0c = me * KS;
-    const float *wkv_m = p.wkv + (long long)me * D * KS;            // [nb][P][D][KS]: my contiguous block of block 0
+    const int OUTK = 2 * D, KS = OUTK / P;
+    const float *wkv_m = p.wkv + (long long)me * D * KS;            // [nb][P][D][KS]: my contiguous block of block 0 = [my K columns | my V columns]
     const long long wkv_b = (long long)P * D * KS;
     gemv_issue<GR>(wr, wkv_m, D, 0, KS, 0, KS, 0);
     for (int b = 0; b < p.nb; ++b) {
@@ -800,8 +800,13 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       gemv_finish<GR>(wr, wb, D, t_s, part_s, 0, D, KS, 0, KS);
       if (b + 1 < p.nb) gemv_issue<GR>(wr, wb + wkv_b, D, 0, KS, 0, KS, 0);
       rf_sync();
-      if (tid < KS)
-        p.kv_out[(long long)w * p.kv_w_stride + step_w * p.kv_row_stride + (long long)b * OUTK + k0c + tid] = gemv_sum(part_s, KS, tid);
+      // my block of wkv holds MY K columns followed by MY V columns (the D / P columns this member reads in the attention
+      // phases): the cache columns a member reads are only ever written by that member -- no data flows between members through
+      // plain memory, so nothing depends on where the members of a team are placed
+      if (tid < KS) {
+        const int col = (tid < DS) ? d0 + tid : D + d0 + (tid - DS);
+        p.kv_out[(long long)w * p.kv_w_stride + step_w * p.kv_row_stride + (long long)b * OUTK + col] = gemv_sum(part_s, KS, tid);
+      }
       rf_sync();
     }
   }
@@ -874,9 +879,10 @@ extern "C" int etm_diag_rollout_trxl_stamps(long long *out) {
 
 extern "C" int etm_rollout_trxl_team(int H) { return (H % 4 == 0) ? 4 : ((H % 2 == 0) ? 2 : 1); }
 
-// Placement of a launch's workgroups (process-wide, read at launch): 0 = a team's members on one XCD, 1 = one member index per
-// XCD (its weight slices stay resident in that XCD's L2).  Results do not depend on it.
-static int g_rf_placement = 1;
+// Placement of a launch's workgroups (process-wide, read at launch): 0 (default) = a team's members on one XCD, 1 = one member
+// index per XCD.  Results do not depend on it: members communicate through system-scope packets only, and every cache / bank
+// location a member reads was written by itself or by an earlier kernel.
+static int g_rf_placement = 0;
 extern "C" int etm_rollout_trxl_set_placement(int mode) {
   if (mode != 0 && mode != 1) return ETM_EINVAL;
   g_rf_placement = mode;

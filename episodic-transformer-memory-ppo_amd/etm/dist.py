@@ -203,7 +203,9 @@ class DataParallel:
         if self.collective == "etm":
             from . import lib as _lib
             if self._comm is None:
-                raise RuntimeError("library communicator missing (DataParallel creates it at construction)")
+                if self.world != 1:
+                    raise RuntimeError("library communicator missing (DataParallel creates it at construction)")
+                self._comm = self._single_rank_comm()     # world size 1 with the collective forced on (tests): no rendezvous needed
             rc = _lib.load().etm_allreduce_f32(self._comm, self.flat.data_ptr(), self.flat.data_ptr(), self.flat.numel(),
                                                torch.cuda.current_stream(self.flat.device).cuda_stream)
             _lib.check(rc, "etm_allreduce_f32")
@@ -211,6 +213,17 @@ class DataParallel:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if average:
             self.flat.div_(self.world)
+
+    def _single_rank_comm(self):
+        import ctypes
+        from . import lib as _lib
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(lib.etm_comm_unique_id(buf), "etm_comm_unique_id")
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(torch.device(self.device)):
+            _lib.check(lib.etm_comm_init(bytes(buf.raw), 0, 1, ctypes.byref(comm)), "etm_comm_init")
+        return comm
 
     @property
     def grad_scale(self):

@@ -97,9 +97,10 @@ class PPOTrainer:
             raise RuntimeError("PPOTrainer needs an MI355X (HIP) device: this build has no CPU training path "
                                "(the CPU restatement under oracle/ is test infrastructure only)")
         etm_lib.load()  # fail loudly if the kernels are not built
-        # placement of the rollout step kernel's workgroups: "member_xcd" (default) keeps each XCD on one member's weight slices
-        # (L2-resident from step to step), "team_xcd" puts a worker's whole team on one XCD (round 2's placement)
-        placement = {"team_xcd": 0, "member_xcd": 1}[config.get("rollout_team_placement", "member_xcd")]
+        # placement of the rollout step kernel's workgroups: "team_xcd" (default) puts a worker's whole team on one XCD (its
+        # exchanges stay inside that XCD), "member_xcd" gives every XCD one member index (it then only touches that member's weight
+        # slices).  Measured equal (111.9 vs 112.2 us per step graph); results do not depend on it (parity test path member_xcd)
+        placement = {"team_xcd": 0, "member_xcd": 1}[config.get("rollout_team_placement", "team_xcd")]
         etm_lib.check(etm_lib.load().etm_rollout_trxl_set_placement(placement), "etm_rollout_trxl_set_placement")
         self.config = config
         self.device = device
@@ -661,9 +662,12 @@ class PPOTrainer:
             if self.device.type == "cuda":
                 # the step kernel's tail reads the projection weights member-blocked: [blocks, P, D, 2D / P] (fixed address)
                 team = etm_lib.load().etm_rollout_trxl_team(tr.num_heads)
-                w = self._kv_weights[0]
-                if w.shape[2] % team == 0:
-                    wb = w.reshape(w.shape[0], w.shape[1], team, w.shape[2] // team).permute(0, 2, 1, 3)
+                w = self._kv_weights[0]                                    # [blocks, D, 2D] = [Wk^T | Wv^T]
+                if w.shape[2] % (2 * team) == 0:
+                    # member m's block = [its D / P columns of K | its D / P columns of V]: exactly the cache columns it reads in the
+                    # attention phases, so the cache rows a member reads are only ever written by that member
+                    nb_, d_, d2_ = w.shape
+                    wb = w.reshape(nb_, d_, 2, team, d2_ // (2 * team)).permute(0, 3, 1, 2, 4).reshape(nb_, team, d_, d2_ // team)
                     if getattr(self, "_kv_w_blocked", None) is None:
                         self._kv_w_blocked = wb.contiguous()
                     else:
@@ -884,7 +888,7 @@ class PPOTrainer:
         if stats3 is None:
             stats3 = ops.adv_stats(mb["advantages"])
         loss, stats = ops.ppo_loss(logits, value, mb["actions"], mb["log_probs"], mb["advantages"], mb["values"], clip_range,
-                                   self.config["value_loss_coefficient"], beta, stats3, dyn=self._dyn)
+                                   self.config["value_loss_coefficient"], beta, stats3, dyn=getattr(self, "_dyn", None))
         # backward() hands every parameter its gradient tensor (no accumulate launch while .grad is None); ONE multi-tensor copy
         # packs them into the flat bucket that the all-reduce, clipping and the fused AdamW read -- ~50 launches fewer per step
         # than accumulating into the zeroed bucket (the python-side re-aliasing below costs nothing under graph replay)
@@ -898,6 +902,27 @@ class PPOTrainer:
         for p, v in zip(self.params, self._grad_views):
             p.grad = v
         return stats
+
+    def minibatch_gradients(self, idx, clip_range: float, beta: float) -> dict:
+        """Un-clipped gradient of the PPO loss (trainer.py:276-310) on the minibatch ``idx`` (flat sample indices of the prepared
+        buffer) under the current weights: {parameter name: tensor}.  No optimiser step, no schedule side effects -- for parity
+        tests and diagnostics (the gradient is what `loss.backward()` leaves in `.grad` before upstream's clip_grad_norm_)."""
+        idx = torch.as_tensor(np.asarray(idx.cpu() if torch.is_tensor(idx) else idx), device=self.device, dtype=torch.long)
+        if self.config.get("sort_minibatch", True):
+            idx = idx.sort().values
+        with torch.no_grad():
+            self._bank_pos = self._bank_with_positions()
+            self._obs_train = self._observations_channels_last()
+        if self._use_train_graph:
+            self._dyn.copy_(torch.tensor([clip_range, beta], dtype=torch.float64))
+            self._sched_host[1:] = [clip_range, beta]
+        stats3 = None
+        if self.dp is not None:
+            stats3 = self.dp.merge_adv_stats(ops.adv_stats(self.buffer.samples_flat["advantages"].index_select(0, idx)))
+        self._train_body_a(idx, clip_range, beta, stats3)
+        grads = {n: p.grad.detach().clone() for n, p in self.model.named_parameters() if p.requires_grad}
+        self._bank_pos = None
+        return grads
 
     def _train_body_b(self, monitor):
         """Second half: global-norm clipping (same rule as torch.nn.utils.clip_grad_norm_, upstream :311) on the flat bucket,

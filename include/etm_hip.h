@@ -276,8 +276,8 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *   h_in [W, D]: transformer input (model.py:96-100); wemb_t [P][D][D / P], bemb [D]: linear_embedding (transposed, member-blocked);
  *   blocks: HOST array of nb x 19 device pointers (wq_t, wo_t, bo, norm1 gain, norm1 bias, wfc_t, bfc, norm2 gain, norm2 bias; gate1:
  *           wy_t = [Wr | Wz | Wg]^T, ux_t = [Ur | Uz]^T, ug_t, bg; gate2: the same four; norm_kv gain, norm_kv bias).  Layouts: *_t =
- *           the weight TRANSPOSED ([in, out]); every matrix that is split by COLUMNS over the team (wemb_t, wq_t, wfc_t, ug_t, wh_t and
- *           wkv per block) is MEMBER-BLOCKED: [P][in][out / P], member m's columns m * out / P ... as one contiguous block (wo_t is
+ *           the weight TRANSPOSED ([in, out]); every matrix that is split by COLUMNS over the team (wemb_t, wq_t, wfc_t, ug_t, wh_t)
+ *           is MEMBER-BLOCKED: [P][in][out / P], member m's columns m * out / P ... as one contiguous block (wo_t is
  *           split by rows and stays [D, D]); wy_t / ux_t are [P][D][j * D / P] (j = 3 / 2 maps side by side per member) if
  *           etm_rollout_trxl_gate_merged(D, H) and [P][j][D][D / P] otherwise; the
  *           gate pointers are read with gtrxl != 0 (GRU gates instead of residuals, transformer.py:255-298), the norm_kv pair by the
@@ -296,14 +296,15 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *   h_splits > 0: h_in is [h_splits, W, D] from etm_rollout_hidden_partial and the input is relu(sum over slices + h_bias [D]);
  *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
  *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
- *           pos[step_l[w]]) wkv[b]  (wkv [nb][P][D][2D / P] = per block [Wk ; Wv]^T member-blocked, pos [T, D] or NULL; transformer.py:236-237 for the
- *           one new row) -- the memory-bank write and K | V projection of trainer.py:174.
+ *           pos[step_l[w]]) [Wk ; Wv]^T  (wkv [nb][P][D][2D / P]: member m's block of a block's [Wk^T | Wv^T] = its D / P columns of Wk^T
+ *           followed by its D / P columns of Wv^T -- the cache columns member m reads are written by member m only; pos [T, D] or NULL;
+ *           transformer.py:236-237 for the one new row) -- the memory-bank write and K | V projection of trainer.py:174.
  * Shape support: etm_rollout_trxl_supported(D, H, L, hid, A, nb) == 1 (D % (4 P) == 0, D <= 512, D / P <= 128, 2 hid / P <= 256,
- * H <= 8, L <= 128, nb <= 8, A < 64) and at most 256 workgroups (8 ceil(W / 8) P); ETM_EUNSUPPORTED otherwise. */
+ * H <= 8, L <= 128, nb <= 8, A < 64) and at most 256 workgroups (etm_rollout_trxl_grid(W, H)); ETM_EUNSUPPORTED otherwise. */
 int etm_rollout_trxl_team(int H);
-/* Workgroup placement of the step kernel (process-wide; results do not depend on it): 0 = the P members of a worker's team on one
- * XCD, 1 (default) = XCD x hosts member x % P of an 8 / P-th of the workers, so that an XCD only ever reads one member's slice of
- * every matrix and those slices stay resident in its L2 from step to step.  etm_rollout_trxl_grid(W, H): workgroups of one launch
+/* Workgroup placement of the step kernel (process-wide; results do not depend on it): 0 (default) = the P members of a worker's
+ * team on one XCD, 1 = XCD x hosts member x % P of an 8 / P-th of the workers, so that an XCD only ever reads one member's slice of
+ * every matrix.  etm_rollout_trxl_grid(W, H): workgroups of one launch
  * under the current placement -- all of them must be resident at once (<= 256 on the MI355X), else ETM_EUNSUPPORTED. */
 int etm_rollout_trxl_set_placement(int mode);
 int etm_rollout_trxl_grid(int W, int H);

@@ -433,16 +433,17 @@ def golden_rollout(only=None):
                                transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=8,
                                                 positional_encoding="relative", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))),
         # ---- BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the real
-        # reference.  Episodes are long enough that windows slide past L, hit the max_episode_steps cut and restart.
+        # reference.  Episodes are long enough that windows slide past L, hit the max_episode_steps cut and restart; at least
+        # three optimiser steps each, so that the GPU trainer's captured optimisation graph (two eager warm-up steps) replays.
         # config 3: minigrid.yaml model (post-LN TrXL, D 384, H 4, L 64, 3 blocks, hidden 384) on 3x84x84 observations, 32 workers
         "cfg3": dict(env=dict(obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=17, p_done=0.006, p_reward=0.05, pool=8),
-                     cfg=dict(gamma=0.995, lamda=0.95, updates=2, epochs=1, n_workers=32, worker_steps=80, n_mini_batch=1,
+                     cfg=dict(gamma=0.995, lamda=0.95, updates=2, epochs=2, n_workers=32, worker_steps=80, n_mini_batch=1,
                               value_loss_coefficient=0.5, hidden_layer_size=384, max_grad_norm=0.5,
                               transformer=dict(num_blocks=3, embed_dim=384, num_heads=4, memory_length=64,
                                                positional_encoding="relative", layer_norm="post", gtrxl=False, gtrxl_bias=0.0))),
         # config 5: pre-LN GTrXL, D 384, H 4, L 128, 4 blocks on 3x84x84 observations (episodes of up to 144 steps: the window slides)
         "cfg5": dict(env=dict(obs_shape=(3, 84, 84), num_actions=4, max_episode_steps=144, seed=19, p_done=0.004, p_reward=0.05, pool=8),
-                     cfg=dict(gamma=0.995, lamda=0.95, updates=1, epochs=1, n_workers=16, worker_steps=150, n_mini_batch=1,
+                     cfg=dict(gamma=0.995, lamda=0.95, updates=1, epochs=3, n_workers=16, worker_steps=150, n_mini_batch=1,
                               value_loss_coefficient=0.5, hidden_layer_size=384, max_grad_norm=0.25,
                               transformer=dict(num_blocks=4, embed_dim=384, num_heads=4, memory_length=128,
                                                positional_encoding="relative", layer_norm="pre", gtrxl=True, gtrxl_bias=0.0))),
@@ -505,11 +506,25 @@ def golden_rollout(only=None):
             else:
                 out[tag + "memories"] = b.memories.clone()
             perms_all.clear()
+            grads_rec = []
+            real_clip = torch.nn.utils.clip_grad_norm_
+
+            def rec_clip(params, *a, **k):
+                # trainer.py:311 -- the gradients of the FIRST minibatch of the update as loss.backward() left them (un-clipped)
+                if not grads_rec:
+                    grads_rec.append({n: p.grad.detach().clone() for n, p in tr.model.named_parameters()})
+                return real_clip(params, *a, **k)
+
             torch.randperm = rec_randperm
+            torch.nn.utils.clip_grad_norm_ = rec_clip
             try:
                 stats, _ = tr._train_epochs(lr, clip, beta)
             finally:
                 torch.randperm = real_randperm
+                torch.nn.utils.clip_grad_norm_ = real_clip
+            for k, g in grads_rec[0].items():
+                out[tag + "grad0_sample/" + k] = dg.sample(g.numpy(), 64)
+                out[tag + "grad0_norm/" + k] = np.float64(g.double().norm())
             out[tag + "perms"] = torch.stack(perms_all)
             out[tag + "stats"] = np.asarray(stats, dtype=np.float64)
             out[tag + "hp"] = np.array([lr, clip, beta], dtype=np.float64)

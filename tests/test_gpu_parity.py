@@ -209,6 +209,9 @@ def test_actor_critic_gradients_away_from_the_relu_kink(golden_dir):
         assert rel <= NOKINK_GRAD_REL, (k, rel)
         assert abs(float(np.linalg.norm(p.grad.detach().cpu().numpy().astype(np.float64))) - norm) <= 10 * NOKINK_GRAD_REL * norm, k
     print(f"[nokink] worst element error of any gradient tensor / its norm: {worst:.2e} (bound {NOKINK_GRAD_REL:.0e})")
+    if os.environ.get("ETM_TF_MEASURE_LOG"):
+        with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
+            f.write(json.dumps({"case": "model_nokink", "grad_worst_element_over_norm": worst}) + "\n")
 
 
 # ------------------------------------------------------------------ kernel #1 vs the oracle: banked gather, LN, positions, Q5
@@ -423,6 +426,7 @@ _ROLLOUT_PATHS = {
     "library_hidden": {"split_hidden_product": False},        # lin_hidden of a rollout step by the library GEMM, not as K-slice sums
     "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
+    "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
@@ -431,7 +435,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("img32", "state_uploaded"), ("img32", "library_hidden"), ("img32", "window_launch"),
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
-             ("cfg5", "default"), ("cfg5", "eager")]
+             ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -483,10 +487,15 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         else:      # image observations: the fixture holds a subsample and the sum
             ob = b.obs.cpu().numpy()
             assert np.array_equal(dg.sample(ob, 8192), z[tag + "obs_sample"]) and np.float64(ob.astype(np.float64).sum()) == z[tag + "obs_sum"]
-        measured = {f: float(np.abs(getattr(b, f).cpu().numpy().astype(np.float64) - z[tag + f]).max()) for f in ("values", "log_probs", "advantages")}
-        close(b.values, z[tag + "values"], atol=TF_ATOL["values"], rtol=0, what="values")
-        close(b.log_probs, z[tag + "log_probs"], atol=TF_ATOL["log_probs"], rtol=0, what="log_probs")
-        close(b.advantages, z[tag + "advantages"], atol=TF_ATOL["advantages"], rtol=0, what="advantages")
+        # error scaled by max(1, |reference|): values / advantages of the cfg2 fixture are O(100) (a reward every step)
+        measured = {f: float((np.abs(getattr(b, f).cpu().numpy().astype(np.float64) - z[tag + f]) / np.maximum(1.0, np.abs(z[tag + f]))).max())
+                    for f in ("values", "log_probs", "advantages")}
+        if os.environ.get("ETM_TF_MEASURE_LOG"):
+            with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
+                f.write(json.dumps({"case": name, "path": path, "update": upd, "stage": "rollout", **measured}) + "\n")
+        bound = tf_bounds(name, upd)
+        for f in ("values", "log_probs", "advantages"):
+            assert measured[f] <= bound["forward"], f"{name}/{path} update {upd}: {f} off by {measured[f]:.2e} (scaled by max(1, |ref|)); bound {bound['forward']:.0e}"
         if tag + "memories" in z:
             e_ref = z[tag + "memories"].shape[0]
             assert b.num_episodes >= e_ref
@@ -500,19 +509,34 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
             assert abs(float(mem.astype(np.float64).sum()) - float(z[tag + "memories_sum"])) < 1e-4 * mem.size ** 0.5 + 1e-3
         lr, clip, beta = (float(x) for x in z[tag + "hp"])
         assert (lr, beta, clip) == tuple(float(x) for x in tr.schedules(upd))
+        # the un-clipped gradient of the update's first minibatch (what loss.backward() leaves behind, trainer.py:310) against the
+        # reference's: error of the sampled elements relative to the tensor's norm (worst tensor) and over all tensors
+        mbs = (W * S) // cfg["n_mini_batch"]
+        grads = tr.minibatch_gradients(z[tag + "perms"][0][:mbs], clip, beta)
+        num = den = g_worst = 0.0
+        g_worst_key = ""
+        for k, g in grads.items():
+            ref, got = z[tag + "grad0_sample/" + k].astype(np.float64), dg.sample(g.cpu().numpy(), 64).astype(np.float64)
+            scale = float(z[tag + "grad0_norm/" + k]) * (ref.size / max(1, g.numel())) ** 0.5      # norm of a 64-element sample of this tensor
+            e = float(np.linalg.norm(got - ref))
+            if scale > 0 and e / scale > g_worst:
+                g_worst, g_worst_key = e / scale, k
+            num, den = num + e * e, den + float(np.sum(ref ** 2))
+        g_all = (num / max(den, 1e-300)) ** 0.5
+        print(f"[teacher-forced {name}/{path} update {upd}] gradient error: all tensors {g_all:.2e}, worst tensor {g_worst:.2e} = {g_worst_key}")
         stats, _ = tr._train_epochs(lr, clip, beta, perms=z[tag + "perms"])
-        st_err = np.abs(np.asarray(stats, dtype=np.float64) - z[tag + "stats"])
-        measured["stats_abs"] = float(st_err.max())
-        measured["stats_rel"] = float((st_err / (np.abs(z[tag + "stats"]) + TF_STATS_ATOL / TF_STATS_RTOL)).max())
-        close(np.asarray(stats), z[tag + "stats"], atol=TF_STATS_ATOL, rtol=TF_STATS_RTOL, what="stats")
+        st_err = np.abs(np.asarray(stats, dtype=np.float64) - z[tag + "stats"]) / np.maximum(1.0, np.abs(z[tag + "stats"]))
+        measured["stats"] = float(st_err.max())
+        assert measured["stats"] <= bound["stats"], f"{name}/{path} update {upd}: loss statistics off by {measured['stats']:.2e}; bound {bound['stats']:.0e}"
         worst, worst_key, overall = movement_error(tr.model.state_dict(), z, tag, keys, prev)
-        measured.update(move_all=overall, move_worst=worst)
+        measured.update(move_all=overall, move_worst=worst, grad_all=g_all, grad_worst=g_worst)
+        assert g_all <= TF_GRAD_TOL_ALL and g_worst <= TF_GRAD_TOL_TENSOR, (g_all, g_worst, g_worst_key)
         print(f"[teacher-forced {name}/{path} update {upd}] parameter-movement error: all tensors {overall:.2e}, worst tensor {worst:.2e} = {worst_key}")
         print(f"[teacher-forced {name}/{path} update {upd}] measured: " + ", ".join(f"{k} {v:.2e}" for k, v in measured.items()))
         if os.environ.get("ETM_TF_MEASURE_LOG"):
             with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
                 f.write(json.dumps({"case": name, "path": path, "update": upd, **measured}) + "\n")
-        assert overall <= TF_MOVE_TOL_ALL and worst <= TF_MOVE_TOL_TENSOR, (worst, worst_key, overall)
+        assert overall <= bound["move_all"] and worst <= bound["move_tensor"], (worst, worst_key, overall)
     if name == "img32" and path == "default":
         assert tr._step_graph is not None and tr._stream_obs and len(tr._groups) == 2 and tr._train_graph is not None, \
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
@@ -537,16 +561,35 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
     tr.close()
 
 
-# SURVEY 8c asks for post-step parameters within 1e-4 relative.  Stated on the MOVEMENT of the update (2 - 4 AdamW steps per
-# update) over all tensors: measured 5e-6 ... 7.6e-5 on the MI355X for the four fixtures (the CPU oracle reaches 4e-6 ... 2e-5
-# against the same fixtures), worst single tensor 5.1e-4 (a GRU-gate matrix of the gtrxl case).  The optimiser kernel follows the
-# arithmetic of the reference's single-tensor AdamW operation by operation (csrc/optim.hip); with the framework's fused AdamW,
-# which evaluates the update in double precision, the same comparison gave 1.4e-4 / 2e-2.
-TF_MOVE_TOL_ALL, TF_MOVE_TOL_TENSOR = 1.5e-4, 2e-3
-# absolute bounds on the rollout outputs (values are O(1)) and on the six loss statistics; measured maxima over all fixtures and
-# paths are in profiles/r03/teacher_forced_measured.jsonl, the bounds are about twice those
-TF_ATOL = {"values": 1e-4, "log_probs": 1e-4, "advantages": 5e-4}
-TF_STATS_ATOL, TF_STATS_RTOL = 1e-4, 5e-3
+# ---- Tolerances of the teacher-forced whole-path comparison.  Measured maxima on the MI355X over all fixtures and paths (round 3,
+# profiles/r03/teacher_forced_measured.jsonl); the bounds are 2 - 5 x those.
+#
+#   forward (values, log-probs, advantages; |got - ref| / max(1, |ref|)):  <= 1.0e-6 on the small fixtures in every update,
+#       <= 2.6e-6 at the BASELINE model sizes while the parameters are still the fixture's (update 0); SURVEY 8c asks for 1e-5.
+#       After an optimiser phase the two parameter sets differ by the optimiser's own amplification of rounding noise (below), so
+#       later updates of the BASELINE-size fixtures are bounded at 1e-4 (measured <= 2.9e-5, cfg2 after 8 AdamW steps).
+#   loss statistics (same scaling): <= 5e-7 small, <= 1.3e-5 BASELINE sizes.
+#   gradient of the update's first minibatch against the reference's (un-clipped, trainer.py:310; error of the sampled elements
+#       over the norm): all tensors <= 3.2e-7 small / <= 7.2e-6 BASELINE sizes; worst single tensor 6e-6 / 1.0e-3 (cfg2's
+#       lin_hidden.weight, 512 elements of cancelling O(100)-valued terms; every other tensor <= 7.7e-5).  SURVEY 8c: 1e-4.
+#   post-update parameters, stated on the MOVEMENT of an update (||got - ref|| / ||ref - before|| on the sampled elements; an
+#       absolute tolerance on parameters would hide errors as large as the movement itself): all tensors <= 7.6e-5, worst tensor
+#       5.2e-4 on the small fixtures (the optimiser kernel follows the reference's single-tensor AdamW operation by operation,
+#       csrc/optim.hip).  AdamW's update lr * m_hat / (sqrt(v_hat) + eps) is scale-free in the gradient: an element whose
+#       gradient is of the size of its evaluation noise moves by +-lr whichever way the noise points, so at the BASELINE sizes
+#       (1e6 - 1e7 such terms per gradient element) the movement metric is dominated by those elements although the gradients agree
+#       to 2e-6: measured <= 8.2e-4 / 4.6e-3, and the REFERENCE's own fp32 result is 7.6e-4 / 3.6e-3 away from the evaluation with
+#       exact (float64) gradients and the same fp32 optimiser arithmetic (tools/fp32_noise_floor.py,
+#       profiles/r03/fp32_noise_floor_*.txt).  Bounds there: 2e-3 / 1e-2.
+TF_GRAD_TOL_ALL, TF_GRAD_TOL_TENSOR = 2e-5, 2e-3
+
+
+def tf_bounds(name, upd):
+    big = name.startswith("cfg")
+    return {"forward": 1e-4 if (big and upd > 0) else 5e-6,
+            "stats": 5e-5 if big else 5e-6,
+            "move_all": 2e-3 if big else 1.5e-4,
+            "move_tensor": 1e-2 if big else 1e-3}
 
 
 def test_trainer_self_consistency_and_free_run():
@@ -782,9 +825,12 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
                    beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
                    clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
         snaps = []
-        for fused in (True, False):
+        # the one-launch step under both workgroup placements (a team on one XCD / one member index per XCD: its members exchange
+        # through system-scope packets only, so results must not depend on where they run), then the multi-launch path
+        for fused, placement in ((True, "team_xcd"), (True, "member_xcd"), (False, "team_xcd")):
             c = json.loads(json.dumps(cfg))
             c["fused_rollout_block"] = fused
+            c["rollout_team_placement"] = placement
             torch.manual_seed(17)
             tr = PPOTrainer(c, run_id="fusedstep", device=dev, tensorboard=False)
             with torch.no_grad():
@@ -797,7 +843,9 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
             b = tr.buffer
             snaps.append({k: getattr(b, k).clone() for k in ("actions", "values", "log_probs", "memory_index")} | {"mem": b.memories.clone()})
             tr.close()
-        a, m = snaps
+        a, a2, m = snaps
+        for k in ("actions", "values", "log_probs", "mem"):
+            assert torch.equal(a[k], a2[k]), (D, ln, gtrxl, k, "the two placements of the step kernel must agree bit for bit")
         assert torch.equal(a["memory_index"], m["memory_index"])
         same = (a["actions"] == m["actions"]).float().mean().item()
         assert same > 0.999, same                            # a different action only where a uniform sits on a CDF boundary

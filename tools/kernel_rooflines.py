@@ -279,7 +279,7 @@ def rollout_step(trainer, launches=40):
                                           bytes_per_launch=m["bytes_per_launch"], achieved=gbs, unit="GB/s", peak=HBM_PEAK_GBS,
                                           frac=gbs / HBM_PEAK_GBS, l2_aggregate_peak_gbs=34500.0, frac_of_l2_peak=gbs / 34500.0,
                                           us_per_dependent_phase=us / m["dependent_phases"], model=m,
-                                          placement=trainer.config.get("rollout_team_placement", "member_xcd"))
+                                          placement=trainer.config.get("rollout_team_placement", "team_xcd"))
     return res
 
 
