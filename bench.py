@@ -57,6 +57,9 @@ def kernel_work(name, N, L, D, H):
         import kernel_rooflines
         fl = kernel_rooflines.encoder_flops(N)[int(name[-1]) - 1]
         return "mfma", fl / (2.0 if "wgrad" in name else 1.0)
+    if name == "grouped_dw_kernel":
+        # every [D, D]-sized weight gradient of the step in one launch (config 3: 3 blocks x 5 + embedding + 2 hidden heads)
+        return "mfma", 2.0 * N * D * D * 18
     if name in ("window_fwd_kernel", "window_bwd_kernel"):
         # folded attention pass: the read of the gathered window, L*D*4 B per sample and block (SURVEY.md 8d's algorithmic
         # figure; the H folded vectors in / out and the attention weights are reported separately as extra_bytes_per_launch)

@@ -275,6 +275,98 @@ def folded_supported(D, L, num_heads):
     return D % 32 == 0 and hd % 2 == 0 and ((D <= 512 and L <= 128) or (D <= 1024 and L <= 64))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Deferred weight gradients: dW = dy^T x of the dense layers, collected during backward and computed by ONE grouped launch
+# (csrc/grouped_dw.hip) straight into the flat gradient arena.  Inactive (no collector) every layer computes its own dW as before.
+class DeferredDw:
+    """Context manager around ``loss.backward()``.  ``dest``: {parameter.data_ptr(): gradient view [out, in] in the arena}.
+    Inside, the autograd functions below hand (dy, x, weight) over instead of multiplying; ``flush()`` (called on exit) runs the
+    grouped kernel.  ``written``: data_ptr()s of the parameters whose gradient now sits in its arena view."""
+    active = None
+
+    def __init__(self, dest):
+        self.dest = dest
+        self.items = []          # (A, B, C view, Ma, Nb, lda, ldb, ldc)
+        self.written = set()
+        self.N = None
+
+    def __enter__(self):
+        DeferredDw.active = self
+        return self
+
+    def __exit__(self, *exc):
+        DeferredDw.active = None
+        if exc[0] is None:
+            self.flush()
+        return False
+
+    def offer(self, a, b, weight, row0=0, rows=None, a_col0=0):
+        """C = weight.grad[row0 : row0 + rows] (all rows if None) = a[:, a_col0 : a_col0 + rows]^T b.  a [N, *], b [N, in] contiguous
+        rows.  Returns True when the problem was taken (shape supported, destination known); else the caller multiplies itself."""
+        view = self.dest.get(weight.data_ptr())
+        if view is None or not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2):
+            return False
+        n, nb = b.shape
+        ma = view.shape[0] if rows is None else rows
+        if a.stride(1) != 1 or b.stride(1) != 1 or a.shape[0] != n or (self.N is not None and n != self.N):
+            return False
+        lda, ldb, ldc = a.stride(0), b.stride(0), view.stride(0)
+        lib = _lib.load()
+        if len(self.items) >= lib.etm_grouped_dw_max_problems() or not lib.etm_grouped_dw_supported(n, ma, nb, lda, ldb, ldc):
+            return False
+        c = view[row0: row0 + ma]
+        if view.shape[1] != nb or (_ptr(b) % 16) or (_ptr(c) % 16) or ((_ptr(a) + 4 * a_col0) % 4):
+            return False
+        self.N = n
+        self.items.append((a, b, c, ma, nb, lda, ldb, ldc, a_col0))
+        self.written.add(weight.data_ptr())
+        return True
+
+    def flush(self):
+        if not self.items:
+            return
+        import ctypes
+        k = len(self.items)
+        pa = (ctypes.c_void_p * k)(*[_ptr(it[0]) + 4 * it[8] for it in self.items])
+        pb = (ctypes.c_void_p * k)(*[_ptr(it[1]) for it in self.items])
+        pc = (ctypes.c_void_p * k)(*[_ptr(it[2]) for it in self.items])
+        dims = (ctypes.c_int32 * (5 * k))(*[v for it in self.items for v in it[3:8]])
+        _lib.check(_lib.load().etm_grouped_dw(pa, pb, pc, dims, k, self.N, _stream()), "etm_grouped_dw")
+        self.items = []
+
+
+def _offer_dw(a, b, weight, **kw):
+    col = DeferredDw.active
+    return col is not None and col.offer(a, b, weight, **kw)
+
+
+class _LinearNoBiasFn(torch.autograd.Function):
+    """y = x W^T (transformer.py:26-29 queries / fc_out, :115 fc without their epilogues): library GEMMs for y and dx; the weight
+    gradient goes to the grouped launch when a DeferredDw collector is active."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x.mm(weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _offer_dw(g, x, weight):
+            dw = g.t().mm(x)
+        return dx, dw
+
+
+def linear_nobias(x, weight):
+    """F.linear(x, weight) for 2-D fp32 device tensors under autograd, weight gradient deferrable (see DeferredDw)."""
+    if torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous():
+        return _LinearNoBiasFn.apply(x, weight)
+    return torch.nn.functional.linear(x, weight)
+
+
 class _HeadFoldFn(torch.autograd.Function):
     """u[h] = q_h Wk_h ([N, hd] x [hd, D] per head): q [N, D], wk [D, D] -> u [H, N, D].  The batched library GEMMs read q and write
     dq through per-head strided views (batch stride hd, row stride D), so no head-major copy of q / dq is ever made."""
@@ -299,7 +391,18 @@ class _HeadFoldFn(torch.autograd.Function):
             dq = torch.empty_like(q)
             torch.bmm(du, wk.view(H, hd, D).transpose(1, 2), out=dq.view(N, H, hd).transpose(0, 1))
         if ctx.needs_input_grad[1]:
-            dwk = torch.bmm(q.view(N, H, hd).permute(1, 2, 0), du).view(D, D)
+            # dWk rows of head h = q_h^T du_h: H problems of the grouped launch (A = the head's columns of q, B = its plane of du)
+            col = DeferredDw.active
+            if col is not None and q.is_contiguous():
+                n0 = len(col.items)
+                ok = all(col.offer(q, du[h], wk, row0=h * hd, rows=hd, a_col0=h * hd) for h in range(H))
+                if not ok:
+                    del col.items[n0:]
+                    col.written.discard(wk.data_ptr())
+            else:
+                ok = False
+            if not ok:
+                dwk = torch.bmm(q.view(N, H, hd).permute(1, 2, 0), du).view(D, D)
         return dq, dwk, None
 
 
@@ -326,7 +429,19 @@ class _HeadUnfoldFn(torch.autograd.Function):
         g = g.contiguous()
         gh = g.view(N, H, hd).transpose(0, 1)                      # [H, N, hd], strided
         dz = torch.bmm(gh, wv.view(H, hd, D)) if ctx.needs_input_grad[0] else None
-        dwv = torch.bmm(gh.transpose(1, 2), z).view(D, D) if ctx.needs_input_grad[1] else None
+        dwv = None
+        if ctx.needs_input_grad[1]:
+            # dWv rows of head h = g_h^T z_h: H problems of the grouped launch
+            col = DeferredDw.active
+            ok = False
+            if col is not None and z.is_contiguous():
+                n0 = len(col.items)
+                ok = all(col.offer(g, z[h], wv, row0=h * hd, rows=hd, a_col0=h * hd) for h in range(H))
+                if not ok:
+                    del col.items[n0:]
+                    col.written.discard(wv.data_ptr())
+            if not ok:
+                dwv = torch.bmm(gh.transpose(1, 2), z).view(D, D)
         return dz, dwv, None
 
 
@@ -909,7 +1024,9 @@ class _LinearReluFn(torch.autograd.Function):
         ws = workspace(nbytes, g.device, "relu_bwd")
         _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), _ptr(db), _ptr(ws), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
         dx = gm.mm(weight) if ctx.needs_input_grad[0] else None
-        dw = gm.t().mm(x) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _offer_dw(gm, x, weight):
+            dw = gm.t().mm(x)
         return dx, dw, db
 
 

@@ -829,12 +829,22 @@ class PPOTrainer:
                                    samples["values"], clip_range, self.config["value_loss_coefficient"], beta, stats3)
         self._set_lr(learning_rate)
         self.flat_grads.zero_()
-        loss.backward()
+        with ops.DeferredDw(self._dw_destinations()):      # dense-layer weight gradients: one grouped launch into the arena
+            loss.backward()
         if self.dp is not None:
             self.dp.all_reduce_grads(average=False)       # the sum; the 1 / world rides in the clip coefficient below
         # global-norm clipping (the rule of torch.nn.utils.clip_grad_norm_, upstream :311) + AdamW on the flat arenas: 2 launches
         self.optimizer.step(self.config["max_grad_norm"], grad_scale=self._grad_scale())
         return stats
+
+    def _dw_destinations(self):
+        """{parameter data_ptr: its [out, in] gradient view in the flat arena} for the 2-D parameters (``grouped_dw_train: false`` in
+        the config: empty, every layer multiplies its own weight gradient)."""
+        if not self.config.get("grouped_dw_train", True):
+            return {}
+        if getattr(self, "_dw_dest", None) is None:
+            self._dw_dest = {p.data_ptr(): v for p, v in zip(self.params, self._grad_views) if p.dim() == 2}
+        return self._dw_dest
 
     def _grad_scale(self):
         return self.dp.grad_scale if self.dp is not None else 1.0
@@ -894,11 +904,17 @@ class PPOTrainer:
         # than accumulating into the zeroed bucket (the python-side re-aliasing below costs nothing under graph replay)
         for p in self.params:
             p.grad = None
-        loss.backward()
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):        # parameter outside this graph (e.g. an unused head): zero gradient
-            grads = [torch.zeros_like(v) if g is None else g for g, v in zip(grads, self._grad_views)]
-        torch._foreach_copy_(self._grad_views, grads)
+        # the weight gradients of the dense layers (dW = dy^T x, a contraction over the minibatch with a small output) are collected
+        # during backward and computed by ONE grouped launch straight into their arena views (csrc/grouped_dw.hip)
+        with ops.DeferredDw(self._dw_destinations()) as dw:
+            loss.backward()
+        views, grads = [], []
+        for p, v in zip(self.params, self._grad_views):
+            if p.data_ptr() in dw.written:
+                continue                             # already in the arena
+            views.append(v)
+            grads.append(p.grad if p.grad is not None else torch.zeros_like(v))   # None: parameter outside this graph (unused head)
+        torch._foreach_copy_(views, grads)
         for p, v in zip(self.params, self._grad_views):
             p.grad = v
         return stats

@@ -37,14 +37,14 @@ class MultiHeadAttention(nn.Module):
     def attend(self, query, spec: WindowSpec, block=0, pos=None, norm_kv=None, raw=False):
         """query [N, D] -> (output [N, D], attention [N, H, L]); window rows come from ``spec``.  ``raw``: the output is
         ``ctx fc_out.weight^T`` WITHOUT ``fc_out.bias`` (the caller folds the bias into the kernel that follows)."""
-        q = self.queries(query)
+        q = ops.linear_nobias(query, self.queries.weight)
         ln_g = ln_b = None
         eps = 1e-5
         if norm_kv is not None:
             ln_g, ln_b, eps = norm_kv.weight, norm_kv.bias, norm_kv.eps
         ctx, att = ops.mha(q, self.keys.weight, self.values.weight, spec, block, self.num_heads, ln_g, ln_b, pos, eps)
         if raw:
-            return torch.nn.functional.linear(ctx, self.fc_out.weight), att
+            return ops.linear_nobias(ctx, self.fc_out.weight), att
         return self.fc_out(ctx), att
 
     def forward(self, values, keys, queries, mask):
@@ -127,7 +127,7 @@ class TransformerBlock(Module):
             att_raw, att_w = self.attention.attend(q_in, spec, block, pos, None, raw=True)
             x = ops.fused_layernorm(att_raw, self.norm1, bias=self.attention.fc_out.bias, res=h)
             fc = self.fc[0]
-            f_raw = torch.nn.functional.linear(x, fc.weight)
+            f_raw = ops.linear_nobias(x, fc.weight)
             return ops.fused_layernorm(f_raw, self.norm2, bias=fc.bias, res=x, relu=True), att_w
         att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
         return self._after_attention(h, att_out), att_w

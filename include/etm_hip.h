@@ -234,6 +234,22 @@ int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const 
                         void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Weight gradients of the dense layers of one optimisation step as ONE grouped launch: replaces the `dW = dy^T x` products that
+ * `loss.backward()` (trainer.py:310) issues one by one for transformer.py:26-29 (queries / keys / values / fc_out), :115 (fc),
+ * :201 (linear_embedding) and model.py:97-107 (lin_policy, lin_value) -- contractions over the N samples of the minibatch with a
+ * small [out, in] result, which only fill the chip when all layers' gradients are computed together.
+ *   C[p] (Ma x Nb, row stride ldc) = A[p]^T B[p];  A[p] [N, Ma] (row stride lda) = the layer's output gradient, B[p] [N, Nb] (row
+ *   stride ldb) = its input; per-head key / value folds are H problems each (the head's columns of A, the head's plane of B, the
+ *   head's rows of C).  A / B / C: HOST arrays of n_problems device pointers; dims: HOST array of 5 ints per problem
+ *   (Ma, Nb, lda, ldb, ldc).  Shapes: etm_grouped_dw_supported(N, Ma, Nb, lda, ldb, ldc) == 1 (Ma % 96 == 0, Nb % 128 == 0, strides
+ *   multiples of 4 floats, byte offsets below 2^31); B and C 16-byte aligned; n_problems <= etm_grouped_dw_max_problems().
+ *   C is overwritten; fp32 MFMA; the four k-ranges of a workgroup are summed in a fixed order (deterministic). */
+int etm_grouped_dw_supported(int N, int Ma, int Nb, int lda, int ldb, int ldc);
+int etm_grouped_dw_max_problems(void);
+int etm_grouped_dw(const float *const *A, const float *const *B, float *const *C, const int32_t *dims, int n_problems, int N,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimiser step on flat fp32 arenas, replaces `clip_grad_norm_(parameters, max_grad_norm)` + `optimizer.step()` of
  * trainer.py:311-312 (torch.optim.AdamW: betas (0.9, 0.999), eps 1e-8, weight_decay 0.01 unless the caller says otherwise).
  * p / g / m / v: parameter, gradient, exp_avg, exp_avg_sq arenas of n floats (n % 4 == 0, 16-byte aligned; padding zero).

@@ -166,8 +166,8 @@ def test_actor_critic_vs_reference(golden_dir):
                 grad_close(p.grad, z, tag, k, 96, rel=1e-3)
 
 
-# Measured on the MI355X (round 3): see the printed line of the test; bounds are 2 x measured, rounded up.
-NOKINK_GRAD_REL = 2e-4
+# Measured on the MI355X (round 3): 3.4e-7 (profiles/r03/teacher_forced_measured.jsonl, case model_nokink).
+NOKINK_GRAD_REL = 2e-6
 
 
 def test_actor_critic_gradients_away_from_the_relu_kink(golden_dir):
@@ -530,7 +530,7 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         assert measured["stats"] <= bound["stats"], f"{name}/{path} update {upd}: loss statistics off by {measured['stats']:.2e}; bound {bound['stats']:.0e}"
         worst, worst_key, overall = movement_error(tr.model.state_dict(), z, tag, keys, prev)
         measured.update(move_all=overall, move_worst=worst, grad_all=g_all, grad_worst=g_worst)
-        assert g_all <= TF_GRAD_TOL_ALL and g_worst <= TF_GRAD_TOL_TENSOR, (g_all, g_worst, g_worst_key)
+        assert g_all <= bound["grad_all"] and g_worst <= bound["grad_tensor"], (g_all, g_worst, g_worst_key)
         print(f"[teacher-forced {name}/{path} update {upd}] parameter-movement error: all tensors {overall:.2e}, worst tensor {worst:.2e} = {worst_key}")
         print(f"[teacher-forced {name}/{path} update {upd}] measured: " + ", ".join(f"{k} {v:.2e}" for k, v in measured.items()))
         if os.environ.get("ETM_TF_MEASURE_LOG"):
@@ -581,12 +581,13 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 #       to 2e-6: measured <= 8.2e-4 / 4.6e-3, and the REFERENCE's own fp32 result is 7.6e-4 / 3.6e-3 away from the evaluation with
 #       exact (float64) gradients and the same fp32 optimiser arithmetic (tools/fp32_noise_floor.py,
 #       profiles/r03/fp32_noise_floor_*.txt).  Bounds there: 2e-3 / 1e-2.
-TF_GRAD_TOL_ALL, TF_GRAD_TOL_TENSOR = 2e-5, 2e-3
-
-
+#       (At the BASELINE sizes the gradient of a LATER update is taken at parameters that already differ by that movement noise:
+#       measured 3.6e-5 / 2.7e-3 (conv1.weight) in cfg3's second update; bounds there 2e-4 / 1e-2.)
 def tf_bounds(name, upd):
     big = name.startswith("cfg")
     return {"forward": 1e-4 if (big and upd > 0) else 5e-6,
+            "grad_all": 2e-4 if (big and upd > 0) else 2e-5,
+            "grad_tensor": 1e-2 if (big and upd > 0) else 2e-3,
             "stats": 5e-5 if big else 5e-6,
             "move_all": 2e-3 if big else 1.5e-4,
             "move_tensor": 1e-2 if big else 1e-3}
@@ -1158,6 +1159,63 @@ def test_train_cli_and_checkpoint_format(tmp_path):
                           capture_output=True, text=True, timeout=300)
     assert play.returncode == 0, play.stderr[-2000:]
     assert "Episode length:" in play.stdout and "Episode reward:" in play.stdout
+
+
+@pytest.mark.parametrize("N", [2048, 2560, 130, 37, 3])
+def test_grouped_weight_gradients_vs_float64(N):
+    """etm_grouped_dw: dW = dy^T x of several layers in one launch -- plain [384, 384] layers, the per-head folds (the head's columns
+    of A, its plane of B, its rows of C) and a [96, 128] corner case -- against the float64 products; odd / tiny N exercise the
+    zero-filled tails of the four k-ranges.  Also through the autograd functions with a DeferredDw collector (what the trainer does)."""
+    import ctypes
+    from etm import lib as etm_lib
+    from etm import ops
+    dev = _dev()
+    lib = etm_lib.load()
+    torch.manual_seed(N)
+    D, H = 384, 4
+    hd = D // H
+    dy1, x1 = torch.randn((N, D), device=dev), torch.randn((N, D), device=dev)
+    q, du = torch.randn((N, D), device=dev), torch.randn((H, N, D), device=dev)
+    dy3, x3 = torch.randn((N, 96), device=dev), torch.randn((N, 128), device=dev)
+    c1, c2, c3 = (torch.full(shape, float("nan"), device=dev) for shape in ((D, D), (D, D), (96, 128)))
+    probs = [(dy1, 0, x1, c1, D, D)] + [(q, h * hd, du[h], c2[h * hd:(h + 1) * hd], hd, D) for h in range(H)] + [(dy3, 0, x3, c3, 96, 128)]
+    k = len(probs)
+    pa = (ctypes.c_void_p * k)(*[a.data_ptr() + 4 * off for a, off, *_ in probs])
+    pb = (ctypes.c_void_p * k)(*[b.data_ptr() for _, _, b, *_ in probs])
+    pc = (ctypes.c_void_p * k)(*[c.data_ptr() for _, _, _, c, *_ in probs])
+    dims = (ctypes.c_int32 * (5 * k))(*[v for a, _, b, c, ma, nb in probs for v in (ma, nb, a.stride(0), b.stride(0), c.stride(0))])
+    etm_lib.check(lib.etm_grouped_dw(pa, pb, pc, dims, k, N, torch.cuda.current_stream(dev).cuda_stream), "etm_grouped_dw")
+    want1 = dy1.double().t() @ x1.double()
+    want2 = torch.cat([q[:, h * hd:(h + 1) * hd].double().t() @ du[h].double() for h in range(H)])
+    want3 = dy3.double().t() @ x3.double()
+    worst = 0.0
+    for got, want in ((c1, want1), (c2, want2), (c3, want3)):
+        rel = float((got.double() - want).abs().max() / want.norm() * want.numel() ** 0.5)     # element error / rms element
+        worst = max(worst, rel)
+        assert rel < 2e-5, rel
+    # the same problems through autograd: linear (no bias), head fold / unfold, linear + ReLU, collected and flushed by DeferredDw
+    w = [torch.randn((D, D), device=dev).mul_(0.05).requires_grad_(True) for _ in range(4)]
+    b = torch.zeros(D, device=dev, requires_grad=True)
+    xin = torch.randn((N, D), device=dev)
+
+    def net():
+        h1 = ops.linear_nobias(xin, w[0])
+        u = ops._HeadFoldFn.apply(h1, w[1], H)                       # [H, N, D]
+        c = ops._HeadUnfoldFn.apply(torch.tanh(u), w[2], H)
+        return ops.linear_relu_train(c, w[3], b)
+
+    gout = torch.randn((N, D), device=dev)
+    (net() * gout).sum().backward()
+    ref = [t.grad.clone() for t in w]
+    for t in w:
+        t.grad = None
+    views = [torch.full((D, D), float("nan"), device=dev) for _ in w]
+    with ops.DeferredDw({t.data_ptr(): v for t, v in zip(w, views)}) as col:
+        (net() * gout).sum().backward()
+    assert col.written == {t.data_ptr() for t in w} and all(t.grad is None for t in w)
+    for v, r in zip(views, ref):
+        assert float((v - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6, float((v - r).abs().max())
+    print(f"[grouped dW N={N}] worst element error / rms element vs float64: {worst:.2e}")
 
 
 def test_linear_relu_backward_kernels_vs_autograd():

@@ -1,7 +1,7 @@
 """Kernel micro-benchmarks behind the roofline fractions of SURVEY.md section 8d (imported by bench.py, runnable on its own
 for rocprofv3 passes):
 
-    python tools/kernel_rooflines.py [window_cold|window_train|window_sorted|mfma3|mfma5|gae|ppo|encoder|rollout_step|all] [launches]
+    python tools/kernel_rooflines.py [window_cold|window_train|window_sorted|mfma3|mfma5|gae|ppo|encoder|grouped_dw|rollout_step|all] [launches]
 
 Every figure is algorithmic work per launch (stated below) / average launch duration from the library's per-launch HIP
 events (etm_profile_*: an event pair on the launch stream around each kernel), against the MI355X peaks of
@@ -230,6 +230,41 @@ def encoder(dev, launches=20, N=2048):
     return res
 
 
+def grouped_dw(dev, launches=20, N=2048, D=384, H=4, nb=3, hid=384):
+    """All dense-layer weight gradients of one minibatch step at config-3 dims as ONE launch (csrc/grouped_dw.hip): per block
+    queries, fc_out, fc ([D, D] each) and the per-head key / value folds (H problems of [hd, D] each), plus linear_embedding,
+    lin_policy, lin_value -- 2 * N * out * in flop per layer, against the fp32 MFMA peak."""
+    import ctypes
+    lib = etm_lib.load()
+    torch.manual_seed(0)
+    hd = D // H
+    probs, keep = [], []
+    for _ in range(nb * 3 + 1):                                         # plain [D, D] layers
+        a, b, c = torch.randn((N, D), device=dev), torch.randn((N, D), device=dev), torch.empty((D, D), device=dev)
+        keep += [a, b, c]
+        probs.append((a.data_ptr(), b.data_ptr(), c.data_ptr(), D, D, D, D, D))
+    for _ in range(2):                                                  # lin_policy, lin_value
+        a, b, c = torch.randn((N, hid), device=dev), torch.randn((N, D), device=dev), torch.empty((hid, D), device=dev)
+        keep += [a, b, c]
+        probs.append((a.data_ptr(), b.data_ptr(), c.data_ptr(), hid, D, hid, D, D))
+    for _ in range(nb * 2):                                             # key / value folds: H problems each
+        a, b, c = torch.randn((N, D), device=dev), torch.randn((H, N, D), device=dev), torch.empty((D, D), device=dev)
+        keep += [a, b, c]
+        for h in range(H):
+            probs.append((a.data_ptr() + 4 * h * hd, b[h].data_ptr(), c[h * hd:].data_ptr(), hd, D, D, D, D))
+    k = len(probs)
+    pa = (ctypes.c_void_p * k)(*[p[0] for p in probs])
+    pb = (ctypes.c_void_p * k)(*[p[1] for p in probs])
+    pc = (ctypes.c_void_p * k)(*[p[2] for p in probs])
+    dims = (ctypes.c_int32 * (5 * k))(*[v for p in probs for v in p[3:8]])
+    st = torch.cuda.current_stream().cuda_stream
+    t = _timed(lambda: etm_lib.check(lib.etm_grouped_dw(pa, pb, pc, dims, k, N, st), "etm_grouped_dw"), launches)
+    flops = sum(2.0 * N * p[3] * p[4] for p in probs)
+    tiles = sum((p[3] // 96) * (p[4] // 128) for p in probs)
+    return _mfma("grouped_dw_kernel", flops, *t["grouped_dw_kernel"], shape=dict(N=N, D=D, H=H, blocks=nb, problems=k, workgroups=tiles),
+                 replaces="the dW GEMMs of these layers, one library launch each (15 us x 19 at config 3, 0.26 of the peak)")
+
+
 def rollout_step_model(cfg, W, hidden_features):
     """What one launch of the rollout step kernel (csrc/rollout_fused.hip) moves and how long its dependency chain is.
     Every worker's team streams every matrix of the chain once (weights are shared by all workers, but a team serves ONE worker:
@@ -296,6 +331,8 @@ def all_rooflines(dev, quick=False):
     torch.cuda.empty_cache()
     out["encoder"] = encoder(dev, n)
     torch.cuda.empty_cache()
+    out["block_weight_gradients"] = grouped_dw(dev, n)
+    torch.cuda.empty_cache()
     return out
 
 
@@ -340,6 +377,8 @@ if __name__ == "__main__":
         res = {"config_size": ppo(dev, 2048, 3, n), "scaled": ppo(dev, 1 << 24, 3, n)}
     elif what == "encoder":
         res = encoder(dev, n)
+    elif what == "grouped_dw":
+        res = grouped_dw(dev, n)
     elif what == "rollout_step":
         tr = _bench_trainer(dev, sys.argv[3:])
         res = rollout_step(tr, n)
