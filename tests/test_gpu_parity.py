@@ -580,7 +580,8 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 #       (1e6 - 1e7 such terms per gradient element) the movement metric is dominated by those elements although the gradients agree
 #       to 2e-6: measured <= 8.2e-4 / 4.6e-3, and the REFERENCE's own fp32 result is 7.6e-4 / 3.6e-3 away from the evaluation with
 #       exact (float64) gradients and the same fp32 optimiser arithmetic (tools/fp32_noise_floor.py,
-#       profiles/r03/fp32_noise_floor_*.txt).  Bounds there: 2e-3 / 1e-2.
+#       profiles/r03/fp32_noise_floor_*.txt).  Bounds there: 2e-3 / 1e-2 in the first update; later updates start from parameters
+#       that already differ by that much (measured 2.0e-3 / 8.3e-3 in cfg3's second update, steps 3 - 4): 5e-3 / 2e-2.
 #       (At the BASELINE sizes the gradient of a LATER update is taken at parameters that already differ by that movement noise:
 #       measured 3.6e-5 / 2.7e-3 (conv1.weight) in cfg3's second update; bounds there 2e-4 / 1e-2.)
 def tf_bounds(name, upd):
@@ -589,8 +590,8 @@ def tf_bounds(name, upd):
             "grad_all": 2e-4 if (big and upd > 0) else 2e-5,
             "grad_tensor": 1e-2 if (big and upd > 0) else 2e-3,
             "stats": 5e-5 if big else 5e-6,
-            "move_all": 2e-3 if big else 1.5e-4,
-            "move_tensor": 1e-2 if big else 1e-3}
+            "move_all": (5e-3 if upd > 0 else 2e-3) if big else 1.5e-4,
+            "move_tensor": (2e-2 if upd > 0 else 1e-2) if big else 1e-3}
 
 
 def test_trainer_self_consistency_and_free_run():
