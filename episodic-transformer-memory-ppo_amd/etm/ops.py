@@ -589,7 +589,8 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
     pointer table ``blocks``); ``kv`` the group's K | V cache [W, T, blocks, 2D]; ``scratch`` from ``rollout_trxl_scratch``; the
     staging arguments as in ``rollout_policy``.  ``window`` = (ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init):
     the launch does the step's window lookup (and the cache reset of workers at episode step 0) itself -- no ``rollout_window``
-    in front of it.  ``tail`` = (wkv [blocks, D, 2D], pos [T, D] or None, step_l [W], slot_l [W],
+    in front of it; a ninth element ``ss_tagged`` = True: the ss words are tagged with the step counter (include/etm_hip.h) and the
+    launch may be enqueued before the host has published them.  ``tail`` = (wkv [blocks, D, 2D], pos [T, D] or None, step_l [W], slot_l [W],
     bank [slots, T, blocks, D]): after the action hand-over the same launch writes the new memory items into
     ``bank[slot_l, step_l]`` and their K | V projection into ``kv[w, step_l]``."""
     lib = _lib.load()
@@ -600,13 +601,14 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
         h_in_shape = h_in.shape[1:]
     else:
         h_in_shape = h_in.shape
-    w_args = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
-    if window is not None:        # (ss [2, W], mask_table, index_table, st_mask, st_idx, latch [2, W], t_row, kv_init or None)
-        ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init = window
+    w_args = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    if window is not None:        # (ss [2, W], mask_table, index_table, st_mask, st_idx, latch [2, W], t_row, kv_init or None[, ss_tagged])
+        ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init = window[:8]
+        ss_tagged = int(bool(window[8])) if len(window) > 8 else 0
         Lw = win_t.shape[1]
         w_args = (_ptr(ss), _ptr(mask_table), _ptr(index_table), st_mask.data_ptr() + w_off * Lw * st_mask.element_size(),
                   st_idx.data_ptr() + w_off * Lw * st_idx.element_size(), _ptr(latch), _ptr(t_row), _ptr(mask_t), _ptr(win_t),
-                  0 if kv_init is None else _ptr(kv_init), index_table.shape[0])
+                  0 if kv_init is None else _ptr(kv_init), index_table.shape[0], ss_tagged)
     t_args = (0, 0, 0, 0, 0, 0, 0)
     if tail is not None:
         wkv, pos, step_l, slot_l, bank = tail

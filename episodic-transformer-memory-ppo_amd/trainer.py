@@ -326,6 +326,10 @@ class PPOTrainer:
             g.stream = torch.cuda.Stream(device=dev)
         g.ss_np = g.ss_pin.numpy()
         g.flag_np = g.flag_pin.numpy()
+        # (episode step, slot) words tagged with the rollout step counter + 1 in their upper half: with early_step_launch the step's
+        # graph is enqueued as soon as the observation rows are on their way and the kernel polls these words (see _sample_training_data)
+        g.ss_tag_pin = torch.zeros((2, Wg), dtype=torch.int64).pin_memory()
+        g.ss_tag_np = g.ss_tag_pin.numpy()
         g.step_dev, g.slot_dev = g.ss_dev[0], g.ss_dev[1]
         # (episode step, slot) as LATCHED by the head of a step for its tail: the host uploads the next step's block on the
         # upload stream while the tail (bank / cache writes under env.step) may still be running, and only the group's own
@@ -391,10 +395,15 @@ class PPOTrainer:
         def obs_stream(g):
             return g.stream.cuda_stream if own_stream else up
 
-        def upload_state(g):
+        early = use_graph and own_stream and all(getattr(g, "early", False) for g in groups)
+
+        def upload_state(g, t_next=0):
             """(episode step, slot) of the group's workers -> where the device finds them, after the host bookkeeping of the step."""
             if not g.full:
                 g.ss_np[:] = ss_global[:, g.lo:g.hi]
+            if early:      # tagged words: value in the lower half, step counter + 1 in the upper -- the kernel of step t_next polls for them
+                np.bitwise_or(ss_global[:, g.lo:g.hi], (t_next + 1) << 32, out=g.ss_tag_np)
+                return
             if own_stream:
                 return
             lib.etm_upload(g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8, up)
@@ -426,7 +435,7 @@ class PPOTrainer:
         if stream_obs:
             for g in groups:                       # observation 0 -> staging row 0
                 lib.etm_upload(stage_base + g.lo * row_bytes, src_base + g.lo * row_bytes, g.W * row_bytes, obs_stream(g))
-                upload_state(g)
+                upload_state(g, 0)
         for g in groups:
             launch(g, 0)
         t_env = t_wait = t_launch = 0.0
@@ -450,8 +459,14 @@ class PPOTrainer:
                     src_g = src_base + lo * row_bytes
                     up_g = obs_stream(g)
 
+                    launched = False
+
                     def rows_ready(a, b):
+                        nonlocal launched
                         lib.etm_upload(dst_base + a * row_bytes, src_g + a * row_bytes, (b - a) * row_bytes, up_g)
+                        if early and b == g.W and not launched:      # last rows of the group are on their way: the step's graph follows
+                            launch(g, t + 1)                          # them at once; its (step, slot) words are published below
+                            launched = True
 
                     _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np, on_rows=rows_ready)
                 else:
@@ -470,8 +485,9 @@ class PPOTrainer:
                 if t + 1 < S:
                     tl = time.perf_counter()
                     if stream_obs:
-                        upload_state(g)              # bookkeeping of this step is final: (step, slot) follow the observation rows
-                    launch(g, t + 1)
+                        upload_state(g, t + 1)       # bookkeeping of this step is final: (step, slot) follow the observation rows
+                    if not (early and stream_obs and launched):
+                        launch(g, t + 1)
                     t_launch += time.perf_counter() - tl
                     if self._chain_log is not None and g is groups[0]:
                         self._chain_log.append((tw, te, tl, time.perf_counter()))
@@ -530,7 +546,9 @@ class PPOTrainer:
         # the sampling kernel) and resets the K/V cache of workers at episode step 0 (they start from the projection of an
         # empty memory)
         # streamed + pipelined mode: the (step, slot) block is read from pinned host memory (see _sample_training_data)
-        ss_src = g.ss_pin if (stream_obs and self._state_zero_copy and g.stream is not None) else g.ss_dev
+        zero_copy = stream_obs and self._state_zero_copy and g.stream is not None
+        ss_src = g.ss_pin if zero_copy else g.ss_dev
+        g.early = False
         rf_ = getattr(self.model, "_rf", None) if self._use_kv_cache else None
         # (every team of the step kernel must be resident at once, and the groups' step kernels run concurrently: the workgroups
         # of ALL groups together must fit the 256 CUs -- one 512-thread workgroup per CU --, else the multi-launch path)
@@ -539,6 +557,14 @@ class PPOTrainer:
                       and n_conc * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256)
         # the fused step kernel does the window lookup (and the cache reset of new episodes) itself: one launch fewer in the chain
         window_in_step = fused_step and self.config.get("window_in_step_kernel", True)
+        # early_step_launch (opt-in; needs zero-copy state + the window lookup inside the step kernel + flag hand-over): the kernel
+        # reads TAGGED (step, slot) words and waits for the tag of its step, so the host may enqueue the step's graph as soon as the
+        # observation rows are on their way, before the bookkeeping of the previous step.  Measured (round 3, config 3): no gain --
+        # 178.2 vs 176.1 us per step: the graph then simply waits for the observation DMA (1.35 MB over PCIe, ~27 us) that the
+        # late launch overlaps with the host's bookkeeping, and the tag poll over PCIe costs ~4 us -- so it stays off.
+        if zero_copy and window_in_step and host_flag and self.config.get("early_step_launch", False):
+            g.early = True
+            ss_src = g.ss_tag_pin
         if not window_in_step:
             ops.rollout_window(ss_src[0], self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
                                st["memory_mask"], st["memory_indices"], t_row=g.t_row,
@@ -575,7 +601,7 @@ class PPOTrainer:
                                  g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo,
                                  tail=tail, h_bias=h_bias,
                                  window=(ss_src, self._mask_table, self._index_table, st["memory_mask"], st["memory_indices"],
-                                         g.ss_latch, g.t_row, self._kv_init) if window_in_step else None)
+                                         g.ss_latch, g.t_row, self._kv_init, g.early) if window_in_step else None)
                 item = g.item
                 fused_policy = True
             elif single and self.model.rollout_heads_fusable():
@@ -711,8 +737,11 @@ class PPOTrainer:
             side = g.stream if g.stream is not None else torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(3):
+                for i in range(3):
+                    # (early_step_launch: the kernel polls for words tagged with its step counter + 1; warm-up run i is step i)
+                    np.bitwise_or(self._ss_pin.numpy()[:, g.lo:g.hi], (i + 1) << 32, out=g.ss_tag_np)
                     self._rollout_step_device(g, so, hf)
+                    side.synchronize()
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             pool = torch.cuda.graph_pool_handle()

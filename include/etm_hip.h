@@ -309,6 +309,9 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *           mask up in index_table [T, L] / mask_table [L, L] (trainer.py:165-169), member 0 also writes them to win_t / mask_t [W, L]
  *           and to row *t_dev of the staging arrays st_idx / st_mask [S, stage_W, L], latches ss into latch [2, W] and *t_dev into
  *           t_row; a worker at episode step 0 first gets its cache rows reset to kv_init [T, nb, 2D] (NULL: no reset);
+ *           ss_tagged != 0: every ss word carries (*t_dev + 1) << 32 in its upper half and the value in its lower half -- the caller
+ *           may enqueue the launch BEFORE it has finished the bookkeeping of the previous step (trainer.py:192-213) and publish the
+ *           tagged words afterwards; the kernel polls its two words (bounded: error word 2 if they never arrive);
  *   h_splits > 0: h_in is [h_splits, W, D] from etm_rollout_hidden_partial and the input is relu(sum over slices + h_bias [D]);
  *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
  *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
@@ -336,7 +339,7 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
                      int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                      int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                     int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+                     int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
 /* lin_hidden of a rollout step (model.py:94-100) as K-slice partial sums: part [splits, W, D], splits =
  * etm_rollout_hidden_splits(F) (<= 16), = the slice sums of x [W, F] @ wt [F, D] (wt = the weight TRANSPOSED, 16-byte aligned,
  * D % 32 == 0).  etm_rollout_trxl(h_in = part, h_bias = the layer's bias, h_splits = splits) adds the slices in slice order,

@@ -427,6 +427,7 @@ _ROLLOUT_PATHS = {
     "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
     "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
+    "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
@@ -435,7 +436,8 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("img32", "state_uploaded"), ("img32", "library_hidden"), ("img32", "window_launch"),
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
-             ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd")]
+             ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd"), ("img32", "early_launch"),
+             ("cfg3", "early_launch")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -542,6 +544,8 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
         assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
         assert tr.model._rf is not None, "img32/default: transformer + heads + sampling of a rollout step are one launch"
+    if path == "early_launch":
+        assert all(g.early for g in tr._groups), "the step graphs are enqueued ahead of the host bookkeeping (tagged state words)"
     if name in ("cfg2", "cfg3", "cfg5") and path == "default":
         # the benchmarked instantiations ran: captured step graphs with the one-launch step kernel (teams of etm_rollout_trxl_team(H)
         # workgroups per worker: 4 at H = 4), captured optimisation step; visual configs: observation streaming, two worker groups,

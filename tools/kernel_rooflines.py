@@ -295,6 +295,7 @@ def rollout_step(trainer, launches=40):
     def step_fn():
         g.t_dev.zero_()
         g.flag_np[0] = 0
+        g.ss_tag_np[:] = trainer._ss_pin.numpy()[:, g.lo:g.hi] | (1 << 32)      # early_step_launch: the words of step 0
         with torch.no_grad():
             trainer._rollout_step_device(g, so, hf)
 
