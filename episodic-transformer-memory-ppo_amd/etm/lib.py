@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 
@@ -80,6 +80,11 @@ SIGNATURES = {
     "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),
     "etm_adv_stats": (_I, [_P, _I, _P, _P]),
     "etm_ppo_loss_workspace_bytes": (_L, [_I]),
+    "etm_heads_loss_supported": (_I, [_I, _I, _I]),
+    "etm_heads_loss_row_floats": (_I, [_I, _I]),
+    "etm_heads_loss_workspace_bytes": (_L, [_I, _I, _I]),
+    "etm_heads_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _D, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _L,
+                            _I, _I, _I, _P]),
     "etm_window_fwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _P]),
     "etm_window_bwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
     "etm_window_dx": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

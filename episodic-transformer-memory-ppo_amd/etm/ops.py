@@ -1133,6 +1133,81 @@ class _PpoLossFn(torch.autograd.Function):
         return d_logits * g_loss, gv, None, None, None, None, None, None, None, None, None, None, None, None
 
 
+class _HeadsLossFn(torch.autograd.Function):
+    """Hidden heads (bias + ReLU), policy branch, value head, PPO loss and the backward pass down to the hidden heads' pre-activations
+    as one kernel pass (csrc/heads_loss.hip); the two hidden GEMMs h W^T (forward) and gm W (backward) stay library GEMMs, the hidden
+    heads' weight gradients go to the grouped launch.  Gradients are those of ``loss`` itself (unit upstream gradient) times
+    ``g_loss``."""
+
+    @staticmethod
+    def forward(ctx, h, wlp, blp, wlv, blv, wb, bb, wv, bv, actions, old_logp, adv, old_value, stats3, clip, vf_coef, beta, dyn, unit_grad):
+        lib = _lib.load()
+        _need_dev(h, wlp, blp, wlv, blv, wb, bb, wv, bv, actions, old_logp, adv, old_value, stats3)
+        h = _f32c(h, "h")
+        N, hid, A = h.shape[0], wlp.shape[0], wb.shape[0]
+        dev = h.device
+        pre_p, pre_v = h.mm(wlp.t()), h.mm(wlv.t())
+        gm_p, gm_v = torch.empty_like(pre_p), torch.empty_like(pre_v)
+        row = lib.etm_heads_loss_row_floats(hid, A)
+        sums = torch.empty(row, dtype=torch.float32, device=dev)
+        out8 = torch.empty(8, dtype=torch.float32, device=dev)
+        nbytes = lib.etm_heads_loss_workspace_bytes(N, hid, A)
+        ws = workspace(nbytes, dev, "heads_loss")
+        actions, old_logp = actions.contiguous(), old_logp.contiguous()
+        B = actions.shape[1] if actions.dim() == 2 else 1
+        rc = lib.etm_heads_loss(_ptr(pre_p), _ptr(pre_v), _ptr(blp), _ptr(blv), _ptr(wb), _ptr(bb), _ptr(wv), _ptr(bv), _ptr(actions), B,
+                                _ptr(old_logp), B, _ptr(_f32c(adv, "adv")), _ptr(_f32c(old_value, "old_value")), _ptr(stats3), float(clip),
+                                float(vf_coef), float(beta), 1.0 / N, 1.0 / N, 1.0 / N, _ptr(dyn), _ptr(gm_p), _ptr(gm_v), _ptr(sums), _ptr(out8),
+                                0, 0, _ptr(ws), nbytes, N, hid, A, _stream())
+        _lib.check(rc, "etm_heads_loss")
+        ctx.save_for_backward(h, wlp, wlv, gm_p, gm_v, sums)
+        ctx.dims = (hid, A)
+        ctx.unit = bool(unit_grad)
+        ctx.mark_non_differentiable(out8)
+        return out8[2].clone(), out8
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        h, wlp, wlv, gm_p, gm_v, sums = ctx.saved_tensors
+        hid, A = ctx.dims
+        unit = ctx.unit                 # the caller promises loss.backward() on the returned loss itself: g_loss == 1, nothing to scale
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = gm_p.mm(wlp)
+            dh.addmm_(gm_v, wlv)
+            if not unit:
+                dh = dh * g_loss
+        dwlp = dwlv = None
+        if ctx.needs_input_grad[1] and not (unit and _offer_dw(gm_p, h, wlp)):
+            dwlp = gm_p.t().mm(h) if unit else gm_p.t().mm(h) * g_loss
+        if ctx.needs_input_grad[3] and not (unit and _offer_dw(gm_v, h, wlv)):
+            dwlv = gm_v.t().mm(h) if unit else gm_v.t().mm(h) * g_loss
+        s = sums if unit else sums * g_loss
+        o = (3 + A) * hid
+        return (dh, dwlp, s[:hid], dwlv, s[hid:2 * hid], s[3 * hid:o].view(A, hid), s[o:o + A], s[2 * hid:3 * hid].view(1, hid),
+                s[o + A:o + A + 1], None, None, None, None, None, None, None, None, None, None)
+
+
+def heads_loss_supported(h, lin_policy, branch):
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32
+            and bool(_lib.load().etm_heads_loss_supported(h.shape[0], lin_policy.weight.shape[0], branch.weight.shape[0])))
+
+
+def heads_ppo_loss(h, lin_policy, lin_value, branch, value_head, actions, old_logp, adv, old_value, clip, vf_coef, beta, stats3=None, dyn=None,
+                   unit_grad=False):
+    """model.py:101-110 + the PPO loss of ``ppo_loss`` for a single-branch policy, from the transformer output ``h`` [N, D]:
+    -> (loss scalar with grad, stats[6]).  ``unit_grad=True``: the caller runs ``backward()`` on the returned loss itself (upstream
+    gradient 1): no scaling launches, weight gradients of the hidden heads deferrable.  See _HeadsLossFn."""
+    if stats3 is None:
+        stats3 = adv_stats(adv)
+    if dyn is not None and (dyn.dtype != torch.float64 or dyn.numel() != 2 or not dyn.is_cuda):
+        raise TypeError("heads_ppo_loss: dyn must be a float64 device tensor (clip, beta)")
+    loss, st = _HeadsLossFn.apply(h, lin_policy.weight, lin_policy.bias, lin_value.weight, lin_value.bias, branch.weight, branch.bias,
+                                  value_head.weight, value_head.bias, actions, old_logp, adv, old_value, stats3, clip, vf_coef, beta, dyn,
+                                  unit_grad)
+    return loss, st[:6]
+
+
 def ppo_loss(logits_list, value, actions, old_logp, adv, old_value, clip, vf_coef, beta, stats3=None, dyn=None):
     """PPO loss over all action branches.  Returns (loss scalar with grad, stats[6] device tensor in trainer.py:318-323 order).
     ``dyn``: optional float64 device tensor (clip, beta) read by the kernels at run time instead of the two scalars."""

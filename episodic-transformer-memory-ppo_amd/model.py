@@ -235,6 +235,10 @@ class ActorCriticModel(nn.Module):
             h = h.reshape(h.shape[0], -1)
         return ops.linear_relu(self.lin_hidden, h)
 
+    def forward_state(self, obs, spec: WindowSpec, want_items=False):
+        """Encoder + transformer: -> (h [N, D] in front of the hidden heads (model.py:100), new memory items or None)."""
+        return self.transformer.forward_window(self._encode(obs), spec, want_items)
+
     def forward_logits(self, obs, spec: WindowSpec, want_items=True):
         """-> (list of raw logits per branch, value [N], new memory items [N, blocks, D] or None)."""
         h, memory = self.transformer.forward_window(self._encode(obs), spec, want_items)

@@ -848,14 +848,12 @@ class PPOTrainer:
         else:
             spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
                                         samples["memory_mask"])
-        logits, value, _ = self.model.forward_logits(samples["obs"], spec)
         stats3 = getattr(self, "_mb_stats3", None)
         if stats3 is None:
             stats3 = ops.adv_stats(samples["advantages"])
             if self.dp is not None:
                 stats3 = self.dp.merge_adv_stats(stats3)
-        loss, stats = ops.ppo_loss(logits, value, samples["actions"], samples["log_probs"], samples["advantages"],
-                                   samples["values"], clip_range, self.config["value_loss_coefficient"], beta, stats3)
+        loss, stats = self._loss_from(samples["obs"], spec, samples, clip_range, beta, stats3, dyn=None)
         self._set_lr(learning_rate)
         self.flat_grads.zero_()
         with ops.DeferredDw(self._dw_destinations()):      # dense-layer weight gradients: one grouped launch into the arena
@@ -865,6 +863,25 @@ class PPOTrainer:
         # global-norm clipping (the rule of torch.nn.utils.clip_grad_norm_, upstream :311) + AdamW on the flat arenas: 2 launches
         self.optimizer.step(self.config["max_grad_norm"], grad_scale=self._grad_scale())
         return stats
+
+    def _loss_from(self, obs, spec, mb, clip_range, beta, stats3, dyn="device"):
+        """Model forward + PPO loss of one minibatch (trainer.py:268-304): -> (loss, stats[6]).  Single-branch policies whose hidden size
+        fits take the fused hidden-heads + loss kernel (``fused_heads_loss``, default on); others the separate heads and loss."""
+        dyn = getattr(self, "_dyn", None) if dyn == "device" else dyn
+        m = self.model
+        if self.config.get("fused_heads_loss", True) and len(m.policy_branches) == 1:
+            h, _ = m.forward_state(obs, spec)
+            if ops.heads_loss_supported(h, m.lin_policy, m.policy_branches[0]):
+                return ops.heads_ppo_loss(h, m.lin_policy, m.lin_value, m.policy_branches[0], m.value, mb["actions"], mb["log_probs"],
+                                          mb["advantages"], mb["values"], clip_range, self.config["value_loss_coefficient"], beta, stats3, dyn=dyn,
+                                          unit_grad=True)       # (both callers run loss.backward() on this loss)
+            h_policy = ops.linear_relu(m.lin_policy, h)
+            h_value = ops.linear_relu(m.lin_value, h)
+            logits, value = [m.policy_branches[0](h_policy)], m.value(h_value).reshape(-1)
+        else:
+            logits, value, _ = m.forward_logits(obs, spec, want_items=False)
+        return ops.ppo_loss(logits, value, mb["actions"], mb["log_probs"], mb["advantages"], mb["values"], clip_range,
+                            self.config["value_loss_coefficient"], beta, stats3, dyn=dyn)
 
     def _dw_destinations(self):
         """{parameter data_ptr: its [out, in] gradient view in the flat arena} for the 2-D parameters (``grouped_dw_train: false`` in
@@ -923,11 +940,9 @@ class PPOTrainer:
         obs = mb.get("obs")
         if self._obs_train is not None:     # NHWC rows of the minibatch: gathered by the first encoder layer itself
             obs = IndexedObservations(self._obs_train, idx)
-        logits, value, _ = self.model.forward_logits(obs, spec, want_items=False)
         if stats3 is None:
             stats3 = ops.adv_stats(mb["advantages"])
-        loss, stats = ops.ppo_loss(logits, value, mb["actions"], mb["log_probs"], mb["advantages"], mb["values"], clip_range,
-                                   self.config["value_loss_coefficient"], beta, stats3, dyn=getattr(self, "_dyn", None))
+        loss, stats = self._loss_from(obs, spec, mb, clip_range, beta, stats3)
         # backward() hands every parameter its gradient tensor (no accumulate launch while .grad is None); ONE multi-tensor copy
         # packs them into the flat bucket that the all-reduce, clipping and the fused AdamW read -- ~50 launches fewer per step
         # than accumulating into the zeroed bucket (the python-side re-aliasing below costs nothing under graph replay)

@@ -234,6 +234,28 @@ int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const 
                         void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Policy / value heads + PPO loss, forward and backward in one pass: replaces, for a single-branch policy, model.py:101-110 (bias +
+ * ReLU of lin_policy / lin_value, the policy branch, the value head) together with the loss section of trainer.py:276-304, :315-316
+ * (= etm_ppo_loss) and the first steps of `loss.backward()` (trainer.py:310) back to the pre-activations of the two hidden heads.
+ *   pre_p / pre_v [N, hid] = h lin_policy.weight^T / h lin_value.weight^T WITHOUT bias (plain GEMMs of the caller); b_lp / b_lv [hid];
+ *   wb [A, hid], bb [A]: policy branch; wv [hid], bv [1]: value head; actions / old_logp / adv / old_value / adv_stats3 / clip /
+ *   vf_coef / beta / scales / dyn_clip_beta: as etm_ppo_loss.
+ *   Outputs: gm_p / gm_v [N, hid] = d loss / d (pre + bias) of the hidden heads (the caller continues with d h = gm_p Wlp + gm_v Wlv and
+ *   d Wlp = gm_p^T h ...); sums [etm_heads_loss_row_floats(hid, A)] = [d b_lp (hid) | d b_lv (hid) | d wv (hid) | d Wb (A x hid) |
+ *   d bb (A) | d bv | 5 raw statistic sums]; out8 as etm_ppo_loss; logits [N, A] / value [N] optional (NULL: not written).
+ *   workspace: etm_heads_loss_workspace_bytes(N, hid, A) bytes (one partial row per 32 samples, summed in row order: deterministic).
+ * Shapes: etm_heads_loss_supported(N, hid, A) == 1 (hid % 64 == 0, hid <= 512, A <= 8). */
+int etm_heads_loss_supported(int N, int hid, int A);
+int etm_heads_loss_row_floats(int hid, int A);
+int64_t etm_heads_loss_workspace_bytes(int N, int hid, int A);
+int etm_heads_loss(const float *pre_p, const float *pre_v, const float *b_lp, const float *b_lv, const float *wb, const float *bb,
+                   const float *wv, const float *bv, const int64_t *actions, int64_t action_stride, const float *old_logp,
+                   int64_t logp_stride, const float *adv, const float *old_value, const float *adv_stats3, double clip, float vf_coef,
+                   float beta, float pol_scale, float ent_scale, float val_scale, const double *dyn_clip_beta, float *gm_p, float *gm_v,
+                   float *sums, float *out8, float *logits, float *value, void *workspace, int64_t workspace_bytes, int N, int hid,
+                   int A, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Weight gradients of the dense layers of one optimisation step as ONE grouped launch: replaces the `dW = dy^T x` products that
  * `loss.backward()` (trainer.py:310) issues one by one for transformer.py:26-29 (queries / keys / values / fc_out), :115 (fc),
  * :201 (linear_embedding) and model.py:97-107 (lin_policy, lin_value) -- contractions over the N samples of the minibatch with a

@@ -427,6 +427,7 @@ _ROLLOUT_PATHS = {
     "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
     "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
+    "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False},   # heads / loss / weight gradients as separate ops (round-2 form)
     "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
@@ -437,7 +438,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
              ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd"), ("img32", "early_launch"),
-             ("cfg3", "early_launch")]
+             ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -1221,6 +1222,43 @@ def test_grouped_weight_gradients_vs_float64(N):
     for v, r in zip(views, ref):
         assert float((v - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6, float((v - r).abs().max())
     print(f"[grouped dW N={N}] worst element error / rms element vs float64: {worst:.2e}")
+
+
+@pytest.mark.parametrize("N,hid,A,D", [(2048, 384, 3, 384), (37, 128, 2, 128), (130, 512, 8, 64), (5, 64, 4, 96)])
+def test_fused_heads_and_loss_vs_composed_ops(N, hid, A, D):
+    """etm_heads_loss (hidden heads' bias + ReLU, policy branch, value head, PPO loss, backward to the hidden heads) against the
+    same computation composed of torch ops + the separate loss kernel (itself pinned to the reference's _train_mini_batch by
+    loss.npz): loss, the six statistics and every gradient."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(N + hid)
+    lin_p, lin_v = torch.nn.Linear(D, hid).to(dev), torch.nn.Linear(D, hid).to(dev)
+    branch, vhead = torch.nn.Linear(hid, A).to(dev), torch.nn.Linear(hid, 1).to(dev)
+    h0 = torch.randn((N, D), device=dev)
+    actions = torch.randint(0, A, (N, 1), device=dev)
+    old_logp = -torch.rand((N, 1), device=dev) - 0.3
+    adv = torch.randn(N, device=dev) * 2 + 0.3
+    old_value = torch.randn(N, device=dev)
+    clip, vf, beta = 0.15, 0.4, 0.01
+    mods = (lin_p, lin_v, branch, vhead)
+    res = []
+    for fused in (False, True):
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        h = h0.clone().requires_grad_(True)
+        if fused:
+            loss, st = ops.heads_ppo_loss(h, lin_p, lin_v, branch, vhead, actions, old_logp, adv, old_value, clip, vf, beta, unit_grad=True)
+        else:
+            hp, hv = torch.relu(lin_p(h)), torch.relu(lin_v(h))
+            loss, st = ops.ppo_loss([branch(hp)], vhead(hv).reshape(-1), actions, old_logp, adv, old_value, clip, vf, beta)
+        loss.backward()
+        res.append((loss.detach().clone(), st.clone(), h.grad.clone(), [p.grad.clone() for m in mods for p in m.parameters()]))
+    (l0, s0, gh0, gp0), (l1, s1, gh1, gp1) = res
+    assert torch.allclose(l0, l1, atol=1e-6, rtol=1e-5) and torch.allclose(s0, s1, atol=1e-6, rtol=1e-5), (l0, l1, s0, s1)
+    scale = float(gh0.abs().max())
+    assert float((gh0 - gh1).abs().max()) <= 2e-5 * scale + 1e-9, float((gh0 - gh1).abs().max())
+    for a, b in zip(gp0, gp1):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-8, (a.shape, float((a - b).abs().max()))
 
 
 def test_linear_relu_backward_kernels_vs_autograd():
