@@ -78,17 +78,29 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const HlParams p0) {
 #pragma unroll
   for (int a = 0; a < HL_MAXA; ++a) s_bb[a] = 0.f;
 
-  const int per_wave = p.samples_per_wg / 4;
-  const int n_begin = blockIdx.x * p.samples_per_wg + wave * per_wave;
-  for (int i = 0; i < per_wave; ++i) {
+  constexpr int PER_WAVE = 2;                                        // = HL_SAMPLES_PER_WG / 4
+  const int n_begin = blockIdx.x * p.samples_per_wg + wave * PER_WAVE;
+  // the rows of both samples are requested before the first one is worked on (a sample is a chain of dependent wave reductions)
+  float pre_p_r[PER_WAVE][HC], pre_v_r[PER_WAVE][HC];
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int n = min(n_begin + i, p.N - 1);
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+      const int k = lane + 64 * c;
+      pre_p_r[i][c] = p.pre_p[(long long)n * hid + k];
+      pre_v_r[i][c] = p.pre_v[(long long)n * hid + k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
     const int n = n_begin + i;
     if (n >= p.N) break;                                             // (wave-uniform)
     float hp[HC], hv[HC];
 #pragma unroll
     for (int c = 0; c < HC; ++c) {
-      const int k = lane + 64 * c;
-      hp[c] = fmaxf(p.pre_p[(long long)n * hid + k] + blp[c], 0.f);
-      hv[c] = fmaxf(p.pre_v[(long long)n * hid + k] + blv[c], 0.f);
+      hp[c] = fmaxf(pre_p_r[i][c] + blp[c], 0.f);
+      hv[c] = fmaxf(pre_v_r[i][c] + blv[c], 0.f);
     }
     float lg[HL_MAXA];
 #pragma unroll
@@ -224,22 +236,45 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const HlParams p0) {
   for (int e = tid; e < row; e += 256) dst[e] = ((hl_lds[e] + hl_lds[row + e]) + hl_lds[2 * row + e]) + hl_lds[3 * row + e];
 }
 
-// sums the workgroup rows in row order (fixed) and finishes the loss statistics: out = [row sums ... | out8]
-__global__ __launch_bounds__(256) void heads_reduce_kernel(const float *__restrict__ partials, int n_wg, int row, int A, int hid, float vf_coef,
-                                                           float beta, float pol_scale, float ent_scale, float val_scale,
-                                                           const double *__restrict__ dyn, float *__restrict__ out, float *__restrict__ out8) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= row) return;
-  float s = 0.f;
-  for (int w = 0; w < n_wg; ++w) s += partials[(long long)w * row + e];
-  out[e] = s;
+// sums the workgroup rows and finishes the loss statistics: out = [row sums ... ], out8.  One workgroup = 64 row elements x 16 row
+// groups: thread (e, g) adds the rows g, g + 16, ... (all requested at once: the sum is a latency chain otherwise), the 16 group
+// sums are added in group order -- a fixed tree, deterministic.
+__global__ __launch_bounds__(1024) void heads_reduce_kernel(const float *__restrict__ partials, int n_wg, int row, int A, int hid, float vf_coef,
+                                                            float beta, float pol_scale, float ent_scale, float val_scale,
+                                                            const double *__restrict__ dyn, float *__restrict__ out, float *__restrict__ out8) {
+  __shared__ float sm[16][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  auto group_sum = [&](int e) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int w = g + 16 * u; v[u] = (e < row && w < n_wg) ? partials[(long long)w * row + e] : 0.f; }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+    for (int w = g + 256; w < n_wg; w += 16) s += partials[(long long)w * row + e];      // (more than 256 rows: the rest in order)
+    return s;
+  };
+  const int e = blockIdx.x * 64 + el;
+  sm[g][el] = group_sum(e);
+  __syncthreads();
+  if (g == 0 && e < row) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k][el];
+    out[e] = s;
+  }
+  if (blockIdx.x != 0) return;
+  // the five statistic sums (the last five row elements) once more in this workgroup, then out8
+  __syncthreads();
   const int st0 = (3 + A) * hid + A + 1;
-  if (e == st0) {                                                    // this thread also folds the five statistic sums into out8
+  sm[g][el] = el < 5 ? group_sum(st0 + el) : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
     float acc[5];
-    for (int k = 0; k < 5; ++k) {
+    for (int k5 = 0; k5 < 5; ++k5) {
       float t = 0.f;
-      for (int w = 0; w < n_wg; ++w) t += partials[(long long)w * row + st0 + k];
-      acc[k] = t;
+      for (int k = 0; k < 16; ++k) t += sm[k][k5];
+      acc[k5] = t;
     }
     if (dyn) beta = (float)dyn[1];
     const float pol = acc[0] * pol_scale, val = acc[1] * val_scale, ent = acc[2] * ent_scale;
@@ -247,7 +282,8 @@ __global__ __launch_bounds__(256) void heads_reduce_kernel(const float *__restri
     out8[4] = acc[3] * pol_scale; out8[5] = acc[4] * pol_scale; out8[6] = 0.f; out8[7] = 0.f;
   }
 }
-constexpr int HL_SAMPLES_PER_WG = 32;
+static_assert(true, "");
+constexpr int HL_SAMPLES_PER_WG = 8;      // two samples per wave: the pass is a latency chain per sample, so many short waves
 }  // namespace
 
 extern "C" int etm_heads_loss_supported(int N, int hid, int A) { return N > 0 && hid > 0 && hid % 64 == 0 && hid / 64 <= HL_MAXC && A > 0 && A <= HL_MAXA; }
@@ -297,7 +333,7 @@ extern "C" int etm_heads_loss(const float *pre_p, const float *pre_v, const floa
   int rc = etm_launch_status();
   if (rc) return rc;
   EtmProfScope prof(ETM_K_PPO_FINAL, st);
-  hipLaunchKernelGGL(heads_reduce_kernel, dim3((unsigned)((row + 255) / 256)), dim3(256), 0, st, (const float *)workspace, n_wg, row, A, hid, vf_coef,
+  hipLaunchKernelGGL(heads_reduce_kernel, dim3((unsigned)((row + 63) / 64)), dim3(1024), 0, st, (const float *)workspace, n_wg, row, A, hid, vf_coef,
                      beta, pol_scale, ent_scale, val_scale, dyn_clip_beta, sums, out8);
   return etm_launch_status();
 }

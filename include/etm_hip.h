@@ -243,7 +243,7 @@ int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const 
  *   Outputs: gm_p / gm_v [N, hid] = d loss / d (pre + bias) of the hidden heads (the caller continues with d h = gm_p Wlp + gm_v Wlv and
  *   d Wlp = gm_p^T h ...); sums [etm_heads_loss_row_floats(hid, A)] = [d b_lp (hid) | d b_lv (hid) | d wv (hid) | d Wb (A x hid) |
  *   d bb (A) | d bv | 5 raw statistic sums]; out8 as etm_ppo_loss; logits [N, A] / value [N] optional (NULL: not written).
- *   workspace: etm_heads_loss_workspace_bytes(N, hid, A) bytes (one partial row per 32 samples, summed in row order: deterministic).
+ *   workspace: etm_heads_loss_workspace_bytes(N, hid, A) bytes (one partial row per 8 samples, summed in row order: deterministic).
  * Shapes: etm_heads_loss_supported(N, hid, A) == 1 (hid % 64 == 0, hid <= 512, A <= 8). */
 int etm_heads_loss_supported(int N, int hid, int A);
 int etm_heads_loss_row_floats(int hid, int A);
