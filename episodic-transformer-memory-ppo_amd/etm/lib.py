@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lib = None
 
@@ -32,6 +32,7 @@ SIGNATURES = {
     "etm_add_layernorm": (_I, [_P, _P, _I, _P, _P, _P, _F, _P, _I, _I, _P]),
     "etm_conv_relu": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_upload": (_I, [_P, _P, _L, _P]),
+    "etm_obs_pull": (_I, [_P, _P, _L, _L, _I, _P, _P, _P, _P]),
     "etm_comm_unique_id": (_I, [_P]),
     "etm_comm_init": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_void_p)]),
     "etm_allreduce_f32": (_I, [_P, _P, _P, _L, _P]),

@@ -991,6 +991,18 @@ def nhwc_columns(weight, channels):
     return weight.view(out, channels, feat // channels).transpose(1, 2).reshape(out, feat)
 
 
+def obs_pull(src_pinned, stage, t_dev, row_flags, w_off=0, err=None):
+    """First node of a rollout step's graph: the device copies the group's observation rows from pinned host memory ``src_pinned``
+    [Wg, ...] into ``stage[*t_dev, w_off : w_off + Wg]`` (time-major staging [S, W, ...]), each row as soon as the host has set
+    ``row_flags[r]`` (pinned int64 [Wg]) to the step index + 1 (etm_obs_pull)."""
+    lib = _lib.load()
+    rows = src_pinned.shape[0]
+    row_bytes = src_pinned[0].numel() * 4
+    dst = stage.data_ptr() + w_off * row_bytes
+    _lib.check(lib.etm_obs_pull(src_pinned.data_ptr(), dst, stage[0].numel() * 4, row_bytes, rows, _ptr(t_dev), row_flags.data_ptr(),
+                                0 if err is None else _ptr(err), _stream()), "etm_obs_pull")
+
+
 def upload(dst, src_pinned, stream):
     """Asynchronous pinned-host -> device copy of a contiguous block on ``stream`` (a torch.cuda.Stream)."""
     lib = _lib.load()

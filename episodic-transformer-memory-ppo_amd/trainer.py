@@ -330,6 +330,12 @@ class PPOTrainer:
         # graph is enqueued as soon as the observation rows are on their way and the kernel polls these words (see _sample_training_data)
         g.ss_tag_pin = torch.zeros((2, Wg), dtype=torch.int64).pin_memory()
         g.ss_tag_np = g.ss_tag_pin.numpy()
+        # pull_observations: per-row "observation row of step t is final in pinned memory" flags (value t + 1) that the step graph's
+        # first kernel polls, and an error word for a flag that never arrives
+        g.row_flags_pin = torch.zeros((Wg,), dtype=torch.int64).pin_memory()
+        g.row_flags_np = g.row_flags_pin.numpy()
+        g.pull_err = torch.zeros((1,), dtype=torch.int64, device=dev)
+        g.pull = False
         g.step_dev, g.slot_dev = g.ss_dev[0], g.ss_dev[1]
         # (episode step, slot) as LATCHED by the head of a step for its tail: the host uploads the next step's block on the
         # upload stream while the tail (bank / cache writes under env.step) may still be running, and only the group's own
@@ -432,12 +438,24 @@ class PPOTrainer:
                     g.act_ready.record(main)
                     self._rollout_step_tail(g, carry)
 
-        if stream_obs:
+        pull = early and all(getattr(g, "pull", False) for g in groups)
+        if pull:
+            # the step graphs start with the pull kernel and are enqueued ONE STEP AHEAD: the rows of observation 0 are in pinned
+            # memory already (flag value 1), the graphs of step 1 wait on the device for the flags of the first env.step
+            for g in groups:
+                g.row_flags_np[:] = 1
+                upload_state(g, 0)
+                launch(g, 0)
+            if S > 1:
+                for g in groups:
+                    launch(g, 1)
+        elif stream_obs:
             for g in groups:                       # observation 0 -> staging row 0
                 lib.etm_upload(stage_base + g.lo * row_bytes, src_base + g.lo * row_bytes, g.W * row_bytes, obs_stream(g))
                 upload_state(g, 0)
-        for g in groups:
-            launch(g, 0)
+        if not pull:
+            for g in groups:
+                launch(g, 0)
         t_env = t_wait = t_launch = 0.0
         for t in range(S):
             for g in groups:
@@ -454,7 +472,15 @@ class PPOTrainer:
                     g.act_ready.synchronize()
                 te = time.perf_counter()
                 t_wait += te - tw
-                if stream_obs and t + 1 < S:
+                if pull:
+                    flags = g.row_flags_np
+
+                    def rows_final(a, b, flags=flags, tag=t + 2):
+                        flags[a:b] = tag              # rows [a, b) of observation t + 1 are final: the waiting pull kernel takes them
+
+                    _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np, on_rows=rows_final)
+                    launched = True
+                elif stream_obs and t + 1 < S:
                     dst_base = stage_base + ((t + 1) * W + lo) * row_bytes
                     src_g = src_base + lo * row_bytes
                     up_g = obs_stream(g)
@@ -486,7 +512,10 @@ class PPOTrainer:
                     tl = time.perf_counter()
                     if stream_obs:
                         upload_state(g, t + 1)       # bookkeeping of this step is final: (step, slot) follow the observation rows
-                    if not (early and stream_obs and launched):
+                    if pull:
+                        if t + 2 < S:
+                            launch(g, t + 2)         # one step ahead: the device never waits for a launch
+                    elif not (early and stream_obs and launched):
                         launch(g, t + 1)
                     t_launch += time.perf_counter() - tl
                     if self._chain_log is not None and g is groups[0]:
@@ -496,6 +525,12 @@ class PPOTrainer:
         for st_ in side_streams:
             main.wait_stream(st_)
         t_ = self.model.transformer
+        for g in groups:
+            if getattr(g, "pull", False):
+                g.row_flags_np[:] = 0
+                if int(g.pull_err.item()) != 0:
+                    g.pull_err.zero_()
+                    raise RuntimeError("pull_observations: a row flag did not arrive within the kernel's limit; this rollout is void")
         for g in groups + [self._group_all]:
             if g.rf_scratch is not None and int(ops.rollout_trxl_error(g.rf_scratch).item()) != 0:
                 # a team member gave up waiting for its partners (not all workgroups were resident): this rollout's data are
@@ -536,6 +571,11 @@ class PPOTrainer:
         rows = None if g.full else (g.lo, g.hi)
         if stream_obs:      # the observation of this step is already in row t of the staging array (see _sample_training_data)
             obs, obs_index = st["obs"], g.t_dev
+            if self._pull_ok(g, host_flag):
+                # ... or gets there now: the device pulls the rows from pinned memory itself as the host marks them final (the graph
+                # is enqueued a step ahead: no runtime copy call and no graph launch between env.step and the device's start)
+                ops.obs_pull(g.obs_pin, st["obs"], g.t_dev, g.row_flags_pin, w_off=g.lo, err=g.pull_err)
+                g.pull = True
         else:
             g.obs_dev.copy_(g.obs_pin, non_blocking=True)
             obs, obs_index, rows = g.obs_dev, None, None
@@ -562,7 +602,9 @@ class PPOTrainer:
         # observation rows are on their way, before the bookkeeping of the previous step.  Measured (round 3, config 3): no gain --
         # 178.2 vs 176.1 us per step: the graph then simply waits for the observation DMA (1.35 MB over PCIe, ~27 us) that the
         # late launch overlaps with the host's bookkeeping, and the tag poll over PCIe costs ~4 us -- so it stays off.
-        if zero_copy and window_in_step and host_flag and self.config.get("early_step_launch", False):
+        if g.pull and not (zero_copy and window_in_step and host_flag):
+            raise RuntimeError("pull_observations needs the one-launch step kernel with its window lookup, zero-copy state and the flag hand-over")
+        if zero_copy and window_in_step and host_flag and (g.pull or self.config.get("early_step_launch", False)):
             g.early = True
             ss_src = g.ss_tag_pin
         if not window_in_step:
@@ -653,6 +695,29 @@ class PPOTrainer:
             g.item.copy_(item)
         return g.item
 
+    def _pull_ok(self, g, host_flag):
+        """pull_observations (opt-in): streamed observations on the group's own stream, flag hand-over, one-launch step kernel.
+        Measured (round 3, config 3): no gain -- 181 vs 175 us per step.  The host's part of a step drops from 42 to 24 us (no
+        runtime copy calls, the graph launch off the path), but 1.35 MB per group and step cross PCIe either way: pulled by the
+        kernel that takes 37 us (36 GB/s), of which only the part under the host's row writes is hidden -- the copy engine's
+        transfer overlaps more of the host's work.  Kept as a tested option."""
+        if not (self.config.get("pull_observations", False) and host_flag and g.stream is not None and self._state_zero_copy and self._use_kv_cache):
+            return False
+        rf_ = getattr(self.model, "_rf", None)
+        return (rf_ is not None and len(self.action_space_shape) == 1 and self.config.get("window_in_step_kernel", True)
+                and len(self._groups) * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256)
+
+    def publish_for_replay(self, on=True):
+        """Tools that replay step graphs without the host loop (tools/rollout_profile.py, tools/kernel_rooflines.py): publish a state /
+        row-flag tag that every replayed step accepts (``on=False``: back to 'nothing published')."""
+        for g in self._groups:
+            if on:
+                np.bitwise_or(self._ss_pin.numpy()[:, g.lo:g.hi], 1 << 40, out=g.ss_tag_np)
+                g.row_flags_np[:] = 1 << 40
+            else:
+                g.ss_tag_np[:] = 0
+                g.row_flags_np[:] = 0
+
     def _rollout_step_tail(self, g, item, stream_obs=False):
         """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
         K/V projection of the new item into the cache, observation staging.  Runs under the host's env.step()."""
@@ -738,10 +803,13 @@ class PPOTrainer:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side), torch.no_grad():
                 for i in range(3):
-                    # (early_step_launch: the kernel polls for words tagged with its step counter + 1; warm-up run i is step i)
+                    # (early_step_launch / pull_observations: the kernels poll for words tagged with their step counter + 1; warm-up
+                    # run i is step i)
                     np.bitwise_or(self._ss_pin.numpy()[:, g.lo:g.hi], (i + 1) << 32, out=g.ss_tag_np)
+                    g.row_flags_np[:] = i + 1
                     self._rollout_step_device(g, so, hf)
                     side.synchronize()
+                g.row_flags_np[:] = 0
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             pool = torch.cuda.graph_pool_handle()

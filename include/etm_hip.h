@@ -449,6 +449,13 @@ int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *s
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
 int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
+/* Observation rows of a rollout step pulled by the device (trainer.py:163, :190-193), capturable as the first node of the step's
+ * graph: row r of `src` (pinned host memory, `rows` rows of row_bytes, % 16 == 0) is copied to dst_base + (*t_dev) *
+ * dst_step_stride_bytes + r * row_bytes as soon as row_flags[r] (pinned int64) >= *t_dev + 1 -- the host sets the flag when the
+ * row is final; the launch itself may be enqueued long before (one step ahead).  err (optional device int64): 3 if a flag
+ * never arrived within ~1 s. */
+int etm_obs_pull(const void *src, void *dst_base, int64_t dst_step_stride_bytes, int64_t row_bytes, int rows, const int64_t *t_dev,
+                 const int64_t *row_flags, int64_t *err, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).

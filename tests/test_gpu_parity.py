@@ -428,6 +428,7 @@ _ROLLOUT_PATHS = {
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
     "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
     "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False},   # heads / loss / weight gradients as separate ops (round-2 form)
+    "pull_obs": {"pull_observations": True},                  # the device pulls the observation rows itself; step graphs enqueued one step ahead
     "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
@@ -438,7 +439,8 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
              ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd"), ("img32", "early_launch"),
-             ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads")]
+             ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "pull_obs"), ("cfg3", "pull_obs"),
+             ("cfg5", "pull_obs")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -545,6 +547,8 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
         assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
         assert tr.model._rf is not None, "img32/default: transformer + heads + sampling of a rollout step are one launch"
+    if path == "pull_obs":
+        assert all(g.pull and g.early for g in tr._groups), "the step graphs start with the observation pull kernel"
     if path == "early_launch":
         assert all(g.early for g in tr._groups), "the step graphs are enqueued ahead of the host bookkeeping (tagged state words)"
     if name in ("cfg2", "cfg3", "cfg5") and path == "default":

@@ -295,7 +295,7 @@ def rollout_step(trainer, launches=40):
     def step_fn():
         g.t_dev.zero_()
         g.flag_np[0] = 0
-        g.ss_tag_np[:] = trainer._ss_pin.numpy()[:, g.lo:g.hi] | (1 << 32)      # early_step_launch: the words of step 0
+        trainer.publish_for_replay(True)          # early_step_launch / pull_observations: a tag every replayed step accepts
         with torch.no_grad():
             trainer._rollout_step_device(g, so, hf)
 
@@ -303,6 +303,7 @@ def rollout_step(trainer, launches=40):
     with torch.cuda.stream(stream):
         t = _timed(step_fn, launches)
     torch.cuda.synchronize()
+    trainer.publish_for_replay(False)
     res = {"kernels": {k: dict(avg_us=v[0] * 1e3, launches_per_step=v[1] / launches) for k, v in t.items()}}
     res["step_sum_us"] = sum(v[0] * 1e3 * v[1] / launches for v in t.values())
     if "rollout_trxl_kernel" in t:
