@@ -564,6 +564,14 @@ static void conv_launch(const ConvG &p, long long tiles, unsigned classes, hipSt
                      0, st, p);
 }
 
+int etm_conv_fwd_lds(const float *x, const int64_t *x_index, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W,
+                     int Cout, int KH, int KW, int S, hipStream_t st);
+// Forward passes that keep their images in LDS (conv_fwd_lds.hip): bit l - 1 = layer l of model.py:29-31 at 84 x 84.  Measured at
+// N = 2048 against conv_gemm_kernel (us): layer 1 131 / 124, layer 2 117 / 137, layer 3 88 / 90 -- layer 2 only by default.
+#define ETM_CONV_FWD_LDS_DEFAULT 2
+static int g_conv_fwd_lds = ETM_CONV_FWD_LDS_DEFAULT;
+extern "C" int etm_conv_train_set_fwd_lds(int layer_mask) { g_conv_fwd_lds = layer_mask < 0 ? ETM_CONV_FWD_LDS_DEFAULT : (layer_mask & 7); return ETM_OK; }
+
 static int conv_geometry_ok(int C, int Cout, int KH, int KW, int S, int W) {
   if (Cout != 32 && Cout != 64) return 0;
   if ((KW * C) % 8 != 0 || (W * C) % 4 != 0 || (S * C) % 4 != 0) return 0;
@@ -589,6 +597,11 @@ extern "C" int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_
   p.inv_chw = 1.0f / (float)(p.cH * p.cW); p.inv_cw = 1.0f / (float)p.cW;
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
+  const int lds_layer = KH == 8 ? 1 : KH == 4 ? 2 : 4;
+  if ((g_conv_fwd_lds & lds_layer) && N >= 512) {          // images resident in LDS (conv_fwd_lds.hip; it checks the whole geometry)
+    const int rc = etm_conv_fwd_lds(x, x_index, w_packed, bias, y, N, C, H, W, Cout, KH, KW, S, st);
+    if (rc != ETM_EUNSUPPORTED) return rc;
+  }
   const int tiles = (p.Mc + 31) / 32;
   if (Cout == 32) {
     const int cands[] = {2, 4};

@@ -438,6 +438,11 @@ int etm_conv_relu(const float *in, const int64_t *in_index, int64_t in_index_str
  *                         (the weights change every optimiser step). */
 int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_t x_images, const float *w_packed, const float *bias, float *y, int N,
                        int C, int H, int W, int Cout, int KH, int KW, int S, int out_nchw, void *stream);
+/* Which forward passes of the three layers of model.py:29-31 on 84 x 84 observations (N >= 512) keep groups of input images resident
+ * in LDS (csrc/conv_fwd_lds.hip): bit 0 / 1 / 2 = layer 1 / 2 / 3; 0: the direct-from-L2 kernel for every shape; negative: the
+ * default (2: layer 2 only, the one layer where it is faster).  Layers 2 / 3 with x_index keep the direct kernel.  Results differ in
+ * summation order only. */
+int etm_conv_train_set_fwd_lds(int layer_mask);
 int etm_conv_train_dgrad(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
                          int KH, int KW, int S, void *stream);
 int etm_conv_pack_weights(const float *w, float *fwd, float *dgrad, int Cout, int C, int KH, int KW, int S, void *stream);

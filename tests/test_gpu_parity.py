@@ -1526,6 +1526,45 @@ def test_train_encoder_fwd_bwd_vs_float64_convs(N, hw):
         assert a.shape == b.shape and _rel(a.cpu().double(), b) < 2e-5, (i, _rel(a.cpu().double(), b))
 
 
+@pytest.mark.parametrize("N", [512, 601, 2048])
+def test_encoder_forward_with_lds_resident_images(N):
+    """csrc/conv_fwd_lds.hip (groups of input images resident in LDS, N >= 512) against the direct-from-L2 forward kernels of the
+    same build layer by layer (both through etm_conv_train_fwd; each is pinned to float64 convolutions at small N by
+    test_train_encoder_fwd_bwd_vs_float64_convs) and -- first 48 images -- against float64 convolutions; with and without the
+    fused minibatch gather (layer 1; layers 2 / 3 with an index keep the direct kernel), ragged last image group
+    (601 = 2 * 300 + 1 = 4 * 150 + 1)."""
+    from etm import lib as etm_lib
+    from etm import ops
+    dev = _dev()
+    lib = etm_lib.load()
+    torch.manual_seed(N)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    layers = [(3, 84, 32, 8, 4), (32, 20, 64, 4, 2), (64, 9, 64, 3, 1)]
+    for (c, hw, cout, k, s) in layers:
+        ho = (hw - k) // s + 1
+        bank = torch.rand((N + 37, hw, hw, c), device=dev)
+        index = torch.randperm(N + 37, device=dev)[:N].contiguous()
+        wt = torch.randn((cout, c, k, k), device=dev) * 0.05
+        b = torch.randn(cout, device=dev) * 0.1
+        packed = ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+        outs = {}
+        for use_index in (False, True):
+            for lds_on in (1, 0):
+                etm_lib.check(lib.etm_conv_train_set_fwd_lds(7 if lds_on else 0), "set_fwd_lds")
+                y = torch.full((N, ho, ho, cout), float("nan"), device=dev)
+                etm_lib.check(lib.etm_conv_train_fwd(bank.data_ptr(), index.data_ptr() if use_index else None, bank.shape[0], packed.data_ptr(),
+                                                     b.data_ptr(), y.data_ptr(), N, c, hw, hw, cout, k, k, s, 0, st), "etm_conv_train_fwd")
+                outs[(use_index, lds_on)] = y
+        etm_lib.check(lib.etm_conv_train_set_fwd_lds(-1), "set_fwd_lds")      # back to the default (layer 2 only)
+        for use_index in (False, True):
+            a, d = outs[(use_index, 1)], outs[(use_index, 0)]
+            assert bool(torch.isfinite(a).all())
+            assert float((a - d).abs().max()) <= 1e-5 * max(1.0, float(d.abs().max())), (c, use_index, float((a - d).abs().max()))
+        x64 = bank[index[:48]].permute(0, 3, 1, 2).double().cpu()
+        want = torch.relu(torch.nn.functional.conv2d(x64, wt.double().cpu(), b.double().cpu(), stride=s)).permute(0, 2, 3, 1)
+        close(outs[(True, 1)][:48], want.numpy(), atol=2e-5, rtol=1e-5, what=f"layer C={c} forward vs float64")
+
+
 def test_train_encoder_minibatch_size_properties():
     """At the minibatch size of BASELINE config 3 (N = 2048, 3 x 84 x 84; too large for the float64 host reference): the features
     agree with the library convolutions, and the weight / bias gradients are ADDITIVE over the batch -- the gradient of the

@@ -1,12 +1,15 @@
 #!/bin/bash
 # One GPU call that collects the round's evidence into gpurun_out/<round>/ (copy what is to be judged into profiles/):
-#   bash tools/collect_evidence.sh r03 [pmc targets...]
+#   [SUITE=1] bash tools/collect_evidence.sh r03 [pmc targets...]      (SUITE=1: the GPU test suite first, its summary line -> gpu_suite.txt)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 ROUND=${1:-r03}; shift
 TARGETS=${@:-encoder grouped_dw rollout_step window_sorted}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
+if [ "${SUITE:-0}" = 1 ]; then
+  echo "== pytest -m gpu"; (cd $ROOT && timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $OUT/gpu_suite.txt)
+fi
 cd /tmp && export TMPDIR=/tmp
 echo "== bench"; timeout 600 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.err
 echo "== rocprofv3 --kernel-trace --stats of the bench command"
