@@ -167,6 +167,39 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
   if (wave == 0 && c < C) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
+// Several column-sum reductions in one launch (the second stage of every LayerNorm / bias gradient of a backward pass, deferred to
+// its end): problem i adds the P[i] rows of `partial[i]` (row stride ld[i] floats) over C[i] columns into out[i]; same summation
+// tree as colsum_reduce_kernel, so the results are bit-identical to the per-call reductions.
+constexpr int CS_MAX = 24;
+struct ColsumGroup {
+  const float *partial[CS_MAX];
+  float *out[CS_MAX];
+  int P[CS_MAX], C[CS_MAX], ld[CS_MAX], first_block[CS_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_reduce_grouped_kernel(const ColsumGroup g) {
+  __shared__ float sm[TR_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;      // uniform
+  const float *__restrict__ partial = g.partial[i];
+  const int P = g.P[i], C = g.C[i], ld = g.ld[i];
+  const int c = ((int)blockIdx.x - g.first_block[i]) * 64 + lane;
+  const int cc = c < C ? c : 0;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int p = wave;
+  for (; p + 7 * TR_WAVES < P; p += 8 * TR_WAVES) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += partial[(long long)(p + k * TR_WAVES) * ld + cc];
+  }
+  for (; p < P; p += TR_WAVES) acc[0] += partial[(long long)p * ld + cc];
+  sm[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && c < C) g.out[i][c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+}
+
 // ---- backward of relu(x W^T + b) up to the GEMMs (model.py:94-107, transformer.py:232): gm = g * (y > 0) and the column sums of
 // gm (= the bias gradient) in one pass; 64 columns x 64 rows per workgroup (wave w takes the rows w, w + 4, ...), partial sums
 // per row chunk, colsum_reduce_kernel adds the chunks in a fixed order.  y == nullptr: no mask (plain linear layer).
@@ -315,7 +348,7 @@ extern "C" int etm_ln_train_bwd(const float *dy, const float *s, const float *st
                                 const float *a_bias, int relu, float *ds, float *da, float *dgamma_dbeta_dbias, float *workspace,
                                 int64_t workspace_bytes, int N, int D, void *stream) {
   (void)hipGetLastError();
-  if (!dy || !s || !stats || !gamma || !ds || !dgamma_dbeta_dbias || !workspace || N <= 0 || D <= 0) return ETM_EINVAL;
+  if (!dy || !s || !stats || !gamma || !ds || !workspace || N <= 0 || D <= 0) return ETM_EINVAL;
   if (relu && (!a || !a_bias || !da)) return ETM_EINVAL;
   if (workspace_bytes < etm_ln_train_bwd_workspace_bytes(N, D)) return ETM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -329,7 +362,7 @@ extern "C" int etm_ln_train_bwd(const float *dy, const float *s, const float *st
       return etm_launch_status();
     });
   }
-  if (rc) return rc;
+  if (rc || !dgamma_dbeta_dbias) return rc;          // no destination: the caller reduces `workspace` later (etm_colsum_reduce_grouped)
   EtmProfScope prof(ETM_K_COLSUM, st);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((3 * D + 63) / 64)), dim3(256), 0, st, workspace, P, 3 * D, dgamma_dbeta_dbias);
   return etm_launch_status();
@@ -344,7 +377,7 @@ extern "C" int64_t etm_relu_bwd_colsum_workspace_bytes(int N, int C) {
 extern "C" int etm_relu_bwd_colsum(const float *g, const float *y, float *gm, float *db, float *workspace, int64_t workspace_bytes, int N, int C,
                                    void *stream) {
   (void)hipGetLastError();
-  if (!g || !db || !workspace || N <= 0 || C <= 0 || (y && !gm)) return ETM_EINVAL;
+  if (!g || !workspace || N <= 0 || C <= 0 || (y && !gm)) return ETM_EINVAL;
   if (workspace_bytes < etm_relu_bwd_colsum_workspace_bytes(N, C)) return ETM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int P = (N + 63) / 64;
@@ -352,7 +385,7 @@ extern "C" int etm_relu_bwd_colsum(const float *g, const float *y, float *gm, fl
     EtmProfScope prof(ETM_K_COLSUM, st);
     hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, st, g, y, gm, workspace, N, C);
     int rc = etm_launch_status();
-    if (rc) return rc;
+    if (rc || !db) return rc;                          // no destination: reduced later (etm_colsum_reduce_grouped)
   }
   EtmProfScope prof(ETM_K_COLSUM, st);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, workspace, P, C, db);
@@ -413,5 +446,31 @@ extern "C" int etm_gate_train_bwd2(const float *drx, const float *x, const float
   hipStream_t st = (hipStream_t)stream;
   EtmProfScope prof(ETM_K_GATE_TRAIN, st);
   hipLaunchKernelGGL(gate_bwd2_kernel, dim3((unsigned)(((long long)N * D + 255) / 256)), dim3(256), 0, st, drx, x, r, dx1, dA, dB, dx2, N, D);
+  return etm_launch_status();
+}
+
+// Row counts of the partial sums the two producers above leave in their workspace (for etm_colsum_reduce_grouped).
+extern "C" int etm_ln_train_bwd_partial_rows(int N) { return N > 0 ? (N + 7) / 8 : 0; }
+extern "C" int etm_relu_bwd_colsum_partial_rows(int N) { return N > 0 ? (N + 63) / 64 : 0; }
+extern "C" int etm_colsum_reduce_max_problems(void) { return CS_MAX; }
+
+// out[i][c] = sum_p partial[i][p * ld[i] + c], p < P[i], c < C[i], for n problems in one launch (host arrays; n <= CS_MAX).
+extern "C" int etm_colsum_reduce_grouped(const float *const *partial, const int *P, const int *C, const int *ld, float *const *out, int n,
+                                         void *stream) {
+  (void)hipGetLastError();
+  if (!partial || !P || !C || !ld || !out || n <= 0 || n > CS_MAX) return ETM_EINVAL;
+  ColsumGroup g{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!partial[i] || !out[i] || P[i] <= 0 || C[i] <= 0 || ld[i] < C[i]) return ETM_EINVAL;
+    g.partial[i] = partial[i]; g.out[i] = out[i]; g.P[i] = P[i]; g.C[i] = C[i]; g.ld[i] = ld[i];
+    g.first_block[i] = blocks;
+    blocks += (C[i] + 63) / 64;
+  }
+  g.first_block[n] = blocks;
+  g.n = n;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_COLSUM, st);
+  hipLaunchKernelGGL(colsum_reduce_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
   return etm_launch_status();
 }

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _lib = None
 
@@ -62,6 +62,10 @@ SIGNATURES = {
     "etm_gru_gate_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_ln_train_fwd": (_I, [_P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P]),
     "etm_ln_train_bwd_workspace_bytes": (_L, [_I, _I]),
+    "etm_ln_train_bwd_partial_rows": (_I, [_I]),
+    "etm_relu_bwd_colsum_partial_rows": (_I, [_I]),
+    "etm_colsum_reduce_max_problems": (_I, []),
+    "etm_colsum_reduce_grouped": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "etm_ln_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_gate_train_rz": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_gate_train_out": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -120,6 +120,7 @@ class _MhaFn(torch.autograd.Function):
         if N != spec.N:
             raise ValueError("query batch and window batch differ")
         need_grad = any(ctx.needs_input_grad[:6])
+        ctx.set_materialize_grads(False)      # the attention weights are an output nobody differentiates: no zero tensor for them
         dev = q.device
         out = torch.empty((N, D), dtype=torch.float32, device=dev)
         att = torch.empty((N, H, L), dtype=torch.float32, device=dev)
@@ -147,6 +148,8 @@ class _MhaFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, _d_att):
+        if d_out is None:
+            return (None,) * 10
         lib = _lib.load()
         spec, block, H = ctx.spec, ctx.block, ctx.H
         saved = list(ctx.saved_tensors)
@@ -195,6 +198,7 @@ class _WindowFn(torch.autograd.Function):
         L = spec.L
         if N != spec.N:
             raise ValueError("query batch and window batch differ")
+        ctx.set_materialize_grads(False)      # (no zero tensor for the gradient of the attention weights)
         dev = u.device
         att = torch.empty((N, H, L), dtype=torch.float32, device=dev)
         z = torch.empty((H, N, D), dtype=torch.float32, device=dev)
@@ -218,6 +222,8 @@ class _WindowFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gz, _d_att):
+        if gz is None:
+            return (None,) * 7
         lib = _lib.load()
         spec, block = ctx.spec, ctx.block
         saved = list(ctx.saved_tensors)
@@ -287,6 +293,7 @@ class DeferredDw:
     def __init__(self, dest):
         self.dest = dest
         self.items = []          # (A, B, C view, Ma, Nb, lda, ldb, ldc)
+        self.colsums = []        # (partial sums, first column, rows P, columns C, row stride, destination view)
         self.written = set()
         self.N = None
 
@@ -322,10 +329,36 @@ class DeferredDw:
         self.written.add(weight.data_ptr())
         return True
 
+    def offer_colsum(self, partial, P, ld, parts):
+        """Second stage of column-sum gradients (LayerNorm weight / bias, linear bias): ``partial`` [P, ld] per-workgroup partial sums
+        (a buffer of the caller's own, kept alive here), ``parts`` = [(first column, columns, parameter data_ptr)].  True: all
+        destinations are known 1-D arena views and the sums will be written by the ONE reduction launch of ``flush()``."""
+        views = [self.dest.get(ptr) for _, _, ptr in parts]
+        if any(v is None or v.dim() != 1 or not v.is_contiguous() for v in views):
+            return False
+        if len(self.colsums) + len(parts) > _lib.load().etm_colsum_reduce_max_problems():
+            return False
+        for (c0, cols, ptr), v in zip(parts, views):
+            if v.numel() != cols or ptr in self.written:
+                return False
+        for (c0, cols, ptr), v in zip(parts, views):
+            self.colsums.append((partial, c0, P, cols, ld, v))
+            self.written.add(ptr)
+        return True
+
     def flush(self):
+        import ctypes
+        if self.colsums:
+            k = len(self.colsums)
+            pp = (ctypes.c_void_p * k)(*[_ptr(it[0]) + 4 * it[1] for it in self.colsums])
+            po = (ctypes.c_void_p * k)(*[_ptr(it[5]) for it in self.colsums])
+            iP = (ctypes.c_int32 * k)(*[it[2] for it in self.colsums])
+            iC = (ctypes.c_int32 * k)(*[it[3] for it in self.colsums])
+            iL = (ctypes.c_int32 * k)(*[it[4] for it in self.colsums])
+            _lib.check(_lib.load().etm_colsum_reduce_grouped(pp, iP, iC, iL, po, k, _stream()), "etm_colsum_reduce_grouped")
+            self.colsums = []
         if not self.items:
             return
-        import ctypes
         k = len(self.items)
         pa = (ctypes.c_void_p * k)(*[_ptr(it[0]) + 4 * it[8] for it in self.items])
         pb = (ctypes.c_void_p * k)(*[_ptr(it[1]) for it in self.items])
@@ -739,6 +772,7 @@ class _FusedLayerNormFn(torch.autograd.Function):
                                         _ptr(s), _ptr(stats), N, D, _stream()), "etm_ln_train_fwd")
         if need:
             ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, res is not None
+            ctx.param_ptrs = (gamma.data_ptr(), beta.data_ptr(), bias.data_ptr() if bias is not None else 0)
             ctx.save_for_backward(s, stats, gamma, a if relu else None, bias if relu else None)
         return y
 
@@ -750,12 +784,22 @@ class _FusedLayerNormFn(torch.autograd.Function):
         N, D = s.shape
         ds = torch.empty_like(s)
         da = torch.empty_like(s) if ctx.relu else None
-        sums = torch.empty((3, D), dtype=torch.float32, device=s.device)
         nbytes = lib.etm_ln_train_bwd_workspace_bytes(N, D)
+        d_a = da if ctx.relu else ds
+        col = DeferredDw.active
+        if col is not None:
+            # the three column sums go to the collector's ONE reduction launch, straight into the parameters' arena views
+            g_ptr, b_ptr, bias_ptr = ctx.param_ptrs
+            parts = [(0, D, g_ptr), (D, D, b_ptr)] + ([(2 * D, D, bias_ptr)] if ctx.has_bias else [])
+            part = torch.empty(nbytes // 4, dtype=torch.float32, device=s.device)
+            if col.offer_colsum(part, lib.etm_ln_train_bwd_partial_rows(N), 3 * D, parts):
+                _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0,
+                                                _ptr(ds), _ptr(da), None, _ptr(part), nbytes, N, D, _stream()), "etm_ln_train_bwd")
+                return d_a, None, (ds if ctx.has_res else None), None, None, None, None
+        sums = torch.empty((3, D), dtype=torch.float32, device=s.device)
         ws = workspace(nbytes, s.device, "ln_bwd")
         _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0, _ptr(ds),
                                         _ptr(da), _ptr(sums), _ptr(ws), nbytes, N, D, _stream()), "etm_ln_train_bwd")
-        d_a = da if ctx.relu else ds
         return d_a, (sums[2] if ctx.has_bias else None), (ds if ctx.has_res else None), sums[0], sums[1], None, None
 
 
@@ -1027,6 +1071,7 @@ class _LinearReluFn(torch.autograd.Function):
             y = torch.addmm(bias, x, weight.t())
             torch.relu_(y)
         ctx.save_for_backward(x, weight, y)
+        ctx.bias_ptr = bias.data_ptr()
         return y
 
     @staticmethod
@@ -1036,10 +1081,17 @@ class _LinearReluFn(torch.autograd.Function):
         g = _f32c(g, "grad")
         n, c = g.shape
         gm = torch.empty_like(g)
-        db = torch.empty(c, dtype=torch.float32, device=g.device)
         nbytes = lib.etm_relu_bwd_colsum_workspace_bytes(n, c)
-        ws = workspace(nbytes, g.device, "relu_bwd")
-        _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), _ptr(db), _ptr(ws), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+        col = DeferredDw.active
+        db = None
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device) if col is not None else None
+        if col is not None and col.offer_colsum(part, lib.etm_relu_bwd_colsum_partial_rows(n), c, [(0, c, ctx.bias_ptr)]):
+            # the bias gradient's second stage rides in the collector's one reduction launch
+            _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), None, _ptr(part), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+        else:
+            db = torch.empty(c, dtype=torch.float32, device=g.device)
+            ws = workspace(nbytes, g.device, "relu_bwd")
+            _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), _ptr(db), _ptr(ws), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
         dx = gm.mm(weight) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _offer_dw(gm, x, weight):
@@ -1138,11 +1190,14 @@ class _PpoLossFn(torch.autograd.Function):
         _lib.check(rc, "etm_ppo_loss")
         ctx.save_for_backward(d_logits, d_value)
         ctx.include_value = include_value
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out8)
         return out8[2].clone(), out8
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
+        if g_loss is None:
+            return (None,) * 14
         d_logits, d_value = ctx.saved_tensors
         gv = d_value * g_loss if ctx.include_value else None
         return d_logits * g_loss, gv, None, None, None, None, None, None, None, None, None, None, None, None
@@ -1178,11 +1233,14 @@ class _HeadsLossFn(torch.autograd.Function):
         ctx.save_for_backward(h, wlp, wlv, gm_p, gm_v, sums)
         ctx.dims = (hid, A)
         ctx.unit = bool(unit_grad)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out8)
         return out8[2].clone(), out8
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
+        if g_loss is None:
+            return (None,) * 19
         h, wlp, wlv, gm_p, gm_v, sums = ctx.saved_tensors
         hid, A = ctx.dims
         unit = ctx.unit                 # the caller promises loss.backward() on the returned loss itself: g_loss == 1, nothing to scale

@@ -925,7 +925,7 @@ class PPOTrainer:
         self._set_lr(learning_rate)
         self.flat_grads.zero_()
         with ops.DeferredDw(self._dw_destinations()):      # dense-layer weight gradients: one grouped launch into the arena
-            loss.backward()
+            loss.backward(self._unit_gradient(loss))
         if self.dp is not None:
             self.dp.all_reduce_grads(average=False)       # the sum; the 1 / world rides in the clip coefficient below
         # global-norm clipping (the rule of torch.nn.utils.clip_grad_norm_, upstream :311) + AdamW on the flat arenas: 2 launches
@@ -952,13 +952,21 @@ class PPOTrainer:
                             self.config["value_loss_coefficient"], beta, stats3, dyn=dyn)
 
     def _dw_destinations(self):
-        """{parameter data_ptr: its [out, in] gradient view in the flat arena} for the 2-D parameters (``grouped_dw_train: false`` in
-        the config: empty, every layer multiplies its own weight gradient)."""
-        if not self.config.get("grouped_dw_train", True):
-            return {}
+        """{parameter data_ptr: its gradient view in the flat arena}: the [out, in] views of the 2-D parameters for the grouped weight-
+        gradient launch (``grouped_dw_train: false`` in the config: none, every layer multiplies its own weight gradient) and the
+        1-D views (LayerNorm weights / biases, linear biases) for the grouped column-sum reduction (``grouped_colsum_train``)."""
         if getattr(self, "_dw_dest", None) is None:
-            self._dw_dest = {p.data_ptr(): v for p, v in zip(self.params, self._grad_views) if p.dim() == 2}
+            dw, cs = self.config.get("grouped_dw_train", True), self.config.get("grouped_colsum_train", True)
+            self._dw_dest = {p.data_ptr(): v for p, v in zip(self.params, self._grad_views)
+                             if (p.dim() == 2 and dw) or (p.dim() == 1 and cs)}
         return self._dw_dest
+
+    def _unit_gradient(self, loss):
+        """d loss / d loss = 1 from a cached tensor (autograd would fill a fresh one every step: one launch)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            one = self._one = torch.ones_like(loss)
+        return one
 
     def _grad_scale(self):
         return self.dp.grad_scale if self.dp is not None else 1.0
@@ -1019,7 +1027,7 @@ class PPOTrainer:
         # the weight gradients of the dense layers (dW = dy^T x, a contraction over the minibatch with a small output) are collected
         # during backward and computed by ONE grouped launch straight into their arena views (csrc/grouped_dw.hip)
         with ops.DeferredDw(self._dw_destinations()) as dw:
-            loss.backward()
+            loss.backward(self._unit_gradient(loss))
         views, grads = [], []
         for p, v in zip(self.params, self._grad_views):
             if p.data_ptr() in dw.written:

@@ -209,6 +209,8 @@ int etm_gru_gate_out(const float *a, const float *c, const float *z, const float
  *                     when relu == 0), da [N,D] (relu != 0 only: ds where a + a_bias > 0), and dgamma_dbeta_dbias [3,D] =
  *                     column sums of (dy * xhat, dy, da).  Two launches (rows, then a fixed-order sum of per-workgroup
  *                     partial sums held in `workspace`, etm_ln_train_bwd_workspace_bytes(N, D) bytes): deterministic.
+ *                     dgamma_dbeta_dbias NULL: the second launch is left out -- `workspace` then holds
+ *                     etm_ln_train_bwd_partial_rows(N) rows of 3 D partial sums for etm_colsum_reduce_grouped.
  *   etm_gate_train_*: the GTrXL GRU gate around three concatenated GEMMs A = y [Wr;Wz;Wg]^T [N,3D], B = x [Ur;Uz]^T [N,2D],
  *                     C = (r x) Ug^T [N,D]:
  *       rz  : r = sigmoid(A_r + B_r), z = sigmoid(A_z + B_z - bg), rx = r x              (writes r, z, rx)
@@ -224,6 +226,12 @@ int64_t etm_ln_train_bwd_workspace_bytes(int N, int D);
 int etm_ln_train_bwd(const float *dy, const float *s, const float *stats, const float *gamma, const float *a, const float *a_bias,
                      int relu, float *ds, float *da, float *dgamma_dbeta_dbias, float *workspace, int64_t workspace_bytes, int N, int D,
                      void *stream);
+int etm_ln_train_bwd_partial_rows(int N);
+/* Second stage of several column-sum gradients in ONE launch (the LayerNorm / bias gradients of a whole backward pass, collected by
+ * etm/ops.py DeferredDw): out[i][c] = sum over p < P[i] of partial[i][p * ld[i] + c], c < C[i]; host arrays of n <=
+ * etm_colsum_reduce_max_problems() entries; the summation tree of the per-call reductions (bit-identical results). */
+int etm_colsum_reduce_max_problems(void);
+int etm_colsum_reduce_grouped(const float *const *partial, const int *P, const int *C, const int *ld, float *const *out, int n, void *stream);
 int etm_gate_train_rz(const float *A, const float *B, const float *bg, const float *x, float *r, float *z, float *rx, int N, int D,
                       void *stream);
 int etm_gate_train_out(const float *A, const float *C, const float *z, const float *x, float *hh, float *out, int N, int D, void *stream);
@@ -371,8 +379,10 @@ int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int
 
 /* Backward of y = relu(x W^T + b) (model.py:94-107, transformer.py:232) up to its two GEMMs, in two launches: gm [N, C] =
  * g * (y > 0) and db [C] = column sums of gm (fixed summation order).  y NULL: plain linear layer (gm = g; gm may be NULL, only
- * db is produced).  workspace: etm_relu_bwd_colsum_workspace_bytes(N, C). */
+ * db is produced).  workspace: etm_relu_bwd_colsum_workspace_bytes(N, C).  db NULL: the reduction is left to
+ * etm_colsum_reduce_grouped (etm_relu_bwd_colsum_partial_rows(N) rows of C partial sums in `workspace`). */
 int64_t etm_relu_bwd_colsum_workspace_bytes(int N, int C);
+int etm_relu_bwd_colsum_partial_rows(int N);
 int etm_relu_bwd_colsum(const float *g, const float *y, float *gm, float *db, float *workspace, int64_t workspace_bytes, int N, int C,
                         void *stream);
 

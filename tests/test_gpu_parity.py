@@ -427,7 +427,8 @@ _ROLLOUT_PATHS = {
     "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
     "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
-    "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False},   # heads / loss / weight gradients as separate ops (round-2 form)
+    "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False,    # heads / loss / weight gradients as separate ops (round-2 form),
+                       "grouped_colsum_train": False},                          # every column-sum gradient reduced by its own launch
     "pull_obs": {"pull_observations": True},                  # the device pulls the observation rows itself; step graphs enqueued one step ahead
     "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
 }
@@ -1226,6 +1227,48 @@ def test_grouped_weight_gradients_vs_float64(N):
     for v, r in zip(views, ref):
         assert float((v - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6, float((v - r).abs().max())
     print(f"[grouped dW N={N}] worst element error / rms element vs float64: {worst:.2e}")
+
+
+@pytest.mark.parametrize("N,D", [(2048, 384), (601, 128), (9, 96), (1, 64)])
+def test_grouped_column_sums_bit_identical_to_per_call_reductions(N, D):
+    """etm_colsum_reduce_grouped: the LayerNorm weight / bias and linear bias gradients of a backward pass (two fused LayerNorms --
+    with bias + ReLU + residual, and plain -- and a linear + ReLU layer) reduced by the DeferredDw collector's ONE launch into 1-D
+    destination views, against the per-call reductions (same summation tree: bit-identical) and float64 column sums."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(N * 7 + D)
+    n1, n2 = torch.nn.LayerNorm(D).to(dev), torch.nn.LayerNorm(D).to(dev)
+    lin = torch.nn.Linear(D, D).to(dev)
+    fcb = torch.randn(D, device=dev).mul_(0.1).requires_grad_(True)
+    with torch.no_grad():
+        for m in (n1, n2):
+            m.weight.add_(torch.randn(D, device=dev) * 0.1)
+            m.bias.add_(torch.randn(D, device=dev) * 0.1)
+    a, res = torch.randn((N, D), device=dev, requires_grad=True), torch.randn((N, D), device=dev, requires_grad=True)
+    gout = torch.randn((N, D), device=dev)
+    params = [n1.weight, n1.bias, n2.weight, n2.bias, lin.bias, fcb]
+
+    def net():
+        x = ops.fused_layernorm(a, n1, bias=fcb, res=res, relu=True)
+        y = ops.linear_relu_train(x, lin.weight, lin.bias)
+        return ops.fused_layernorm(y, n2)
+
+    (net() * gout).sum().backward()
+    ref = [t.grad.clone() for t in params]
+    ref_in = (a.grad.clone(), res.grad.clone(), lin.weight.grad.clone())
+    for t in params + [a, res, lin.weight]:
+        t.grad = None
+    views = [torch.full((D,), float("nan"), device=dev) for _ in params]
+    with ops.DeferredDw({t.data_ptr(): v for t, v in zip(params, views)}) as col:
+        (net() * gout).sum().backward()
+    assert col.written == {t.data_ptr() for t in params} and all(t.grad is None for t in params)
+    for v, r in zip(views, ref):
+        assert torch.equal(v, r), float((v - r).abs().max())
+    for got, want in zip((a.grad, res.grad, lin.weight.grad), ref_in):
+        assert torch.equal(got, want)
+    # float64: d n2.bias = column sums of the upstream gradient
+    want = gout.double().sum(0)
+    assert float((views[3].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())) * max(1.0, N ** 0.5)
 
 
 @pytest.mark.parametrize("N,hid,A,D", [(2048, 384, 3, 384), (37, 128, 2, 128), (130, 512, 8, 64), (5, 64, 4, 96)])
