@@ -93,7 +93,7 @@ __device__ __forceinline__ void store_partials(float (&acc)[NACC][NJ], float *sm
 // dy -> ds (LayerNorm input gradient, also the residual-branch gradient), da (= ds under the ReLU mask; only written when
 // relu), partial[wg][3][D] = column sums of (dy * xhat, dy, da) over the workgroup's rows.
 template <int NJ>
-__global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ s,
+__global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ s,
                                                            const float *__restrict__ stats, const float *__restrict__ gamma,
                                                            const float *__restrict__ a, const float *__restrict__ a_bias, int relu,
                                                            float *__restrict__ ds, float *__restrict__ da, float *__restrict__ partial,
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float *__restri
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + 64 * j, cc = c < D ? c : 0;
       const long long o = (long long)row * D + cc;
-      const float d = dy[o], sv = s[o];
+      const float d = dy2 ? dy[o] + dy2[o] : dy[o], sv = s[o];      // (two consumers of the output: their gradients meet here)
       pre[j] = relu ? a[o] + bi[j] : 1.f;
       dyv[j] = (c < D) ? d : 0.f;
       xh[j] = (c < D) ? (sv - mean) * rstd : 0.f;
@@ -344,7 +344,7 @@ extern "C" int64_t etm_ln_train_bwd_workspace_bytes(int N, int D) {
   return (int64_t)((N + rows - 1) / rows) * 3 * D * sizeof(float);
 }
 
-extern "C" int etm_ln_train_bwd(const float *dy, const float *s, const float *stats, const float *gamma, const float *a,
+extern "C" int etm_ln_train_bwd(const float *dy, const float *dy2, const float *s, const float *stats, const float *gamma, const float *a,
                                 const float *a_bias, int relu, float *ds, float *da, float *dgamma_dbeta_dbias, float *workspace,
                                 int64_t workspace_bytes, int N, int D, void *stream) {
   (void)hipGetLastError();
@@ -357,7 +357,7 @@ extern "C" int etm_ln_train_bwd(const float *dy, const float *s, const float *st
   {
     EtmProfScope prof(ETM_K_LN_TRAIN_BWD, st);
     rc = dispatch_nj(D, [&](auto nj) {
-      hipLaunchKernelGGL((ln_train_bwd_kernel<decltype(nj)::value>), dim3((unsigned)P), dim3(256), 0, st, dy, s, stats, gamma, a, a_bias, relu, ds,
+      hipLaunchKernelGGL((ln_train_bwd_kernel<decltype(nj)::value>), dim3((unsigned)P), dim3(256), 0, st, dy, dy2, s, stats, gamma, a, a_bias, relu, ds,
                          da, workspace, N, D, rows);
       return etm_launch_status();
     });

@@ -537,6 +537,87 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4 *__restrict_
   for (int k = 0; k < 4; ++k) o[k] = yv[k] > 0.f ? gv[k] : 0.f;
   out[i] = o;
 }
+
+// The three layers' re-packings / weight-gradient reductions as ONE launch each (a launch of this size costs ~5 us whatever it does).
+constexpr int CV_MAX = 4;
+struct PackGroup {
+  const float *w[CV_MAX];
+  float *fwd[CV_MAX], *dgrad[CV_MAX];
+  int Cout[CV_MAX], C[CV_MAX], KH[CV_MAX], KW[CV_MAX], S[CV_MAX], first_block[CV_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void conv_pack_grouped_kernel(const PackGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;      // uniform
+  const float *__restrict__ w = g.w[i];
+  float *__restrict__ fwd = g.fwd[i], *__restrict__ dgrad = g.dgrad[i];
+  const int Cout = g.Cout[i], C = g.C[i], KH = g.KH[i], KW = g.KW[i], S = g.S[i];
+  const int total = Cout * C * KH * KW;
+  const int e = ((int)blockIdx.x - g.first_block[i]) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = e & 3, col = (e >> 2) & 31, half = (e >> 7) & 1;
+  if (fwd) {
+    const int NT = Cout >> 5;
+    const int gt = e >> 8, t = gt % NT, gg = gt / NT;
+    const int co = t * 32 + col, k = gg * 8 + half * 4 + j;
+    const int c = k % C, kx = (k / C) % KW, ky = k / (C * KW);
+    fwd[e] = w[((co * C + c) * KH + ky) * KW + kx];
+  }
+  if (dgrad) {
+    const int T = KH / S, Kd = T * T * Cout, per_class = C * Kd, NT = C >> 5;
+    const int cls = e / per_class, el = e - cls * per_class;
+    const int py = cls / S, px = cls - py * S;
+    const int gt = el >> 8, t = gt % NT, gg = gt / NT;
+    const int c = t * 32 + col, kd = gg * 8 + half * 4 + j;
+    const int co = kd % Cout, jx = (kd / Cout) % T, a = kd / (Cout * T);
+    dgrad[e] = w[((co * C + c) * KH + (py + S * a)) * KW + (px + S * (T - 1 - jx))];
+  }
+}
+
+struct WgradReduceGroup {
+  const float *partial[CV_MAX];
+  float *dw[CV_MAX], *db[CV_MAX];
+  int splits[CV_MAX], Cout[CV_MAX], C[CV_MAX], KH[CV_MAX], KW[CV_MAX], first_block[CV_MAX + 1];
+  int n;
+};
+// conv_wgrad_reduce_kernel for several layers: same fixed summation order; the weight part goes to dw (native [Cout, C, KH, KW]
+// layout), the bias part to db.
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_grouped_kernel(const WgradReduceGroup g) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;      // uniform
+  const float *__restrict__ partial = g.partial[i];
+  const int splits = g.splits[i], Cout = g.Cout[i], C = g.C[i], KH = g.KH[i], KW = g.KW[i];
+  const long long KC = (long long)KH * KW * C * Cout, elems = KC + Cout;
+  const long long e = (long long)((int)blockIdx.x - g.first_block[i]) * 64 + lane;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (e < elems) {
+    for (int s0 = wave; s0 < splits; s0 += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s0 + 16 * u;
+        if (sl < splits) acc[u] += partial[(long long)sl * elems + e];
+      }
+    }
+  }
+  red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && e < elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    if (e < KC) {
+      const int co = (int)(e % Cout), k = (int)(e / Cout);
+      const int c = k % C, kx = (k / C) % KW, ky = k / (C * KW);
+      g.dw[i][(((long long)co * C + c) * KH + ky) * KW + kx] = t;
+    } else {
+      g.db[i][e - KC] = t;
+    }
+  }
+}
 }  // namespace
 
 // Pixel tiles per wave.  A wave's work grows with MT (and the operand loads per MFMA fall), but the chip finishes in
@@ -692,11 +773,21 @@ extern "C" int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int
   return (int64_t)wgrad_splits(N * Ho * Wo, wgrad_k_ranges(Cout, (int)K)) * (K * Cout + Cout) * (int64_t)sizeof(float);
 }
 
+// Pixel slices etm_conv_train_wgrad leaves in its workspace ([slices][K * Cout + Cout]) for the reduction.
+extern "C" int etm_conv_train_wgrad_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S) {
+  if (N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return 0;
+  const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1, M = N * Ho * Wo, K = KH * KW * C;
+  const int splits = wgrad_splits(M, wgrad_k_ranges(Cout, K));
+  const int rows = ((M + splits - 1) / splits + WG_MC - 1) / WG_MC * WG_MC;
+  return (M + rows - 1) / rows;
+}
+
 // dw [Cout, C, KH, KW] (the parameter's own layout) followed by dbias [Cout], in one buffer of K * Cout + Cout floats.
+// dw_kc_dbias NULL: only the pixel slices are produced (etm_conv_wgrad_reduce_grouped sums them later).
 extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, const float *dy, float *dw_kc_dbias, float *workspace, int64_t workspace_bytes, int N,
                                     int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
-  if (!x || !dy || !dw_kc_dbias || !workspace || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
+  if (!x || !dy || !workspace || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   if (!conv_geometry_ok(C, Cout, KH, KW, S, W)) return ETM_EUNSUPPORTED;
   if (workspace_bytes < etm_conv_train_wgrad_workspace_bytes(N, C, H, W, Cout, KH, KW, S)) return ETM_EWORKSPACE;
   ConvW p{};
@@ -737,6 +828,7 @@ extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, cons
     int rc = etm_launch_status();
     if (rc) return rc;
   }
+  if (!dw_kc_dbias) return ETM_OK;      // no destination: the caller reduces the slices later (etm_conv_wgrad_reduce_grouped)
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_WGRAD, ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, KH), st);
   const long long elems = (long long)p.K * Cout + Cout;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, workspace, splits_used, elems, dw_kc_dbias,
@@ -763,5 +855,53 @@ extern "C" int etm_relu_mask(const float *g, const float *y, float *out, int64_t
   EtmProfScope prof(ETM_K_CONV_TRAIN_DGRAD, st);
   hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const f32x4 *)g, (const f32x4 *)y, (f32x4 *)out,
                      (long long)(n / 4));
+  return etm_launch_status();
+}
+
+// etm_conv_pack_weights for n <= 4 layers in one launch (host arrays; fwd[i] / dgrad[i] may be NULL as there).
+extern "C" int etm_conv_pack_weights_grouped(const float *const *w, float *const *fwd, float *const *dgrad, const int *Cout, const int *C,
+                                             const int *KH, const int *KW, const int *S, int n, void *stream) {
+  (void)hipGetLastError();
+  if (!w || !fwd || !dgrad || !Cout || !C || !KH || !KW || !S || n <= 0 || n > CV_MAX) return ETM_EINVAL;
+  PackGroup g{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || (!fwd[i] && !dgrad[i]) || Cout[i] <= 0 || C[i] <= 0 || KH[i] <= 0 || KW[i] <= 0 || S[i] <= 0) return ETM_EINVAL;
+    if (Cout[i] % 32 != 0 || (KH[i] * KW[i] * C[i]) % 8 != 0) return ETM_EUNSUPPORTED;
+    if (dgrad[i] && (C[i] % 32 != 0 || KH[i] % S[i] != 0 || KW[i] % S[i] != 0 || KH[i] != KW[i] ||
+                     ((KH[i] / S[i]) * (KW[i] / S[i]) * Cout[i]) % 8 != 0))
+      return ETM_EUNSUPPORTED;
+    g.w[i] = w[i]; g.fwd[i] = fwd[i]; g.dgrad[i] = dgrad[i];
+    g.Cout[i] = Cout[i]; g.C[i] = C[i]; g.KH[i] = KH[i]; g.KW[i] = KW[i]; g.S[i] = S[i];
+    g.first_block[i] = blocks;
+    blocks += (Cout[i] * C[i] * KH[i] * KW[i] + 255) / 256;
+  }
+  g.first_block[n] = blocks;
+  g.n = n;
+  hipLaunchKernelGGL(conv_pack_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  return etm_launch_status();
+}
+
+// The reductions of n <= 4 etm_conv_train_wgrad calls made with a NULL destination, in one launch: partial[i] = that call's
+// workspace ([slices[i]][K * Cout + Cout]), dw[i] [Cout, C, KH, KW] and db[i] [Cout] the destinations (e.g. the parameters' views in
+// a flat gradient arena).  Same summation order as the per-call reduction: bit-identical.
+extern "C" int etm_conv_wgrad_reduce_grouped(const float *const *partial, const int *slices, float *const *dw, float *const *db,
+                                             const int *Cout, const int *C, const int *KH, const int *KW, int n, void *stream) {
+  (void)hipGetLastError();
+  if (!partial || !slices || !dw || !db || !Cout || !C || !KH || !KW || n <= 0 || n > CV_MAX) return ETM_EINVAL;
+  WgradReduceGroup g{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!partial[i] || !dw[i] || !db[i] || slices[i] <= 0 || Cout[i] <= 0 || C[i] <= 0 || KH[i] <= 0 || KW[i] <= 0) return ETM_EINVAL;
+    g.partial[i] = partial[i]; g.dw[i] = dw[i]; g.db[i] = db[i]; g.splits[i] = slices[i];
+    g.Cout[i] = Cout[i]; g.C[i] = C[i]; g.KH[i] = KH[i]; g.KW[i] = KW[i];
+    g.first_block[i] = blocks;
+    blocks += (int)(((long long)KH[i] * KW[i] * C[i] * Cout[i] + Cout[i] + 63) / 64);
+  }
+  g.first_block[n] = blocks;
+  g.n = n;
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_CONV_TRAIN_WGRAD, st);
+  hipLaunchKernelGGL(conv_wgrad_reduce_grouped_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, g);
   return etm_launch_status();
 }

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _lib = None
 
@@ -66,7 +66,7 @@ SIGNATURES = {
     "etm_relu_bwd_colsum_partial_rows": (_I, [_I]),
     "etm_colsum_reduce_max_problems": (_I, []),
     "etm_colsum_reduce_grouped": (_I, [_P, _P, _P, _P, _P, _I, _P]),
-    "etm_ln_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "etm_ln_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_gate_train_rz": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_gate_train_out": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_gate_train_bwd_workspace_bytes": (_L, [_I, _I]),
@@ -74,6 +74,9 @@ SIGNATURES = {
     "etm_gate_train_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_conv_train_fwd": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_train_set_fwd_lds": (_I, [_I]),
+    "etm_conv_pack_weights_grouped": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "etm_conv_train_wgrad_slices": (_I, [_I] * 8),
+    "etm_conv_wgrad_reduce_grouped": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "etm_conv_train_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_train_wgrad_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "etm_conv_train_wgrad": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -294,6 +294,7 @@ class DeferredDw:
         self.dest = dest
         self.items = []          # (A, B, C view, Ma, Nb, lda, ldb, ldc)
         self.colsums = []        # (partial sums, first column, rows P, columns C, row stride, destination view)
+        self.conv_wgrads = []    # (pixel slices, slice count, dw view, db view, Cout, C, KH, KW) of the encoder layers
         self.written = set()
         self.N = None
 
@@ -348,6 +349,13 @@ class DeferredDw:
 
     def flush(self):
         import ctypes
+        if self.conv_wgrads:
+            k = len(self.conv_wgrads)
+            vp = lambda j: (ctypes.c_void_p * k)(*[_ptr(it[j]) for it in self.conv_wgrads])
+            ia = lambda j: (ctypes.c_int32 * k)(*[it[j] for it in self.conv_wgrads])
+            _lib.check(_lib.load().etm_conv_wgrad_reduce_grouped(vp(0), ia(1), vp(2), vp(3), ia(4), ia(5), ia(6), ia(7), k, _stream()),
+                       "etm_conv_wgrad_reduce_grouped")
+            self.conv_wgrads = []
         if self.colsums:
             k = len(self.colsums)
             pp = (ctypes.c_void_p * k)(*[_ptr(it[0]) + 4 * it[1] for it in self.colsums])
@@ -758,7 +766,7 @@ class _FusedLayerNormFn(torch.autograd.Function):
     """y = LayerNorm(act(a + bias) + res) * gamma + beta with hand-written forward and backward (csrc/block_train.hip)."""
 
     @staticmethod
-    def forward(ctx, a, bias, res, gamma, beta, relu, eps):
+    def forward(ctx, a, bias, res, gamma, beta, relu, eps, fork=False):
         lib = _lib.load()
         _need_dev(a, bias, res, gamma, beta)
         a, bias, res = _f32c(a, "a"), _f32c(bias, "bias"), _f32c(res, "res")
@@ -774,13 +782,22 @@ class _FusedLayerNormFn(torch.autograd.Function):
             ctx.relu, ctx.has_bias, ctx.has_res = bool(relu), bias is not None, res is not None
             ctx.param_ptrs = (gamma.data_ptr(), beta.data_ptr(), bias.data_ptr() if bias is not None else 0)
             ctx.save_for_backward(s, stats, gamma, a if relu else None, bias if relu else None)
+        ctx.fork = bool(fork)
+        if fork:         # the output twice (one storage): the gradients of its two consumers arrive separately and are added on load
+            ctx.set_materialize_grads(False)
+            return y, y.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         lib = _lib.load()
         s, stats, gamma, a, bias = ctx.saved_tensors
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            return (None,) * 8
         dy = _f32c(dy, "dy")
+        dy2 = _f32c(dy2, "dy2")
         N, D = s.shape
         ds = torch.empty_like(s)
         da = torch.empty_like(s) if ctx.relu else None
@@ -793,21 +810,25 @@ class _FusedLayerNormFn(torch.autograd.Function):
             parts = [(0, D, g_ptr), (D, D, b_ptr)] + ([(2 * D, D, bias_ptr)] if ctx.has_bias else [])
             part = torch.empty(nbytes // 4, dtype=torch.float32, device=s.device)
             if col.offer_colsum(part, lib.etm_ln_train_bwd_partial_rows(N), 3 * D, parts):
-                _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0,
+                _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(dy2), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0,
                                                 _ptr(ds), _ptr(da), None, _ptr(part), nbytes, N, D, _stream()), "etm_ln_train_bwd")
-                return d_a, None, (ds if ctx.has_res else None), None, None, None, None
+                return d_a, None, (ds if ctx.has_res else None), None, None, None, None, None
         sums = torch.empty((3, D), dtype=torch.float32, device=s.device)
         ws = workspace(nbytes, s.device, "ln_bwd")
-        _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0, _ptr(ds),
+        _lib.check(lib.etm_ln_train_bwd(_ptr(dy), _ptr(dy2), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(a), _ptr(bias), 1 if ctx.relu else 0, _ptr(ds),
                                         _ptr(da), _ptr(sums), _ptr(ws), nbytes, N, D, _stream()), "etm_ln_train_bwd")
-        return d_a, (sums[2] if ctx.has_bias else None), (ds if ctx.has_res else None), sums[0], sums[1], None, None
+        return d_a, (sums[2] if ctx.has_bias else None), (ds if ctx.has_res else None), sums[0], sums[1], None, None, None
 
 
-def fused_layernorm(a, norm, bias=None, res=None, relu=False):
+def fused_layernorm(a, norm, bias=None, res=None, relu=False, fork=False):
     """``norm(act(a + bias) + res)`` (``norm``: an nn.LayerNorm over the last dimension of the [N, D] input) as one forward and
     one backward kernel (+ a tiny fixed-order column-sum kernel): the bias / ReLU of the linear layer that produced ``a`` and the
     residual add ride along, so that layer runs as a plain GEMM.  Training path (differentiable); the rollout uses
-    ``add_layernorm``."""
+    ``add_layernorm``.  ``fork``: returns the result TWICE (two tensors, one storage) for its two consumers -- the next GEMM and
+    the next residual branch (transformer.py:143-149, :160-170) -- so that their gradients reach the backward kernel separately
+    and are added on load, not by a launch of autograd's."""
+    if fork:
+        return _FusedLayerNormFn.apply(a, bias, res, norm.weight, norm.bias, relu, norm.eps, True)
     return _FusedLayerNormFn.apply(a, bias, res, norm.weight, norm.bias, relu, norm.eps)
 
 
@@ -962,27 +983,33 @@ class _EncoderFn(torch.autograd.Function):
         _need_dev(x_nhwc, w1, b1, w2, b2, w3, b3)
         x = _f32c(x_nhwc, "obs")
         st = _stream()
-        acts, shapes, dgrad_packs = [x], [], []
+        acts, shapes = [x], []
         n, h, w, c = x.shape
         x_images = n
         if index is not None:          # batch image i = x[index[i]]: the minibatch gather rides in the first layer's loads
             n = index.numel()
-        for i, (wt, bs, s) in enumerate(((w1, b1, strides[0]), (w2, b2, strides[1]), (w3, b3, strides[2]))):
+        # both packings of the three layers' weights in ONE launch; the backward-data ones ride in the context
+        import ctypes
+        layers = ((w1, b1, strides[0]), (w2, b2, strides[1]), (w3, b3, strides[2]))
+        wts = [_f32c(wt.detach(), "conv weight") for wt, _, _ in layers]
+        packs = [torch.empty(wt.numel(), dtype=torch.float32, device=x.device) for wt in wts]
+        dgrad_packs = [None] + [torch.empty(wt.numel(), dtype=torch.float32, device=x.device) for wt in wts[1:]]
+        vp = lambda ts: (ctypes.c_void_p * 3)(*[_ptr(t) for t in ts])
+        ia = lambda vs: (ctypes.c_int32 * 3)(*vs)
+        _lib.check(lib.etm_conv_pack_weights_grouped(vp(wts), vp(packs), vp(dgrad_packs), ia([wt.shape[0] for wt in wts]),
+                                                     ia([wt.shape[1] for wt in wts]), ia([wt.shape[2] for wt in wts]),
+                                                     ia([wt.shape[3] for wt in wts]), ia([l[2] for l in layers]), 3, st),
+                   "etm_conv_pack_weights_grouped")
+        for i, (wt, bs, s) in enumerate(layers):
             cout, _, kh, kw = wt.shape
             ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
-            # both packings of the layer's weights in one launch; the backward-data one rides in the context
-            wt_c = _f32c(wt.detach(), "conv weight")
-            packed = torch.empty(wt_c.numel(), dtype=torch.float32, device=x.device)
-            pd = torch.empty(wt_c.numel(), dtype=torch.float32, device=x.device) if i > 0 else None
-            _lib.check(lib.etm_conv_pack_weights(_ptr(wt_c), _ptr(packed), 0 if pd is None else _ptr(pd), cout, c, kh, kw, s, st),
-                       "etm_conv_pack_weights")
-            dgrad_packs.append(pd)
             y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-            _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, x_images, _ptr(packed),
+            _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, x_images, _ptr(packs[i]),
                                               _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s, 0, st), "etm_conv_train_fwd")
             shapes.append((c, h, w, cout, kh, kw, s, ho, wo))
             acts.append(y)
             h, w, c = ho, wo, cout
+        ctx.param_ptrs = tuple(t.data_ptr() for t in (w1, b1, w2, b2, w3, b3))
         ctx.shapes = shapes
         ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2], index)
         return acts[3].view(n, -1)
@@ -1001,21 +1028,38 @@ class _EncoderFn(torch.autograd.Function):
         grads = [None] * 6
         inputs = (x0, y1, y2)
         dgrad_packs = (None, pd2, pd3)
+        # with a collector that knows the six parameters' arena views the three slice reductions become ONE launch at its flush
+        col = DeferredDw.active
+        dests = None
+        if col is not None:
+            dests = [col.dest.get(ptr) for ptr in ctx.param_ptrs]
+            if any(v is None or not v.is_contiguous() for v in dests) or any(ptr in col.written for ptr in ctx.param_ptrs):
+                dests = None
+        deferred = []
         for i in (2, 1, 0):
             c, h, w, cout, kh, kw, s, ho, wo = ctx.shapes[i]
             K = kh * kw * c
-            buf = torch.empty(K * cout + cout, dtype=torch.float32, device=dev)
             nbytes = lib.etm_conv_train_wgrad_workspace_bytes(n, c, h, w, cout, kh, kw, s)
-            ws = workspace(nbytes, dev, "conv_wgrad")
+            if dests is not None:
+                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)      # (lives until the collector's flush)
+                buf = None
+                deferred.append((ws, lib.etm_conv_train_wgrad_slices(n, c, h, w, cout, kh, kw, s), dests[2 * i], dests[2 * i + 1], cout, c, kh, kw))
+            else:
+                ws = workspace(nbytes, dev, "conv_wgrad")
+                buf = torch.empty(K * cout + cout, dtype=torch.float32, device=dev)
             _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w,
                                                 cout, kh, kw, s, st), "etm_conv_train_wgrad")
-            grads[2 * i] = buf[: K * cout].view(cout, c, kh, kw)
-            grads[2 * i + 1] = buf[K * cout:]
+            if buf is not None:
+                grads[2 * i] = buf[: K * cout].view(cout, c, kh, kw)
+                grads[2 * i + 1] = buf[K * cout:]
             if i > 0:
                 dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
                 _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
                            "etm_conv_train_dgrad")
                 dy = dx
+        if deferred:
+            col.conv_wgrads.extend(deferred)
+            col.written.update(ctx.param_ptrs)
         return (None, *grads, None, None)
 
 

@@ -954,11 +954,12 @@ class PPOTrainer:
     def _dw_destinations(self):
         """{parameter data_ptr: its gradient view in the flat arena}: the [out, in] views of the 2-D parameters for the grouped weight-
         gradient launch (``grouped_dw_train: false`` in the config: none, every layer multiplies its own weight gradient) and the
-        1-D views (LayerNorm weights / biases, linear biases) for the grouped column-sum reduction (``grouped_colsum_train``)."""
+        1-D views (LayerNorm weights / biases, linear / convolution biases) and the convolution weights' views for the grouped
+        column-sum / slice reductions (``grouped_colsum_train``)."""
         if getattr(self, "_dw_dest", None) is None:
             dw, cs = self.config.get("grouped_dw_train", True), self.config.get("grouped_colsum_train", True)
             self._dw_dest = {p.data_ptr(): v for p, v in zip(self.params, self._grad_views)
-                             if (p.dim() == 2 and dw) or (p.dim() == 1 and cs)}
+                             if (p.dim() == 2 and dw) or (p.dim() == 1 and cs) or (p.dim() == 4 and cs)}
         return self._dw_dest
 
     def _unit_gradient(self, loss):

@@ -116,21 +116,29 @@ class TransformerBlock(Module):
             self.norm_kv = nn.LayerNorm(embed_dim)
         self.fc = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.ReLU())
 
-    def forward_window(self, h, spec: WindowSpec, block=0, pos=None):
-        """h [N, D] query state; returns (new state [N, D], attention [N, H, L])."""
+    def forward_window(self, h, spec: WindowSpec, block=0, pos=None, h_res=None, fork=False):
+        """h [N, D] query state; returns (new state [N, D], attention [N, H, L]).  ``h_res``: the second copy of ``h`` for the
+        residual branch when the producer forked it (ops.fused_layernorm); ``fork``: return the new state forked for the next
+        block, (state, attention, state for the residual) -- both only on the fused post-LN training path."""
         pre = self.layer_norm == "pre"
         fused = self._fused_train(h)
         q_in = (ops.fused_layernorm(h, self.norm1) if fused else self.norm1(h)) if pre else h
         if fused and self.layer_norm == "post" and not self.use_gtrxl:
             # training, post-LN: fc_out and fc run as plain GEMMs; bias, ReLU, residual add and LayerNorm (and all of their
             # gradients) are one forward and one backward kernel each (transformer.py:143-149, :160-170)
+            # norm1's output feeds fc AND the residual of norm2 (and the block's output the next block's query projection and
+            # residual): forked, so that the two gradients are added by the LayerNorm backward kernel on load
             att_raw, att_w = self.attention.attend(q_in, spec, block, pos, None, raw=True)
-            x = ops.fused_layernorm(att_raw, self.norm1, bias=self.attention.fc_out.bias, res=h)
+            x, x_res = ops.fused_layernorm(att_raw, self.norm1, bias=self.attention.fc_out.bias, res=h if h_res is None else h_res, fork=True)
             fc = self.fc[0]
             f_raw = ops.linear_nobias(x, fc.weight)
-            return ops.fused_layernorm(f_raw, self.norm2, bias=fc.bias, res=x, relu=True), att_w
+            if fork:
+                out, out_res = ops.fused_layernorm(f_raw, self.norm2, bias=fc.bias, res=x_res, relu=True, fork=True)
+                return out, att_w, out_res
+            return ops.fused_layernorm(f_raw, self.norm2, bias=fc.bias, res=x_res, relu=True), att_w
         att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
-        return self._after_attention(h, att_out), att_w
+        out = self._after_attention(h, att_out)
+        return (out, att_w, None) if fork else (out, att_w)
 
     @staticmethod
     def _fused_train(h):
@@ -222,10 +230,15 @@ class Transformer(nn.Module):
         h = ops.linear_relu(self.linear_embedding, h)
         pos = None if spec.pos_included else self._pos()
         items = []
+        h_res = None
+        last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             if want_items:
                 items.append(h.detach())
-            h, _ = blk.forward_window(h, spec, i, pos)
+            if i < last:       # the state forked for the next block's two consumers (fused post-LN training path; None otherwise)
+                h, _, h_res = blk.forward_window(h, spec, i, pos, h_res=h_res, fork=True)
+            else:
+                h, _ = blk.forward_window(h, spec, i, pos, h_res=h_res)
         return h, (torch.stack(items, dim=1) if want_items else None)
 
     def bank_with_positions(self, bank):

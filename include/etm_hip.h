@@ -205,7 +205,9 @@ int etm_gru_gate_out(const float *a, const float *c, const float *z, const float
  *                     what etm_ln_train_bwd needs.  Replaces `self.norm1(attention + query)`, `self.norm2(forward + h)`
  *                     (post-LN, transformer.py:145-149, :166-170) and the plain `self.norm1(query)` / `self.norm2(h)` of the
  *                     pre-LN layout (:131-141).
- *   etm_ln_train_bwd: dy [N,D] -> ds [N,D] (gradient of the LayerNorm input = gradient of the residual branch b, and of `a`
+ *   etm_ln_train_bwd: dy (+ dy2, optional: the output's second consumer -- a GEMM and the next residual branch both read it --
+ *                     whose gradient is added on load instead of by a launch of its own) [N,D] -> ds [N,D] (gradient of the
+ *                     LayerNorm input = gradient of the residual branch b, and of `a`
  *                     when relu == 0), da [N,D] (relu != 0 only: ds where a + a_bias > 0), and dgamma_dbeta_dbias [3,D] =
  *                     column sums of (dy * xhat, dy, da).  Two launches (rows, then a fixed-order sum of per-workgroup
  *                     partial sums held in `workspace`, etm_ln_train_bwd_workspace_bytes(N, D) bytes): deterministic.
@@ -223,7 +225,7 @@ int etm_gru_gate_out(const float *a, const float *c, const float *z, const float
 int etm_ln_train_fwd(const float *a, const float *a_bias, int relu, const float *b, const float *gamma, const float *beta, float eps,
                      float *y, float *s_out, float *stats, int N, int D, void *stream);
 int64_t etm_ln_train_bwd_workspace_bytes(int N, int D);
-int etm_ln_train_bwd(const float *dy, const float *s, const float *stats, const float *gamma, const float *a, const float *a_bias,
+int etm_ln_train_bwd(const float *dy, const float *dy2, const float *s, const float *stats, const float *gamma, const float *a, const float *a_bias,
                      int relu, float *ds, float *da, float *dgamma_dbeta_dbias, float *workspace, int64_t workspace_bytes, int N, int D,
                      void *stream);
 int etm_ln_train_bwd_partial_rows(int N);
@@ -453,6 +455,15 @@ int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_t x_images,
  * default (2: layer 2 only, the one layer where it is faster).  Layers 2 / 3 with x_index keep the direct kernel.  Results differ in
  * summation order only. */
 int etm_conv_train_set_fwd_lds(int layer_mask);
+/* Grouped forms for the three layers (a launch of this size costs ~5 us whatever it does): etm_conv_pack_weights for n <= 4 layers
+ * in one launch; etm_conv_train_wgrad with dw_kc_dbias == NULL leaves etm_conv_train_wgrad_slices(...) pixel slices in its workspace
+ * and etm_conv_wgrad_reduce_grouped sums the slices of n <= 4 such calls in one launch into dw[i] [Cout, C, KH, KW] / db[i] [Cout]
+ * (the per-call summation order: bit-identical).  Host arrays throughout. */
+int etm_conv_pack_weights_grouped(const float *const *w, float *const *fwd, float *const *dgrad, const int *Cout, const int *C,
+                                  const int *KH, const int *KW, const int *S, int n, void *stream);
+int etm_conv_train_wgrad_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
+int etm_conv_wgrad_reduce_grouped(const float *const *partial, const int *slices, float *const *dw, float *const *db, const int *Cout,
+                                  const int *C, const int *KH, const int *KW, int n, void *stream);
 int etm_conv_train_dgrad(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
                          int KH, int KW, int S, void *stream);
 int etm_conv_pack_weights(const float *w, float *fwd, float *dgrad, int Cout, int C, int KH, int KW, int S, void *stream);

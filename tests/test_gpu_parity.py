@@ -1271,6 +1271,30 @@ def test_grouped_column_sums_bit_identical_to_per_call_reductions(N, D):
     assert float((views[3].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())) * max(1.0, N ** 0.5)
 
 
+@pytest.mark.parametrize("N", [96, 7])
+def test_encoder_weight_gradients_through_the_grouped_slice_reduction(N):
+    """etm_conv_wgrad_reduce_grouped (+ etm_conv_pack_weights_grouped in the forward): the six encoder gradients written by the
+    DeferredDw collector's one reduction launch into destination views, against the per-layer reductions of the same build (same
+    summation order: bit-identical; those are pinned to float64 convolutions by test_train_encoder_fwd_bwd_vs_float64_convs)."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(N)
+    convs = [torch.nn.Conv2d(3, 32, 8, 4).to(dev), torch.nn.Conv2d(32, 64, 4, 2).to(dev), torch.nn.Conv2d(64, 64, 3, 1).to(dev)]
+    obs = torch.rand((N, 84, 84, 3), device=dev)
+    params = [t for c in convs for t in (c.weight, c.bias)]
+    gout = torch.randn((N, 7 * 7 * 64), device=dev)
+    (ops.encoder_train(obs, *convs) * gout).sum().backward()
+    ref = [t.grad.clone() for t in params]
+    for t in params:
+        t.grad = None
+    views = [torch.full_like(t, float("nan")) for t in params]
+    with ops.DeferredDw({t.data_ptr(): v for t, v in zip(params, views)}) as col:
+        (ops.encoder_train(obs, *convs) * gout).sum().backward()
+    assert col.written == {t.data_ptr() for t in params} and all(t.grad is None for t in params)
+    for v, r in zip(views, ref):
+        assert torch.equal(v, r), float((v - r).abs().max())
+
+
 @pytest.mark.parametrize("N,hid,A,D", [(2048, 384, 3, 384), (37, 128, 2, 128), (130, 512, 8, 64), (5, 64, 4, 96)])
 def test_fused_heads_and_loss_vs_composed_ops(N, hid, A, D):
     """etm_heads_loss (hidden heads' bias + ReLU, policy branch, value head, PPO loss, backward to the hidden heads) against the
