@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_partials(float (&acc)[NACC][NJ], float *sm
 
 // dy -> ds (LayerNorm input gradient, also the residual-branch gradient), da (= ds under the ReLU mask; only written when
 // relu), partial[wg][3][D] = column sums of (dy * xhat, dy, da) over the workgroup's rows.
-template <int NJ>
+template <int NJ, bool TWO>
 __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ s,
                                                            const float *__restrict__ stats, const float *__restrict__ gamma,
                                                            const float *__restrict__ a, const float *__restrict__ a_bias, int relu,
@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float *__restri
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + 64 * j, cc = c < D ? c : 0;
       const long long o = (long long)row * D + cc;
-      const float d = dy2 ? dy[o] + dy2[o] : dy[o], sv = s[o];      // (two consumers of the output: their gradients meet here)
+      float d = dy[o];
+      const float sv = s[o];
+      if (TWO) d += dy2[o];                                         // (two consumers of the output: their gradients meet here)
       pre[j] = relu ? a[o] + bi[j] : 1.f;
       dyv[j] = (c < D) ? d : 0.f;
       xh[j] = (c < D) ? (sv - mean) * rstd : 0.f;
@@ -357,8 +359,12 @@ extern "C" int etm_ln_train_bwd(const float *dy, const float *dy2, const float *
   {
     EtmProfScope prof(ETM_K_LN_TRAIN_BWD, st);
     rc = dispatch_nj(D, [&](auto nj) {
-      hipLaunchKernelGGL((ln_train_bwd_kernel<decltype(nj)::value>), dim3((unsigned)P), dim3(256), 0, st, dy, dy2, s, stats, gamma, a, a_bias, relu, ds,
-                         da, workspace, N, D, rows);
+      if (dy2)
+        hipLaunchKernelGGL((ln_train_bwd_kernel<decltype(nj)::value, true>), dim3((unsigned)P), dim3(256), 0, st, dy, dy2, s, stats, gamma, a, a_bias,
+                           relu, ds, da, workspace, N, D, rows);
+      else
+        hipLaunchKernelGGL((ln_train_bwd_kernel<decltype(nj)::value, false>), dim3((unsigned)P), dim3(256), 0, st, dy, dy2, s, stats, gamma, a, a_bias,
+                           relu, ds, da, workspace, N, D, rows);
       return etm_launch_status();
     });
   }

@@ -147,8 +147,8 @@ class PPOTrainer:
                 # one results file per rank: data-parallel ranks tune independently and must not write the same file
                 rank_tag = "" if dp is None else f"_rank{dp.rank}"
                 tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"etm_tunableop_results{rank_tag}.csv"), True)
-                tunable.set_max_tuning_duration(30)
-                tunable.set_max_tuning_iterations(20)
+                tunable.set_max_tuning_duration(int(config.get("tunable_gemm_duration_ms", os.environ.get("ETM_TUNABLE_MS", 30))))
+                tunable.set_max_tuning_iterations(int(config.get("tunable_gemm_iterations", os.environ.get("ETM_TUNABLE_ITERS", 20))))
             except Exception as exc:        # an older / newer torch without this API: run with the default heuristics
                 print(f"[trainer] per-shape GEMM tuning not available ({exc})")
         self.buffer = Buffer(config, self.observation_space, self.action_space_shape, self.max_episode_length, device)
