@@ -1066,17 +1066,10 @@ class _EncoderFn(torch.autograd.Function):
 def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None):
     """Differentiable encoder forward on an NHWC observation batch [N, H, W, C] -- or, with ``index`` (int64 [n]), on the images
     ``obs_nhwc[index]`` without gathering them first: features [N, Ho * Wo * Cout], NHWC-flattened
-    (``nhwc_columns`` gives the matching column order of the following linear layer's weight).  Gradients flow to the
+    (``linear_relu_nhwc`` is the following linear layer on that column order).  Gradients flow to the
     convolution weights and biases (observations need none)."""
     return _EncoderFn.apply(obs_nhwc, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias,
                             (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index)
-
-
-def nhwc_columns(weight, channels):
-    """Weight [out, C*H*W] of a linear layer that consumes upstream's (c, h, w)-flattened features -> the same map on
-    (h, w, c)-flattened features (differentiable: the gradient is permuted back)."""
-    out, feat = weight.shape
-    return weight.view(out, channels, feat // channels).transpose(1, 2).reshape(out, feat)
 
 
 def obs_pull(src_pinned, stage, t_dev, row_flags, w_off=0, err=None):
@@ -1141,6 +1134,63 @@ class _LinearReluFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _offer_dw(gm, x, weight):
             dw = gm.t().mm(x)
         return dx, dw, db
+
+
+class _LinearReluNhwcFn(torch.autograd.Function):
+    """relu(x Wp^T + b) for NHWC-flattened features x [N, HW * C] and a weight kept in upstream's (c, h, w) column order
+    (model.py:94): Wp = the weight with its columns in (h, w, c) order.  The permutation lives INSIDE the node: one permuting copy
+    of the weight forward, and backward the weight gradient is permuted straight into the parameter's arena view when a DeferredDw
+    collector knows it (one permuting copy instead of a permute-back copy plus the gradient packing copy)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, channels):
+        out, feat = weight.shape
+        hw = feat // channels
+        wp = weight.detach().view(out, channels, hw).transpose(1, 2).reshape(out, feat)       # [out, (h, w, c)]
+        if _fused_linear_relu:
+            y = torch._addmm_activation(bias, x, wp.t(), use_gelu=False)
+        else:
+            y = torch.addmm(bias, x, wp.t())
+            torch.relu_(y)
+        ctx.save_for_backward(x, wp, y)
+        ctx.bias_ptr, ctx.weight_ptr, ctx.channels = bias.data_ptr(), weight.data_ptr(), channels
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wp, y = ctx.saved_tensors
+        lib = _lib.load()
+        g = _f32c(g, "grad")
+        n, c = g.shape
+        out, feat = wp.shape
+        hw = feat // ctx.channels
+        gm = torch.empty_like(g)
+        nbytes = lib.etm_relu_bwd_colsum_workspace_bytes(n, c)
+        col = DeferredDw.active
+        db = None
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device) if col is not None else None
+        if col is not None and col.offer_colsum(part, lib.etm_relu_bwd_colsum_partial_rows(n), c, [(0, c, ctx.bias_ptr)]):
+            _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), None, _ptr(part), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+        else:
+            db = torch.empty(c, dtype=torch.float32, device=g.device)
+            ws = workspace(nbytes, g.device, "relu_bwd")
+            _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), _ptr(y), _ptr(gm), _ptr(db), _ptr(ws), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+        dx = gm.mm(wp) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dwp = gm.t().mm(x).view(out, hw, ctx.channels).transpose(1, 2)                # [out, c, hw] view of the (h, w, c) result
+            dest = col.dest.get(ctx.weight_ptr) if col is not None else None
+            if dest is not None and dest.is_contiguous() and ctx.weight_ptr not in col.written:
+                dest.view(out, ctx.channels, hw).copy_(dwp)
+                col.written.add(ctx.weight_ptr)
+            else:
+                dw = dwp.reshape(out, feat)
+        return dx, dw, db, None
+
+
+def linear_relu_nhwc(x, weight, bias, channels):
+    """relu(F.linear(x, nhwc_columns(weight, channels), bias)) as one autograd node (see _LinearReluNhwcFn)."""
+    return _LinearReluNhwcFn.apply(x, weight, bias, channels)
 
 
 def linear_relu_train(x, weight, bias):

@@ -204,8 +204,7 @@ class ActorCriticModel(nn.Module):
                 if self._train_encoder_ok and ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3),
                                                                             batch=int(obs.index.numel())):
                     feats = ops.encoder_train(obs.bank, self.conv1, self.conv2, self.conv3, index=obs.index)
-                    w_nhwc = ops.nhwc_columns(self.lin_hidden.weight, self.conv3.out_channels)
-                    return ops.linear_relu_train(feats, w_nhwc, self.lin_hidden.bias)
+                    return ops.linear_relu_nhwc(feats, self.lin_hidden.weight, self.lin_hidden.bias, self.conv3.out_channels)
             obs = obs.bank.index_select(0, obs.index).permute(0, 3, 1, 2)      # NCHW view of the gathered NHWC rows
         if obs_index is not None:
             if not self._fused_encoder_ok(obs[0]):
@@ -222,8 +221,7 @@ class ActorCriticModel(nn.Module):
                 # optimisation phase: the three relu(conv2d) layers forward and backward on the hand-written MFMA kernels
                 # (NHWC activations; the trainer hands over an NCHW view of NHWC memory, which permutes back for free)
                 feats = ops.encoder_train(obs.permute(0, 2, 3, 1), self.conv1, self.conv2, self.conv3)      # (h, w, c) flatten order
-                w_nhwc = ops.nhwc_columns(self.lin_hidden.weight, self.conv3.out_channels)
-                return ops.linear_relu_train(feats, w_nhwc, self.lin_hidden.bias)
+                return ops.linear_relu_nhwc(feats, self.lin_hidden.weight, self.lin_hidden.bias, self.conv3.out_channels)
         if self.visual:
             if self.channels_last and h.is_cuda:
                 # NHWC activations: MIOpen's implicit-GEMM kernels run without layout transposes (1.35 vs 2.1 ms for
