@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
   fetch(m_lo, 0);
   stash(0, 0);
   if (m_lo + WG_MC < m_hi) fetch(m_lo + WG_MC, 1);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   auto chunk = [&](int m0, auto bufc) {                 // bufc: compile-time buffer index (register sets must not be indexed at run time)
     constexpr int buf = decltype(bufc)::value;
     const bool more = m0 + WG_MC < m_hi;
@@ -415,8 +415,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[kt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], dv[ct], acc[kt][ct], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1, buf ^ 1);                  // the other buffer: its last readers passed the barrier of the previous chunk
-    __syncthreads();
+    // the other buffer.  No workgroup barrier: the staging rows a wave writes (srow = 8 wave .. 8 wave + 7) are exactly the rows
+    // it reads, LDS operations of one wave execute in order, so the waves of a workgroup drift apart freely
+    if (more) stash(buf ^ 1, buf ^ 1);
+    __builtin_amdgcn_wave_barrier();
   };
   for (int m0 = m_lo; m0 < m_hi; m0 += 2 * WG_MC) {
     chunk(m0, std::integral_constant<int, 0>());
