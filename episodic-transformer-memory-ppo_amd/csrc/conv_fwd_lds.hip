@@ -59,8 +59,10 @@ constexpr int fl_younger(int kg, int PD, int NST, int NQ) {
 
 __device__ __forceinline__ i32x4v fl_rsrc(const void *base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
-  return i32x4v{__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)(a >> 32)),
-                __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+  i32x4v r{__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)(a >> 32)),
+          __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+  etm_rsrc_fence(r);
+  return r;
 }
 
 template <int C, int HW, int KS, int S, int COUT, int G, int CP>

@@ -655,6 +655,21 @@ int etm_conv_fwd_lds(const float *x, const int64_t *x_index, const float *w_pack
 static int g_conv_fwd_lds = ETM_CONV_FWD_LDS_DEFAULT;
 extern "C" int etm_conv_train_set_fwd_lds(int layer_mask) { g_conv_fwd_lds = layer_mask < 0 ? ETM_CONV_FWD_LDS_DEFAULT : (layer_mask & 7); return ETM_OK; }
 
+// Weight gradients with both operands image-resident in LDS (conv_wgrad_lds.hip): bit l - 1 = layer l, as for the forward pass.
+// Measured at N = 2048 against conv_wgrad_kernel (us, reductions included): layer 1 127 / 148, layers 2 and 3 within 4 -- layer 1 only.
+int etm_conv_wgrad_lds_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
+int etm_conv_wgrad_lds(const float *x, const int64_t *x_index, const float *dy, float *partial, int N, int C, int H, int W, int Cout, int KH,
+                       int KW, int S, hipStream_t st);
+#define ETM_CONV_WGRAD_LDS_DEFAULT 1
+static int g_conv_wgrad_lds = ETM_CONV_WGRAD_LDS_DEFAULT;
+extern "C" int etm_conv_train_set_wgrad_lds(int layer_mask) { g_conv_wgrad_lds = layer_mask < 0 ? ETM_CONV_WGRAD_LDS_DEFAULT : (layer_mask & 7); return ETM_OK; }
+// slices of the image-resident kernel if it takes this call (N >= 512, its layer enabled, a gather index on the first layer only), else 0
+static int wgrad_lds_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S, bool indexed) {
+  const int layer_bit = KH == 8 ? 1 : KH == 4 ? 2 : 4;
+  if (!(g_conv_wgrad_lds & layer_bit) || N < 512 || (indexed && layer_bit != 1)) return 0;
+  return etm_conv_wgrad_lds_slices(N, C, H, W, Cout, KH, KW, S);
+}
+
 static int conv_geometry_ok(int C, int Cout, int KH, int KW, int S, int W) {
   if (Cout != 32 && Cout != 64) return 0;
   if ((KW * C) % 8 != 0 || (W * C) % 4 != 0 || (S * C) % 4 != 0) return 0;
@@ -772,12 +787,15 @@ static int wgrad_k_ranges(int Cout, int K) { const int kw = wgrad_kt(Cout, K) * 
 extern "C" int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cout, int KH, int KW, int S) {
   const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1;
   const long long K = (long long)KH * KW * C;
-  return (int64_t)wgrad_splits(N * Ho * Wo, wgrad_k_ranges(Cout, (int)K)) * (K * Cout + Cout) * (int64_t)sizeof(float);
+  const int a = wgrad_splits(N * Ho * Wo, wgrad_k_ranges(Cout, (int)K)), b = wgrad_lds_slices(N, C, H, W, Cout, KH, KW, S, false);
+  return (int64_t)(a > b ? a : b) * (K * Cout + Cout) * (int64_t)sizeof(float);
 }
 
 // Pixel slices etm_conv_train_wgrad leaves in its workspace ([slices][K * Cout + Cout]) for the reduction.
 extern "C" int etm_conv_train_wgrad_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S) {
   if (N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return 0;
+  const int lds_slices = wgrad_lds_slices(N, C, H, W, Cout, KH, KW, S, false);       // (x_index: first layer only, see etm_hip.h)
+  if (lds_slices > 0) return lds_slices;
   const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1, M = N * Ho * Wo, K = KH * KW * C;
   const int splits = wgrad_splits(M, wgrad_k_ranges(Cout, K));
   const int rows = ((M + splits - 1) / splits + WG_MC - 1) / WG_MC * WG_MC;
@@ -792,6 +810,23 @@ extern "C" int etm_conv_train_wgrad(const float *x, const int64_t *x_index, cons
   if (!x || !dy || !workspace || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   if (!conv_geometry_ok(C, Cout, KH, KW, S, W)) return ETM_EUNSUPPORTED;
   if (workspace_bytes < etm_conv_train_wgrad_workspace_bytes(N, C, H, W, Cout, KH, KW, S)) return ETM_EWORKSPACE;
+  {
+    const int lds_slices = wgrad_lds_slices(N, C, H, W, Cout, KH, KW, S, x_index != nullptr);
+    if (lds_slices > 0) {                    // both operands image-resident in LDS, one slice per workgroup (conv_wgrad_lds.hip)
+      hipStream_t st = (hipStream_t)stream;
+      {
+        EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_WGRAD, ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, KH), st);
+        const int rc = etm_conv_wgrad_lds(x, x_index, dy, workspace, N, C, H, W, Cout, KH, KW, S, st);
+        if (rc) return rc;
+      }
+      if (!dw_kc_dbias) return ETM_OK;
+      EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_WGRAD, ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, KH), st);
+      const long long elems = (long long)KH * KW * C * Cout + Cout;
+      hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, workspace, lds_slices, elems, dw_kc_dbias,
+                         Cout, C, KH, KW);
+      return etm_launch_status();
+    }
+  }
   ConvW p{};
   p.x = x; p.img_index = (const long long *)x_index; p.dy = dy; p.partial = workspace; p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.S = S;
   p.Ho = (H - KH) / S + 1; p.Wo = (W - KW) / S + 1;

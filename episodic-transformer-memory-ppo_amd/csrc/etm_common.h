@@ -12,6 +12,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane holds column (lane & 31); register r holds row
 //   (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)          (cdna_hip_programming.md section 3)
+// A buffer descriptor whose words come from v_readfirstlane (a VALU write of SGPRs) must not be read by a vector-memory instruction
+// within 5 wait states.  The compiler pads that hazard for its own instructions but cannot see a buffer_load / buffer_store inside
+// inline assembly: a descriptor built right in front of hand-written loads read stale SGPRs (memory access fault at {base_hi, 0}).
+// Every descriptor that feeds inline-assembly memory instructions goes through this fence once.
+template <class R>
+__device__ __forceinline__ void etm_rsrc_fence(R &r) { asm volatile("s_nop 4" : "+s"(r)); }
+
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // Wave-wide reductions on the DPP path (no LDS round trips): xor-1 / xor-2 inside a quad, the other quad of the 8-group

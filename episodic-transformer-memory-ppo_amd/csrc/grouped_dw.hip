@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256) void grouped_dw_kernel(const GdParams P) {
   // k-step, the padding k-steps of the last pipeline round -- reads as zeros (buffer range check) and adds nothing
   const unsigned bytes_a = (unsigned)(r1 - r0) * (unsigned)pr.lda * 4u, bytes_b = (unsigned)(r1 - r0) * (unsigned)pr.ldb * 4u;
   const unsigned long long base_a = (unsigned long long)(pr.A + (long long)r0 * pr.lda), base_b = (unsigned long long)(pr.B + (long long)r0 * pr.ldb);
-  const i32x4 ra = {(int)(base_a & 0xffffffffu), (int)(base_a >> 32), (int)bytes_a, 0x00020000};
-  const i32x4 rb = {(int)(base_b & 0xffffffffu), (int)(base_b >> 32), (int)bytes_b, 0x00020000};
+  i32x4 ra = {(int)(base_a & 0xffffffffu), (int)(base_a >> 32), (int)bytes_a, 0x00020000};
+  i32x4 rb = {(int)(base_b & 0xffffffffu), (int)(base_b >> 32), (int)bytes_b, 0x00020000};
+  etm_rsrc_fence(ra);                                  // (their words come from v_readfirstlane: see etm_common.h)
+  etm_rsrc_fence(rb);
   int va = (half * pr.lda + m0 + GD_MT * li) * 4, vb = (half * pr.ldb + n0 + GD_NT * li) * 4;
   const int sa_step = 2 * pr.lda * 4, sb_step = 2 * pr.ldb * 4;
   const int ksteps = (r1 - r0 + 1) >> 1;                           // two rows each

@@ -455,6 +455,10 @@ int etm_conv_train_fwd(const float *x, const int64_t *x_index, int64_t x_images,
  * default (2: layer 2 only, the one layer where it is faster).  Layers 2 / 3 with x_index keep the direct kernel.  Results differ in
  * summation order only. */
 int etm_conv_train_set_fwd_lds(int layer_mask);
+/* Likewise for the weight gradients (csrc/conv_wgrad_lds.hip: layer input and gradient image both resident in LDS, one partial result
+ * per workgroup): bit per layer, negative = the default (1: the first layer, where it is faster).  A gather index (x_index) is taken on the first layer only; other layers
+ * called with one keep conv_wgrad_kernel -- etm_conv_train_wgrad_slices reports the count for x_index == NULL there. */
+int etm_conv_train_set_wgrad_lds(int layer_mask);
 /* Grouped forms for the three layers (a launch of this size costs ~5 us whatever it does): etm_conv_pack_weights for n <= 4 layers
  * in one launch; etm_conv_train_wgrad with dw_kc_dbias == NULL leaves etm_conv_train_wgrad_slices(...) pixel slices in its workspace
  * and etm_conv_wgrad_reduce_grouped sums the slices of n <= 4 such calls in one launch into dw[i] [Cout, C, KH, KW] / db[i] [Cout]

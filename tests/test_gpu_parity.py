@@ -1271,6 +1271,54 @@ def test_grouped_column_sums_bit_identical_to_per_call_reductions(N, D):
     assert float((views[3].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())) * max(1.0, N ** 0.5)
 
 
+@pytest.mark.parametrize("N", [512, 601, 2048])
+def test_encoder_weight_gradients_with_lds_resident_images(N):
+    """csrc/conv_wgrad_lds.hip (layer input and gradient image resident in LDS, pixel pairs, one slice per workgroup; N >= 512)
+    against conv_wgrad_kernel of the same build layer by layer (both through etm_conv_train_wgrad; different summation order) and
+    -- N = 512 -- against float64 weight / bias gradients; with the fused minibatch gather on the first layer, ragged last group
+    (601 = 2 * 300 + 1), odd images (81 and 49 pixels: one zero pixel in the last pair)."""
+    from etm import lib as etm_lib
+    dev = _dev()
+    lib = etm_lib.load()
+    torch.manual_seed(N + 1)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    layers = [(3, 84, 32, 8, 4), (32, 20, 64, 4, 2), (64, 9, 64, 3, 1)]
+    worst = 0.0
+    try:
+        for li, (c, hw, cout, k, s) in enumerate(layers):
+            ho = (hw - k) // s + 1
+            K = k * k * c
+            bank = torch.rand((N + 19, hw, hw, c), device=dev)
+            index = torch.randperm(N + 19, device=dev)[:N].contiguous()
+            dy = torch.randn((N, ho, ho, cout), device=dev)
+            for use_index in ((False, True) if li == 0 else (False,)):
+                res = {}
+                for mask in (7, 0):
+                    etm_lib.check(lib.etm_conv_train_set_wgrad_lds(mask), "set_wgrad_lds")
+                    nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, hw, hw, cout, k, k, s)
+                    ws = torch.full((nbytes // 4,), float("nan"), device=dev)
+                    buf = torch.full((K * cout + cout,), float("nan"), device=dev)
+                    etm_lib.check(lib.etm_conv_train_wgrad(bank.data_ptr(), index.data_ptr() if use_index else None, dy.data_ptr(), buf.data_ptr(),
+                                                           ws.data_ptr(), nbytes, N, c, hw, hw, cout, k, k, s, st), "etm_conv_train_wgrad")
+                    res[mask] = buf
+                a, d = res[7], res[0]
+                assert bool(torch.isfinite(a).all())
+                for lo, hi in ((0, K * cout), (K * cout, K * cout + cout)):
+                    rel = float((a[lo:hi] - d[lo:hi]).double().norm() / d[lo:hi].double().norm())
+                    worst = max(worst, rel)
+                    assert rel < 2e-6, (li, use_index, lo, rel)          # measured ~2e-7: fp32 summation order only
+                if N == 512:
+                    x64 = (bank[index] if use_index else bank[:N]).permute(0, 3, 1, 2).double().cpu()
+                    g64 = dy.permute(0, 3, 1, 2).double().cpu()
+                    w64 = torch.nn.grad.conv2d_weight(x64, (cout, c, k, k), g64, stride=s)
+                    got = a[: K * cout].view(cout, c, k, k).double().cpu()
+                    assert float((got - w64).norm() / w64.norm()) < 2e-6
+                    assert float((a[K * cout:].double().cpu() - g64.sum((0, 2, 3))).norm() / g64.sum((0, 2, 3)).norm()) < 2e-6
+    finally:
+        etm_lib.check(lib.etm_conv_train_set_wgrad_lds(-1), "set_wgrad_lds")
+    print(f"[wgrad lds N={N}] worst relative difference to conv_wgrad_kernel: {worst:.2e}")
+
+
 @pytest.mark.parametrize("N", [96, 7])
 def test_encoder_weight_gradients_through_the_grouped_slice_reduction(N):
     """etm_conv_wgrad_reduce_grouped (+ etm_conv_pack_weights_grouped in the forward): the six encoder gradients written by the
