@@ -670,6 +670,13 @@ static int wgrad_lds_slices(int N, int C, int H, int W, int Cout, int KH, int KW
   return etm_conv_wgrad_lds_slices(N, C, H, W, Cout, KH, KW, S);
 }
 
+// Backward-data of the 4 x 4 / stride 2 layer from LDS-resident gradient images (conv_dgrad_lds.hip)
+int etm_conv_dgrad_lds(const float *dy, const float *w_packed, const float *y_below, float *dx, int N, int C, int H, int W, int Cout, int KH,
+                       int KW, int S, hipStream_t st);
+#define ETM_CONV_DGRAD_LDS_DEFAULT 1
+static int g_conv_dgrad_lds = ETM_CONV_DGRAD_LDS_DEFAULT;
+extern "C" int etm_conv_train_set_dgrad_lds(int on) { g_conv_dgrad_lds = on < 0 ? ETM_CONV_DGRAD_LDS_DEFAULT : (on ? 1 : 0); return ETM_OK; }
+
 static int conv_geometry_ok(int C, int Cout, int KH, int KW, int S, int W) {
   if (Cout != 32 && Cout != 64) return 0;
   if ((KW * C) % 8 != 0 || (W * C) % 4 != 0 || (S * C) % 4 != 0) return 0;
@@ -723,6 +730,12 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   (void)hipGetLastError();
   if (!dy || !w_packed || !dx || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   if (KH != KW || KH % S != 0 || H % S != 0 || W % S != 0 || Cout % 8 != 0 || (C != 32 && C != 64)) return ETM_EUNSUPPORTED;
+  if (g_conv_dgrad_lds && N >= 512) {
+    hipStream_t st = (hipStream_t)stream;
+    EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
+    const int rc = etm_conv_dgrad_lds(dy, w_packed, y_below, dx, N, C, H, W, Cout, KH, KW, S, st);
+    if (rc != ETM_EUNSUPPORTED) return rc;
+  }
   const int Ho = (H - KH) / S + 1, Wo = (W - KW) / S + 1;
   ConvG p{};
   p.src = dy; p.wp = w_packed; p.bias = nullptr; p.ymask = y_below; p.out = dx; p.N = N;

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _lib = None
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "etm_conv_train_fwd": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_train_set_fwd_lds": (_I, [_I]),
     "etm_conv_train_set_wgrad_lds": (_I, [_I]),
+    "etm_conv_train_set_dgrad_lds": (_I, [_I]),
     "etm_conv_pack_weights_grouped": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "etm_conv_train_wgrad_slices": (_I, [_I] * 8),
     "etm_conv_wgrad_reduce_grouped": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -459,6 +459,9 @@ int etm_conv_train_set_fwd_lds(int layer_mask);
  * per workgroup): bit per layer, negative = the default (1: the first layer, where it is faster).  A gather index (x_index) is taken on the first layer only; other layers
  * called with one keep conv_wgrad_kernel -- etm_conv_train_wgrad_slices reports the count for x_index == NULL there. */
 int etm_conv_train_set_wgrad_lds(int layer_mask);
+/* Backward-data of the 4 x 4 / stride 2 layer (model.py:30) at N >= 512 from gradient images resident in LDS
+ * (csrc/conv_dgrad_lds.hip): 1 (default) / 0; negative = the default. */
+int etm_conv_train_set_dgrad_lds(int on);
 /* Grouped forms for the three layers (a launch of this size costs ~5 us whatever it does): etm_conv_pack_weights for n <= 4 layers
  * in one launch; etm_conv_train_wgrad with dw_kc_dbias == NULL leaves etm_conv_train_wgrad_slices(...) pixel slices in its workspace
  * and etm_conv_wgrad_reduce_grouped sums the slices of n <= 4 such calls in one launch into dw[i] [Cout, C, KH, KW] / db[i] [Cout]

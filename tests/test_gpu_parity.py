@@ -1272,6 +1272,45 @@ def test_grouped_column_sums_bit_identical_to_per_call_reductions(N, D):
 
 
 @pytest.mark.parametrize("N", [512, 601, 2048])
+def test_encoder_backward_data_with_lds_resident_gradient_images(N):
+    """csrc/conv_dgrad_lds.hip (4 x 4 / stride 2 layer: zero-bordered gradient images resident in LDS, the four stride classes as four
+    channel tiles of a dense 2 x 2 convolution, ReLU mask of the layer below in the epilogue) against conv_gemm_kernel of the same
+    build through etm_conv_train_dgrad, with and without the mask, ragged last group (601 = 4 * 150 + 1) -- and, N = 512, against
+    the float64 transposed convolution."""
+    from etm import lib as etm_lib
+    from etm import ops
+    dev = _dev()
+    lib = etm_lib.load()
+    torch.manual_seed(N + 2)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    c, hw, cout, k, s = 32, 20, 64, 4, 2
+    ho = (hw - k) // s + 1
+    wt = torch.randn((cout, c, k, k), device=dev) * 0.05
+    pd = ops.conv_pack_dgrad_weights(wt, s)
+    dy = torch.randn((N, ho, ho, cout), device=dev)
+    y_below = torch.randn((N, hw, hw, c), device=dev)
+    try:
+        for mask in (y_below, None):
+            res = {}
+            for on in (1, 0):
+                etm_lib.check(lib.etm_conv_train_set_dgrad_lds(on), "set_dgrad_lds")
+                dx = torch.full((N, hw, hw, c), float("nan"), device=dev)
+                etm_lib.check(lib.etm_conv_train_dgrad(dy.data_ptr(), pd.data_ptr(), None if mask is None else mask.data_ptr(), dx.data_ptr(),
+                                                       N, c, hw, hw, cout, k, k, s, st), "etm_conv_train_dgrad")
+                res[on] = dx
+            a, d = res[1], res[0]
+            assert bool(torch.isfinite(a).all())
+            assert bool(((a == 0) == (d == 0)).all()) or mask is None        # the same elements are masked
+            rel = float((a - d).double().norm() / d.double().norm())
+            assert rel < 2e-6, (mask is not None, rel)                         # measured ~2e-7: fp32 summation order only
+            if N == 512 and mask is None:
+                want = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), stride=s).permute(0, 2, 3, 1)
+                assert float((a.double().cpu() - want).norm() / want.norm()) < 2e-6
+    finally:
+        etm_lib.check(lib.etm_conv_train_set_dgrad_lds(-1), "set_dgrad_lds")
+
+
+@pytest.mark.parametrize("N", [512, 601, 2048])
 def test_encoder_weight_gradients_with_lds_resident_images(N):
     """csrc/conv_wgrad_lds.hip (layer input and gradient image resident in LDS, pixel pairs, one slice per workgroup; N >= 512)
     against conv_wgrad_kernel of the same build layer by layer (both through etm_conv_train_wgrad; different summation order) and

@@ -1,6 +1,6 @@
 """Training-side encoder kernels one by one (N = 2048, 3 x 84 x 84): HIP-event time and TFLOP/s of forward / backward-data /
 backward-weight of every layer through the C ABI (tools/kernel_rooflines.py encoder is the bench.py form of the same figures).
-python tools/conv_layer_time.py [N] [--fwd-lds] [--wgrad-lds]   (--fwd-lds: ALL forward passes with the images resident in LDS, csrc/conv_fwd_lds.hip;
+python tools/conv_layer_time.py [N] [--fwd-lds] [--wgrad-lds] [--dgrad-lds]   (--fwd-lds: ALL forward passes with the images resident in LDS, csrc/conv_fwd_lds.hip;
 without: none of them -- the library default is layer 2 only; --wgrad-lds: ALL weight gradients through csrc/conv_wgrad_lds.hip, without:
 none -- the default is layer 1 only)"""
 import os, sys
@@ -15,6 +15,7 @@ N = int(_args[0]) if _args else 2048
 dev = torch.device("cuda", 0); torch.manual_seed(0)
 lib = etm_lib.load()
 etm_lib.check(lib.etm_conv_train_set_fwd_lds(7 if FWD_LDS else 0), "set_fwd_lds")
+etm_lib.check(lib.etm_conv_train_set_dgrad_lds(1 if "--dgrad-lds" in sys.argv else 0), "set_dgrad_lds")
 etm_lib.check(lib.etm_conv_train_set_wgrad_lds(7 if "--wgrad-lds" in sys.argv else 0), "set_wgrad_lds")
 st = torch.cuda.current_stream().cuda_stream
 P = lambda t: t.data_ptr()
