@@ -74,7 +74,7 @@ def kernel_work(name, N, L, D, H):
 # profile name of this build -> kernel symbol (prefix) in the rocprofv3 counter files
 PMC_SYMBOL = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel",
               "conv_fwd_layer1": "conv_gemm_kernel<2, 1, false", "conv_fwd_layer2": "conv_fwd_lds_kernel<32, 20",
-              "conv_fwd_layer3": "conv_gemm_kernel<4, 2, false", "conv_dgrad_layer2": "conv_gemm_kernel<2, 1, true",
+              "conv_fwd_layer3": "conv_gemm_kernel<4, 2, false", "conv_dgrad_layer2": "conv_dgrad_lds_kernel<64, 9",
               "conv_dgrad_layer3": "conv_gemm_kernel<1, 2, true", "conv_wgrad_layer1": "conv_wgrad_lds_kernel<3, 84",
               "conv_wgrad_layer2": "conv_wgrad_kernel<4, 2>", "conv_wgrad_layer3": "conv_wgrad_kernel<3, 2>"}
 

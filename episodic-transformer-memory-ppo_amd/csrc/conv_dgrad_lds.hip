@@ -53,6 +53,13 @@ constexpr int dl_younger(int kg, int PD, int NEP, int NQ) {
   for (int j = kg < PD ? 0 : kg - PD + 1; j < kg; ++j) y += 1 + (j < NQ ? 1 : 0);
   return y;
 }
+// epilogue: groups of 4 operations issued after tile t's mask loads and before their wait.  Order: masks of tiles 0 .. D - 1; then per
+// tile u: [masks of tile u + D], [wait for tile u's], stores of tile u.
+constexpr int dl_ep_younger(int t, int D, int TPW) {
+  int y = t < D ? D - 1 - t : 1;                       // rest of the first requests / the stores of tile t - D
+  for (int u = t < D ? 0 : t - D + 1; u < t; ++u) y += (u + D < TPW ? 1 : 0) + 1;
+  return y + (t + D < TPW ? 1 : 0);
+}
 __device__ __forceinline__ i32x4d dl_rsrc(const void *base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
   i32x4d r{__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)(a >> 32)),
@@ -138,32 +145,33 @@ __global__ __launch_bounds__(256) void conv_dgrad_lds_kernel(const DgL p) {
   // weight offset of k step kg: tap row a' of the walk = packed tap row T - 1 - a'; beyond the last step: outside the descriptor
   auto w_off = [](int kg) { return kg < KG ? ((T - 1 - kg / GPS) * GPS + kg % GPS) * 1024 : 0x7ff00000; };
 
-  // the epilogue of one group: per tile 4 mask loads (requested one tile ahead), 4 stores; all issued whether or not there is a result
+  // the epilogue of one group: per tile 4 mask loads, requested ED tiles ahead (one tile ahead left most of a memory round trip per
+  // tile exposed), and 4 stores; all of them are issued whether or not there is a result
+  constexpr int ED = TPW < 3 ? TPW : 3;
   auto epilogue = [&](bool live, int gdone) {
-    f32x4 mk[2][4];
+    f32x4 mk[ED + 1][4];
+    auto request = [&](auto tc) {
+      constexpr int t = decltype(tc)::value, slot = t % (ED + 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dl_load(mk[0][i], rm, out_off(0, (lane >> 3) + 8 * i, gdone, live && masked));
+      for (int i = 0; i < 4; ++i) dl_load(mk[slot][i], rm, out_off(t, (lane >> 3) + 8 * i, gdone, live && masked));
+    };
+    dl_for<ED>([&](auto tc) { request(tc); });
     dl_for<TPW>([&](auto tc) {
-      constexpr int t = decltype(tc)::value, cur = t & 1, nxt = cur ^ 1;
-      if constexpr (t + 1 < TPW) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dl_load(mk[nxt][i], rm, out_off(t + 1, (lane >> 3) + 8 * i, gdone, live && masked));
-      }
+      constexpr int t = decltype(tc)::value, slot = t % (ED + 1);
+      if constexpr (t + ED < TPW) request(std::integral_constant<int, t + ED>{});
       if (live) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile[mfma32_row(r, lane)][col] = acc[t][r];
       }
-      // younger than tile t's mask loads: the stores of tile t - 1 and the mask loads of tile t + 1
-      constexpr int younger = (t > 0 ? 4 : 0) + (t + 1 < TPW ? 4 : 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dl_wait<younger>(mk[cur][i]);
+      for (int i = 0; i < 4; ++i) dl_wait<4 * dl_ep_younger(t, ED, TPW)>(mk[slot][i]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i;
         f32x4 v = *reinterpret_cast<const f32x4 *>(&tile[row][(lane & 7) * 4]);
         if (masked) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = mk[cur][i][q] > 0.f ? v[q] : 0.f;
+          for (int q = 0; q < 4; ++q) v[q] = mk[slot][i][q] > 0.f ? v[q] : 0.f;
         }
         dl_store(v, ro, out_off(t, row, gdone, live));
       }
