@@ -730,7 +730,7 @@ extern "C" int etm_conv_train_dgrad(const float *dy, const float *w_packed, cons
   (void)hipGetLastError();
   if (!dy || !w_packed || !dx || N <= 0 || C <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || S <= 0) return ETM_EINVAL;
   if (KH != KW || KH % S != 0 || H % S != 0 || W % S != 0 || Cout % 8 != 0 || (C != 32 && C != 64)) return ETM_EUNSUPPORTED;
-  if (g_conv_dgrad_lds && N >= 512) {
+  if (g_conv_dgrad_lds && N >= 512 && C == 32 && H == 20 && W == 20 && Cout == 64 && KH == 4 && KW == 4 && S == 2) {   // (its one geometry)
     hipStream_t st = (hipStream_t)stream;
     EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
     const int rc = etm_conv_dgrad_lds(dy, w_packed, y_below, dx, N, C, H, W, Cout, KH, KW, S, st);
