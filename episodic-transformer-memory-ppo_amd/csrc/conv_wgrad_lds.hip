@@ -12,7 +12,7 @@
 //     register + an immediate: no vector-ALU instruction next to the MFMAs (which would not overlap with them); an odd row count
 //     costs one zero row per image (9 -> 10, 7 -> 8 rows) instead of the forward pass's 32-pixel tiles;
 //   * the accumulators stay in registers over all images of a persistent workgroup (weights-stationary); the tiles are split over
-//     the four waves by k range / channel tile (layers 2, 3) or, where there are only 6 tiles (layer 1), by pixel pairs with one
+//     the four waves by k range / channel tile (layers 2, 3) or, where there are only 6 tiles (layer 1), by column ranges with one
 //     cross-wave sum at the very end;
 //   * one partial result per WORKGROUP goes to the workspace ([slices][K * Cout + Cout], the layout conv_wgrad_reduce_kernel sums);
 //   * one workgroup per CU; the next group of images (layer 1: one image, 84.7 + 51.2 KB; layers 2 / 3: two / four) is requested into
@@ -22,7 +22,7 @@
 // the first layer takes it by default (etm_conv_train_set_wgrad_lds).  Kernel only, layer 1: 124 us, of which 29 us are the
 // refills (34 vector-memory instructions per thread next to the MFMA stream, the LDS rewrite and two barriers per image) and 64 us
 // the MFMAs themselves.
-// The bias gradient (column sums of dY) rides in the pair loop: the B operands ARE the gradient pixels.
+// The bias gradient (column sums of dY) rides in the loop: the B operands ARE the gradient pixels.
 #include "etm_common.h"
 
 namespace {
@@ -46,7 +46,7 @@ __device__ __forceinline__ i32x4w wl_rsrc(const void *base, unsigned bytes) {
   return r;
 }
 
-// KTW x CTW accumulator tiles per wave; PSPLIT: the pixel pairs of an image are dealt to PSPLIT waves (the k / channel split then
+// KTW x CTW accumulator tiles per wave; PSPLIT: the output columns of an image are dealt to PSPLIT waves (the k / channel split then
 // covers 4 / PSPLIT waves).  PREFETCH: the next group's images are requested into registers while this group is multiplied.
 template <int C, int HW, int KS, int S, int COUT, int G, int KTW, int CTW, int PSPLIT, bool PREFETCH, int WGS_PER_CU>
 __global__ __launch_bounds__(256, WGS_PER_CU) void conv_wgrad_lds_kernel(const WgL p) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void conv_wgrad_lds_kernel(const W
         }
   }
   __syncthreads();
-  // bias gradient: every wave of the first k group holds, per channel tile of its range, the sums over its pixel pairs (one half-wave
+  // bias gradient: every wave of the first k group holds, per channel tile of its range, the sums over its pixels (one half-wave
   // per pixel of a pair); channel c = ct * 32 + col adds the waves that cover ct, in wave order, first pixel then second
   float *bs = lds;                                          // [4 waves][CTW][64 lanes]
 #pragma unroll
