@@ -70,7 +70,9 @@ constexpr int CG_WAVES = 4;
 template <int MT, int NT, bool DGRAD, int CLS = 1, bool BLDS = true>
 __global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT * (NT * CLS == 1 ? 4 : 2) > 8)) ? 2 : ETM_CONV_MINW)) void conv_gemm_kernel(const ConvG p) {
   constexpr int NTT = NT * CLS;                     // accumulator tiles per pixel tile: (class, channel tile)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform, and known to be: everything derived from it -- the k range,
+                                                                 // the weight fragment a wave fetches -- is scalar arithmetic, not VALU next to the MFMAs)
   const int cls0 = (int)blockIdx.y * CLS;           // first parity class of this workgroup (backward-data), 0 for forward
   const int tile0 = ((int)blockIdx.x * CG_WAVES + wave) * MT;
   // (with the shared weight fragments every wave of the workgroup takes part in the barriers: a wave past the last pixel tile
