@@ -67,7 +67,10 @@ constexpr int CG_WAVES = 4;
 // T x T gradient taps -- only their weights differ -- so with CLS = S * S the classes are just more channel tiles of one GEMM:
 // an A fragment feeds 4 NT CLS MFMAs instead of 4 NT (the vector-memory instructions per MFMA are what bounds these kernels).
 // BLDS: weight fragments through LDS, shared by the four waves of a workgroup (false: every wave loads its own)
-template <int MT, int NT, bool DGRAD, int CLS = 1, bool BLDS = true>
+// EVEN (shared-fragment path): the host promises that every wave's group count is a multiple of the chunk size, so the k walk needs no
+// clamping and a chunk no per-group validity test -- scalar bookkeeping that sits between the MFMAs of a wave (151 scalar
+// instructions per 64 MFMAs on the first layer's forward pass without it).
+template <int MT, int NT, bool DGRAD, int CLS = 1, bool BLDS = true, bool EVEN = false>
 __global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT * (NT * CLS == 1 ? 4 : 2) > 8)) ? 2 : ETM_CONV_MINW)) void conv_gemm_kernel(const ConvG p) {
   constexpr int NTT = NT * CLS;                     // accumulator tiles per pixel tile: (class, channel tile)
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT *
       for (int cg = 0; cg < CH; ++cg) {
         koff[cg] = (DGRAD ? -seg_n : seg_n) * row_elems + gi_n * 8;
         gidx[cg] = seg_n * gps + gi_n;
-        if (i_n + 1 < n_groups) {                     // uniform
-          ++i_n;
+        if (EVEN || i_n + 1 < n_groups) {             // uniform
+          if (!EVEN) ++i_n;
           if (++gi_n == gi_hi) { gi_n = gi_lo; ++seg_n; }
         }
       }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(CG_WAVES * 64, ((MT * NT * CLS > 4 || (BLDS && MT *
       if (c + 1 < n_chunks) fetch_chunk(std::integral_constant<int, 1 - B>{});
 #pragma unroll
       for (int cg = 0; cg < CH; ++cg) {
-        if (c * CH + cg < n_groups) {                  // uniform
+        if (EVEN || c * CH + cg < n_groups) {          // uniform
           f32x4 bf[NTT];
 #pragma unroll
           for (int t = 0; t < NTT; ++t) bf[t] = *reinterpret_cast<const f32x4 *>(&bt_s[B][cg * NTT + t][wl]);
@@ -645,8 +648,17 @@ static int conv_pick_mt(long long tiles, const int *cands, int n_cands, bool pre
 }
 template <int MT, int NT, bool DGRAD, int CLS = 1, bool BLDS = true>
 static void conv_launch(const ConvG &p, long long tiles, unsigned classes, hipStream_t st) {
-  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, DGRAD, CLS, BLDS>), dim3((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), dim3(CG_WAVES * 64),
-                     0, st, p);
+  const dim3 grid((unsigned)((tiles + CG_WAVES * MT - 1) / (CG_WAVES * MT)), classes), block(CG_WAVES * 64);
+  if constexpr (BLDS && (DGRAD || NT == 2)) {      // (measured: the 32-channel forward pass is 8 % SLOWER with it, the others 4 - 7 % faster)
+    // every wave's group count a multiple of the chunk size?  forward: all groups; backward-data: whole taps of sC / 8 groups each
+    constexpr int CH = NT * CLS == 1 ? 4 : 2;
+    const int unit = DGRAD ? p.sC / 8 : p.groups;
+    if (unit % CH == 0) {
+      hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, DGRAD, CLS, true, true>), grid, block, 0, st, p);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, DGRAD, CLS, BLDS>), grid, block, 0, st, p);
 }
 
 int etm_conv_fwd_lds(const float *x, const int64_t *x_index, const float *w_packed, const float *bias, float *y, int N, int C, int H, int W,
