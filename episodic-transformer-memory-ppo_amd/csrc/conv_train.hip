@@ -374,11 +374,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const ConvW p) {
     const long long ns = p.img_index ? p.img_index[n] : n;
     const float *xrow = p.x + ((ns * p.H + oy * p.S) * p.W + ox * p.S) * p.C;
     const float *drow = p.dy + (long long)mc * p.Cout;
+    // (only the gradient row is zeroed for a pixel past the slice: its product with ANY finite input row is zero, and the clamped
+    // addresses read real inputs; k rows past K are computed but never stored.  Selects per loaded element are vector-ALU work
+    // that cannot overlap the MFMAs: 24 of the 85 such instructions per 64 MFMAs of this loop.)
 #pragma unroll
-    for (int j = 0; j < A_J; ++j) {
-      const f32x4 val = *reinterpret_cast<const f32x4 *>(xrow + a_off[j]);
-      a_st[rb][j] = (ok && a_ok[j]) ? val : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < A_J; ++j) a_st[rb][j] = *reinterpret_cast<const f32x4 *>(xrow + a_off[j]);
 #pragma unroll
     for (int j = 0; j < D_J; ++j) {
       const f32x4 val = *reinterpret_cast<const f32x4 *>(drow + (t8 + 8 * j) * 4);
