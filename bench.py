@@ -30,6 +30,9 @@ import time
 # the host driver shares device memory between the ranks of a node through dmabuf handles only (RCCL, multi-process runs);
 # must be in the environment before the HIP runtime starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# eight hardware queues: four rollout worker groups (two streams each) run concurrently (trainer.py, rollout_groups: auto);
+# read by the HIP runtime when it starts, like the variable above
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "episodic-transformer-memory-ppo_amd")
@@ -411,7 +414,8 @@ def main():
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
-                       "rollout_team_placement": cfg.get("rollout_team_placement", "team_xcd")},
+                       "rollout_team_placement": cfg.get("rollout_team_placement", "team_xcd"),
+                       "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline if roofline is not None else roofline_train,
             "roofline_train": roofline_train,

@@ -15,6 +15,9 @@ import os
 # the host driver shares device memory between the ranks of a node through dmabuf handles only (RCCL, multi-process runs); the HIP
 # runtime reads this when it starts, i.e. at the first device call below -- so it is set here, before anything touches the device
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# eight hardware queues: four rollout worker groups (two streams each) run concurrently (trainer.py, rollout_groups: auto);
+# read by the HIP runtime when it starts, like the variable above
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 

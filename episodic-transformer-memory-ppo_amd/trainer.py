@@ -27,6 +27,27 @@ from collections import deque
 import numpy as np
 import torch
 
+# Four worker groups want four pairs of streams (upload + step graph) running CONCURRENTLY; the HIP runtime maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and reads that variable once, when it starts (the first device query of the
+# process).  With 4 queues four groups serialise (rollout 0.161 s per update instead of 0.087 s; two groups: 0.094 s), so "auto"
+# only trusts a value that is in the environment when this module is imported -- the entry points (bench.py, train.py, the
+# tools) set GPU_MAX_HW_QUEUES=8 as their first statement, before torch is imported; a caller who does not gets two groups.
+try:
+    _HW_QUEUES_AT_IMPORT = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+except ValueError:
+    _HW_QUEUES_AT_IMPORT = 0
+
+
+def default_rollout_groups(num_workers: int, min_group: int) -> int:
+    """``rollout_groups: auto``: 4 when the runtime has 8 hardware queues (see above) and the groups keep ``min_group`` workers,
+    else 2 (when THEY keep ``min_group`` workers), else 1."""
+    if _HW_QUEUES_AT_IMPORT >= 8 and num_workers % 4 == 0 and num_workers // 4 >= min_group:
+        return 4
+    if num_workers % 2 == 0 and num_workers // 2 >= min_group:
+        return 2
+    return 1
+
+
 from buffer import Buffer
 from environments.vec_env import make_vec_env
 from etm import lib as etm_lib
@@ -116,16 +137,19 @@ class PPOTrainer:
         self.writer = _make_writer(run_id) if tensorboard else _NullWriter()
 
         # environments (batched front-end over the upstream per-worker protocol)
-        # rollout_groups (default 2): the workers are stepped as that many groups in a software pipeline -- while the host steps
-        # one group's environments the device runs the other group's forward pass (two small head graphs overlap almost
-        # perfectly on the GPU: 163 us per pair vs 150 us each, tools/two_group_probe.py).  Needs an environment front-end made
+        # rollout_groups (default "auto": 4 with 8 hardware queues, else 2): the workers are stepped as that many groups in a software
+        # pipeline -- while the host steps one group's environments the device runs the other groups' forward passes (small step
+        # graphs overlap almost perfectly on the GPU: 117 us per round of two, 122 us per round of four vs 112 us each,
+        # tools/rollout_profile.py; config 3: rollout 0.094 s per update with two groups, 0.087 s with four).  Needs an environment front-end made
         # of parts (make_vec_env(groups=...)); an externally supplied environment is stepped as one group.
         # Groups of fewer than 8 workers are not formed: they do not pay off, and one intermittent mismatch was seen with
         # groups of 2 workers while both groups' graphs had been captured on torch's shared capture stream, i.e. with ONE
         # BLAS scratch buffer between them (split-K solutions at a handful of rows per GEMM); the graphs are captured per
         # group stream now (_capture_step_graph), the threshold stays until that has been re-measured.
-        n_groups = int(config.get("rollout_groups", 2))
-        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < int(config.get("rollout_min_group_size", 8)):
+        min_group = int(config.get("rollout_min_group_size", 8))
+        n_groups = config.get("rollout_groups", "auto")
+        n_groups = default_rollout_groups(self.num_workers, min_group) if n_groups == "auto" else int(n_groups)
+        if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < min_group:
             n_groups = 1
         self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers

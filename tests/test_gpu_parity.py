@@ -427,6 +427,7 @@ _ROLLOUT_PATHS = {
     "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
     "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
     "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
+    "four_groups": {"rollout_groups": 4, "rollout_min_group_size": 2},          # four worker groups (correct with any number of hardware queues)
     "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False,    # heads / loss / weight gradients as separate ops (round-2 form),
                        "grouped_colsum_train": False},                          # every column-sum gradient reduced by its own launch
     "pull_obs": {"pull_observations": True},                  # the device pulls the observation rows itself; step graphs enqueued one step ahead
@@ -440,7 +441,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
              ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd"), ("img32", "early_launch"),
-             ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "pull_obs"), ("cfg3", "pull_obs"),
+             ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "pull_obs"), ("cfg3", "pull_obs"), ("img32", "four_groups"), ("cfg3", "four_groups"),
              ("cfg5", "pull_obs")]
 
 

@@ -2,6 +2,7 @@
 python tools/config_bench.py NAME [updates] [key=value ...]   (config keys, dotted for a section: 0/1 -> bool unless the key holds an integer, integers otherwise; ETM_DIAG_LIB=... selects
 another build of the library)"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: rollout_groups "auto" = 4 (trainer.py)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
 import torch

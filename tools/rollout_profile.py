@@ -1,5 +1,6 @@
 """Where does a rollout step go?  Host-side timers around graph replay / sync / env step (BASELINE config 3)."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: rollout_groups "auto" = 4 (trainer.py)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
 import numpy as np, torch
