@@ -14,7 +14,8 @@
 //     [(tap j, co) / 8][256]); its tap rows run against the image rows (tap a reads row cy - a), so the k walk takes them in
 //     reverse order -- an address constant per step of the fully unrolled loop;
 //   * epilogue per tile through a per-wave LDS tile: rows = class pixels, 16-byte pieces of dx[n, 2 cy + py, 2 cx + px, 0:32] times
-//     the ReLU mask of the layer below (y_below > 0), whose 16-byte loads are requested one tile ahead;
+//     the ReLU mask of the layer below (y_below > 0); tiles in batches of four, a batch's mask loads issued before the previous
+//     batch's stores (a load behind a store waits for the store: vmcnt is one in-order counter);
 //   * persistence, the next group's fill during the k loop, hand-written wait counts and unconditional inline-assembly memory
 //     instructions exactly as in conv_fwd_lds.hip (counts beyond the 6-bit vmcnt range are clamped: a smaller count only waits longer).
 #include "etm_common.h"
@@ -53,13 +54,6 @@ constexpr int dl_younger(int kg, int PD, int NEP, int NQ) {
   for (int j = kg < PD ? 0 : kg - PD + 1; j < kg; ++j) y += 1 + (j < NQ ? 1 : 0);
   return y;
 }
-// epilogue: groups of 4 operations issued after tile t's mask loads and before their wait.  Order: masks of tiles 0 .. D - 1; then per
-// tile u: [masks of tile u + D], [wait for tile u's], stores of tile u.
-constexpr int dl_ep_younger(int t, int D, int TPW) {
-  int y = t < D ? D - 1 - t : 1;                       // rest of the first requests / the stores of tile t - D
-  for (int u = t < D ? 0 : t - D + 1; u < t; ++u) y += (u + D < TPW ? 1 : 0) + 1;
-  return y + (t + D < TPW ? 1 : 0);
-}
 __device__ __forceinline__ i32x4d dl_rsrc(const void *base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
   i32x4d r{__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)(a >> 32)),
@@ -81,12 +75,20 @@ __global__ __launch_bounds__(256) void conv_dgrad_lds_kernel(const DgL p) {
   constexpr int PD = 4;
   constexpr int NEP = TPW * 8;                             // epilogue operations per wave and group: 4 mask loads + 4 stores per tile
   static_assert(SEG % 8 == 0 && CG % 8 == 0 && KG % PD == 0 && NQ <= KG, "layer geometry");
-  extern __shared__ __attribute__((aligned(16))) float img[];   // [G][IMG], then the per-wave epilogue tiles [4][32][36]
+  extern __shared__ __attribute__((aligned(16))) float img[];   // [G][IMG], the per-wave epilogue tiles [4][32][36], the offset table [M]
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int py = cls / S, px = cls - py * S;
   float(*tile)[36] = reinterpret_cast<float(*)[36]>(img + G * IMG + cls * (32 * 36));
   const f32x4 *img4 = reinterpret_cast<const f32x4 *>(img);
+  // byte offset of class pixel m's first element inside its group's block of dx (class (0, 0), channel 0): looked up in the
+  // epilogue -- decoding m there costs two integer divisions per row, vector-ALU work that nothing overlaps
+  unsigned *otab = reinterpret_cast<unsigned *>(img + G * IMG + 4 * 32 * 36);
+  for (int m = tid; m < M; m += 256) {
+    const int g = m / PIX, r = m - g * PIX, cy = r / HO, cx = r - cy * HO;
+    otab[m] = (unsigned)(((g * H + S * cy) * H + S * cx) * CIN) * 4u;
+  }
+  const unsigned lane_off = (unsigned)(((py * H + px) * CIN + (lane & 7) * 4) * 4);
 
   for (int e = tid; e < G * IMG / 4; e += 256) reinterpret_cast<f32x4 *>(img)[e] = f32x4{0.f, 0.f, 0.f, 0.f};   // borders stay zero
 
@@ -120,13 +122,12 @@ __global__ __launch_bounds__(256) void conv_dgrad_lds_kernel(const DgL p) {
     for (int u = 0; u < NQ; ++u)
       if (tid + u * 256 < G * Q_IMG) *reinterpret_cast<f32x4 *>(img + fill_dst(u)) = fill[u];
   };
-  // dx / mask element offset (bytes) of row `row` of tile t of group grp_done, or an offset outside every descriptor
-  auto out_off = [&](int t, int row, int grp_done, bool live) {
+  // dx / mask byte offset of row `row` of tile t of group gdone, or an offset outside every descriptor
+  auto out_off = [&](int t, int row, int gdone, bool live) {
     const int m = t * 32 + row;
-    const int g = m / PIX, r = m - g * PIX, cy = r / HO, cx = r - cy * HO;
-    const int n = grp_done * G + g;
-    const bool ok = live && m < M && n < p.N;
-    return ok ? (int)((((unsigned)(n * H + S * cy + py) * H + S * cx + px) * CIN + (lane & 7) * 4) * 4u) : (int)0xfffffff0;
+    const int valid = min(G, p.N - gdone * G) * PIX;                       // class pixels of the images this group really has (uniform)
+    const unsigned off = otab[min(m, M - 1)] + (unsigned)gdone * (unsigned)(G * H * H * CIN * 4) + lane_off;
+    return (live && m < valid) ? (int)off : (int)0xfffffff0;
   };
 
   int grp = blockIdx.x;
@@ -145,36 +146,55 @@ __global__ __launch_bounds__(256) void conv_dgrad_lds_kernel(const DgL p) {
   // weight offset of k step kg: tap row a' of the walk = packed tap row T - 1 - a'; beyond the last step: outside the descriptor
   auto w_off = [](int kg) { return kg < KG ? ((T - 1 - kg / GPS) * GPS + kg % GPS) * 1024 : 0x7ff00000; };
 
-  // the epilogue of one group: per tile 4 mask loads, requested ED tiles ahead (one tile ahead left most of a memory round trip per
-  // tile exposed), and 4 stores; all of them are issued whether or not there is a result
-  constexpr int ED = TPW < 3 ? TPW : 3;
+  // The epilogue of one group: per tile 4 mask loads and 4 stores, all issued whether or not there is a result.  vmcnt counts a
+  // wave's loads AND stores in issue order, so a mask load issued behind a store is not "back" before that store is (measured:
+  // 1.5 us per tile with loads and stores alternating = 40 of the kernel's 154 us).  Tiles therefore go in batches of EB: the NEXT
+  // batch's mask loads are issued before THIS batch's stores, every wait has only younger stores behind it.
+  constexpr int EB = 4, NB = (TPW + EB - 1) / EB;
   auto epilogue = [&](bool live, int gdone) {
-    f32x4 mk[ED + 1][4];
-    auto request = [&](auto tc) {
-      constexpr int t = decltype(tc)::value, slot = t % (ED + 1);
+    f32x4 mk[2][EB][4], val[EB][4];
+    int so[EB][4];
+    auto request = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dl_load(mk[slot][i], rm, out_off(t, (lane >> 3) + 8 * i, gdone, live && masked));
-    };
-    dl_for<ED>([&](auto tc) { request(tc); });
-    dl_for<TPW>([&](auto tc) {
-      constexpr int t = decltype(tc)::value, slot = t % (ED + 1);
-      if constexpr (t + ED < TPW) request(std::integral_constant<int, t + ED>{});
-      if (live) {
+      for (int j = 0; j < EB; ++j)
+        if (k * EB + j < TPW) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[mfma32_row(r, lane)][col] = acc[t][r];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dl_wait<4 * dl_ep_younger(t, ED, TPW)>(mk[slot][i]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (lane >> 3) + 8 * i;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(&tile[row][(lane & 7) * 4]);
-        if (masked) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = mk[slot][i][q] > 0.f ? v[q] : 0.f;
+          for (int i = 0; i < 4; ++i) dl_load(mk[k & 1][j][i], rm, out_off(k * EB + j, (lane >> 3) + 8 * i, gdone, live && masked));
         }
-        dl_store(v, ro, out_off(t, row, gdone, live));
-      }
+    };
+    request(std::integral_constant<int, 0>{});
+    dl_for<NB>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int nt = TPW - k * EB < EB ? TPW - k * EB : EB;                                   // tiles of this batch
+      constexpr int nnext = k + 1 < NB ? (TPW - (k + 1) * EB < EB ? TPW - (k + 1) * EB : EB) : 0;   // ... and of the next one
+      if constexpr (k + 1 < NB) request(std::integral_constant<int, k + 1>{});
+      dl_for<nt>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, t = k * EB + j;
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tile[mfma32_row(r, lane)][col] = acc[t][r];
+        }
+        // younger than this tile's mask loads: the rest of its batch's, the previous batch's stores, the next batch's mask loads
+        constexpr int younger = 4 * (nt - 1 - j) + (k > 0 ? 4 * EB : 0) + 4 * nnext;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dl_wait<younger>(mk[k & 1][j][i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lane >> 3) + 8 * i;
+          f32x4 v = *reinterpret_cast<const f32x4 *>(&tile[row][(lane & 7) * 4]);
+          if (masked) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = mk[k & 1][j][i][q] > 0.f ? v[q] : 0.f;
+          }
+          val[j][i] = v;
+          so[j][i] = out_off(t, row, gdone, live);
+        }
+      });
+#pragma unroll
+      for (int j = 0; j < nt; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dl_store(val[j][i], ro, so[j][i]);
     });
   };
 
@@ -233,7 +253,7 @@ int launch_dgrad_lds(const DgL &p0, hipStream_t st) {
   constexpr int PW = HG + 2 * (T - 1), H = S * (HG + T - 1);
   if ((long long)p.N * H * H * CIN * 4 >= 0xfffffff0ll) return ETM_EUNSUPPORTED;    // 32-bit byte offsets into dx / the mask
   p.n_groups = (p.N + G - 1) / G;
-  constexpr size_t lds = ((size_t)G * PW * PW * CP + 4 * 32 * 36) * sizeof(float);
+  constexpr size_t lds = ((size_t)G * PW * PW * CP + 4 * 32 * 36 + (size_t)G * (HG + T - 1) * (HG + T - 1)) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS of a CU");
   auto kern = conv_dgrad_lds_kernel<CG, HG, T, S, CIN, G, CP>;
   static bool attr_set = false;
