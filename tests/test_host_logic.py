@@ -375,3 +375,19 @@ def test_host_copier_and_threaded_environment_rows():
         logs.append(log)
         assert seen and seen[-1][1] == 6
     assert all(np.array_equal(a, b) for a, b in zip(*logs))
+
+
+def test_rollout_group_count_follows_the_hardware_queues(monkeypatch):
+    """``rollout_groups: auto`` (trainer.py): four worker groups only when GPU_MAX_HW_QUEUES >= 8 was in the environment when the
+    module was imported (the HIP runtime reads it once; with 4 queues four groups serialise), and only while the groups keep
+    ``rollout_min_group_size`` workers; otherwise two, otherwise one."""
+    import trainer
+    monkeypatch.setattr(trainer, "_HW_QUEUES_AT_IMPORT", 8)
+    assert trainer.default_rollout_groups(32, 8) == 4
+    assert trainer.default_rollout_groups(16, 8) == 2          # groups of 4 would be below the minimum
+    assert trainer.default_rollout_groups(8, 8) == 1
+    assert trainer.default_rollout_groups(30, 4) == 2          # not divisible by four
+    monkeypatch.setattr(trainer, "_HW_QUEUES_AT_IMPORT", 0)    # runtime defaults (or started before the variable was set)
+    assert trainer.default_rollout_groups(32, 8) == 2
+    monkeypatch.setattr(trainer, "_HW_QUEUES_AT_IMPORT", 4)
+    assert trainer.default_rollout_groups(32, 8) == 2
