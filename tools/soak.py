@@ -1,4 +1,5 @@
 import os, sys, time, math
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # as bench.py / train.py: four worker groups (trainer.py, rollout_groups: auto)
 sys.path.insert(0, "episodic-transformer-memory-ppo_amd")
 import torch
 from yaml_parser import YamlParser
