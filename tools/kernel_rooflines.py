@@ -24,6 +24,8 @@ events (etm_profile_*: an event pair on the launch stream around each kernel), a
                 (W x every matrix of the chain + the workers' K | V window columns) / time, and the length of its dependency chain
 """
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (as bench.py: the rollout_step target builds a trainer -- rollout_groups: auto)
+
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
