@@ -33,6 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # eight hardware queues: four rollout worker groups (two streams each) run concurrently (trainer.py, rollout_groups: auto);
 # read by the HIP runtime when it starts, like the variable above
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("ETM_HW_QUEUES_SET_EARLY", "1")   # marker for trainer.py: the line above ran before the HIP runtime started
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "episodic-transformer-memory-ppo_amd")
@@ -55,14 +56,15 @@ def load_config():
 def kernel_work(name, N, L, D, H):
     """Algorithmic work of one launch at the training shape (DESIGN.md section 'Kernels'): ("hbm", bytes) or ("mfma", flops)."""
     if name.startswith("conv_") and name[-1] in "123" and "layer" in name:
-        # encoder pass of one layer: 2 * N * Ho * Wo * k * k * C * Cout flop (forward, backward-data and backward-weight alike);
-        # the weight-gradient id covers two launches per pass (main kernel + slice reduction): flops per LAUNCH = half
+        # encoder pass of one layer: 2 * N * Ho * Wo * k * k * C * Cout flop (forward, backward-data and backward-weight alike; the
+        # slice reduction of the weight gradients is a launch of its own with its own profile id since round 3)
         import kernel_rooflines
-        fl = kernel_rooflines.encoder_flops(N)[int(name[-1]) - 1]
-        return "mfma", fl / (2.0 if "wgrad" in name else 1.0)
+        return "mfma", kernel_rooflines.encoder_flops(N)[int(name[-1]) - 1]
     if name == "grouped_dw_kernel":
-        # every [D, D]-sized weight gradient of the step in one launch (config 3: 3 blocks x 5 + embedding + 2 hidden heads)
-        return "mfma", 2.0 * N * D * D * 18
+        # every dense-layer weight gradient of the step in one launch: the flops of the problems the collector really handed over
+        # (etm/ops.py:DeferredDw.flush; config 3: 3 blocks x 5 + embedding + 2 hidden heads = 18 products of 2 * N * D * D)
+        from etm import ops
+        return "mfma", ops.DeferredDw.last_flops or 2.0 * N * D * D * 18
     if name in ("window_fwd_kernel", "window_bwd_kernel"):
         # folded attention pass: the read of the gathered window, L*D*4 B per sample and block (SURVEY.md 8d's algorithmic
         # figure; the H folded vectors in / out and the attention weights are reported separately as extra_bytes_per_launch)
@@ -354,6 +356,7 @@ def main():
             roofline = {"kernel": "rollout_trxl_kernel", "bound": "hbm", "achieved": rs["achieved"], "peak": rs["peak"], "unit": "GB/s",
                         "frac": rs["frac"], "traffic": None, "traffic_unit": "bytes per launch", "avg_launch_ms": rs["avg_launch_ms"],
                         "launches": rs["launches"], "bytes_per_launch": rs["bytes_per_launch"], "dtype": "f32",
+                        "unique_bytes_per_launch": rs.get("unique_bytes_per_launch"), "frac_unique": rs.get("frac_unique"),
                         "est_region_ms": est[dom_all], "us_per_dependent_phase": rs["us_per_dependent_phase"], "model": rs["model"],
                         "note": "dominant kernel of ALL GPU time (rollout: one launch per worker group and step).  It is a dependency "
                                 "chain (products -> exchange -> LayerNorm ...), bound by round-trip latency, not by a roofline: "

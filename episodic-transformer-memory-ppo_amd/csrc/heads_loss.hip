@@ -251,7 +251,8 @@ __global__ __launch_bounds__(1024) void heads_reduce_kernel(const float *__restr
     float s = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) s += v[u];
-    for (int w = g + 256; w < n_wg; w += 16) s += partials[(long long)w * row + e];      // (more than 256 rows: the rest in order)
+    if (e < row)
+      for (int w = g + 256; w < n_wg; w += 16) s += partials[(long long)w * row + e];    // (more than 256 rows: the rest in order)
     return s;
   };
   const int e = blockIdx.x * 64 + el;

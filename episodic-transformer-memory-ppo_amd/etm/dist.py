@@ -121,12 +121,15 @@ class DataParallel:
         the same torch.distributed collectives in the same order whatever happens locally -- so a failure on one rank (RCCL not
         loadable, CPU tensors, gloo backend, several ranks on one device) can never leave ranks in different collectives:
 
-          1. local pre-check                      -> all_reduce(MIN) of "I can try"          (everybody leaves here together if not)
+          1. local pre-check (library loads, RCCL resolves -- every rank draws a throw-away rendezvous id --, the device answers)
+                                                  -> all_reduce(MIN) of "I can try"          (everybody leaves here together if not)
           2. rank 0 draws the rendezvous id       -> broadcast of [status byte | 128-byte id] (rank 0 ALWAYS broadcasts; a failure
                                                                                                travels as status 1 + a zeroed id)
           3. etm_comm_init + self-test all-reduce -> all_reduce(MIN) of "mine works"
 
-        A rendezvous that cannot complete is bounded by RCCL's own timeouts (and the process group's), not by a helper thread."""
+        Everything that can fail LOCALLY inside etm_comm_init is exercised in step 1, so no rank enters the RCCL rendezvous alone; a
+        peer that dies between steps 1 and 3 is covered by a watchdog (ETM_COMM_TIMEOUT_S, default 600 s: message + exit), because
+        RCCL's bootstrap waits without a bound for a peer that never connects."""
         from . import lib as _lib
         on_dev = dist.get_backend() == "nccl"
         flag_dev = self.device if on_dev else "cpu"
@@ -140,8 +143,17 @@ class DataParallel:
         if self.device is None or torch.device(self.device).type != "cuda" or not on_dev:
             why = "needs HIP device tensors and the nccl (RCCL) backend"
         else:
+            # EVERY local precondition of etm_comm_init is exercised here, before anybody enters the RCCL rendezvous (a rank that
+            # failed locally inside step 3 would leave its peers waiting in ncclCommInitRank for a peer that never connects):
+            # the library loads, RCCL is found and its symbols resolve (drawing a rendezvous id does exactly that -- every rank
+            # draws one, only rank 0's is used), the device answers
             try:
-                _lib.load()
+                import ctypes
+                with torch.cuda.device(torch.device(self.device)):
+                    torch.cuda.synchronize()
+                    rc = _lib.load().etm_comm_unique_id(ctypes.create_string_buffer(128))
+                if rc != 0:
+                    why = f"etm_comm_unique_id failed ({rc}): RCCL not usable on this rank"
             except Exception as exc:       # noqa: BLE001
                 why = repr(exc)
         if not agree(why is None):                                        # step 1
@@ -158,6 +170,19 @@ class DataParallel:
             else:
                 msg[0] = 1
                 why = f"etm_comm_unique_id failed ({rc})"
+        # watchdog for the rendezvous itself (a peer that died between step 1 and step 3): RCCL's bootstrap waits without a bound
+        # for a peer that never connects, so after ETM_COMM_TIMEOUT_S (default 600) the process is ended with a message instead
+        import threading
+        limit = float(os.environ.get("ETM_COMM_TIMEOUT_S", "600"))
+
+        def _give_up():
+            print(f"[etm.dist] rank {self.rank}: RCCL rendezvous did not complete within {limit:.0f} s (a peer is gone?) -- aborting",
+                  flush=True)
+            os._exit(3)
+
+        watchdog = threading.Timer(limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         msg = msg.to(dev)
         dist.broadcast(msg, src=0)                                        # step 2 (unconditional on every rank)
         msg = msg.cpu()
@@ -178,7 +203,11 @@ class DataParallel:
                 ok, why = False, repr(exc)
         elif why is None:
             why = "rank 0 could not draw a rendezvous id"
-        if not agree(ok):                                                 # step 3
+        try:
+            agreed = agree(ok)                                            # step 3
+        finally:
+            watchdog.cancel()
+        if not agreed:
             return self._use_torch_collective(why)
 
     def _use_torch_collective(self, why):

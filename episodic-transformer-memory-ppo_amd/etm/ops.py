@@ -289,9 +289,11 @@ class DeferredDw:
     Inside, the autograd functions below hand (dy, x, weight) over instead of multiplying; ``flush()`` (called on exit) runs the
     grouped kernel.  ``written``: data_ptr()s of the parameters whose gradient now sits in its arena view."""
     active = None
+    last_flops = 0.0             # 2 * N * Ma * Nb summed over the problems of the most recent grouped launch (bench.py prices it with this)
 
     def __init__(self, dest):
         self.dest = dest
+        self.rows = {}           # parameter data_ptr -> [(first row, rows)] already taken (a second use of the same rows is refused)
         self.items = []          # (A, B, C view, Ma, Nb, lda, ldb, ldc)
         self.colsums = []        # (partial sums, first column, rows P, columns C, row stride, destination view)
         self.conv_wgrads = []    # (pixel slices, slice count, dw view, db view, Cout, C, KH, KW) of the encoder layers
@@ -325,6 +327,12 @@ class DeferredDw:
         c = view[row0: row0 + ma]
         if view.shape[1] != nb or (_ptr(b) % 16) or (_ptr(c) % 16) or ((_ptr(a) + 4 * a_col0) % 4):
             return False
+        # the grouped kernel OVERWRITES its destination: a parameter used twice in one graph (tied weights, a layer applied twice)
+        # keeps its first use here and the caller multiplies the second one itself (autograd then accumulates it, _train_body_a adds it)
+        taken = self.rows.setdefault(weight.data_ptr(), [])
+        if any(row0 < r0 + m and r0 < row0 + ma for r0, m in taken):
+            return False
+        taken.append((row0, ma))
         self.N = n
         self.items.append((a, b, c, ma, nb, lda, ldb, ldc, a_col0))
         self.written.add(weight.data_ptr())
@@ -373,6 +381,7 @@ class DeferredDw:
         pc = (ctypes.c_void_p * k)(*[_ptr(it[2]) for it in self.items])
         dims = (ctypes.c_int32 * (5 * k))(*[v for it in self.items for v in it[3:8]])
         _lib.check(_lib.load().etm_grouped_dw(pa, pb, pc, dims, k, self.N, _stream()), "etm_grouped_dw")
+        DeferredDw.last_flops = float(sum(2.0 * self.N * it[3] * it[4] for it in self.items))
         self.items = []
 
 

@@ -18,6 +18,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # eight hardware queues: four rollout worker groups (two streams each) run concurrently (trainer.py, rollout_groups: auto);
 # read by the HIP runtime when it starts, like the variable above
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("ETM_HW_QUEUES_SET_EARLY", "1")   # marker for trainer.py: the line above ran before the HIP runtime started
 
 import torch  # noqa: E402
 

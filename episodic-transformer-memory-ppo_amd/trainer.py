@@ -32,10 +32,28 @@ import torch
 # process).  With 4 queues four groups serialise (rollout 0.161 s per update instead of 0.087 s; two groups: 0.094 s), so "auto"
 # only trusts a value that is in the environment when this module is imported -- the entry points (bench.py, train.py, the
 # tools) set GPU_MAX_HW_QUEUES=8 as their first statement, before torch is imported; a caller who does not gets two groups.
-try:
-    _HW_QUEUES_AT_IMPORT = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
-except ValueError:
-    _HW_QUEUES_AT_IMPORT = 0
+def _trusted_hw_queues() -> int:
+    """GPU_MAX_HW_QUEUES as the HIP runtime of this process has read it (or will): the value in os.environ counts only if the runtime
+    has not started yet, or the process was STARTED with it (/proc/self/environ), or one of this package's entry points set it as
+    its first statement (they leave the marker ETM_HW_QUEUES_SET_EARLY).  An application that initialised torch.cuda first and set
+    the variable afterwards runs on the runtime's default four queues whatever os.environ says now: 0."""
+    try:
+        val = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+    except ValueError:
+        return 0
+    if val < 8 or not torch.cuda.is_initialized() or os.environ.get("ETM_HW_QUEUES_SET_EARLY") == "1":
+        return val
+    try:
+        with open("/proc/self/environ", "rb") as f:
+            for item in f.read().split(b"\0"):
+                if item.startswith(b"GPU_MAX_HW_QUEUES=") and int(item.split(b"=", 1)[1]) >= 8:
+                    return val
+    except (OSError, ValueError):
+        pass
+    return 0
+
+
+_HW_QUEUES_AT_IMPORT = _trusted_hw_queues()
 
 
 def default_rollout_groups(num_workers: int, min_group: int) -> int:
@@ -151,6 +169,9 @@ class PPOTrainer:
         n_groups = default_rollout_groups(self.num_workers, min_group) if n_groups == "auto" else int(n_groups)
         if n_groups < 1 or self.num_workers % n_groups != 0 or self.num_workers // n_groups < min_group:
             n_groups = 1
+        if config.get("rollout_groups", "auto") == "auto" and os.environ.get("ETM_QUIET") != "1":
+            print(f"[etm] rollout worker groups: {n_groups} (rollout_groups: auto; hardware queues the HIP runtime is known to have been "
+                  f"started with: {_HW_QUEUES_AT_IMPORT or 'runtime default (4)'})", flush=True)
         self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers
         obs_shape = tuple(self.env.observation_space_shape)
@@ -947,9 +968,7 @@ class PPOTrainer:
                 stats3 = self.dp.merge_adv_stats(stats3)
         loss, stats = self._loss_from(samples["obs"], spec, samples, clip_range, beta, stats3, dyn=None)
         self._set_lr(learning_rate)
-        self.flat_grads.zero_()
-        with ops.DeferredDw(self._dw_destinations()):      # dense-layer weight gradients: one grouped launch into the arena
-            loss.backward(self._unit_gradient(loss))
+        self._backward_into_arena(loss)
         if self.dp is not None:
             self.dp.all_reduce_grads(average=False)       # the sum; the 1 / world rides in the clip coefficient below
         # global-norm clipping (the rule of torch.nn.utils.clip_grad_norm_, upstream :311) + AdamW on the flat arenas: 2 launches
@@ -1044,6 +1063,11 @@ class PPOTrainer:
         if stats3 is None:
             stats3 = ops.adv_stats(mb["advantages"])
         loss, stats = self._loss_from(obs, spec, mb, clip_range, beta, stats3)
+        self._backward_into_arena(loss)
+        return stats
+
+    def _backward_into_arena(self, loss):
+        """``loss.backward()`` with every gradient ending up in its view of the flat gradient arena."""
         # backward() hands every parameter its gradient tensor (no accumulate launch while .grad is None); ONE multi-tensor copy
         # packs them into the flat bucket that the all-reduce, clipping and the fused AdamW read -- ~50 launches fewer per step
         # than accumulating into the zeroed bucket (the python-side re-aliasing below costs nothing under graph replay)
@@ -1056,13 +1080,14 @@ class PPOTrainer:
         views, grads = [], []
         for p, v in zip(self.params, self._grad_views):
             if p.data_ptr() in dw.written:
+                if p.grad is not None:               # a second use of the parameter that the collector refused: add it to the arena view
+                    v.add_(p.grad)
                 continue                             # already in the arena
             views.append(v)
             grads.append(p.grad if p.grad is not None else torch.zeros_like(v))   # None: parameter outside this graph (unused head)
         torch._foreach_copy_(views, grads)
         for p, v in zip(self.params, self._grad_views):
             p.grad = v
-        return stats
 
     def minibatch_gradients(self, idx, clip_range: float, beta: float) -> dict:
         """Un-clipped gradient of the PPO loss (trainer.py:276-310) on the minibatch ``idx`` (flat sample indices of the prepared

@@ -407,6 +407,34 @@ class _InProcWorker:
         _InProcWorker.counter += 1
 
 
+
+def _exact_gradients(tr, samples, lr, clip, beta):
+    """Gradient of the reference's own `_train_mini_batch` loss (trainer.py:258-310) evaluated in float64 at the trainer's current
+    fp32 parameters on the same minibatch: a deep copy of the model in double, the minibatch fields up-cast, the reference's
+    method run on a stand-in trainer whose optimiser does nothing.  No random numbers are drawn and the fp32 trainer is untouched,
+    so the recorded fp32 trajectory is bit-identical with or without this evaluation."""
+    import copy
+    shim = types.SimpleNamespace()
+    shim.model = copy.deepcopy(tr.model).double()
+    shim.config = tr.config
+    shim.action_space_shape = tr.action_space_shape
+    shim.optimizer = types.SimpleNamespace(param_groups=[], zero_grad=lambda: None, step=lambda: None)
+    s64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in samples.items()}
+    hooked = torch.nn.utils.clip_grad_norm_
+    got = {}
+
+    def grab(params, *a, **k):
+        got.update({n: p.grad.detach().clone() for n, p in shim.model.named_parameters()})
+        return None
+
+    torch.nn.utils.clip_grad_norm_ = grab
+    try:
+        ref_trainer.PPOTrainer._train_mini_batch(shim, s64, lr, clip, beta)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = hooked
+    return got
+
+
 def golden_rollout(only=None):
     cases = {
         "vec": dict(env=dict(obs_shape=(6,), num_actions=3, max_episode_steps=12, seed=3, p_done=0.08, p_reward=0.3, pool=16),
@@ -507,24 +535,69 @@ def golden_rollout(only=None):
                 out[tag + "memories"] = b.memories.clone()
             perms_all.clear()
             grads_rec = []
+            step_recs = []          # BASELINE-size cases: one record per optimiser step (round 4, see _exact_gradients)
+            per_step = name.startswith("cfg")
             real_clip = torch.nn.utils.clip_grad_norm_
+            real_tmb = tr._train_mini_batch
+            cur = {}
+
+            def rec_tmb(samples, lr_, clip_, beta_):
+                cur["samples"], cur["hp"] = samples, (lr_, clip_, beta_)
+                res = real_tmb(samples, lr_, clip_, beta_)
+                if per_step:
+                    step_recs[-1]["sd_after"] = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+                return res
 
             def rec_clip(params, *a, **k):
                 # trainer.py:311 -- the gradients of the FIRST minibatch of the update as loss.backward() left them (un-clipped)
                 if not grads_rec:
                     grads_rec.append({n: p.grad.detach().clone() for n, p in tr.model.named_parameters()})
+                if per_step:
+                    # every optimiser step: the reference's fp32 gradient and, AT THE SAME PARAMETERS AND MINIBATCH, the gradient of
+                    # the reference's own loss code evaluated in float64 ("exact": rounding error 1e-16)
+                    rec = {"grad": {n: p.grad.detach().clone() for n, p in tr.model.named_parameters()},
+                           "params": {n: p.detach().clone() for n, p in tr.model.named_parameters()},
+                           "xgrad": _exact_gradients(tr, cur["samples"], *cur["hp"])}
+                    step_recs.append(rec)
                 return real_clip(params, *a, **k)
 
             torch.randperm = rec_randperm
             torch.nn.utils.clip_grad_norm_ = rec_clip
+            tr._train_mini_batch = rec_tmb
             try:
                 stats, _ = tr._train_epochs(lr, clip, beta)
             finally:
                 torch.randperm = real_randperm
                 torch.nn.utils.clip_grad_norm_ = real_clip
+                tr._train_mini_batch = real_tmb
             for k, g in grads_rec[0].items():
                 out[tag + "grad0_sample/" + k] = dg.sample(g.numpy(), 64)
                 out[tag + "grad0_norm/" + k] = np.float64(g.double().norm())
+            # per optimiser step s of this update: `s{s}/grad_*` the reference's fp32 gradient (un-clipped), `s{s}/xgrad_*` the float64
+            # evaluation at the same parameters (samples as float64; `xgrad_err/<k>` = ||fp32 - exact|| over the WHOLE tensor, i.e. the
+            # reference's own evaluation noise per tensor), `s{s}/sd_sample/<k>` the parameters after the step
+            for s_i, rec in enumerate(step_recs):
+                st = f"{tag}s{s_i}/"
+                for k, g in rec["grad"].items():
+                    x = rec["xgrad"][k]
+                    out[st + "grad_sample/" + k] = dg.sample(g.numpy(), 256)
+                    out[st + "grad_norm/" + k] = np.float64(g.double().norm())
+                    out[st + "xgrad_sample/" + k] = dg.sample(x.numpy(), 256)
+                    out[st + "xgrad_norm/" + k] = np.float64(x.norm())
+                    out[st + "xgrad_err/" + k] = np.float64((g.double() - x).norm())
+                    out[st + "sd_sample/" + k] = dg.sample(rec["sd_after"][k].numpy(), 256)
+            out[tag + "n_steps"] = np.int64(len(step_recs))
+            dump = os.environ.get("ETM_GOLDEN_FULL_DUMP")
+            if dump and step_recs:       # diagnostics only (tools/parity_decompose.py): whole tensors, not part of the fixture
+                os.makedirs(dump, exist_ok=True)
+                full = {}
+                for s_i, rec in enumerate(step_recs):
+                    for k in rec["grad"]:
+                        full[f"s{s_i}/grad/{k}"] = rec["grad"][k].numpy()
+                        full[f"s{s_i}/xgrad/{k}"] = rec["xgrad"][k].numpy()
+                        full[f"s{s_i}/params/{k}"] = rec["params"][k].numpy()
+                        full[f"s{s_i}/sd_after/{k}"] = rec["sd_after"][k].numpy()
+                np.savez(os.path.join(dump, f"ref_full_{name}_u{upd}.npz"), **full)
             out[tag + "perms"] = torch.stack(perms_all)
             out[tag + "stats"] = np.asarray(stats, dtype=np.float64)
             out[tag + "hp"] = np.array([lr, clip, beta], dtype=np.float64)

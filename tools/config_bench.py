@@ -3,6 +3,7 @@ python tools/config_bench.py NAME [updates] [key=value ...]   (config keys, dott
 another build of the library)"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: rollout_groups "auto" = 4 (trainer.py)
+os.environ.setdefault("ETM_HW_QUEUES_SET_EARLY", "1")   # marker for trainer.py: the line above ran before the HIP runtime started
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "episodic-transformer-memory-ppo_amd"))
 import torch

@@ -25,6 +25,7 @@ events (etm_profile_*: an event pair on the launch stream around each kernel), a
 """
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (as bench.py: the rollout_step target builds a trainer -- rollout_groups: auto)
+os.environ.setdefault("ETM_HW_QUEUES_SET_EARLY", "1")   # marker for trainer.py: the line above ran before the HIP runtime started
 
 import sys
 
@@ -282,7 +283,8 @@ def rollout_step_model(cfg, W, hidden_features):
     products = 2 + nb * (15 if t.get("gtrxl") else 3)
     return dict(weight_bytes_per_worker_to_handover=4 * w_chain, weight_bytes_per_worker_tail=4 * w_tail, kv_bytes_per_worker=4 * kv,
                 bytes_per_launch=4 * W * (w_chain + w_tail + kv), bytes_per_launch_to_handover=4 * W * (w_chain + kv),
-                unique_weight_bytes=4 * (w_chain + w_tail), dependent_products=products, team_exchanges=exchanges,
+                unique_weight_bytes=4 * (w_chain + w_tail), unique_bytes_per_launch=4 * (w_chain + w_tail + W * kv),
+                dependent_products=products, team_exchanges=exchanges,
                 dependent_phases=products + exchanges + nb * 2 + 1, workers=W)
 
 
@@ -317,6 +319,10 @@ def rollout_step(trainer, launches=40):
                                           "Infinity-Cache streams, not HBM)", avg_launch_ms=us * 1e-3, launches=t["rollout_trxl_kernel"][1],
                                           bytes_per_launch=m["bytes_per_launch"], achieved=gbs, unit="GB/s", peak=HBM_PEAK_GBS,
                                           frac=gbs / HBM_PEAK_GBS, l2_aggregate_peak_gbs=34500.0, frac_of_l2_peak=gbs / 34500.0,
+                                          # every team re-reads the SHARED weight set: the bytes that are distinct addresses (weights once
+                                          # + every worker's own K | V window columns) against the same time and peak
+                                          unique_bytes_per_launch=m["unique_bytes_per_launch"],
+                                          frac_unique=m["unique_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                           us_per_dependent_phase=us / m["dependent_phases"], model=m,
                                           placement=trainer.config.get("rollout_team_placement", "team_xcd"))
     return res

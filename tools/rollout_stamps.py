@@ -1,6 +1,6 @@
 """Phase timeline of the fused rollout-step kernel (workgroup 0), from the diagnostic build `make -C .../csrc diag-stamps`.
 
-    ETM_DIAG_LIB=$PWD/episodic-transformer-memory-ppo_amd/etm/libetm_hip_stamps.so python tools/rollout_stamps.py
+    ETM_DIAG_LIB=$PWD/tools/scratch/libetm_hip_stamps.so python tools/rollout_stamps.py
 """
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
 import os, sys, time, math
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # as bench.py / train.py: four worker groups (trainer.py, rollout_groups: auto)
+os.environ.setdefault("ETM_HW_QUEUES_SET_EARLY", "1")   # marker for trainer.py: the line above ran before the HIP runtime started
 sys.path.insert(0, "episodic-transformer-memory-ppo_amd")
 import torch
 from yaml_parser import YamlParser
