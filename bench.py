@@ -183,6 +183,10 @@ def main():
                          "before any pinned buffer is allocated; auto = on for multi-GPU runs (8 ranks share the host), off for one GPU")
     ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
                     help="kernel family of the window attention (etm.ops.set_attention_impl); folded is the product default")
+    ap.add_argument("--worker-processes", choices=("config", "on", "off"), default="config",
+                    help="environments in worker processes over shared memory + the native rollout driver (config: what the YAML says)")
+    ap.add_argument("--envs-per-process", type=int, default=None, help="environments per worker process (with worker processes)")
+    ap.add_argument("--rollout-groups", default=None, help="override rollout_groups (auto, 1, 2, 4, 8)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,6 +239,13 @@ def main():
     etm_ops.set_attention_impl(args.attention)
 
     cfg = load_config()
+    if args.worker_processes != "config":
+        cfg["worker_processes"] = args.worker_processes == "on"
+    if args.envs_per_process is not None:
+        cfg["envs_per_process"] = args.envs_per_process
+    if args.rollout_groups is not None:
+        cfg["rollout_groups"] = args.rollout_groups if args.rollout_groups == "auto" else int(args.rollout_groups)
+        cfg["rollout_min_group_size"] = min(int(cfg.get("rollout_min_group_size", 8)), 4)
     dp = DataParallel(device, backend=args.dist_backend, collective=args.dp_collective) if world > 1 else None
     torch.manual_seed(0)
     np.random.seed(0)
@@ -418,7 +429,9 @@ def main():
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_team_placement": cfg.get("rollout_team_placement", "team_xcd"),
-                       "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                       "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": cfg.get("envs_per_process", 1) if cfg.get("worker_processes", False) else None,
+                       "native_rollout_driver": bool(getattr(trainer, "_native_rollout", False))},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline if roofline is not None else roofline_train,
             "roofline_train": roofline_train,

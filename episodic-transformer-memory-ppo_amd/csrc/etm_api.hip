@@ -1,7 +1,7 @@
 // ABI version + error strings of libetm_hip.so.
 #include "etm_common.h"
 
-extern "C" int etm_abi_version(void) { return 33; }
+extern "C" int etm_abi_version(void) { return 34; }
 
 extern "C" const char *etm_error_string(int code) {
   switch (code) {
@@ -9,6 +9,8 @@ extern "C" const char *etm_error_string(int code) {
     case ETM_EINVAL: return "etm: invalid argument (null pointer or bad dimension)";
     case ETM_EUNSUPPORTED: return "etm: shape not supported by the gfx950 kernels (need D % 32 == 0, head_dim in {32,64,96,128}, L <= 128)";
     case ETM_EWORKSPACE: return "etm: workspace too small";
+    case ETM_ETIMEOUT: return "etm: rollout driver: a worker group did not publish its step within the time limit";
+    case ETM_EABORTED: return "etm: rollout driver: an environment worker failed (or the abort word was set)";
     case ETM_ENOCOMM: return "etm: librccl.so could not be loaded, or a communicator call came before etm_comm_init";
   }
   if (code >= ETM_ERCCL_BASE) return "etm: an RCCL call failed (code - ETM_ERCCL_BASE is the ncclResult_t)";

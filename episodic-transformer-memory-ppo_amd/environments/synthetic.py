@@ -114,13 +114,18 @@ class SyntheticVecEnv:
     """Batched form of ``num_envs`` ``SyntheticEnv`` instances (same streams, auto-reset on done)."""
 
     def __init__(self, num_envs, obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=0,
-                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1, row_chunks=None):
+                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1, row_chunks=None, step_cost_us=0.0, min_chunked_envs=None):
         """``copy_threads`` > 1: the observation rows of a step are written by that many threads (the kernel library's host
         copier; the reference's workers write theirs in n_workers processes) instead of one numpy copy."""
         self.num_envs = int(num_envs)
+        # step_cost_us: a simulated simulator -- every environment of this front-end burns that much CPU time per step, one after
+        # the other (what stepping real Python environments in one process costs; worker processes run them side by side)
+        self._step_cost_s = float(step_cost_us) * 1e-6
         self._copy_threads = int(copy_threads)
         if row_chunks is not None:
             self.ROW_CHUNKS = int(row_chunks)          # instance override of the on_rows granularity
+        if min_chunked_envs is not None:
+            self.MIN_CHUNKED_ENVS = int(min_chunked_envs)
         self._row_bytes = int(np.prod(obs_shape)) * 4
         self.observation_space_shape = tuple(obs_shape)
         self.num_actions = int(num_actions)
@@ -135,8 +140,13 @@ class SyntheticVecEnv:
         self._u = np.empty((self.num_envs, _CHUNK, 2))
         self._upos = _CHUNK
         self._cursor = 0
+        # episode state AFTER the planned chunk (see _plan); per-position plan of the current chunk of uniforms
         self._t = np.zeros(self.num_envs, dtype=np.int64)
         self._ret = np.zeros(self.num_envs, dtype=np.float64)
+        self._rew_c = np.zeros((_CHUNK, self.num_envs), dtype=np.float32)
+        self._done_c = np.zeros((_CHUNK, self.num_envs), dtype=bool)
+        self._any_done = np.zeros(_CHUNK, dtype=bool)
+        self._info_c = {}
 
     ROW_CHUNKS = 2   # on_rows granularity (vec_env protocol); 2 measured best: every upload call costs ~9 us of host time
     MIN_CHUNKED_ENVS = 16   # fewer environments (a small worker group): one notification for all rows
@@ -169,28 +179,66 @@ class SyntheticVecEnv:
     def reset(self, out=None):
         self._t[:] = 0
         self._ret[:] = 0.0
+        if self._upos < _CHUNK:
+            self._plan(self._upos)           # the rest of the current chunk, from fresh episodes
         return self._emit(out)
+
+    def _plan(self, p0):
+        """Rewards, done flags and episode results of the chunk positions [p0, _CHUNK) from the pre-drawn uniforms, starting from
+        the episode state (self._t, self._ret) -- what the per-step arithmetic of ``SyntheticEnv.step`` yields, evaluated once per
+        chunk instead of with a handful of small array operations per step (they were ~10 us of every rollout step on the host).
+        Leaves (self._t, self._ret) at the state AFTER the chunk's last position."""
+        k, T = self.num_envs, self.max_episode_steps
+        rew = self._u[:, p0:, 0] < self._p_r                    # [k, n]
+        bern = self._u[:, p0:, 1] < self._p_d
+        n = rew.shape[1]
+        self._rew_c[p0:] = rew.T
+        done = self._done_c
+        done[p0:] = False
+        self._info_c = {key: val for key, val in self._info_c.items() if key[0] < p0}
+        csum = np.cumsum(rew, axis=1, dtype=np.int64)
+        for w in range(k):
+            t0, ret0, start, j = int(self._t[w]), float(self._ret[w]), 0, 0
+            pos = np.flatnonzero(bern[w])
+            while True:
+                cut = start + T - t0 - 1                        # position at which the episode reaches max_episode_steps
+                while j < len(pos) and pos[j] < start:
+                    j += 1
+                i = min(cut, int(pos[j]) if j < len(pos) else n)
+                if i >= n:
+                    break
+                before = int(csum[w, start - 1]) if start > 0 else 0
+                done[p0 + i, w] = True
+                self._info_c[(p0 + i, w)] = (ret0 + float(int(csum[w, i]) - before), t0 + (i - start + 1))
+                start, t0, ret0 = i + 1, 0, 0.0
+            before = int(csum[w, start - 1]) if start > 0 else 0
+            self._t[w] = t0 + (n - start)
+            self._ret[w] = ret0 + float((int(csum[w, n - 1]) if n > 0 else 0) - before)
+        self._any_done = done.any(axis=1)
 
     def step(self, actions, out=None, on_rows=None):
         # the frame a worker shows next does not depend on its done flag (a finished worker's next frame IS its reset observation),
         # so the rows go out first: their upload overlaps the bookkeeping below
+        if self._step_cost_s > 0.0:
+            import time
+            t_end = time.perf_counter() + self._step_cost_s * self.num_envs
+            while time.perf_counter() < t_end:
+                pass
         obs = self._emit(out, on_rows)
         if self._upos >= _CHUNK:
             for w, rng in enumerate(self._rngs):
                 self._u[w] = rng.random((_CHUNK, 2))
             self._upos = 0
-        u = self._u[:, self._upos]
+            self._info_c = {}
+            self._plan(0)
+        i = self._upos
         self._upos += 1
-        rewards = (u[:, 0] < self._p_r).astype(np.float32)
-        self._t += 1
-        self._ret += rewards
-        dones = (self._t >= self.max_episode_steps) | (u[:, 1] < self._p_d)
+        rewards, dones = self._rew_c[i].copy(), self._done_c[i].copy()
         infos = [None] * self.num_envs
-        if dones.any():
+        if self._any_done[i]:
             for w in np.flatnonzero(dones):
-                infos[w] = {"reward": float(self._ret[w]), "length": int(self._t[w])}
-            self._t[dones] = 0
-            self._ret[dones] = 0.0
+                ret, length = self._info_c[(i, int(w))]
+                infos[w] = {"reward": float(ret), "length": int(length)}
         return obs, rewards, dones, infos
 
     def close(self):

@@ -172,6 +172,15 @@ class PPOTrainer:
         if config.get("rollout_groups", "auto") == "auto" and os.environ.get("ETM_QUIET") != "1":
             print(f"[etm] rollout worker groups: {n_groups} (rollout_groups: auto; hardware queues the HIP runtime is known to have been "
                   f"started with: {_HW_QUEUES_AT_IMPORT or 'runtime default (4)'})", flush=True)
+        # worker_processes (round 4; upstream trainer.py:62-66, worker.py): the environments live in worker PROCESSES over one shared,
+        # HIP-registered segment (environments/shm_env.py): they take their actions straight from the device and step concurrently;
+        # the per-step host loop is then the native driver of the kernel library (etm_rollout_drive) -- see _sample_training_data
+        self._shm_env = None
+        if env is None and config.get("worker_processes", False):
+            from environments.shm_env import ShmVecEnv
+            self._shm_env = ShmVecEnv(config["environment"], self.num_workers, first_worker_id, groups=n_groups,
+                                      envs_per_proc=int(config.get("envs_per_process", 1)), steps_per_rollout=config["worker_steps"])
+            env = self._shm_env
         self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers
         obs_shape = tuple(self.env.observation_space_shape)
@@ -226,9 +235,18 @@ class PPOTrainer:
         self._build_grad_groups()
 
         # host <-> device staging (pinned)
-        self._obs_pin = torch.zeros((W,) + obs_shape, dtype=torch.float32).pin_memory()
+        if self._shm_env is not None:
+            # observation rows and action words live in the workers' shared segment, registered with the HIP runtime: the copy
+            # engine reads the rows there, the sampling kernel writes the actions (and the step's sequence number) there
+            seg = np.frombuffer(self._shm_env.shm.buf, dtype=np.uint8)
+            etm_lib.check(etm_lib.load().etm_host_register(seg.ctypes.data, seg.nbytes), "etm_host_register")
+            self._shm_registered = seg.ctypes.data
+            self._obs_pin = torch.from_numpy(self._shm_env.v["obs"])
+            self._act_pin = torch.from_numpy(self._shm_env.v["act"])
+        else:
+            self._obs_pin = torch.zeros((W,) + obs_shape, dtype=torch.float32).pin_memory()
+            self._act_pin = torch.zeros((W, len(self.action_space_shape)), dtype=torch.int64).pin_memory()
         self.obs = self._obs_pin.numpy()
-        self._act_pin = torch.zeros((W, len(self.action_space_shape)), dtype=torch.int64).pin_memory()
         # (episode step, episode slot) of every worker: one pinned [2, W] block, uploaded with ONE copy per rollout step
         self._ss_pin = torch.zeros((2, W), dtype=torch.int64).pin_memory()
         self._step_pin, self._slot_pin = self._ss_pin[0], self._ss_pin[1]
@@ -483,6 +501,11 @@ class PPOTrainer:
                     g.act_ready.record(main)
                     self._rollout_step_tail(g, carry)
 
+        if use_graph and getattr(self, "_native_rollout", False):
+            # the device's step counter restarts at 1: go = 0 on every group, acknowledged by every worker, BEFORE step 0 is launched;
+            # the workers then spin (no self-parking) until the rollout is over
+            self._shm_env.activate(hold=True)
+            self._shm_env.restart_sequence()
         pull = early and all(getattr(g, "pull", False) for g in groups)
         if pull:
             # the step graphs start with the pull kernel and are enqueued ONE STEP AHEAD: the rows of observation 0 are in pinned
@@ -502,7 +525,11 @@ class PPOTrainer:
             for g in groups:
                 launch(g, 0)
         t_env = t_wait = t_launch = 0.0
-        for t in range(S):
+        native = (use_graph and getattr(self, "_native_rollout", False) and host_flag and own_stream and not early and not pull
+                  and all(g.graphs[1] is None for g in groups))
+        if native:
+            t_wait, t_launch = self._drive_rollout_native(groups, episode_infos)
+        for t in (range(S) if not native else ()):
             for g in groups:
                 lo, hi = g.lo, g.hi
                 tw = time.perf_counter()
@@ -601,6 +628,66 @@ class PPOTrainer:
         buf.calc_advantages(last_value, self.config["gamma"], self.config["lamda"])
         self.last_update_timing.update(env_s=t_env, wait_s=t_wait, launch_s=t_launch)
         return episode_infos
+
+    def _drive_rollout_native(self, groups, episode_infos):
+        """Steps 0 .. S - 1 of a rollout through the kernel library's driver (csrc/rollout_driver.hip): step 0 of every group is
+        already enqueued; the workers (processes, environments/shm_env.py) take their actions from the device and publish their
+        results in the shared segment; this call blocks until the bookkeeping of the last step is done.  Afterwards: rewards /
+        done flags / episode results / memory_index rows are taken over from the segment and the driver's event list."""
+        import ctypes
+        buf, W, S = self.buffer, self.num_workers, self.config["worker_steps"]
+        env, lib = self._shm_env, etm_lib.load()
+        G = len(groups)
+        arr = (etm_lib.RolloutGroup * G)()
+        row_bytes = self._obs_pin[0].numel() * 4
+        stage = self._stage["obs"]
+        for gi, g in enumerate(groups):
+            a = arr[gi]
+            a.graph_exec = g.graphs[0].raw_cuda_graph_exec()
+            a.stream = g.stream.cuda_stream
+            first = gi * env.procs_per_group
+            a.ready = env.v["ready"][first:].ctypes.data
+            a.n_procs, a.ready_stride = env.procs_per_group, env.v["ready"].shape[1]
+            a.lo, a.hi = g.lo, g.hi
+            a.obs_src = self._obs_pin.data_ptr() + g.lo * row_bytes
+            a.stage_dst = stage.data_ptr() + g.lo * row_bytes
+            a.ss_dst = g.ss_pin.data_ptr()
+            a.tagged = 0
+            # upload_rows_early (measured, round 4, off): the rows of a process uploaded one by one while it still writes -- four 85 KB copies
+            # instead of one 340 KB copy per group cost MORE device time than they hide (step cycle 166 -> 206 us)
+            early_rows = bool(self.config.get("upload_rows_early", False))
+            a.rows_per_proc = env.envs_per_proc if early_rows else 0
+            a.rows = env.v["rows"][first:].ctypes.data if early_rows else None
+        if getattr(self, "_drive_events", None) is None:
+            self._drive_events = np.zeros((W * S, 3), dtype=np.int64)
+            self._drive_counters = np.zeros(2, dtype=np.int64)          # [next slot, number of events]
+            self._drive_timing = np.zeros(2, dtype=np.float64)
+        ctr = self._drive_counters
+        ctr[0], ctr[1] = buf.num_episodes, 0
+        chain = None
+        if self._chain_log is not None:
+            chain = np.zeros((S, 4), dtype=np.float64)
+        abort = env.v["err"]          # the workers' error words (one cache line apart) ...
+        rc = lib.etm_rollout_drive(ctypes.cast(arr, ctypes.c_void_p), G, 0, S, W, row_bytes, W * row_bytes,
+                                   env.v["dones"].ctypes.data, self._ss_pin[0].data_ptr(), self._ss_pin[1].data_ptr(),
+                                   ctr.ctypes.data, int(buf.bank.shape[0]), self._drive_events.ctypes.data, self._drive_events.shape[0],
+                                   ctr[1:].ctypes.data, abort.ctypes.data, abort.shape[0], abort.shape[1],
+                                   float(self.config.get("rollout_step_timeout_s", 30.0)), self._drive_timing.ctypes.data,
+                                   chain.ctypes.data if chain is not None else None)
+        env.park()
+        if rc != 0:
+            env._check()
+            etm_lib.check(rc, "etm_rollout_drive")
+        buf.num_episodes = int(ctr[0])
+        buf.rewards[:, :] = env.v["rewards"].T
+        buf.dones[:, :] = env.v["dones"].T.astype(bool)
+        for t, w, slot in self._drive_events[: int(ctr[1])]:
+            episode_infos.append(env.info_at(int(t), int(w)))
+            if t < S - 1:
+                buf.memory_index_host[w, t + 1:] = slot
+        if chain is not None:
+            self._chain_log.extend(tuple(r) for r in chain[: S - 1])
+        return float(self._drive_timing[0]), float(self._drive_timing[1])
 
     def _rollout_step_device(self, g, stream_obs=False, host_flag=False):
         """Device side of one rollout step of group ``g`` (upstream trainer.py:161-186) = head + tail."""
@@ -830,6 +917,16 @@ class PPOTrainer:
         if len(groups) > 1 and not fusable:
             raise RuntimeError("rollout_groups > 1 needs a single-branch policy and the K/V cache (set rollout_groups: 1)")
         so, hf = self._stream_obs, self._host_flag
+        # native rollout driver (worker_processes): needs the flag hand-over, streamed observations on the groups' own streams and
+        # the (step, slot) block read in place -- then the sampling kernels write the step's sequence number into the SEGMENT's go
+        # words (the workers spin on them) instead of a private pinned word (decided here: the address is captured below)
+        self._native_rollout = bool(self._shm_env is not None and self.config.get("native_rollout_driver", True) and so and hf
+                                    and self._state_zero_copy and all(g.stream is not None for g in groups)
+                                    and not self.config.get("early_step_launch", False) and not self.config.get("pull_observations", False))
+        if self._native_rollout:
+            for gi, g in enumerate(groups):
+                g.flag_pin = torch.from_numpy(self._shm_env.v["go"][gi, 0:1])
+                g.flag_np = g.flag_pin.numpy()
         # the warm-up executions below write the CURRENT step's memory item (and its K/V projection) into the bank / cache rows
         # (slot, step) of every worker.  A worker at episode step 0 attends over a fully masked window -- uniform weights over
         # ALL L rows, row 0 included (upstream quirk, transformer.py:66-68 with an all-zero mask row) -- so a row 0 left behind by
@@ -1236,6 +1333,13 @@ class PPOTrainer:
 
     def close(self, exit_process: bool = False) -> None:
         """Releases environments and the summary writer (upstream also ``exit(0)``s; opt in with exit_process)."""
+        if getattr(self, "_shm_registered", None):
+            try:
+                torch.cuda.synchronize(self.device)
+                etm_lib.load().etm_host_unregister(self._shm_registered)
+            except Exception:
+                pass
+            self._shm_registered = None
         for closer in (self.env.close, self.writer.close):
             try:
                 closer()

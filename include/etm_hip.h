@@ -31,6 +31,8 @@ extern "C" {
 #define ETM_EUNSUPPORTED (-2) /* shape outside what the gfx950 kernels are built for */
 #define ETM_EWORKSPACE (-3)  /* workspace too small */
 #define ETM_ENOCOMM (-4)     /* librccl could not be loaded / communicator entry used before etm_comm_init */
+#define ETM_ETIMEOUT (-5)    /* etm_rollout_drive: a worker group did not publish a step within the time limit */
+#define ETM_EABORTED (-6)    /* etm_rollout_drive: an environment worker reported an error / the abort word was set */
 #define ETM_ERCCL_BASE 100000 /* ETM_ERCCL_BASE + ncclResult_t: an RCCL call failed */
 
 /* ABI version of this header (bumped on any signature change). */
@@ -482,6 +484,51 @@ int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *s
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
 int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
+/* ---------------------------------------------------------------------------------------------
+ * Native rollout driver (round 4): the per-step host loop of the sampler, upstream trainer.py:159-218, for environment workers
+ * that are PROCESSES over a shared segment (episodic-transformer-memory-ppo_amd/environments/shm_env.py; upstream worker.py:20-48
+ * speaks to them over pipes).  The device hands the actions to the workers itself (the sampling kernel of etm_rollout_trxl /
+ * etm_rollout_policy stores them and the step's sequence number into the segment); the workers publish `ready = t + 1` when
+ * the observation rows, rewards and done flags of step t are final.
+ *
+ * etm_host_register / etm_host_unregister: hipHostRegister (portable | mapped) of the shared segment, so that the device can
+ *   write the action / sequence words and the copy engine can read the observation rows.  The kernels are handed HOST addresses:
+ *   ETM_EUNSUPPORTED if the device address of the registered range differs from the host address.
+ * etm_rollout_drive: for t = t_first .. S - 1 and every group in order (the (step, group) order of the loop it replaces, so the
+ *   slot numbering is upstream's `len(self.buffer.memories) - 1`, trainer.py:211):
+ *     wait until the group's n_procs `ready` words (ready_stride int64 apart) equal t + 1;
+ *     bookkeeping of upstream :195-213 over dones[t, lo..hi): ep_step += 1, or (done) ep_step = 0 and slot = (*next_slot)++ with
+ *       an event (t, worker, slot) appended to `events` [max_events][3] / *n_events (ETM_EWORKSPACE when the bank -- `capacity`
+ *       slots -- or the event list is full);
+ *     if t + 1 < S: (ep_step, slot) of the group -> ss_dst [2, Wg] (pinned; `tagged`: OR-ed with (t + 2) << 32, the
+ *       early_step_launch protocol of etm_rollout_trxl), hipMemcpyAsync of the group's observation rows (obs_src, Wg * row_bytes)
+ *       to stage_dst + (t + 1) * stage_step_bytes and hipGraphLaunch(graph_exec) -- both on the group's `stream`.  With row
+ *       progress words (`rows`, rows_per_proc > 0) the rows are uploaded in pieces WHILE the workers still write (a piece = the
+ *       rows of one process that became final since the last look), i.e. before `ready`; only the graph launch follows it.
+ *   Blocking; returns when the bookkeeping of step S - 1 is done (the last launched step may still run).  abort_words: n words,
+ *   abort_stride int64 apart (the workers' error words + the segment's abort word), polled while waiting -> ETM_EABORTED;
+ *   ETM_ETIMEOUT after timeout_s without progress.  timing (optional): [0] seconds waiting for workers, [1] seconds of
+ *   bookkeeping + enqueueing; chain_log (optional, [S][4] doubles): wait start / ready seen / ready seen / launched, group 0. */
+typedef struct etm_rollout_group {
+  void *graph_exec;               /* hipGraphExec_t of the group's captured rollout step */
+  void *stream;                   /* hipStream_t of the group (step graph and observation upload) */
+  const volatile int64_t *ready;  /* first `ready` word of the group's worker processes */
+  int32_t n_procs, ready_stride;
+  int32_t lo, hi;                 /* worker range of the group */
+  const void *obs_src;            /* the group's observation rows in the shared segment */
+  void *stage_dst;                /* device: staging row 0 of the group's first worker */
+  int64_t *ss_dst;                /* pinned [2, hi - lo]: where the step kernel reads (episode step, slot) */
+  int32_t tagged;
+  int32_t rows_per_proc;          /* environments of one worker process (0: no row progress words, upload after `ready`) */
+  const volatile int64_t *rows;   /* first row-progress word of the group's processes (ready_stride apart): ((t + 1) << 16) | rows final */
+} etm_rollout_group;
+int etm_host_register(void *ptr, int64_t bytes);
+int etm_host_unregister(void *ptr);
+int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,
+                      const uint8_t *dones, int64_t *ep_step, int64_t *slot, int64_t *next_slot, int64_t capacity, int64_t *events,
+                      int64_t max_events, int64_t *n_events, const volatile int64_t *abort_words, int n_abort_words, int abort_stride,
+                      double timeout_s, double *timing, double *chain_log);
+
 /* Observation rows of a rollout step pulled by the device (trainer.py:163, :190-193), capturable as the first node of the step's
  * graph: row r of `src` (pinned host memory, `rows` rows of row_bytes, % 16 == 0) is copied to dst_base + (*t_dev) *
  * dst_step_stride_bytes + r * row_bytes as soon as row_flags[r] (pinned int64) >= *t_dev + 1 -- the host sets the flag when the

@@ -435,6 +435,136 @@ def _exact_gradients(tr, samples, lr, clip, beta):
     return got
 
 
+def _pack(tensors, names, n=64, dtype=np.float32):
+    """[len(names), n] deterministic samples (detgen.sample) of the named tensors, NaN-padded where a tensor has fewer elements."""
+    rows = np.full((len(names), n), np.nan, dtype=dtype)
+    for i, k in enumerate(names):
+        v = dg.sample(np.asarray(tensors[k].detach().numpy() if torch.is_tensor(tensors[k]) else tensors[k]), n)
+        rows[i, : v.size] = v
+    return rows
+
+
+KINK_MARGIN = 1e-5      # |pre-activation| below this (float64 forward) marks a sample as "near a ReLU kink"
+_RELU_SITES = ("conv1", "conv2", "conv3", "lin_hidden", "lin_policy", "lin_value", "transformer.linear_embedding")
+
+
+def _relu_margins(model64, samples64):
+    """min |pre-activation| over every ReLU input of the reference's forward pass (model.py:90-106, transformer.py:115, :234), per
+    sample, from a float64 forward pass of ``samples64`` through ``model64`` (forward hooks on the modules in front of the ReLUs)."""
+    n = samples64["obs"].shape[0]
+    margin = torch.full((n,), float("inf"), dtype=torch.float64)
+    counts = {}
+    mods = dict(model64.named_modules())
+    sites = [s for s in _RELU_SITES if s in mods] + [k for k in mods if k.endswith(".fc.0")]
+    hooks = []
+
+    def make(site):
+        def hook(mod, inp, out):
+            m = out.detach().abs().reshape(n, -1)
+            margin.copy_(torch.minimum(margin, m.min(dim=1).values))
+            counts[site] = int((m < KINK_MARGIN).sum())
+        return hook
+
+    for sname in sites:
+        hooks.append(mods[sname].register_forward_hook(make(sname)))
+    try:
+        with torch.no_grad():
+            memory = ref_utils.batched_index_select(samples64["memories"], 1, samples64["memory_indices"])
+            model64(samples64["obs"], memory, samples64["memory_mask"], samples64["memory_indices"])
+    finally:
+        for h in hooks:
+            h.remove()
+    return margin, counts
+
+
+def _kink_free_run(tr, cfg, lr, clip, beta, first_minibatch, steps):
+    """A short optimisation run from the trainer's CURRENT state (called before the update's `_train_epochs`, on copies) on
+    minibatches without near-kink samples: before every step the candidate samples (the update's first minibatch) are screened in
+    float64 at the fp32 twin's current parameters and only samples whose every ReLU input keeps |x| >= KINK_MARGIN are used.  Two
+    twins take the same steps through the reference's own `_train_mini_batch`: the fp32 one (= what the reference computes) and the
+    "exact-gradient" one (float64 gradient rounded once to fp32, then the same fp32 clipping + AdamW).  On such minibatches every
+    correct fp32 implementation agrees with both to accumulation noise -- no ReLU can flip -- so gradient and parameter-movement
+    bounds of the GPU test can follow the floor measured HERE (the distance of the two twins), step by step."""
+    import copy
+    buf = tr.buffer
+    flat = buf.samples_flat
+    A = copy.deepcopy(tr.model)
+    X = copy.deepcopy(tr.model)
+    opt_a = torch.optim.AdamW(A.parameters(), lr=cfg["learning_rate_schedule"]["initial"])
+    opt_x = torch.optim.AdamW(X.parameters(), lr=cfg["learning_rate_schedule"]["initial"])
+    shim = types.SimpleNamespace(config=tr.config, action_space_shape=tr.action_space_shape)
+    out = {}
+    cand = first_minibatch.clone()
+
+    def samples_of(idx, double):
+        mb = {}
+        for key, value in flat.items():
+            if key == "memory_index":
+                mb["memories"] = buf.memories[value[idx]]
+            else:
+                mb[key] = value[idx]
+        if double:
+            mb = {k: (v.double() if v.is_floating_point() else v) for k, v in mb.items()}
+        return mb
+
+    init = {n: p.detach().clone() for n, p in A.named_parameters()}
+    for s_i in range(steps):
+        margin, counts = _relu_margins(copy.deepcopy(A).double(), samples_of(cand, True))
+        keep = cand[margin >= KINK_MARGIN]
+        st = f"kf/s{s_i}/"
+        out[st + "idx"] = keep.clone()
+        out[st + "near_kink_units"] = np.array(sorted(counts.items()), dtype=str)
+        out[st + "dropped"] = np.int64(cand.numel() - keep.numel())
+        # float64 gradient at the fp32 twin's parameters (before its step): what its fp32 gradient is compared with
+        x_at_a = _exact_gradients(types.SimpleNamespace(model=A, config=tr.config, action_space_shape=tr.action_space_shape),
+                                  samples_of(keep, False), lr, clip, beta)
+        # fp32 twin: the reference's step
+        grabbed = {}
+        real_clip = torch.nn.utils.clip_grad_norm_
+
+        def grab(params, *a, **k):
+            grabbed["g"] = {n: p.grad.detach().clone() for n, p in shim.model.named_parameters()}
+            return real_clip(params, *a, **k)
+
+        torch.nn.utils.clip_grad_norm_ = grab
+        try:
+            shim.model, shim.optimizer = A, opt_a
+            stats = ref_trainer.PPOTrainer._train_mini_batch(shim, samples_of(keep, False), lr, clip, beta)
+        finally:
+            torch.nn.utils.clip_grad_norm_ = real_clip
+        g32 = grabbed["g"]
+        # exact-gradient twin: float64 gradient at ITS parameters, rounded to fp32, the reference's clipping + AdamW
+        x_at_x = _exact_gradients(types.SimpleNamespace(model=X, config=tr.config, action_space_shape=tr.action_space_shape),
+                                  samples_of(keep, False), lr, clip, beta)
+        for pg in opt_x.param_groups:
+            pg["lr"] = lr
+        opt_x.zero_grad()
+        for n, p in X.named_parameters():
+            p.grad = x_at_x[n].float()
+        real_clip(X.parameters(), max_norm=cfg["max_grad_norm"])
+        opt_x.step()
+        pnames = [n for n, _ in A.named_parameters()]
+        pa, px = dict(A.named_parameters()), dict(X.named_parameters())
+        out[st + "grad_samples"] = _pack(g32, pnames)
+        out[st + "xgrad_samples"] = _pack(x_at_a, pnames, dtype=np.float64)
+        out[st + "xgrad_norm"] = np.array([float(x_at_a[k].norm()) for k in pnames])
+        out[st + "xgrad_err"] = np.array([float((g32[k].double() - x_at_a[k]).norm()) for k in pnames])      # whole tensors
+        out[st + "sd_samples"] = _pack({k: v.detach() for k, v in pa.items()}, pnames)
+        out[st + "sd_exact_samples"] = _pack({k: v.detach() for k, v in px.items()}, pnames)
+        errs = np.array([float((pa[k].detach().double() - px[k].detach().double()).norm()) for k in pnames])
+        moves = np.array([float((px[k].detach().double() - init[k].double()).norm()) for k in pnames])
+        out[st + "floor_move_err"] = errs             # whole tensors: ||fp32 twin - exact twin||
+        out[st + "floor_move_norm"] = moves           #                ||exact twin - initial parameters||
+        num, den = float((errs ** 2).sum()), float((moves ** 2).sum())
+        out[st + "floor_move_all"] = np.float64((num / max(den, 1e-300)) ** 0.5)
+        out[st + "stats"] = np.asarray(stats, dtype=np.float64)
+        print(f"    kink-free step {s_i}: kept {keep.numel()} of {cand.numel()} samples, near-kink units {sum(counts.values())}, "
+              f"floor movement error {out[st + 'floor_move_all']:.2e}", flush=True)
+    out["kf/steps"] = np.int64(steps)
+    out["kf/margin"] = np.float64(KINK_MARGIN)
+    return out
+
+
 def golden_rollout(only=None):
     cases = {
         "vec": dict(env=dict(obs_shape=(6,), num_actions=3, max_episode_steps=12, seed=3, p_done=0.08, p_reward=0.3, pool=16),
@@ -561,6 +691,20 @@ def golden_rollout(only=None):
                     step_recs.append(rec)
                 return real_clip(params, *a, **k)
 
+            if per_step and upd == 0:
+                # the kink-free run starts from the same parameters / buffer as the update below and leaves the trainer untouched;
+                # its candidate samples are the update's first minibatch, so the update's permutation is drawn FIRST (and handed to
+                # the update's first epoch below) -- torch.randperm is called exactly as often as without this run
+                first_perm = real_randperm(b.batch_size)
+                kf_steps = {"cfg2": 3}.get(name, 2)
+                out.update(_kink_free_run(tr, cfg, lr, clip, beta, first_perm[: b.batch_size // b.n_mini_batches], kf_steps))
+                pending = [first_perm]
+
+                def rec_randperm(n, *a, _pending=pending, **k):      # noqa: F811 -- first call returns the permutation drawn above
+                    p = _pending.pop() if _pending else real_randperm(n, *a, **k)
+                    perms_all.append(p.clone())
+                    return p
+
             torch.randperm = rec_randperm
             torch.nn.utils.clip_grad_norm_ = rec_clip
             tr._train_mini_batch = rec_tmb
@@ -576,16 +720,16 @@ def golden_rollout(only=None):
             # per optimiser step s of this update: `s{s}/grad_*` the reference's fp32 gradient (un-clipped), `s{s}/xgrad_*` the float64
             # evaluation at the same parameters (samples as float64; `xgrad_err/<k>` = ||fp32 - exact|| over the WHOLE tensor, i.e. the
             # reference's own evaluation noise per tensor), `s{s}/sd_sample/<k>` the parameters after the step
+            pnames = [n for n, _ in tr.model.named_parameters()]
+            out["param_keys"] = np.array(pnames)
             for s_i, rec in enumerate(step_recs):
                 st = f"{tag}s{s_i}/"
-                for k, g in rec["grad"].items():
-                    x = rec["xgrad"][k]
-                    out[st + "grad_sample/" + k] = dg.sample(g.numpy(), 256)
-                    out[st + "grad_norm/" + k] = np.float64(g.double().norm())
-                    out[st + "xgrad_sample/" + k] = dg.sample(x.numpy(), 256)
-                    out[st + "xgrad_norm/" + k] = np.float64(x.norm())
-                    out[st + "xgrad_err/" + k] = np.float64((g.double() - x).norm())
-                    out[st + "sd_sample/" + k] = dg.sample(rec["sd_after"][k].numpy(), 256)
+                out[st + "grad_samples"] = _pack(rec["grad"], pnames)
+                out[st + "xgrad_samples"] = _pack(rec["xgrad"], pnames, dtype=np.float64)
+                out[st + "sd_samples"] = _pack(rec["sd_after"], pnames)
+                out[st + "grad_norm"] = np.array([float(rec["grad"][k].double().norm()) for k in pnames])
+                out[st + "xgrad_norm"] = np.array([float(rec["xgrad"][k].norm()) for k in pnames])
+                out[st + "xgrad_err"] = np.array([float((rec["grad"][k].double() - rec["xgrad"][k]).norm()) for k in pnames])
             out[tag + "n_steps"] = np.int64(len(step_recs))
             dump = os.environ.get("ETM_GOLDEN_FULL_DUMP")
             if dump and step_recs:       # diagnostics only (tools/parity_decompose.py): whole tensors, not part of the fixture

@@ -153,17 +153,15 @@ def test_actor_critic_vs_reference(golden_dir):
         loss.backward()
         for k, p in m.named_parameters():
             if k.startswith("conv"):
-                # ReLU-kink sensitivity: a handful of the ~85k conv activations of THESE fixtures lie within fp32 rounding of zero,
-                # so their gates can differ between the CPU reference and the device; with a batch of 4 one flipped gate moves
-                # the encoder gradients by several per cent.  Direction and scale only here; the encoder gradients are pinned at
-                # full tolerance by test_actor_critic_gradients_away_from_the_relu_kink (a fixture without ambiguous gates) and
-                # by test_train_encoder_fwd_bwd_vs_float64_convs.
-                want = z[tag + "grad_sample/" + k].astype(np.float64)
-                got = dg.sample(p.grad.detach().cpu().numpy(), 96).astype(np.float64)
-                cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
-                assert cos > 0.98 and 0.8 < np.linalg.norm(got) / (np.linalg.norm(want) + 1e-30) < 1.25, (k, cos)
-            else:
-                grad_close(p.grad, z, tag, k, 96, rel=1e-3)
+                # THESE fixtures (batch of 4, ~85k convolution activations) hold units within fp32 rounding of the ReLU kink, whose gates
+                # any two fp32 evaluation orders may decide differently -- one flipped gate moves the encoder gradients of a batch of
+                # 4 by per cents.  The encoder gradients are therefore compared where no gate is ambiguous, at full tolerance and
+                # element-wise: test_actor_critic_gradients_away_from_the_relu_kink (2e-6 of the norm),
+                # test_kink_free_update_vs_reference (BASELINE sizes, against the float64 evaluation) and
+                # test_train_encoder_fwd_bwd_vs_float64_convs.  (Round 3 kept a `cos > 0.98` check here; it asserted nothing the
+                # three tests above do not assert better and is gone.)
+                continue
+            grad_close(p.grad, z, tag, k, 96, rel=1e-3)
 
 
 # Measured on the MI355X (round 3): 3.4e-7 (profiles/r03/teacher_forced_measured.jsonl, case model_nokink).
@@ -432,6 +430,11 @@ _ROLLOUT_PATHS = {
                        "grouped_colsum_train": False},                          # every column-sum gradient reduced by its own launch
     "pull_obs": {"pull_observations": True},                  # the device pulls the observation rows itself; step graphs enqueued one step ahead
     "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
+    # round 4: environments in worker PROCESSES over a shared, HIP-registered segment; the per-step host loop is the library's native
+    # driver (etm_rollout_drive) where the step is a flag-hand-over graph with streamed observations, else the host-driven protocol
+    "worker_processes": {"worker_processes": True},
+    "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
+    "worker_processes_eager": {"worker_processes": True, "envs_per_process": 2, "hip_graph_rollout": False},
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
@@ -442,7 +445,9 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
              ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd"), ("img32", "early_launch"),
              ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "pull_obs"), ("cfg3", "pull_obs"), ("img32", "four_groups"), ("cfg3", "four_groups"),
-             ("cfg5", "pull_obs")]
+             ("cfg5", "pull_obs"),
+             ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
+             ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -565,6 +570,12 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         assert tr.model._rf["pre_ln"] == int(cfg["transformer"]["layer_norm"] == "pre") and tr.model._rf["gtrxl"] == int(cfg["transformer"]["gtrxl"])
         if name != "cfg2":
             assert tr._stream_obs and tr._host_flag and len(tr._groups) == 2 and tr.model._train_encoder_ok, name
+    if path.startswith("worker_processes"):
+        assert tr._shm_env is not None and tr._shm_env.envs_per_proc == cfg.get("envs_per_process", 1)
+        # visual observations + graphs: the native driver ran the per-step loop; vector observations / eager: the host-driven protocol
+        assert bool(getattr(tr, "_native_rollout", False)) == (name != "vec" and path != "worker_processes_eager"), (name, path)
+        if path == "worker_processes_k4":
+            assert len(tr._groups) == 4
     if path == "groups4":
         assert len(tr._groups) == 4
     if path == "event_handover":
@@ -582,19 +593,24 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 #   loss statistics (same scaling): <= 5e-7 small, <= 1.3e-5 BASELINE sizes.
 #   gradient of the update's first minibatch against the reference's (un-clipped, trainer.py:310; error of the sampled elements
 #       over the norm): all tensors <= 3.2e-7 small / <= 7.2e-6 BASELINE sizes; worst single tensor 6e-6 / 1.0e-3 (cfg2's
-#       lin_hidden.weight, 512 elements of cancelling O(100)-valued terms; every other tensor <= 7.7e-5).  SURVEY 8c: 1e-4.
+#       lin_hidden.weight: ONE flipped ReLU unit of the layer above it, see below; every other tensor <= 7.7e-5).  SURVEY 8c: 1e-4.
 #   post-update parameters, stated on the MOVEMENT of an update (||got - ref|| / ||ref - before|| on the sampled elements; an
 #       absolute tolerance on parameters would hide errors as large as the movement itself): all tensors <= 7.6e-5, worst tensor
 #       5.2e-4 on the small fixtures (the optimiser kernel follows the reference's single-tensor AdamW operation by operation,
-#       csrc/optim.hip).  AdamW's update lr * m_hat / (sqrt(v_hat) + eps) is scale-free in the gradient: an element whose
-#       gradient is of the size of its evaluation noise moves by +-lr whichever way the noise points, so at the BASELINE sizes
-#       (1e6 - 1e7 such terms per gradient element) the movement metric is dominated by those elements although the gradients agree
-#       to 2e-6: measured <= 8.2e-4 / 4.6e-3, and the REFERENCE's own fp32 result is 7.6e-4 / 3.6e-3 away from the evaluation with
-#       exact (float64) gradients and the same fp32 optimiser arithmetic (tools/fp32_noise_floor.py,
-#       profiles/r03/fp32_noise_floor_*.txt).  Bounds there: 2e-3 / 1e-2 in the first update; later updates start from parameters
-#       that already differ by that much (measured 2.0e-3 / 8.3e-3 in cfg3's second update, steps 3 - 4): 5e-3 / 2e-2.
-#       (At the BASELINE sizes the gradient of a LATER update is taken at parameters that already differ by that movement noise:
-#       measured 3.6e-5 / 2.7e-3 (conv1.weight) in cfg3's second update; bounds there 2e-4 / 1e-2.)
+#       csrc/optim.hip).  At the BASELINE sizes the FULL-minibatch trajectory cannot be held to a floor: a minibatch there holds
+#       1e7 - 1e8 ReLU inputs, a few of them within fp32 rounding of zero, and two correct fp32 evaluations may put such a unit on
+#       different sides of the kink.  Round 4 traced the whole round-3 excess to exactly that (profiles/r04/parity_decomposition.md):
+#       cfg2 -- unit 107 of linear_embedding for one observation, pre-activation 5.3e-8; cfg3 -- one unit of lin_value; the error of
+#       every affected tensor is rank 1 with a one-hot left factor, and the REFERENCE shows the same against its own float64
+#       evaluation (cfg3 u0 step 1: lin_policy 2.1e-4; cfg2 u1 step 2: gate1.Wr 1.7e-3).  One flipped dense unit moves the
+#       tensors below it by 1e-5 .. 1e-3 of their norm, and AdamW (update lr * m_hat / (sqrt(v_hat) + eps): scale-free) turns that
+#       into sign changes of every element whose gradient is smaller -- measured 8.2e-4 / 4.6e-3 (cfg3), 1.4e-4 / 1.3e-3 (cfg2) in
+#       the first update where the flip-free cfg5 / img32 sit at 4e-5 .. 8e-5.  Bounds of this test at the BASELINE sizes therefore
+#       stay at 2e-3 / 1e-2 (first update), 5e-3 / 2e-2 later; gradient of the first minibatch 2e-5 / 2e-3 of the norm (a flipped
+#       unit: cfg2 lin_hidden.weight 1.0e-3).  The TIGHT statement -- per tensor and per optimiser step against the float64
+#       evaluation, with bounds that are multiples of the floor of the same step -- is test_kink_free_update_vs_reference below, on
+#       minibatches from which the near-kink samples are removed: gradients <= 3 x the reference's own error (measured 0.24 - 1.9 x:
+#       1.3e-7 vs 5.4e-7 at cfg3), per tensor <= max(4 x, 2e-6), movement <= 3 x the twins' distance (measured 0.9 - 1.6 x).
 def tf_bounds(name, upd):
     big = name.startswith("cfg")
     return {"forward": 1e-4 if (big and upd > 0) else 5e-6,
@@ -603,6 +619,101 @@ def tf_bounds(name, upd):
             "stats": 5e-5 if big else 5e-6,
             "move_all": (5e-3 if upd > 0 else 2e-3) if big else 1.5e-4,
             "move_tensor": (2e-2 if upd > 0 else 1e-2) if big else 1e-3}
+
+
+# ---- Kink-free optimisation run (round 4).  Why it exists: at the BASELINE model sizes a minibatch holds 10^7 - 10^8 ReLU inputs, and
+# a handful of them lie within fp32 rounding distance of zero.  Two CORRECT fp32 evaluations can put such a unit on different sides of
+# the kink; one flipped dense-layer unit changes every gradient tensor below it by a rank-1 term of 1e-5 .. 1e-3 of the tensor's norm
+# (profiles/r04/parity_decomposition.md: cfg2 -- unit 107 of linear_embedding, pre-activation 5.3e-8; cfg3 -- one unit of lin_value; the
+# reference's own fp32 result shows the same against its float64 evaluation, lin_policy at cfg3 u0/s1: 2.1e-4), and AdamW turns that
+# into parameter-movement differences that no accumulation order can remove.  The fixture generator therefore also records a short
+# run on minibatches from which every sample with a ReLU input |x| < 1e-5 (float64 forward at the step's parameters) is removed, with
+# two twins: the reference's fp32 step and the float64-gradient step (same fp32 clipping + AdamW).  On those minibatches no unit can
+# flip, so the HIP path must agree with BOTH to accumulation noise, per tensor and per step -- and the bounds below are multiples of
+# the floor measured in the same step (the twins' distance), not free constants.
+_KF_GRAD_RATIO_ALL = 3.0       # HIP-vs-float64 gradient error over all tensors <= this x reference-vs-float64 (same step, same samples)
+_KF_GRAD_RATIO_TENSOR = 4.0    # ... per tensor (64-element samples scatter more), or the absolute floor below
+_KF_GRAD_ABS_TENSOR = (2e-6, 1e-5)   # per-tensor error / tensor norm that is accepted whatever the reference's own error is: first step
+#                                      (identical parameters) / later steps (the parameters then differ from the fp32 twin's by the
+#                                      movement error of the earlier steps, which the most sensitive tensors -- the query / key
+#                                      projections, whose gradients are the smallest -- answer with ~5e-6 of their norm: measured)
+_KF_MOVE_RATIO = 3.0           # parameter movement error (vs either twin) <= this x the twins' own distance in the same step
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg5"])
+def test_kink_free_update_vs_reference(golden_dir, name):
+    from trainer import PPOTrainer
+    dev = _dev()
+    z = load(golden_dir, f"rollout_{name}.npz")
+    info = json.loads(str(z["cfg_json"]))
+    cfg, envk = info["cfg"], info["env"]
+    cfg = {**cfg, "environment": {"type": "Synthetic", **envk}}
+    tr = PPOTrainer(cfg, run_id="kinkfree", device=dev, tensorboard=False)
+    keys, shapes = shapes_of(z, "")
+    load_det(tr.model, "rollout_" + name, keys, shapes)
+    tr._sample_training_data(forced_actions=z["u0/actions"][:, :, 0])
+    tr.buffer.prepare_batch_dict()
+    lr, clip, beta = (float(x) for x in z["u0/hp"])
+    pnames = [str(k) for k in z["param_keys"]]
+    params = dict(tr.model.named_parameters())
+    assert list(params) == pnames
+    init = {k: dg.sample(params[k].detach().cpu().numpy(), 64).astype(np.float64) for k in pnames}
+
+    def rows(key):
+        a = z[key]
+        return [a[i][~np.isnan(a[i])].astype(np.float64) for i in range(a.shape[0])]
+
+    for s in range(int(z["kf/steps"])):
+        st = f"kf/s{s}/"
+        idx = z[st + "idx"]
+        assert int(z[st + "dropped"]) + idx.size == (cfg["n_workers"] * cfg["worker_steps"]) // cfg["n_mini_batch"]
+        # ---- gradient: HIP vs the float64 evaluation, beside the reference's fp32 gradient vs the same
+        grads = tr.minibatch_gradients(idx, clip, beta)
+        xs, rs, xnorm = rows(st + "xgrad_samples"), rows(st + "grad_samples"), z[st + "xgrad_norm"]
+        num_h = num_r = den = 0.0
+        worst = (0.0, "", 0.0)
+        violations = []
+        for i, k in enumerate(pnames):
+            got = dg.sample(grads[k].cpu().numpy(), 64).astype(np.float64)
+            scale = float(xnorm[i]) * (xs[i].size / grads[k].numel()) ** 0.5          # norm of a sample of this size
+            eh, er = float(np.linalg.norm(got - xs[i])), float(np.linalg.norm(rs[i] - xs[i]))
+            num_h, num_r, den = num_h + eh * eh, num_r + er * er, den + float(np.sum(xs[i] ** 2))
+            if scale > 0:
+                allowed = max(_KF_GRAD_RATIO_TENSOR * er / scale, _KF_GRAD_ABS_TENSOR[min(s, 1)])
+                if eh / scale / allowed > worst[0]:
+                    worst = (eh / scale / allowed, k, eh / scale)
+                if eh / scale > allowed:
+                    violations.append(f"{k}: {eh / scale:.2e} of its norm from the float64 evaluation; the reference's fp32 gradient "
+                                      f"is {er / scale:.2e} from it (bound {allowed:.2e})")
+        hip_all, ref_all = (num_h / den) ** 0.5, (num_r / den) ** 0.5
+        print(f"[kink-free {name} step {s}] {idx.size} samples; gradient vs float64, all tensors: HIP {hip_all:.2e}, reference {ref_all:.2e} "
+              f"(ratio {hip_all / ref_all:.2f}); tensor closest to its bound: {worst[1]} at {worst[2]:.2e} ({worst[0]:.2f} of the bound)")
+        assert not violations, f"{name} kink-free step {s}: " + "; ".join(violations)
+        assert hip_all <= _KF_GRAD_RATIO_ALL * ref_all, (hip_all, ref_all)
+        # ---- the step itself (the upstream-API path: gathered minibatch -> _train_mini_batch), then the parameter movement
+        tr._train_mini_batch(tr.buffer.gather(torch.as_tensor(idx, device=dev)), lr, clip, beta)
+        a_rows, x_rows = rows(st + "sd_samples"), rows(st + "sd_exact_samples")
+        num_a = num_x = num_f = den = 0.0
+        for i, k in enumerate(pnames):
+            got = dg.sample(params[k].detach().cpu().numpy(), 64).astype(np.float64)
+            num_a += float(np.sum((got - a_rows[i]) ** 2))
+            num_x += float(np.sum((got - x_rows[i]) ** 2))
+            num_f += float(np.sum((a_rows[i] - x_rows[i]) ** 2))
+            den += float(np.sum((x_rows[i] - init[k]) ** 2))
+        mv_a, mv_x, floor_s = (num_a / den) ** 0.5, (num_x / den) ** 0.5, (num_f / den) ** 0.5
+        # the twins' distance: over whole tensors (recorded by the generator) or over the 64-element samples, whichever is larger --
+        # the movement error sits in few elements (those whose gradient is of the size of its noise), so a 64-element sample of it
+        # scatters by a factor of a few either way (cfg3 step 0: 2.4e-6 on the samples, 9.3e-6 over whole tensors)
+        floor = max(floor_s, float(z[st + "floor_move_all"]))
+        print(f"[kink-free {name} step {s}] parameter movement error (sampled elements, from the initial parameters): HIP vs the reference's "
+              f"fp32 twin {mv_a:.2e}, vs the float64-gradient twin {mv_x:.2e}; the twins differ by {floor_s:.2e} "
+              f"(whole tensors: {float(z[st + 'floor_move_all']):.2e})")
+        if os.environ.get("ETM_TF_MEASURE_LOG"):
+            with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
+                f.write(json.dumps({"case": name, "path": "kink_free", "step": s, "samples": int(idx.size), "grad_hip_vs_exact": hip_all,
+                                    "grad_ref_vs_exact": ref_all, "move_vs_ref": mv_a, "move_vs_exact": mv_x, "move_floor": floor}) + "\n")
+        assert mv_a <= _KF_MOVE_RATIO * floor and mv_x <= _KF_MOVE_RATIO * floor, (mv_a, mv_x, floor)
+    tr.close()
 
 
 def test_trainer_self_consistency_and_free_run():

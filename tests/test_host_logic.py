@@ -391,3 +391,35 @@ def test_rollout_group_count_follows_the_hardware_queues(monkeypatch):
     assert trainer.default_rollout_groups(32, 8) == 2
     monkeypatch.setattr(trainer, "_HW_QUEUES_AT_IMPORT", 4)
     assert trainer.default_rollout_groups(32, 8) == 2
+
+
+def test_worker_processes_over_shared_memory_replay_the_in_process_streams():
+    """environments/shm_env.py (round 4): environments in worker processes over one shared segment produce exactly the streams of the
+    in-process front-end -- observations, rewards, done flags, episode results -- through the host-driven protocol, for the whole
+    front-end and group by group, with one or several environments per process; a sequence restart is acknowledged by every worker."""
+    import numpy as np
+    from environments.shm_env import ShmVecEnv
+    from environments.synthetic import SyntheticVecEnv
+    kw = dict(obs_shape=(3, 12, 12), num_actions=3, max_episode_steps=9, seed=5, p_done=0.08, p_reward=0.3, pool=8)
+    for per_proc, groups in ((1, 2), (2, 2), (4, 1)):
+        env = ShmVecEnv({"type": "Synthetic", **{**kw, "obs_shape": list(kw["obs_shape"])}}, 8, first_worker_id=3, groups=groups,
+                        envs_per_proc=per_proc, steps_per_rollout=16)
+        try:
+            ref = SyntheticVecEnv(8, first_worker_id=3, **kw)
+            assert np.array_equal(env.reset().copy(), ref.reset())
+            rng = np.random.default_rng(0)
+            for t in range(40):
+                a = rng.integers(0, 3, size=8)
+                if t % 2 == 0:
+                    ob, r, d, inf = env.step(a)
+                else:      # group by group, like the trainer's pipelined rollout
+                    outs = [p.step(a[lo:hi]) for p, (lo, hi) in zip(env.parts, env.bounds)]
+                    ob = np.concatenate([o[0] for o in outs])
+                    r, d = np.concatenate([o[1] for o in outs]), np.concatenate([o[2] for o in outs])
+                    inf = [i for o in outs for i in o[3]]
+                ob2, r2, d2, inf2 = ref.step(a)
+                assert np.array_equal(ob, ob2) and np.array_equal(r, r2) and np.array_equal(d, d2) and inf == inf2, (per_proc, groups, t)
+            env.restart_sequence()
+            assert (env.v["ready"][:, 0] == 0).all()
+        finally:
+            env.close()

@@ -59,6 +59,20 @@ def run(name, variant, full, dump_dir=None):
     tr.buffer.prepare_batch_dict()
     lr, clip, beta = (float(x) for x in z[tag + "hp"])
     mbs = (cfg["n_workers"] * cfg["worker_steps"]) // cfg["n_mini_batch"]
+    if dump_dir is not None:
+        # the rollout buffer fields the loss reads (rollout forward pass) and the optimisation-phase forward pass of the SAME samples
+        # under the same weights: values / log-probs of the two HIP paths against each other and against the reference's rollout
+        from etm.ops import WindowSpec
+        os.makedirs(dump_dir, exist_ok=True)
+        b, flat = tr.buffer, tr.buffer.samples_flat
+        with torch.no_grad():
+            spec = WindowSpec.from_bank(b.memories, flat["memory_index"], flat["memory_indices"], flat["memory_indices"], flat["memory_mask"])
+            logits, value, _ = tr.model.forward_logits(flat["obs"], spec)
+            lsm = torch.log_softmax(logits[0], dim=-1)
+            logp = lsm.gather(1, flat["actions"][:, :1]).squeeze(1)
+        np.savez(os.path.join(dump_dir, f"hip_buffer_{name}_{variant}.npz"), values=b.values.cpu().numpy(), log_probs=b.log_probs.cpu().numpy(),
+                 advantages=b.advantages.cpu().numpy(), train_values=value.cpu().numpy().reshape(b.values.shape),
+                 train_log_probs=logp.cpu().numpy().reshape(b.values.shape))
     grads = tr.minibatch_gradients(z[tag + "perms"][0][:mbs], clip, beta)
     rows = []
     num_r = num_h = den = num_hr = 0.0

@@ -47,6 +47,19 @@ if tr._chain_log:
     print(f"first group, per step: flag seen -> env.step done {(c[:, 2] - c[:, 1]).mean() * 1e6:.1f} us, -> launch done "
           f"{(c[:, 3] - c[:, 2]).mean() * 1e6:.1f} us, launch done -> next flag seen {(c[1:, 1] - c[:-1, 3]).mean() * 1e6:.1f} us "
           f"(of which spinning {(c[1:, 1] - c[1:, 0]).mean() * 1e6:.1f} us); cycle {cyc.mean() * 1e6:.1f} us")
+    if getattr(tr, "_native_rollout", False):
+        # worker processes + native driver: the workers' own clocks (CLOCK_MONOTONIC, like the driver's) per step
+        trw = tr._shm_env.v["trace"][8:S - 2]                     # [steps, processes, (go seen, ready set)]
+        ppg = tr._shm_env.procs_per_group
+        g0 = trw[:, :ppg]                                          # processes of the first group
+        seen, done = g0[:, :, 0].min(axis=1), g0[:, :, 1].max(axis=1)
+        cc = _np.array(tr._chain_log[8:S - 2])
+        k = min(len(cc), len(seen))
+        print(f"first group, native driver: go seen by a worker -> last worker done {(done - seen).mean() * 1e6:.1f} us (one worker's step "
+              f"{(g0[:, :, 1] - g0[:, :, 0]).mean() * 1e6:.1f} us), -> driver saw ready {(cc[:k, 1] - done[:k]).mean() * 1e6:.1f} us, -> "
+              f"upload + graph enqueued {(cc[:k, 3] - cc[:k, 1]).mean() * 1e6:.1f} us, enqueued -> next go seen "
+              f"{(seen[1:k] - cc[:k - 1, 3]).mean() * 1e6:.1f} us; trainer-thread work per group and step "
+              f"{tr._drive_timing[1] / S / len(tr._groups) * 1e6:.1f} us, waiting {tr._drive_timing[0] / S / len(tr._groups) * 1e6:.1f} us")
 tr._chain_log = None
 
 # device time of the step graphs alone (no host work in between): head = critical path of a step, tail = under env.step
