@@ -183,6 +183,9 @@ def main():
                          "before any pinned buffer is allocated; auto = on for multi-GPU runs (8 ranks share the host), off for one GPU")
     ap.add_argument("--attention", choices=("folded", "dense"), default="folded",
                     help="kernel family of the window attention (etm.ops.set_attention_impl); folded is the product default")
+    ap.add_argument("--dp-overlap", choices=("on", "off"), default="off",
+                    help="data-parallel runs: all-reduce of the head / transformer / lin_hidden gradient slice on a side stream under the "
+                         "encoder's backward pass (bit-identical parameters; default off until a multi-GPU run has A/B-ed it)")
     ap.add_argument("--worker-processes", choices=("config", "on", "off"), default="config",
                     help="environments in worker processes over shared memory + the native rollout driver (config: what the YAML says)")
     ap.add_argument("--envs-per-process", type=int, default=None, help="environments per worker process (with worker processes)")
@@ -239,6 +242,7 @@ def main():
     etm_ops.set_attention_impl(args.attention)
 
     cfg = load_config()
+    cfg["dp_overlap"] = args.dp_overlap == "on"
     if args.worker_processes != "config":
         cfg["worker_processes"] = args.worker_processes == "on"
     if args.envs_per_process is not None:
@@ -314,7 +318,20 @@ def main():
             nbytes = bucket.numel() * 4
             allreduce = {"bytes": nbytes, "avg_ms": ar_ms, "includes": "sum all-reduce of the flat fp32 gradient arena (the division by the world size rides in the optimiser kernel)",
                          "bus_gbs": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9, "xgmi_link_peak_gbs": 153.0,
-                         "per_update": cfg["epochs"] * cfg["n_mini_batch"]}
+                         "per_update": cfg["epochs"] * cfg["n_mini_batch"], "overlap": bool(cfg.get("dp_overlap", False))}
+            # what the optimisation step really waits for the collective: without overlap all of it; with --dp-overlap on the main
+            # stream's wait for the side stream after the encoder's backward pass, measured on one extra (eager) minibatch step
+            exposed = ar_ms
+            if cfg.get("dp_overlap", False) and getattr(trainer, "_train_graph_a2", None) is not None:
+                trainer._ar_probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                trainer._train_graph[0].replay()
+                trainer._allreduce_rest_async()
+                trainer._train_graph_a2.replay()
+                trainer._allreduce_conv_and_join()
+                torch.cuda.synchronize(device)
+                exposed = dp.max_over_ranks(trainer._ar_probe[0].elapsed_time(trainer._ar_probe[1]))
+                trainer._ar_probe = None
+            allreduce["exposed_ms"] = exposed
         except Exception as exc:       # reporting only: never lose the throughput line over it
             allreduce = {"error": repr(exc)}
 

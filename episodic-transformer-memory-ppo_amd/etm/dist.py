@@ -223,6 +223,26 @@ class DataParallel:
             self._comm = None
         self.collective = "torch"
 
+    def all_reduce_slice(self, lo: int, hi: int, stream):
+        """Sum ``flat[lo:hi]`` over the ranks on ``stream`` (a torch.cuda.Stream): the pieces of the overlapped data-parallel step
+        (trainer.py: dp_overlap).  No averaging: the division by the world size rides in the optimiser's clip coefficient."""
+        if not self.active or hi <= lo:
+            return
+        part = self.flat[lo:hi]
+        if self.collective == "etm":
+            from . import lib as _lib
+            if self._comm is None:
+                if self.world != 1:
+                    raise RuntimeError("library communicator missing (DataParallel creates it at construction)")
+                self._comm = self._single_rank_comm()
+            _lib.check(_lib.load().etm_allreduce_f32(self._comm, part.data_ptr(), part.data_ptr(), part.numel(), stream.cuda_stream),
+                       "etm_allreduce_f32")
+        elif stream is not None and part.is_cuda:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(part, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+
     def all_reduce_grads(self, average=True):
         """Sum the flat gradient bucket over ranks (one RCCL all-reduce).  ``average=True`` also divides by the world size (one more
         launch over the bucket); the trainer passes False and hands ``grad_scale = 1 / world`` to the optimiser step instead, where

@@ -204,6 +204,8 @@ class ActorCriticModel(nn.Module):
                 if self._train_encoder_ok and ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3),
                                                                             batch=int(obs.index.numel())):
                     feats = ops.encoder_train(obs.bank, self.conv1, self.conv2, self.conv3, index=obs.index)
+                    if getattr(self, "_keep_encoder_features", False):      # data-parallel overlap: the backward pass is cut here
+                        self._encoder_features = feats                      # (trainer._train_body_a1; released by _train_body_a2)
                     return ops.linear_relu_nhwc(feats, self.lin_hidden.weight, self.lin_hidden.bias, self.conv3.out_channels)
             obs = obs.bank.index_select(0, obs.index).permute(0, 3, 1, 2)      # NCHW view of the gathered NHWC rows
         if obs_index is not None:

@@ -1163,6 +1163,91 @@ class PPOTrainer:
         self._backward_into_arena(loss)
         return stats
 
+    # ---- data-parallel overlap (dp_overlap, SURVEY 8e / upstream insertion point trainer.py:310-311): the backward pass is cut at the
+    # encoder output.  Part 1 (heads, transformer, lin_hidden: 98 % of the gradient arena) is summed over the ranks on a side stream
+    # while part 2 (the encoder's backward, ~0.5 ms at config 3) runs; the small convolution slice follows on the main stream.
+    def _train_body_a1(self, idx, clip_range, beta, stats3=None):
+        """Gather, forward, loss, backward DOWN TO the encoder features; every gradient except the convolutions' is in its arena
+        view afterwards.  Returns (stats[6], d loss / d features) -- the features themselves stay in ``self.model._encoder_features``."""
+        buf = self.buffer
+        skip = ("obs",) if self._obs_train is not None else ()
+        keys = [k for k in buf.samples_flat if k not in skip]
+        mb = dict(zip(keys, ops.gather_rows([buf.samples_flat[k] for k in keys], idx)))
+        if self._bank_pos is not None:
+            spec = WindowSpec.from_bank(self._bank_pos_buf, mb["memory_index"], mb["memory_indices"], None, mb["memory_mask"])
+            spec.pos_included = True
+        else:
+            spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
+        obs = IndexedObservations(self._obs_train, idx)
+        if stats3 is None:
+            stats3 = ops.adv_stats(mb["advantages"])
+        self.model._encoder_features, self.model._keep_encoder_features = None, True
+        try:
+            loss, stats = self._loss_from(obs, spec, mb, clip_range, beta, stats3)
+        finally:
+            self.model._keep_encoder_features = False
+        feats = self.model._encoder_features
+        if feats is None or feats.grad_fn is None:
+            raise RuntimeError("dp_overlap needs the hand-written training encoder (visual observations, fused_train_encoder)")
+        n_conv = self._n_conv_params
+        rest = self.params[n_conv:]
+        for p in self.params:
+            p.grad = None
+        with ops.DeferredDw(self._dw_destinations()) as dw:
+            got = torch.autograd.grad(loss, [feats] + rest, grad_outputs=self._unit_gradient(loss), allow_unused=True)
+        dfeats, grads_rest = got[0], got[1:]
+        views, grads = [], []
+        for p, v, g in zip(rest, self._grad_views[n_conv:], grads_rest):
+            if p.data_ptr() in dw.written:
+                if g is not None:
+                    v.add_(g)
+                continue
+            views.append(v)
+            grads.append(g if g is not None else torch.zeros_like(v))
+        if views:
+            torch._foreach_copy_(views, grads)
+        return stats, dfeats
+
+    def _train_body_a2(self, dfeats):
+        """The encoder's backward pass from d loss / d features; the convolutions' gradients end up in their arena views."""
+        feats = self.model._encoder_features
+        n_conv = self._n_conv_params
+        convs = self.params[:n_conv]
+        with ops.DeferredDw(self._dw_destinations()) as dw:
+            got = torch.autograd.grad(feats, convs, grad_outputs=dfeats, allow_unused=True)
+        views, grads = [], []
+        for p, v, g in zip(convs, self._grad_views[:n_conv], got):
+            if p.data_ptr() in dw.written:
+                if g is not None:
+                    v.add_(g)
+                continue
+            views.append(v)
+            grads.append(g if g is not None else torch.zeros_like(v))
+        if views:
+            torch._foreach_copy_(views, grads)
+        for p, v in zip(self.params, self._grad_views):
+            p.grad = v
+        self.model._encoder_features = None
+
+    def _dp_overlap_ready(self):
+        """dp_overlap applies when the run is data parallel, the optimisation phase runs the hand-written encoder on indexed
+        observations, and the convolution parameters are the FIRST parameters of the arena (model.py: conv1..3 are created first)."""
+        if self.dp is None or not self.config.get("dp_overlap", False) or self._obs_train is None:
+            return False
+        if getattr(self, "_n_conv_params", None) is None:
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            k = 0
+            while k < len(names) and names[k].startswith("conv"):
+                k += 1
+            self._n_conv_params = k if (k > 0 and not any(n.startswith("conv") for n in names[k:])) else 0
+            self._conv_floats = sum(p.numel() for p in self.params[: self._n_conv_params])
+            v0, vk = self._grad_views[0], self._grad_views[self._n_conv_params]
+            if self._n_conv_params and (vk.data_ptr() - v0.data_ptr()) // 4 != self._conv_floats:
+                self._conv_floats = (vk.data_ptr() - v0.data_ptr()) // 4        # (arena views are padded: the slice boundary in floats)
+            self._ar_side = torch.cuda.Stream(device=self.device)
+            self._ar_fork, self._ar_fork2, self._ar_join = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        return self._n_conv_params > 0
+
     def _backward_into_arena(self, loss):
         """``loss.backward()`` with every gradient ending up in its view of the flat gradient arena."""
         # backward() hands every parameter its gradient tensor (no accumulate launch while .grad is None); ONE multi-tensor copy
@@ -1235,34 +1320,75 @@ class PPOTrainer:
         self._mb_counter += 1
         sample_eager = self.profile_sample_every and self._mb_counter % self.profile_sample_every == 0
         key = (monitor, self._bank_pos is not None)
+        overlap = self._dp_overlap_ready()
         if (self._train_graph is None and self._train_warm < 2) or sample_eager:
             self._train_warm += 1
-            st = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
-            if dp is not None:
-                dp.all_reduce_grads(average=False)
+            if overlap:
+                st, dfe = self._train_body_a1(self._tg_idx, clip_range, beta, self._tg_stats3)
+                self._allreduce_rest_async()
+                self._train_body_a2(dfe)
+                self._allreduce_conv_and_join()
+            else:
+                st = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
+                if dp is not None:
+                    dp.all_reduce_grads(average=False)
             nm = self._train_body_b(monitor)
             return st.clone(), (nm.clone() if nm is not None else None)
         if self._train_graph is None or self._tg_key != key:
             torch.cuda.synchronize(self.device)
             ga = torch.cuda.CUDAGraph()
-            gb = None
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                self._tg_stats = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
+            gb = ga2 = None
+            # (one memory pool for the pieces of the overlapped step: part 2 reads tensors part 1 allocated)
+            pool = torch.cuda.graph_pool_handle() if overlap else None
+            with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                if overlap:
+                    self._tg_stats, self._tg_dfeats = self._train_body_a1(self._tg_idx, clip_range, beta, self._tg_stats3)
+                else:
+                    self._tg_stats = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
                 if dp is None:
                     self._tg_norms = self._train_body_b(monitor)
+            if overlap:
+                ga2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga2, pool=pool, capture_error_mode="thread_local"):
+                    self._train_body_a2(self._tg_dfeats)
             if dp is not None:
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
                     self._tg_norms = self._train_body_b(monitor)
-            self._train_graph, self._tg_key = (ga, gb), key
+            self._train_graph, self._tg_key, self._train_graph_a2 = (ga, gb), key, ga2
             self.buffer.address_captured = True
             ops.freeze_workspaces(self.device)
         ga, gb = self._train_graph
         ga.replay()
         if gb is not None:
-            dp.all_reduce_grads(average=False)
+            if getattr(self, "_train_graph_a2", None) is not None:
+                self._allreduce_rest_async()                # heads + transformer + lin_hidden slice on the side stream ...
+                self._train_graph_a2.replay()               # ... under the encoder's backward pass
+                self._allreduce_conv_and_join()
+            else:
+                dp.all_reduce_grads(average=False)
             gb.replay()
         return self._tg_stats.clone(), (self._tg_norms.clone() if monitor else None)
+
+    def _allreduce_rest_async(self):
+        main = torch.cuda.current_stream(self.device)
+        self._ar_fork.record(main)
+        self._ar_side.wait_event(self._ar_fork)
+        self.dp.all_reduce_slice(self._conv_floats, self.flat_grads.numel(), self._ar_side)
+
+    def _allreduce_conv_and_join(self):
+        """The convolutions' slice follows on the SAME side stream (one communicator: its collectives stay on one stream, in one
+        order on every rank), after the encoder's backward pass; the main stream then waits for both."""
+        main = torch.cuda.current_stream(self.device)
+        self._ar_fork2.record(main)
+        self._ar_side.wait_event(self._ar_fork2)
+        self.dp.all_reduce_slice(0, self._conv_floats, self._ar_side)
+        self._ar_join.record(self._ar_side)
+        if getattr(self, "_ar_probe", None) is not None:       # bench.py: how long the main stream really waits for the side stream
+            self._ar_probe[0].record(main)
+        main.wait_event(self._ar_join)
+        if getattr(self, "_ar_probe", None) is not None:
+            self._ar_probe[1].record(main)
 
     def _build_grad_groups(self):
         """Group-membership matrix so all monitored gradient norms come from one pass over per-parameter norms."""

@@ -50,6 +50,17 @@ def _worker(rank, world, port, out_dir):
     ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     assert torch.allclose(flat, ref_flat, atol=1e-6), (flat - ref_flat).abs().max()
 
+    # the overlapped step sums the bucket in two slices (trainer.py: dp_overlap): slice sums == the whole bucket's sum, bit for bit
+    dp.flat = torch.arange(1000, dtype=torch.float32) * (rank + 1) / 7.0
+    whole = dp.flat.clone()
+    dp.all_reduce_slice(37, 1000, None)
+    dp.all_reduce_slice(0, 37, None)
+    parts = dp.flat.clone()
+    dp.flat = whole
+    dp.all_reduce_grads(average=False)
+    assert torch.equal(parts, dp.flat)
+    dp.flat = flat
+
     # advantage statistics: merged (count, mean, M2) == statistics of the concatenated minibatch
     adv = torch.randn((100,), generator=g) * 3 + 1
     mine = adv[rank * 50:(rank + 1) * 50]

@@ -1253,6 +1253,69 @@ print("dp-graph-ok")
     assert "dp-graph-ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
+def test_dp_overlapped_step_single_rank(tmp_path):
+    """dp_overlap (round 4): the backward pass cut at the encoder output, the all-reduce of the head / transformer / lin_hidden slice
+    on a side stream under the encoder's backward pass, the convolution slice after it -- on one device with the collectives really
+    issued (world size 1, library RCCL communicator): parameters BIT-IDENTICAL to the non-overlapped data-parallel step (the same
+    kernels in the same order per stream; only the all-reduce is split) and equal to the single-GPU step within rounding."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(here, "..", "episodic-transformer-memory-ppo_amd")
+    code = f"""
+import os, sys, json
+sys.path.insert(0, {pkg!r})
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+from etm.dist import DataParallel
+from trainer import PPOTrainer
+
+class ForcedDP(DataParallel):
+    @property
+    def active(self):
+        return True
+
+cfg = dict(environment=dict(type="Synthetic", obs_shape=[3, 36, 36], num_actions=3, max_episode_steps=24, seed=2, p_done=0.06, pool=8),
+           gamma=0.99, lamda=0.95, updates=1, epochs=2, n_workers=8, worker_steps=48, n_mini_batch=4, value_loss_coefficient=0.5,
+           hidden_layer_size=64, max_grad_norm=0.5,
+           transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=16, positional_encoding="relative",
+                            layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
+           learning_rate_schedule=dict(initial=3e-4, final=1e-4, power=1.0, max_decay_steps=4),
+           beta_schedule=dict(initial=1e-3, final=1e-4, power=1.0, max_decay_steps=4),
+           clip_range_schedule=dict(initial=0.2, final=0.1, power=1.0, max_decay_steps=4))
+rng = np.random.default_rng(0)
+acts = rng.integers(0, 3, size=(3, 8, 48))
+perms = [[rng.permutation(8 * 48) for _ in range(2)] for _ in range(3)]
+res = {{}}
+for mode in ("single", "dp", "dp_overlap"):
+    dp = ForcedDP(dev, collective="etm") if mode != "single" else None
+    torch.manual_seed(5)
+    c = json.loads(json.dumps(cfg))
+    c["dp_overlap"] = mode == "dp_overlap"
+    tr = PPOTrainer(c, run_id="dpo", device=dev, dp=dp, tensorboard=False)
+    for u in range(3):
+        lr, beta, clip = tr.schedules(u)
+        tr._sample_training_data(forced_actions=acts[u])
+        tr.buffer.prepare_batch_dict()
+        tr._train_epochs(lr, clip, beta, perms=perms[u])
+    assert tr._train_graph is not None and tr.model._train_encoder_ok
+    assert (getattr(tr, "_train_graph_a2", None) is not None) == (mode == "dp_overlap"), mode
+    res[mode] = [p.detach().clone() for p in tr.model.parameters()]
+    tr.close()
+for a, b in zip(res["dp"], res["dp_overlap"]):
+    assert torch.equal(a, b), float((a - b).abs().max())
+for a, b in zip(res["single"], res["dp_overlap"]):
+    assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), float((a - b).abs().max())
+dist.destroy_process_group()
+print("dp-overlap-ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "dp-overlap-ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_train_cli_and_checkpoint_format(tmp_path):
     """`train.py --config ... --run-id ...` runs end to end and writes upstream's checkpoint format:
     pickle((state_dict, config)) at ./models/<run_id>.nn with the reference's key names (trainer.py:356-362, enjoy.py:48-55)."""
