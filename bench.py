@@ -154,7 +154,13 @@ def cpu_baseline(cfg, seed=0):
     finally:
         torch.set_num_threads(prev)
     steps = c["n_workers"] * c["worker_steps"]
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    quota = None
+    try:      # the CPU time the container may really use (cgroup v2): "max" or "<quota us> <period us>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "cgroup_cpu_quota": quota,
             "sample": f"1 update of {c['n_workers']} workers x {c['worker_steps']} steps (= {steps} env steps) with {c['epochs']} epochs x 1 "
                       f"minibatch of {steps} samples: same per-env-step work as the full config (minibatch 2048, 5 epochs); "
                       f"{dt:.1f} s (rollout {split['rollout_s']:.1f} s on {roll_threads} torch threads, train {split['train_s']:.1f} s on "

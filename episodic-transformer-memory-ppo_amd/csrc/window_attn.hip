@@ -49,6 +49,7 @@ struct WinParams {
   int N, L, D, H, bwd;
   float sqrt_d;
   int xcd_chunk;         // workgroup b handles sample (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk), see launch_pass3
+  int no_skip;           // diagnostics (ETM_WIN_NOSKIP=1): load and multiply fully masked waves' rows too
 };
 
 // Value of `v` in lane (lane ^ OFF).  xor 1 / 2 / 8 are single DPP controls (quad_perm, row_ror:8), xor 4 is a row_shl:4
@@ -197,6 +198,18 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
     }
     mask_pre = (mb[0] != 0 ? 1u : 0u) | (mb[1] != 0 ? 2u : 0u);
   }
+  // Rows whose mask byte is 0 get the weight exp(-1e20 / sqrt(D) - max) = 0 EXACTLY as soon as the sample has one unmasked row
+  // (transformer.py:66-69), in the backward pass dE = 0 (masked_fill): a wave ALL of whose rows are masked neither loads them nor
+  // multiplies them -- its logits / partial sums are the zeros they would have been.  (A sample without any unmasked row attends
+  // uniformly over all L rows, upstream's quirk: nothing is skipped there.)  Episode step t of a rollout has min(t, L) unmasked
+  // rows, so on average a third of the window of a training sample is never read.
+  bool skip;
+  {
+    const unsigned long long v0 = __ballot(lane < L && (mask_pre & 1u)), v1 = __ballot(lane + 64 < L && (mask_pre & 2u));
+    const int l0 = wave * RW;
+    const unsigned long long mine = (l0 < 64 ? (v0 >> l0) : (v1 >> (l0 - 64))) & ((RW >= 64) ? ~0ull : ((1ull << RW) - 1ull));
+    skip = (v0 | v1) != 0ull && mine == 0ull && !p.no_skip;
+  }
 
   // Row bookkeeping is fetched ONCE per wave, lane i holding what row i needs (window offset, positional offset,
   // LayerNorm statistics), and handed to the row loads through v_readlane: one memory round trip instead of one per row.
@@ -229,8 +242,15 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
   // the vec rows of the first chunk arrived with the row bookkeeping (same round trip); they go to LDS before the row
   // loads are issued, so the barrier in front of pass 1 is reached while the rows are still in flight
   store_vec();
+  if (!skip) {
 #pragma unroll
-  for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
+    for (int i = 0; i < RW; ++i) ETM_LOAD_ROW(i, x[i])
+  } else {
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) x[i][j] = f32x2{0.f, 0.f};
+  }
 
   // ---- pass 1: logits[h][l] = x[l] . vec[h]
   {
@@ -246,6 +266,10 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
 #pragma unroll 1
       for (int hh = 0; hh < HG; ++hh) {
         if (h0 + hh >= H) break;
+        if (skip) {                       // (wave-uniform) all rows masked: their logits are never used, keep them finite
+          if (lane < RW) a_s[(h0 + hh) * LP + wave * RW + lane] = 0.f;
+          continue;
+        }
         f32x2 uvj[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) uvj[j] = *reinterpret_cast<const f32x2 *>(&zs[hh * DP + j * 128 + 2 * lane]);
@@ -358,11 +382,13 @@ __global__ __launch_bounds__(NW * 64) void window_pass_kernel(const WinParams p)
         f32x2 zq[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) zq[j] = f32x2{0.f, 0.f};
+        if (!skip) {
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-          const float w = a_s[(h0 + hh) * LP + wave * RW + i];
+          for (int i = 0; i < RW; ++i) {
+            const float w = a_s[(h0 + hh) * LP + wave * RW + i];
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) zq[j] += w * x[i][j];
+            for (int j = 0; j < NJ; ++j) zq[j] += w * x[i][j];
+          }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x2 *>(&zs[(wave * HG + hh) * DP + j * 128 + 2 * lane]) = zq[j];
@@ -396,6 +422,8 @@ int launch_pass3(const WinParams &p, hipStream_t st) {
   EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
   WinParams q = p;
   q.xcd_chunk = (p.N + 7) / 8;
+  static const int no_skip = [] { const char *e = getenv("ETM_WIN_NOSKIP"); return (e && e[0] == '1') ? 1 : 0; }();
+  q.no_skip = no_skip;
   hipLaunchKernelGGL(kern, dim3(8 * q.xcd_chunk), dim3(NW * 64), lds, st, q);
   return etm_launch_status();
 }
