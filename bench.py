@@ -92,7 +92,7 @@ def pmc_traffic(kernel):
     symbol = PMC_SYMBOL.get(kernel, kernel)
     try:
         doc = path = None
-        for cand in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel
+        for cand in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel
             path = os.path.join(REPO, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -168,6 +168,9 @@ def cpu_baseline(cfg, seed=0):
 
 
 def main():
+    # the contract is ONE JSON line on stdout: whatever the libraries / the trainer print on the way goes to stderr
+    json_out = sys.stdout
+    sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -225,7 +228,8 @@ def main():
         assert abs(float(flat[0]) - want) < 1e-6, (float(flat[0]), want)
         if rank == 0:
             print(json.dumps({"metric": "plumbing-check", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "first_worker_of_last_rank": (world - 1) * 32, "allreduce_mean": float(flat[0]), "elapsed_s": elapsed}), flush=True)
+                              "first_worker_of_last_rank": (world - 1) * 32, "allreduce_mean": float(flat[0]), "elapsed_s": elapsed}),
+                  file=json_out, flush=True)
         if dp is not None:
             dp.barrier()
             dp.close()
@@ -477,7 +481,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dp is not None:
         dp.barrier()            # rank 0 ran the kernel micro-benchmarks: leave together
     if trainer is not None:

@@ -20,6 +20,7 @@ for the GPU:
 There is no CPU path: constructing the trainer without a HIP device raises.
 """
 import os
+import sys
 import pickle
 import time
 from collections import deque
@@ -171,7 +172,7 @@ class PPOTrainer:
             n_groups = 1
         if config.get("rollout_groups", "auto") == "auto" and os.environ.get("ETM_QUIET") != "1":
             print(f"[etm] rollout worker groups: {n_groups} (rollout_groups: auto; hardware queues the HIP runtime is known to have been "
-                  f"started with: {_HW_QUEUES_AT_IMPORT or 'runtime default (4)'})", flush=True)
+                  f"started with: {_HW_QUEUES_AT_IMPORT or 'runtime default (4)'})", file=sys.stderr, flush=True)
         # worker_processes (round 4; upstream trainer.py:62-66, worker.py): the environments live in worker PROCESSES over one shared,
         # HIP-registered segment (environments/shm_env.py): they take their actions straight from the device and step concurrently;
         # the per-step host loop is then the native driver of the kernel library (etm_rollout_drive) -- see _sample_training_data

@@ -8,7 +8,7 @@ TARGETS=${@:-encoder grouped_dw rollout_step window_sorted}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 if [ "${SUITE:-0}" = 1 ]; then
-  echo "== pytest -m gpu"; (cd $ROOT && timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $OUT/gpu_suite.txt)
+  echo "== pytest -m gpu"; rm -f $OUT/tf_measured.jsonl; (cd $ROOT && ETM_QUIET=1 ETM_TF_MEASURE_LOG=$OUT/tf_measured.jsonl timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $OUT/gpu_suite.txt)
 fi
 cd /tmp && export TMPDIR=/tmp
 echo "== bench"; timeout 600 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.err
