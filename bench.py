@@ -169,7 +169,10 @@ def cpu_baseline(cfg, seed=0):
 
 def main():
     # the contract is ONE JSON line on stdout: whatever the libraries / the trainer print on the way goes to stderr
-    json_out = sys.stdout
+    # (at the descriptor level: RCCL / gloo / the HIP runtime print from C)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

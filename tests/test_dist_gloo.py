@@ -149,5 +149,6 @@ def test_bench_multi_process_plumbing_on_cpu():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout          # exactly one JSON line, from rank 0
+    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, out.stdout      # ... and nothing else on stdout (bench.py contract)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and abs(rec["allreduce_mean"] - 1.5) < 1e-6

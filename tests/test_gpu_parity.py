@@ -1948,3 +1948,18 @@ def test_poc_memory_env_learns():
             break
     tr.close()
     assert success >= 0.9, success
+
+
+def test_bench_prints_one_json_line(tmp_path):
+    """bench.py's contract with the driver: rank 0 prints ONE JSON line on stdout and nothing else (trainer / library notes go to
+    stderr) -- a stray informational print in round 4 would have broken the driver's parsing."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "1", "--warmup", "1", "--no-rooflines", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=repo)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[:2000]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["unit"] == "env-steps/s" and rec["value"] > 0 and "roofline" in rec
