@@ -896,7 +896,10 @@ def test_small_worker_groups_stress():
                 clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
     acts = np.random.default_rng(7).integers(0, 3, size=(R, W, S))
     results = []
-    for over in (dict(hip_graph_rollout=False), dict(rollout_groups=2, rollout_min_group_size=2)):
+    # ... and (round 4) the same through worker PROCESSES of one environment each and the native per-step driver: the workers answer
+    # within microseconds of the device's go word, the driver's (step, slot) block and step graph follow at once
+    for over in (dict(hip_graph_rollout=False), dict(rollout_groups=2, rollout_min_group_size=2),
+                 dict(rollout_groups=2, rollout_min_group_size=2, worker_processes=True, envs_per_process=1)):
         cfg = json.loads(json.dumps(base))
         cfg.update(over)
         torch.manual_seed(5)
@@ -911,6 +914,7 @@ def test_small_worker_groups_stress():
             snaps.append(snap)
         if "rollout_groups" in over:
             assert len(tr._groups) == 2 and tr._groups[0].W == 2 and tr._stream_obs
+            assert bool(getattr(tr, "_native_rollout", False)) == bool(over.get("worker_processes")), over
         results.append(snaps)
         tr.close()
     for other in results[1:]:
