@@ -21,6 +21,11 @@ inline double now_s() {
 }
 }  // namespace
 
+extern "C" int etm_graph_launch(void *graph_exec, void *stream) {
+  if (!graph_exec) return ETM_EINVAL;
+  return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+}
+
 extern "C" int etm_host_register(void *ptr, int64_t bytes) {
   if (!ptr || bytes <= 0) return ETM_EINVAL;
   hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);

@@ -522,6 +522,9 @@ typedef struct etm_rollout_group {
   int32_t rows_per_proc;          /* environments of one worker process (0: no row progress words, upload after `ready`) */
   const volatile int64_t *rows;   /* first row-progress word of the group's processes (ready_stride apart): ((t + 1) << 16) | rows final */
 } etm_rollout_group;
+/* hipGraphLaunch(graph_exec, stream) without the framework's per-replay bookkeeping (stream switches, generator checks): the
+ * in-process rollout loop launches a group's captured step with it (same call the native driver makes). */
+int etm_graph_launch(void *graph_exec, void *stream);
 int etm_host_register(void *ptr, int64_t bytes);
 int etm_host_unregister(void *ptr);
 int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,
