@@ -138,6 +138,7 @@ def worker_main(argv):
         ready[0] = n                                      # (x86: the stores above are visible before this one)
 
     last = int(go[0])
+    parent = os.getppid()
     try:
         while True:
             # ---- parked: block on the command pipe
@@ -178,6 +179,8 @@ def worker_main(argv):
                 if spins & 1023 == 0:
                     if ctl[0] != 0:
                         break
+                    if spins & 0xfffff == 0 and os.getppid() != parent:      # the trainer is gone (killed mid-rollout): do not spin on
+                        return
                     if ctl[1] == 0 and time.perf_counter() - idle_since > IDLE_PARK_S:
                         break
             if ctl[0] != 0:
