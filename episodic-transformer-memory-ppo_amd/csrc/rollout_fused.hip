@@ -37,7 +37,7 @@ namespace {
 constexpr int RF_T = 512;                  // 8 waves, up to 256 VGPRs each: room for a whole product slice in flight
 constexpr int RF_WAVES = RF_T / 64;
 constexpr int RF_MAXB = 8;
-constexpr int RF_MAXSPLIT = 16;            // K slices of the lin_hidden product in front of the kernel
+constexpr int RF_MAXSPLIT = 64;            // partial rows of the lin_hidden product in front of the kernel (16 K slices, or one per pixel: 49)
 constexpr int RF_SPIN_LIMIT = 1 << 22;     // ~1 s of polling: a partner that never ran
 
 struct RfGate {                      // GRU gate (transformer.py:255-298), maps transposed ([in, out]) and member-blocked:
@@ -956,8 +956,9 @@ extern "C" int64_t etm_rollout_trxl_scratch_bytes(int W, int D, int H, int nb) {
 extern "C" int etm_rollout_hidden_splits(int F) {
   if (F <= 0) return 0;
   int s = (F + HP_KMAX - 1) / HP_KMAX;            // slices of at most HP_KMAX rows ...
-  if (s < RF_MAXSPLIT && F >= 32 * RF_MAXSPLIT) s = RF_MAXSPLIT;   // ... and as many as the consumer adds when K is long
-  return s <= RF_MAXSPLIT ? s : 0;
+  constexpr int HP_SPLITS = 16;                   // (the consumer adds up to RF_MAXSPLIT = 64 rows; this kernel's grid is tuned for 16)
+  if (s < HP_SPLITS && F >= 32 * HP_SPLITS) s = HP_SPLITS;   // ... and as many as that when K is long
+  return s <= HP_SPLITS ? s : 0;
 }
 extern "C" int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int W, int F, int D, void *stream) {
   (void)hipGetLastError();

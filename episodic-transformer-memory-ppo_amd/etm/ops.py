@@ -725,6 +725,26 @@ def rollout_hidden_partial(x, wt, out=None):
     return out
 
 
+def rollout_conv3_hidden_supported(conv3, hi, wi, d):
+    return bool(_lib.load().etm_rollout_conv3_hidden_supported(conv3.in_channels, hi, wi, conv3.out_channels, conv3.kernel_size[0],
+                                                               conv3.kernel_size[1], conv3.stride[0], d))
+
+
+def rollout_conv3_hidden(x2, w3k, b3, hid_t, out=None):
+    """Last encoder layer + lin_hidden's partial sums of a rollout step in one launch (etm_rollout_conv3_hidden): ``x2`` [W, Hi, Wi, 64]
+    NHWC, ``w3k`` [576, 64], ``hid_t`` [64 * Ho * Wo, D] -> [Ho * Wo, W, D] (``rollout_trxl(h_bias=...)`` adds the rows)."""
+    lib = _lib.load()
+    x2 = _f32c(x2, "x2")
+    W, hi, wi, _ = x2.shape
+    D = hid_t.shape[1]
+    npix = (hi - 2) * (wi - 2)
+    if out is None:
+        out = torch.empty((npix, W, D), dtype=torch.float32, device=x2.device)
+    _lib.check(lib.etm_rollout_conv3_hidden(_ptr(x2), _ptr(w3k), _ptr(b3), _ptr(hid_t), _ptr(out), W, hi, wi, D, _stream()),
+               "etm_rollout_conv3_hidden")
+    return out
+
+
 def rollout_heads(h2, branch, value_head):
     """logits [W,A] and value [W] from h2 = [relu(lin_policy(h)) | relu(lin_value(h))] ([W, 2*hid]); no-grad path."""
     lib = _lib.load()

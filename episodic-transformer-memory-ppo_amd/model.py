@@ -106,6 +106,12 @@ class ActorCriticModel(nn.Module):
                     setattr(self, name, perm.contiguous())
                 else:
                     buf.copy_(perm)
+            # the last layer as [(ky, kx, c), co]: what the fused conv3 + lin_hidden launch of a rollout step reads (ops.rollout_conv3_hidden)
+            w3k = self.conv3.weight.permute(2, 3, 1, 0).reshape(-1, self.conv3.out_channels)
+            if getattr(self, "_w3k", None) is None or self._w3k.shape != w3k.shape or self._w3k.device != w3k.device:
+                self._w3k = w3k.contiguous()
+            else:
+                self._w3k.copy_(w3k)
             self._wver = (self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
 
     def rollout_block_fusable(self):
@@ -188,6 +194,8 @@ class ActorCriticModel(nn.Module):
         h1, w1 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)
         h2, w2 = x.shape[1], x.shape[2]
+        if features_only == "conv2":          # the caller runs the last layer together with lin_hidden (ops.rollout_conv3_hidden)
+            return x
         x = ops.conv_relu(x, self._w3p, self.conv3.bias, 64, h2, w2, 3, 3, 1, True, True)                                # -> NCHW
         if features_only:
             return x.reshape(n, -1)

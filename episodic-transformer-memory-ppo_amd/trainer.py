@@ -768,10 +768,24 @@ class PPOTrainer:
                 h_bias = None
                 if obs_index is not None and "hid_t" in rf and self.config.get("split_hidden_product", True):
                     # lin_hidden as K-slice partial sums on 12 x 16 workgroups; the step kernel adds slices + bias + ReLU
-                    feats = self.model._encode_fused(obs, obs_index, rows, features_only=True)
-                    if getattr(g, "h_part", None) is None:
-                        g.h_part = ops.rollout_hidden_partial(feats, rf["hid_t"])
-                    h_in = ops.rollout_hidden_partial(feats, rf["hid_t"], out=g.h_part)
+                    m_ = self.model
+                    hh_, ww_ = m_.observation_space_shape[-2:]
+                    h2_, w2_ = hh_, ww_
+                    for cv in (m_.conv1, m_.conv2):                                                      # spatial size after conv1, conv2
+                        h2_, w2_ = (h2_ - cv.kernel_size[0]) // cv.stride[0] + 1, (w2_ - cv.kernel_size[1]) // cv.stride[1] + 1
+                    if (self.config.get("fused_conv3_hidden", True)
+                            and ops.rollout_conv3_hidden_supported(m_.conv3, h2_, w2_, rf["hid_t"].shape[1])):
+                        # round 4: the last encoder layer and lin_hidden's partial sums as ONE launch, one workgroup per output pixel
+                        # (csrc/conv3_hidden.hip): the step graph is conv1, conv2, this, the step kernel
+                        x2 = m_._encode_fused(obs, obs_index, rows, features_only="conv2")
+                        if getattr(g, "h_part", None) is None:
+                            g.h_part = ops.rollout_conv3_hidden(x2, m_._w3k, m_.conv3.bias, rf["hid_t"])
+                        h_in = ops.rollout_conv3_hidden(x2, m_._w3k, m_.conv3.bias, rf["hid_t"], out=g.h_part)
+                    else:
+                        feats = m_._encode_fused(obs, obs_index, rows, features_only=True)
+                        if getattr(g, "h_part", None) is None:
+                            g.h_part = ops.rollout_hidden_partial(feats, rf["hid_t"])
+                        h_in = ops.rollout_hidden_partial(feats, rf["hid_t"], out=g.h_part)
                     h_bias = self.model.lin_hidden.bias
                 else:
                     h_in = self.model._encode(obs, obs_index, rows)

@@ -380,6 +380,14 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
  * the bias and the ReLU: one memory round trip on 12 x splits workgroups instead of a 49-step K walk on 24. */
 int etm_rollout_hidden_splits(int F);
 int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int W, int F, int D, void *stream);
+/* Rollout only: the last encoder layer (model.py:92, Conv2d(64, 64, 3, 1) + ReLU) and lin_hidden's partial sums (model.py:94-97) as
+ * ONE launch: one workgroup per output pixel finishes the pixel's 64 channels for every image and multiplies them with the pixel's
+ * 64 rows of lin_hidden^T.  x2 [W, Hi, Wi, 64] NHWC (output of the second etm_conv_relu), w3k [(ky, kx, c), co] = [576, 64],
+ * hid_t [64 * Ho * Wo, D] (feature = co * Ho * Wo + pixel), part [Ho * Wo, W, D] -- the consumer (etm_rollout_trxl with
+ * h_splits = Ho * Wo <= 64) adds the slices, the bias and the ReLU.  etm_rollout_conv3_hidden_supported: 1 for this geometry. */
+int etm_rollout_conv3_hidden_supported(int C, int Hi, int Wi, int Cout, int KH, int KW, int S, int D);
+int etm_rollout_conv3_hidden(const float *x2, const float *w3k, const float *b3, const float *hid_t, float *part, int W, int Hi, int Wi,
+                             int D, void *stream);
 
 /* Backward of y = relu(x W^T + b) (model.py:94-107, transformer.py:232) up to its two GEMMs, in two launches: gm [N, C] =
  * g * (y > 0) and db [C] = column sums of gm (fixed summation order).  y NULL: plain linear layer (gm = g; gm may be NULL, only

@@ -432,6 +432,7 @@ _ROLLOUT_PATHS = {
     "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
     # round 4: environments in worker PROCESSES over a shared, HIP-registered segment; the per-step host loop is the library's native
     # driver (etm_rollout_drive) where the step is a flag-hand-over graph with streamed observations, else the host-driven protocol
+    "kslice_hidden": {"fused_conv3_hidden": False},              # lin_hidden of a rollout step as 16 K-slice sums behind the third convolution (round 3)
     "worker_processes": {"worker_processes": True},
     "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
     "worker_processes_eager": {"worker_processes": True, "envs_per_process": 2, "hip_graph_rollout": False},
@@ -447,7 +448,8 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "pull_obs"), ("cfg3", "pull_obs"), ("img32", "four_groups"), ("cfg3", "four_groups"),
              ("cfg5", "pull_obs"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
-             ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes")]
+             ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
+             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -714,6 +716,29 @@ def test_kink_free_update_vs_reference(golden_dir, name):
                                     "grad_ref_vs_exact": ref_all, "move_vs_ref": mv_a, "move_vs_exact": mv_x, "move_floor": floor}) + "\n")
         assert mv_a <= _KF_MOVE_RATIO * floor and mv_x <= _KF_MOVE_RATIO * floor, (mv_a, mv_x, floor)
     tr.close()
+
+
+def test_rollout_conv3_hidden_vs_float64():
+    """csrc/conv3_hidden.hip (round 4): the last encoder layer + lin_hidden's partial sums of a rollout step in one launch, one
+    workgroup per output pixel -- the summed rows + bias + ReLU against relu(linear(flatten(relu(conv2d)))) in float64
+    (model.py:92-97), for ragged image counts and both hidden sizes of the BASELINE configs."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(11)
+    for (W, hi, wi, D) in ((8, 9, 9, 384), (5, 9, 9, 384), (16, 9, 9, 512), (3, 5, 6, 128)):
+        conv = torch.nn.Conv2d(64, 64, 3, 1).to(dev)
+        lin = torch.nn.Linear(64 * (hi - 2) * (wi - 2), D).to(dev)
+        x2 = torch.rand((W, hi, wi, 64), device=dev)                     # NHWC, as the second convolution leaves it
+        assert ops.rollout_conv3_hidden_supported(conv, hi, wi, D)
+        w3k = conv.weight.detach().permute(2, 3, 1, 0).reshape(-1, 64).contiguous()
+        part = ops.rollout_conv3_hidden(x2, w3k, conv.bias.detach(), lin.weight.detach().t().contiguous())
+        assert part.shape == ((hi - 2) * (wi - 2), W, D)
+        got = torch.relu(part.sum(dim=0) + lin.bias.detach())
+        with torch.no_grad():
+            f = torch.relu(torch.nn.functional.conv2d(x2.permute(0, 3, 1, 2).double().cpu(), conv.weight.double().cpu(), conv.bias.double().cpu()))
+            ref = torch.relu(f.reshape(W, -1) @ lin.weight.double().cpu().t() + lin.bias.double().cpu())
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (W, hi, wi, D, err)
 
 
 def test_trainer_self_consistency_and_free_run():
