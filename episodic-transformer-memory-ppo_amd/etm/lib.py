@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 _lib = None
 
@@ -69,6 +69,8 @@ SIGNATURES = {
                               _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_rollout_hidden_splits": (_I, [_I]),
     "etm_rollout_hidden_partial": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "etm_rollout_conv12_supported": (_I, [_I] * 11),
+    "etm_rollout_conv12": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_rollout_conv3_hidden_supported": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "etm_rollout_conv3_hidden": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

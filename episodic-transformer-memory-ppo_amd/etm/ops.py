@@ -725,6 +725,37 @@ def rollout_hidden_partial(x, wt, out=None):
     return out
 
 
+def rollout_conv12_supported(conv1, conv2, h, w):
+    return bool(_lib.load().etm_rollout_conv12_supported(conv1.in_channels, h, w, conv1.out_channels, conv1.kernel_size[0], conv1.kernel_size[1],
+                                                         conv1.stride[0], conv2.out_channels, conv2.kernel_size[0], conv2.kernel_size[1],
+                                                         conv2.stride[0]))
+
+
+def rollout_conv12(x, w1k, b1, w2k, b2, C, H, W, index=None, rows=None):
+    """First two encoder layers of a rollout step in one launch (etm_rollout_conv12): ``x`` NCHW [N, C, H, W] or, with ``index``, a
+    time-major stack [S, N, C, H, W] of which row x[index] (images ``rows`` = (lo, hi)) is read -> NHWC [N, Ho2, Wo2, 64]."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    stride = 0
+    if index is not None:
+        stride = x[0].numel()
+        N = x.shape[1]
+    else:
+        N = x.shape[0]
+    base = x.data_ptr()
+    if rows is not None:
+        if index is None:
+            raise TypeError("rollout_conv12: rows needs index (stacked input)")
+        lo, hi = rows
+        base += lo * x[0, 0].numel() * 4
+        N = hi - lo
+    h1, w1 = (H - 8) // 4 + 1, (W - 8) // 4 + 1
+    out = torch.empty((N, (h1 - 4) // 2 + 1, (w1 - 4) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    _lib.check(lib.etm_rollout_conv12(base, _ptr(index), stride, _ptr(w1k), _ptr(b1), _ptr(w2k), _ptr(b2), _ptr(out), N, C, H, W, _stream()),
+               "etm_rollout_conv12")
+    return out
+
+
 def rollout_conv3_hidden_supported(conv3, hi, wi, d):
     return bool(_lib.load().etm_rollout_conv3_hidden_supported(conv3.in_channels, hi, wi, conv3.out_channels, conv3.kernel_size[0],
                                                                conv3.kernel_size[1], conv3.stride[0], d))

@@ -36,6 +36,9 @@ class ActorCriticModel(nn.Module):
         self.channels_last = bool(config.get("encoder_channels_last", True))
         self.fused_encoder = bool(config.get("fused_rollout_encoder", True))
         self.train_encoder = bool(config.get("fused_train_encoder", True))     # False: library convolutions in the optimisation phase
+        # rollout: conv1 + conv2 as one launch (csrc/conv12_fused.hip).  Measured (round 4) and OFF: the first layer on the vector
+        # ALU of one CU per (second-layer pixel, 4 images) costs more than the launch it saves -- step graph 112.6 vs 107.9 us
+        self.fused_conv12 = bool(config.get("fused_conv12", False))
         self.fused_rollout_block = bool(config.get("fused_rollout_block", True))   # False: one launch per GEMM / LayerNorm / attention
         self._rf = None
         self._train_encoder_ok = None
@@ -106,6 +109,14 @@ class ActorCriticModel(nn.Module):
                     setattr(self, name, perm.contiguous())
                 else:
                     buf.copy_(perm)
+            # the first two layers as [(c, ky, kx), c1] / [(ky, kx, c1), co]: the fused conv1 + conv2 launch of a rollout step (ops.rollout_conv12)
+            for name, w in (("_w1k", self.conv1.weight.permute(1, 2, 3, 0).reshape(-1, self.conv1.out_channels)),
+                            ("_w2k", self.conv2.weight.permute(2, 3, 1, 0).reshape(-1, self.conv2.out_channels))):
+                buf = getattr(self, name, None)
+                if buf is None or buf.shape != w.shape or buf.device != w.device:
+                    setattr(self, name, w.contiguous())
+                else:
+                    buf.copy_(w)
             # the last layer as [(ky, kx, c), co]: what the fused conv3 + lin_hidden launch of a rollout step reads (ops.rollout_conv3_hidden)
             w3k = self.conv3.weight.permute(2, 3, 1, 0).reshape(-1, self.conv3.out_channels)
             if getattr(self, "_w3k", None) is None or self._w3k.shape != w3k.shape or self._w3k.device != w3k.device:
@@ -190,6 +201,9 @@ class ActorCriticModel(nn.Module):
         n, c, hh, ww = obs.shape[-4:]      # with obs_index: obs is a stack [S, N, C, H, W] and the layer reads obs[obs_index]
         if obs_rows is not None:
             n = obs_rows[1] - obs_rows[0]
+        if features_only == "conv2" and self.fused_conv12 and ops.rollout_conv12_supported(self.conv1, self.conv2, hh, ww):
+            # round 4: the first two layers as ONE launch (csrc/conv12_fused.hip); the caller runs the last layer together with lin_hidden
+            return ops.rollout_conv12(obs, self._w1k, self.conv1.bias, self._w2k, self.conv2.bias, c, hh, ww, index=obs_index, rows=obs_rows)
         x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False, index=obs_index, rows=obs_rows)  # -> NHWC
         h1, w1 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)

@@ -385,6 +385,12 @@ int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int
  * 64 rows of lin_hidden^T.  x2 [W, Hi, Wi, 64] NHWC (output of the second etm_conv_relu), w3k [(ky, kx, c), co] = [576, 64],
  * hid_t [64 * Ho * Wo, D] (feature = co * Ho * Wo + pixel), part [Ho * Wo, W, D] -- the consumer (etm_rollout_trxl with
  * h_splits = Ho * Wo <= 64) adds the slices, the bias and the ReLU.  etm_rollout_conv3_hidden_supported: 1 for this geometry. */
+/* Rollout only: the first two encoder layers (model.py:90-91: Conv2d(C <= 3, 32, 8, 4) + ReLU, Conv2d(32, 64, 4, 2) + ReLU) as ONE launch,
+ * one workgroup per output pixel of the second layer and four images (csrc/conv12_fused.hip).  in [W, C, H, Wd] NCHW (row *in_index of a
+ * time-major stack when in_index != NULL, as etm_conv_relu), w1k [(c, ky, kx), 32], w2k [(ky, kx, c1), 64], out [W, Ho2, Wo2, 64] NHWC. */
+int etm_rollout_conv12_supported(int C, int H, int Wd, int C1, int K1h, int K1w, int S1, int C2, int K2h, int K2w, int S2);
+int etm_rollout_conv12(const float *in, const int64_t *in_index, int64_t in_index_stride, const float *w1k, const float *b1, const float *w2k,
+                       const float *b2, float *out, int W, int C, int H, int Wd, void *stream);
 int etm_rollout_conv3_hidden_supported(int C, int Hi, int Wi, int Cout, int KH, int KW, int S, int D);
 int etm_rollout_conv3_hidden(const float *x2, const float *w3k, const float *b3, const float *hid_t, float *part, int W, int Hi, int Wi,
                              int D, void *stream);

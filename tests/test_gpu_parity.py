@@ -433,6 +433,7 @@ _ROLLOUT_PATHS = {
     # round 4: environments in worker PROCESSES over a shared, HIP-registered segment; the per-step host loop is the library's native
     # driver (etm_rollout_drive) where the step is a flag-hand-over graph with streamed observations, else the host-driven protocol
     "kslice_hidden": {"fused_conv3_hidden": False},              # lin_hidden of a rollout step as 16 K-slice sums behind the third convolution (round 3)
+    "conv12": {"fused_conv12": True},                            # the first two encoder layers of a rollout step as ONE launch (measured, off by default)
     "worker_processes": {"worker_processes": True},
     "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
     "worker_processes_eager": {"worker_processes": True, "envs_per_process": 2, "hip_graph_rollout": False},
@@ -449,7 +450,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("cfg5", "pull_obs"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
-             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden")]
+             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("img32", "conv12"), ("cfg3", "conv12")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -716,6 +717,34 @@ def test_kink_free_update_vs_reference(golden_dir, name):
                                     "grad_ref_vs_exact": ref_all, "move_vs_ref": mv_a, "move_vs_exact": mv_x, "move_floor": floor}) + "\n")
         assert mv_a <= _KF_MOVE_RATIO * floor and mv_x <= _KF_MOVE_RATIO * floor, (mv_a, mv_x, floor)
     tr.close()
+
+
+def test_rollout_conv12_vs_float64():
+    """csrc/conv12_fused.hip (round 4): the first two encoder layers of a rollout step in one launch against
+    relu(conv2d(relu(conv2d(x)))) in float64 (model.py:90-91): 84 x 84 and 36 x 36 inputs, ragged image counts, one and three input
+    channels, plain input and a row of a time-major stack restricted to a worker group."""
+    from etm import ops
+    dev = _dev()
+    torch.manual_seed(12)
+    for (N, C, H, W) in ((8, 3, 84, 84), (5, 3, 84, 84), (6, 1, 36, 36), (16, 3, 36, 36)):
+        c1, c2 = torch.nn.Conv2d(C, 32, 8, 4).to(dev), torch.nn.Conv2d(32, 64, 4, 2).to(dev)
+        assert ops.rollout_conv12_supported(c1, c2, H, W)
+        w1k = c1.weight.detach().permute(1, 2, 3, 0).reshape(-1, 32).contiguous()
+        w2k = c2.weight.detach().permute(2, 3, 1, 0).reshape(-1, 64).contiguous()
+        x = torch.rand((N, C, H, W), device=dev)
+        got = ops.rollout_conv12(x, w1k, c1.bias.detach(), w2k, c2.bias.detach(), C, H, W)
+        with torch.no_grad():
+            ref = torch.relu(torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(
+                x.double().cpu(), c1.weight.double().cpu(), c1.bias.double().cpu(), 4)), c2.weight.double().cpu(), c2.bias.double().cpu(), 2))
+        ref = ref.permute(0, 2, 3, 1)
+        assert tuple(got.shape) == tuple(ref.shape)
+        assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6, (N, C, H, W)
+        # row 2 of a time-major stack, images [1, N - 1) (a worker group)
+        stack = torch.rand((4, N, C, H, W), device=dev)
+        stack[2] = x
+        got2 = ops.rollout_conv12(stack, w1k, c1.bias.detach(), w2k, c2.bias.detach(), C, H, W,
+                                  index=torch.tensor(2, dtype=torch.int64, device=dev), rows=(1, N - 1))
+        assert torch.equal(got2, got[1:N - 1])
 
 
 def test_rollout_conv3_hidden_vs_float64():
