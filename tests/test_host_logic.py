@@ -423,3 +423,28 @@ def test_worker_processes_over_shared_memory_replay_the_in_process_streams():
             assert (env.v["ready"][:, 0] == 0).all()
         finally:
             env.close()
+
+
+def test_worker_processes_step_a_python_environment():
+    """The worker processes of environments/shm_env.py build ANY configured environment through utils.create_env (upstream
+    worker.py:20-34): PocMemoryEnv (pure python, upstream's config 1) steps behind the shared segment, episodes finish with upstream's
+    info keys, and the front-end reports the environment's spaces."""
+    import numpy as np
+    from environments.shm_env import ShmVecEnv
+    env = ShmVecEnv({"type": "PocMemoryEnv"}, 4, groups=2, envs_per_proc=1, steps_per_rollout=8)
+    try:
+        assert env.observation_space_shape == (3,) and env.num_actions == 2 and env.max_episode_steps == 32
+        obs = env.reset()
+        assert obs.shape == (4, 3) and np.isfinite(obs).all()
+        rng = np.random.default_rng(1)
+        finished = 0
+        for _ in range(80):
+            ob, r, d, infos = env.step(rng.integers(0, 2, size=4))
+            assert ob.shape == (4, 3) and r.shape == (4,) and d.shape == (4,)
+            for w in np.flatnonzero(d):
+                finished += 1
+                assert {"reward", "length"} <= set(infos[w]) and 1 <= infos[w]["length"] <= 32
+            assert all(i is None for w, i in enumerate(infos) if not d[w])
+        assert finished >= 4
+    finally:
+        env.close()
