@@ -60,10 +60,22 @@ class Buffer:
         # default capacity = worst case (every step ends an episode): the bank then never reallocates, which keeps its
         # address stable for the captured rollout graph; 288 GB of HBM make this affordable (7.3 GB at BASELINE config 3)
         cap = config.get("episode_bank_capacity", W + self.batch_size)
-        self.bank = torch.zeros((cap, max_episode_length, self.num_blocks, self.embed_dim), dtype=torch.float32, device=dev)
+        # BLOCK-MAJOR in memory (round 4): [blocks][slots][T][D] -- the L window rows of a (sample, block) are one
+        # contiguous run of L * D floats (upstream's [slots, T, blocks, D] order interleaves the blocks: a row every blocks * D floats).
+        # ``bank`` keeps upstream's logical shape [slots, T, blocks, D] as a VIEW; every kernel addresses it through its strides
+        # (etm/ops.py:WindowSpec.from_bank, the tail of etm_rollout_trxl).  ``episode_bank_layout: interleaved`` restores round 3's order.
+        self.block_major = config.get("episode_bank_layout", "block_major") == "block_major"
+        self.bank = self._new_bank(cap)
         self.num_episodes = W
         self.address_captured = False      # set by the trainer once a captured graph reads / writes the bank
         self.samples_flat = None
+
+    def _new_bank(self, slots: int) -> torch.Tensor:
+        shape = (slots, self.max_episode_length, self.num_blocks, self.embed_dim)
+        if not self.block_major:
+            return torch.zeros(shape, dtype=torch.float32, device=self.device)
+        store = torch.zeros((self.num_blocks, slots, self.max_episode_length, self.embed_dim), dtype=torch.float32, device=self.device)
+        return store.permute(1, 2, 0, 3)
 
     # ------------------------------------------------------------------ episode bank
     @property
@@ -88,7 +100,7 @@ class Buffer:
                 raise RuntimeError(f"episode bank is full ({self.bank.shape[0]} slots) and captured HIP graphs hold its address: raise "
                                    "episode_bank_capacity (default n_workers * (worker_steps + 1) never fills) or disable "
                                    "hip_graph_rollout / hip_graph_train")
-            grown = torch.zeros((2 * self.bank.shape[0],) + tuple(self.bank.shape[1:]), dtype=torch.float32, device=self.device)
+            grown = self._new_bank(2 * self.bank.shape[0])
             grown[: self.bank.shape[0]].copy_(self.bank)
             self.bank = grown
         slot = self.num_episodes

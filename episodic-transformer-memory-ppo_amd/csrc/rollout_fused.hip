@@ -91,7 +91,7 @@ struct RfParams {
   const long long *step_l, *slot_l;  // [W] episode step / memory slot of this step (the latch of etm_rollout_window)
   float *kv_out;                     // = kv (written at row step_l[w])
   float *bank;                       // [slots, T, nb, D]
-  long long bank_slot_stride, bank_row_stride;
+  long long bank_slot_stride, bank_row_stride, bank_block_stride;   // floats: bank[slot, step, block, :] (block-major bank: block stride = slots * T * D)
   int W, D, H, L, hid, A, stage_W, P;
   int map_mode;                      // block -> (worker, member) placement, see etm_rollout_trxl_set_placement
   float eps, sqrt_d;
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
       float xin = 0.f;
       if (tid < D) {
         const float it = items_s[b * D + tid];
-        if (me == 0) p.bank[slot_w * p.bank_slot_stride + step_w * p.bank_row_stride + (long long)b * D + tid] = it;
+        if (me == 0) p.bank[slot_w * p.bank_slot_stride + step_w * p.bank_row_stride + (long long)b * p.bank_block_stride + tid] = it;
         xin = it + pos_r;
         ((GEN && p.blk[b].nkv_g) ? n_s : t_s)[tid] = xin;
       }
@@ -991,7 +991,7 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
                                 const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                                 float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter,
                                 float ln_eps, void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
-                                const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
+                                const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride, const float *h_bias,
                                 int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                                 int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
                                 int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
@@ -1029,7 +1029,7 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
   p.host_flag = (long long *)host_flag; p.sync_counter = (int *)sync_counter;
   p.n_slots = 6 * nb + 2;
   p.wkv = wkv; p.pos = pos; p.step_l = (const long long *)step_l; p.slot_l = (const long long *)slot_l; p.kv_out = kv; p.bank = bank;
-  p.bank_slot_stride = bank_slot_stride; p.bank_row_stride = bank_row_stride;
+  p.bank_slot_stride = bank_slot_stride; p.bank_row_stride = bank_row_stride; p.bank_block_stride = bank_block_stride;
   p.ctl = (long long *)scratch;
   p.xbuf = reinterpret_cast<float *>((char *)scratch + 64);
   p.W = W; p.D = D; p.H = H; p.L = L; p.hid = hid; p.A = A; p.stage_W = stage_W; p.P = P;

@@ -659,12 +659,14 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
         w_args = (_ptr(ss), _ptr(mask_table), _ptr(index_table), st_mask.data_ptr() + w_off * Lw * st_mask.element_size(),
                   st_idx.data_ptr() + w_off * Lw * st_idx.element_size(), _ptr(latch), _ptr(t_row), _ptr(mask_t), _ptr(win_t),
                   0 if kv_init is None else _ptr(kv_init), index_table.shape[0], ss_tagged)
-    t_args = (0, 0, 0, 0, 0, 0, 0)
+    t_args = (0, 0, 0, 0, 0, 0, 0, 0)
     if tail is not None:
         wkv, pos, step_l, slot_l, bank = tail
-        if not (wkv.is_contiguous() and bank.stride(3) == 1 and bank.stride(2) == bank.shape[3] and (pos is None or pos.is_contiguous())):
-            raise ValueError("rollout_trxl tail: wkv / pos contiguous and bank rows [blocks, D] contiguous expected")
-        t_args = (_ptr(wkv), 0 if pos is None else _ptr(pos), _ptr(step_l), _ptr(slot_l), _ptr(bank), bank.stride(0), bank.stride(1))
+        if not (wkv.is_contiguous() and bank.stride(3) == 1 and (pos is None or pos.is_contiguous())):
+            raise ValueError("rollout_trxl tail: wkv / pos contiguous and a bank with contiguous feature rows expected")
+        # bank [slots, T, blocks, D] by STRIDES: the episode bank is block-major in memory (buffer.py), upstream's layout as a view
+        t_args = (_ptr(wkv), 0 if pos is None else _ptr(pos), _ptr(step_l), _ptr(slot_l), _ptr(bank), bank.stride(0), bank.stride(1),
+                  bank.stride(2))
     W, D = h_in_shape
     L = win_t.shape[1]
     A, hid = policy_head.weight.shape

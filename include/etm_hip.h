@@ -370,8 +370,8 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
                      float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter, float ln_eps,
                      void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
-                     const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, const float *h_bias,
-                     int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
+                     const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride,
+                     const float *h_bias, int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                      int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
                      int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
 /* lin_hidden of a rollout step (model.py:94-100) as K-slice partial sums: part [splits, W, D], splits =

@@ -433,6 +433,7 @@ _ROLLOUT_PATHS = {
     # round 4: environments in worker PROCESSES over a shared, HIP-registered segment; the per-step host loop is the library's native
     # driver (etm_rollout_drive) where the step is a flag-hand-over graph with streamed observations, else the host-driven protocol
     "kslice_hidden": {"fused_conv3_hidden": False},              # lin_hidden of a rollout step as 16 K-slice sums behind the third convolution (round 3)
+    "interleaved_bank": {"episode_bank_layout": "interleaved"},  # upstream's [slots, T, blocks, D] memory order (round 3) instead of block-major
     "conv12": {"fused_conv12": True},                            # the first two encoder layers of a rollout step as ONE launch (measured, off by default)
     "worker_processes": {"worker_processes": True},
     "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
@@ -450,7 +451,8 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("cfg5", "pull_obs"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
-             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("img32", "conv12"), ("cfg3", "conv12")]
+             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("img32", "conv12"), ("cfg3", "conv12"),
+             ("img32", "interleaved_bank"), ("cfg3", "interleaved_bank"), ("gtrxl", "interleaved_bank")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -579,6 +581,8 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         assert bool(getattr(tr, "_native_rollout", False)) == (name != "vec" and path != "worker_processes_eager"), (name, path)
         if path == "worker_processes_k4":
             assert len(tr._groups) == 4
+    blk_major = path != "interleaved_bank"
+    assert tr.buffer.block_major == blk_major and (tr.buffer.bank.stride(2) > tr.buffer.bank.stride(0)) == blk_major   # [blocks][slots][T][D] in memory
     if path == "groups4":
         assert len(tr._groups) == 4
     if path == "event_handover":

@@ -24,7 +24,7 @@ for kv in (a for a in sys.argv[2:] if "=" in a):
         node = node[part]
     old = node.get(key)
     as_int = isinstance(old, int) and not isinstance(old, bool)       # an integer key stays one (copy_threads=1)
-    node[key] = (val == "1") if val in ("0", "1") and not as_int else int(val)
+    node[key] = (val == "1") if val in ("0", "1") and not as_int else (int(val) if val.lstrip("-").isdigit() else val)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="cfgbench", device=dev, tensorboard=False)
