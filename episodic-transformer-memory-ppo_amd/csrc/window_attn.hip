@@ -27,6 +27,11 @@
 // samples share most of their window rows and the re-reads become hits of that XCD's L2.
 #include "etm_common.h"
 
+// etm_window_set_skip_masked (A/B diagnostics of the masked-wave skip; no environment variable is read by the library)
+static int g_win_no_skip = 0;
+extern "C" int etm_window_set_skip_masked(int on) { g_win_no_skip = on ? 0 : 1; return ETM_OK; }
+
+
 #include <math.h>
 #include <stdlib.h>
 
@@ -49,7 +54,7 @@ struct WinParams {
   int N, L, D, H, bwd;
   float sqrt_d;
   int xcd_chunk;         // workgroup b handles sample (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk), see launch_pass3
-  int no_skip;           // diagnostics (ETM_WIN_NOSKIP=1): load and multiply fully masked waves' rows too
+  int no_skip;           // diagnostics (etm_window_set_skip_masked(0)): load and multiply fully masked waves' rows too
 };
 
 // Value of `v` in lane (lane ^ OFF).  xor 1 / 2 / 8 are single DPP controls (quad_perm, row_ror:8), xor 4 is a row_shl:4
@@ -422,8 +427,7 @@ int launch_pass3(const WinParams &p, hipStream_t st) {
   EtmProfScope prof(p.bwd ? ETM_K_WINDOW_BWD : ETM_K_WINDOW_FWD, st);
   WinParams q = p;
   q.xcd_chunk = (p.N + 7) / 8;
-  static const int no_skip = [] { const char *e = getenv("ETM_WIN_NOSKIP"); return (e && e[0] == '1') ? 1 : 0; }();
-  q.no_skip = no_skip;
+  q.no_skip = g_win_no_skip;
   hipLaunchKernelGGL(kern, dim3(8 * q.xcd_chunk), dim3(NW * 64), lds, st, q);
   return etm_launch_status();
 }

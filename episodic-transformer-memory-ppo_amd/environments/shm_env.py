@@ -50,7 +50,8 @@ class ShmLayout:
         row = int(np.prod(self.obs_shape))
         fields = [("obs", np.float32, (W,) + self.obs_shape), ("act", np.int64, (W, B)), ("go", np.int64, (G, LINE)),
                   ("ready", np.int64, (P, LINE)), ("rows", np.int64, (P, LINE)), ("state", np.int64, (P, LINE)), ("err", np.int64, (P, LINE)),
-                  ("ctl", np.int64, (LINE,)),                                    # [0] abort, [1] hold (no self-parking)
+                  ("ctl", np.int64, (LINE,)),                                    # [0] abort, [1] hold (no self-parking), [2] activation epoch
+                  #                                                                (state[p]: [0] ST_*, [1] the last activation epoch process p has SEEN while active)
                   ("rewards", np.float32, (S, W)), ("dones", np.uint8, (S, W)), ("info_reward", np.float64, (S, W)),
                   ("info_length", np.int64, (S, W)), ("info_success", np.int8, (S, W)),
                   ("last_rewards", np.float32, (W,)), ("last_dones", np.uint8, (W,)),
@@ -161,7 +162,10 @@ def worker_main(argv):
                 if cmd != b"wake":
                     continue
                 state[0] = ST_ACTIVE
-            # ---- active: spin on the group's go word
+            # ---- active: spin on the group's go word.  state[1] = the activation epoch this process has seen: the trainer's
+            # activate() stores hold (ctl[1]) BEFORE the epoch (ctl[2]), so a process that has acknowledged the current epoch reads the
+            # current hold flag in every later parking decision (x86: stores are seen in program order, loads are not reordered)
+            state[1] = int(ctl[2])
             idle_since = time.perf_counter()
             spins = 0
             while True:
@@ -179,6 +183,9 @@ def worker_main(argv):
                 if spins & 1023 == 0:
                     if ctl[0] != 0:
                         break
+                    if state[1] != ctl[2]:
+                        state[1] = int(ctl[2])
+                        idle_since = time.perf_counter()        # a new activation: the idle clock starts again
                     if spins & 0xfffff == 0 and os.getppid() != parent:      # the trainer is gone (killed mid-rollout): do not spin on
                         return
                     if ctl[1] == 0 and time.perf_counter() - idle_since > IDLE_PARK_S:
@@ -212,6 +219,11 @@ def _probe_env(env_config):
     else:
         from utils import create_env
         e = create_env(env_config)
+    if not hasattr(e.action_space, "n"):
+        e.close()
+        raise NotImplementedError("worker_processes supports single-branch (Discrete) action spaces only: the shared segment carries one "
+                                  "action word per environment and the trainer's device-side hand-over writes one; use the in-process "
+                                  "environments (worker_processes: false) for a MultiDiscrete space")
     res = tuple(e.observation_space.shape), int(e.action_space.n), int(e.max_episode_steps)
     e.close()
     return res
@@ -287,18 +299,37 @@ class ShmVecEnv:
 
     def activate(self, hold=True):
         """Make every worker spin on its group's go word (``hold``: until ``park()``; else they park themselves when idle)."""
-        self.v["ctl"][1] = 1 if hold else 0
-        state = self.v["state"][:, 0]
-        for p, pr in enumerate(self._procs):
-            if state[p] == ST_PARKED:
-                pr.stdin.write(b"wake\n")
-                pr.stdin.flush()
+        ctl = self.v["ctl"]
+        ctl[1] = 1 if hold else 0
+        epoch = int(ctl[2]) + 1
+        ctl[2] = epoch                      # (stored AFTER hold: a worker that acknowledges this epoch has the hold flag too)
+        state, seen = self.v["state"][:, 0], self.v["state"][:, 1]
+        # A worker counts as awake when it is ACTIVE and has acknowledged THIS epoch -- a worker that read "not held, idle" just
+        # before the stores above still shows ACTIVE for a moment, then parks and blocks on its pipe: it never acknowledges, shows
+        # PARKED on a later pass of this loop and is woken then (ADVICE round 4: one pass over the states missed exactly that worker).
         t0 = time.perf_counter()
-        while (state != ST_ACTIVE).any():
-            if time.perf_counter() - t0 > 30.0:
+        last_wake = [0.0] * len(self._procs)
+        while True:
+            pending = [p for p in range(len(self._procs)) if state[p] != ST_ACTIVE or seen[p] != epoch]
+            if not pending:
+                return self
+            now = time.perf_counter()
+            for p in pending:
+                if state[p] == ST_PARKED and now - last_wake[p] > 0.002:
+                    self._wake(p)
+                    last_wake[p] = now
+            if now - t0 > 30.0:
                 self._check()
                 raise RuntimeError("environment workers did not wake up within 30 s")
-        return self
+
+    def _wake(self, p):
+        """One "wake" line to process p (a surplus line is consumed at its next parking and costs one idle period of spinning)."""
+        try:
+            self._procs[p].stdin.write(b"wake\n")
+            self._procs[p].stdin.flush()
+        except (BrokenPipeError, OSError):
+            self._check()
+            raise
 
     def park(self):
         """Let the workers go back to blocking on their pipes (they park after IDLE_PARK_S without work)."""
@@ -318,16 +349,32 @@ class ShmVecEnv:
 
     # ---- VecEnv protocol (host-driven)
     def reset(self, out=None):
+        import select
+        # Workers read their pipe only when PARKED, and a held worker (ctl[1] = 1) never parks: drop the hold for the duration of
+        # the reset (active workers then park after IDLE_PARK_S and take the command), restore it afterwards.  Every reply is
+        # awaited with a deadline -- a dead worker must raise, not hang the trainer.
+        held = bool(self.v["ctl"][1])
+        self.v["ctl"][1] = 0
         for pr in self._procs:
             pr.stdin.write(b"reset\n")
             pr.stdin.flush()
-        # parked workers take the command at once; active ones after their idle time -- wake-free: make them park first
-        for pr in self._procs:
+        deadline = time.perf_counter() + 30.0
+        for p, pr in enumerate(self._procs):
+            while True:
+                left = deadline - time.perf_counter()
+                ready, _, _ = select.select([pr.stdout], [], [], max(0.0, min(left, 0.5)))
+                if ready:
+                    break
+                self._check()
+                if left <= 0:
+                    raise RuntimeError(f"environment worker process {p} did not answer the reset within 30 s")
             line = pr.stdout.readline()
             if line.strip() != b"ok":
                 self._check()
                 raise RuntimeError("environment worker did not answer the reset")
         self._seq = [int(x) for x in self.v["go"][:, 0]]
+        if held:
+            self.activate(hold=True)
         if out is not None and out.ctypes.data != self.v["obs"].ctypes.data:
             np.copyto(out, self.v["obs"])
             return out
@@ -344,19 +391,29 @@ class ShmVecEnv:
             self._seq[g] += 1
             v["go"][g, 0] = self._seq[g]
         procs = [p for p in range(len(self._procs)) if self.proc_group[p] in gs]
+        last_wake = {}
         for p in procs:                                    # a parked worker misses the go word: wake it (it re-reads go first)
             if state[p] != ST_ACTIVE:
-                self._procs[p].stdin.write(b"wake\n")
-                self._procs[p].stdin.flush()
+                self._wake(p)
+                last_wake[p] = time.perf_counter()
         ready = v["ready"][:, 0]
         t0 = time.perf_counter()
         spins = 0
         while any(ready[p] != self._seq[self.proc_group[p]] for p in procs):
             spins += 1
-            if spins % 4096 == 0:
-                self._check()
-                if time.perf_counter() - t0 > 60.0:
-                    raise RuntimeError("environment workers did not finish a step within 60 s")
+            if spins % 256 == 0:
+                # "store go, load state" here against "store PARKED, load go" in the worker is a Dekker pair without fences: both
+                # sides can read the old value.  So the states are read AGAIN while waiting and a worker that shows PARKED with its
+                # step outstanding gets (another) wake -- no missed wake-up can outlive a few milliseconds.
+                now = time.perf_counter()
+                for p in procs:
+                    if ready[p] != self._seq[self.proc_group[p]] and state[p] == ST_PARKED and now - last_wake.get(p, 0.0) > 0.002:
+                        self._wake(p)
+                        last_wake[p] = now
+                if spins % 4096 == 0:
+                    self._check()
+                    if now - t0 > 60.0:
+                        raise RuntimeError("environment workers did not finish a step within 60 s")
         obs = v["obs"][lo:hi]
         if out is not None and out.ctypes.data != obs.ctypes.data:
             np.copyto(out, obs)

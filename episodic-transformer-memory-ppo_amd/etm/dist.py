@@ -183,27 +183,27 @@ class DataParallel:
         watchdog = threading.Timer(limit, _give_up)
         watchdog.daemon = True
         watchdog.start()
-        msg = msg.to(dev)
-        dist.broadcast(msg, src=0)                                        # step 2 (unconditional on every rank)
-        msg = msg.cpu()
-        ok = int(msg[0]) == 0
-        if ok:
-            try:
-                comm = ctypes.c_void_p()
-                with torch.cuda.device(dev):
-                    _lib.check(lib.etm_comm_init(bytes(msg[1:].numpy().tobytes()), self.rank, self.world, ctypes.byref(comm)), "etm_comm_init")
-                    self._comm = comm
-                    probe = torch.ones(4, dtype=torch.float32, device=dev)
-                    _lib.check(lib.etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream),
-                               "etm_allreduce_f32")
-                    torch.cuda.synchronize(dev)
-                if probe.tolist() != [float(self.world)] * 4:
-                    ok, why = False, f"self-test all-reduce returned {probe.tolist()}"
-            except Exception as exc:       # noqa: BLE001 -- any failure: use the framework's collective
-                ok, why = False, repr(exc)
-        elif why is None:
-            why = "rank 0 could not draw a rendezvous id"
-        try:
+        try:      # everything from the start of the watchdog to the last hand-shake step: the timer never outlives this call
+            msg = msg.to(dev)
+            dist.broadcast(msg, src=0)                                        # step 2 (unconditional on every rank)
+            msg = msg.cpu()
+            ok = int(msg[0]) == 0
+            if ok:
+                try:
+                    comm = ctypes.c_void_p()
+                    with torch.cuda.device(dev):
+                        _lib.check(lib.etm_comm_init(bytes(msg[1:].numpy().tobytes()), self.rank, self.world, ctypes.byref(comm)), "etm_comm_init")
+                        self._comm = comm
+                        probe = torch.ones(4, dtype=torch.float32, device=dev)
+                        _lib.check(lib.etm_allreduce_f32(comm, probe.data_ptr(), probe.data_ptr(), 4, torch.cuda.current_stream(dev).cuda_stream),
+                                   "etm_allreduce_f32")
+                        torch.cuda.synchronize(dev)
+                    if probe.tolist() != [float(self.world)] * 4:
+                        ok, why = False, f"self-test all-reduce returned {probe.tolist()}"
+                except Exception as exc:       # noqa: BLE001 -- any failure: use the framework's collective
+                    ok, why = False, repr(exc)
+            elif why is None:
+                why = "rank 0 could not draw a rendezvous id"
             agreed = agree(ok)                                            # step 3
         finally:
             watchdog.cancel()

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _lib = None
 
@@ -67,6 +67,13 @@ SIGNATURES = {
     "etm_rollout_trxl": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                               _P, _L, _P, _P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
                               _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_rollout_trxl_group": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
+                                    _P, _L, _P, _P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
+                                    _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_rollout_trxl_group_supported": (_I, [_I] * 8),
+    "etm_rollout_trxl_group_grid": (_I, []),
+    "etm_rollout_trxl_group_scratch_bytes": (_L, [_I]),
+    "etm_window_set_skip_masked": (_I, [_I]),
     "etm_rollout_hidden_splits": (_I, [_I]),
     "etm_rollout_hidden_partial": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "etm_rollout_conv12_supported": (_I, [_I] * 11),

@@ -322,7 +322,7 @@ class DeferredDw:
             return False
         lda, ldb, ldc = a.stride(0), b.stride(0), view.stride(0)
         lib = _lib.load()
-        if len(self.items) >= lib.etm_grouped_dw_max_problems() or not lib.etm_grouped_dw_supported(n, ma, nb, lda, ldb, ldc):
+        if not lib.etm_grouped_dw_supported(n, ma, nb, lda, ldb, ldc):       # (any number of problems: flush() launches them in chunks)
             return False
         c = view[row0: row0 + ma]
         if view.shape[1] != nb or (_ptr(b) % 16) or (_ptr(c) % 16) or ((_ptr(a) + 4 * a_col0) % 4):
@@ -375,12 +375,16 @@ class DeferredDw:
             self.colsums = []
         if not self.items:
             return
-        k = len(self.items)
-        pa = (ctypes.c_void_p * k)(*[_ptr(it[0]) + 4 * it[8] for it in self.items])
-        pb = (ctypes.c_void_p * k)(*[_ptr(it[1]) for it in self.items])
-        pc = (ctypes.c_void_p * k)(*[_ptr(it[2]) for it in self.items])
-        dims = (ctypes.c_int32 * (5 * k))(*[v for it in self.items for v in it[3:8]])
-        _lib.check(_lib.load().etm_grouped_dw(pa, pb, pc, dims, k, self.N, _stream()), "etm_grouped_dw")
+        lib = _lib.load()
+        cap = lib.etm_grouped_dw_max_problems()          # problems per launch (the kernel-argument table): gated models need two launches
+        for lo in range(0, len(self.items), cap):
+            items = self.items[lo: lo + cap]
+            k = len(items)
+            pa = (ctypes.c_void_p * k)(*[_ptr(it[0]) + 4 * it[8] for it in items])
+            pb = (ctypes.c_void_p * k)(*[_ptr(it[1]) for it in items])
+            pc = (ctypes.c_void_p * k)(*[_ptr(it[2]) for it in items])
+            dims = (ctypes.c_int32 * (5 * k))(*[v for it in items for v in it[3:8]])
+            _lib.check(lib.etm_grouped_dw(pa, pb, pc, dims, k, self.N, _stream()), "etm_grouped_dw")
         DeferredDw.last_flops = float(sum(2.0 * self.N * it[3] * it[4] for it in self.items))
         self.items = []
 
@@ -610,10 +614,20 @@ def rollout_policy(h2, policy_head, value_head, uniforms, forced, t_dev, actions
                "etm_rollout_policy")
 
 
-def rollout_trxl_scratch(W, D, H, nb, device):
-    """Zeroed scratch of one worker group for ``rollout_trxl`` (launch counter, error word, exchange slots)."""
+def rollout_trxl_group_ok(fused_group, W, L, hid, A):
+    """Does the group form of the step kernel (etm_rollout_trxl_group, csrc/rollout_group.hip) take a worker group of W workers of
+    this model?  ``fused_group``: ``ActorCriticModel._rfg`` (None: the model has no group packings)."""
+    if fused_group is None:
+        return False
+    D = fused_group["emb_t"].shape[1]
+    return bool(_lib.load().etm_rollout_trxl_group_supported(D, fused_group["H"], L, hid, A, fused_group["nb"], W, fused_group["gtrxl"]))
+
+
+def rollout_trxl_scratch(W, D, H, nb, device, group=False):
+    """Zeroed scratch of one worker group for ``rollout_trxl`` (launch counter, error word, exchange slots); ``group``: for the
+    group form of the kernel."""
     lib = _lib.load()
-    nbytes = lib.etm_rollout_trxl_scratch_bytes(W, D, H, nb)
+    nbytes = lib.etm_rollout_trxl_group_scratch_bytes(nb) if group else lib.etm_rollout_trxl_scratch_bytes(W, D, H, nb)
     return torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
 
 
@@ -677,14 +691,16 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
     off = lambda t: None if t is None else t.data_ptr() + w_off * t.element_size()
     ha = 0 if host_actions is None else host_actions.data_ptr()
     hf = 0 if host_flag is None else host_flag.data_ptr()
-    _lib.check(lib.etm_rollout_trxl(_ptr(h_in), _ptr(fused["emb_t"]), _ptr(fused["emb_b"]), fused["blocks"], fused["nb"], _ptr(kv), kv.stride(0),
+    # ``fused`` with the group packings (ActorCriticModel._rfg, "group": True) selects the group form of the kernel: same arguments
+    entry, name = (lib.etm_rollout_trxl_group, "etm_rollout_trxl_group") if fused.get("group") else (lib.etm_rollout_trxl, "etm_rollout_trxl")
+    _lib.check(entry(_ptr(h_in), _ptr(fused["emb_t"]), _ptr(fused["emb_b"]), fused["blocks"], fused["nb"], _ptr(kv), kv.stride(0),
                                     kv.stride(1), _ptr(win_t), _ptr(mask_t), _ptr(items), _ptr(fused["heads_t"]), _ptr(fused["heads_b"]),
                                     _ptr(policy_head.weight), _ptr(policy_head.bias), _ptr(value_head.weight), _ptr(value_head.bias),
                                     off(uniforms), off(forced), _ptr(t_dev), _ptr(actions), off(st_actions), off(st_logp), off(st_values),
                                     ha, hf, _ptr(sync), float(fused["eps"]), _ptr(scratch), scratch.numel() * 8, *t_args,
                                     0 if h_bias is None else _ptr(h_bias), h_splits, *w_args, int(fused.get("pre_ln", 0)),
                                     int(fused.get("gtrxl", 0)), W, D, fused["H"], L, hid, A, stage_w, _stream()),
-               "etm_rollout_trxl")
+               name)
 
 
 def gather_rows(fields, idx):
@@ -916,6 +932,7 @@ class _GruGateFn(torch.autograd.Function):
         _lib.check(lib.etm_gate_train_out(_ptr(A), _ptr(C), _ptr(z), _ptr(x), _ptr(hh), _ptr(out), N, D, _stream()), "etm_gate_train_out")
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, y, r, z, rx, hh, wy, ux, ug)
+            ctx.gate_weights = (wr, ur, wz, uz, wg)      # (the parameters themselves: DeferredDw looks their arena views up by address)
         return out
 
     @staticmethod
@@ -939,10 +956,20 @@ class _GruGateFn(torch.autograd.Function):
                    "etm_gate_train_bwd2")
         dy = torch.mm(dA, wy)
         dx = torch.addmm(dx2, dB, ux)
-        dwy = torch.mm(dA.t(), y)                       # [3D, D] = d [Wr; Wz; Wg]
-        dux = torch.mm(dB.t(), x)                       # [2D, D] = d [Ur; Uz]
-        dug = torch.mm(dC.t(), rx)
-        return dx, dy, dwy[:D], dux[:D], dwy[D:2 * D], dux[D:], dwy[2 * D:], dug, dbg
+        # Weight gradients.  Round 5: with a DeferredDw collector active (the trainer's backward pass) the six D x D products go to the
+        # grouped fp32-MFMA launch (csrc/grouped_dw.hip) like every other dense layer's -- column blocks of dA / dB as the left
+        # operands (a_col0), written straight into the arena views.  Two reasons: 24 library GEMMs fewer per minibatch step at
+        # config 5, and accuracy -- the library's [3D, N] x [N, D] product walks the N samples in ONE fp32 chain (measured 2.8e-6 of
+        # the tensor norm against float64 at N = 1,686: the worst tensors of the kink-free parity test were the gate matrices), the
+        # grouped kernel in four chains summed pairwise (7e-7).
+        wr, ur, wz, uz, wg = ctx.gate_weights
+        took = [_offer_dw(dA, y, wr, a_col0=0), _offer_dw(dB, x, ur, a_col0=0), _offer_dw(dA, y, wz, a_col0=D),
+                _offer_dw(dB, x, uz, a_col0=D), _offer_dw(dA, y, wg, a_col0=2 * D), _offer_dw(dA, rx, ug, a_col0=2 * D)]
+        dwy = torch.mm(dA.t(), y) if not (took[0] and took[2] and took[4]) else None     # [3D, D] = d [Wr; Wz; Wg]
+        dux = torch.mm(dB.t(), x) if not (took[1] and took[3]) else None                 # [2D, D] = d [Ur; Uz]
+        pick = lambda t, full, lo: None if t else full[lo: lo + D]
+        return (dx, dy, pick(took[0], dwy, 0), pick(took[1], dux, 0), pick(took[2], dwy, D), pick(took[3], dux, D),
+                pick(took[4], dwy, 2 * D), None if took[5] else torch.mm(dC.t(), rx), dbg)
 
 
 def gru_gate_train(gate, x, y):

@@ -40,7 +40,11 @@ class ActorCriticModel(nn.Module):
         # ALU of one CU per (second-layer pixel, 4 images) costs more than the launch it saves -- step graph 112.6 vs 107.9 us
         self.fused_conv12 = bool(config.get("fused_conv12", False))
         self.fused_rollout_block = bool(config.get("fused_rollout_block", True))   # False: one launch per GEMM / LayerNorm / attention
+        # round 5: GRU-gated layouts -- the step kernel of a worker GROUP (csrc/rollout_group.hip: workers as the rows of every product,
+        # every matrix read once per group and step); False keeps the per-worker teams of csrc/rollout_fused.hip
+        self.rollout_group_kernel = bool(config.get("rollout_group_kernel", True))
         self._rf = None
+        self._rfg = None
         self._train_encoder_ok = None
         if self.visual:
             c = self.observation_space_shape[0]
@@ -141,7 +145,7 @@ class ActorCriticModel(nn.Module):
         """Transposed ([in, out]) fixed-address copies of the matrices etm_rollout_trxl walks, and the host table of their
         device pointers (built once: the buffers keep their addresses, so captured graphs stay valid)."""
         if not self.lin_policy.weight.is_cuda or not self.rollout_block_fusable():
-            self._rf = None
+            self._rf = self._rfg = None
             return
         import ctypes
         t = self.transformer
@@ -192,6 +196,68 @@ class ActorCriticModel(nn.Module):
                 for k, v in fresh.items():
                     rf[k].copy_(v)
             self._rf["heads_b"] = self._b_heads          # concatenated hidden-head bias (refreshed above)
+        self._refresh_group_block_weights()
+
+    def _refresh_group_block_weights(self):
+        """The packings etm_rollout_trxl_group reads (csrc/rollout_group.hip; GRU-gated blocks, groups of <= 8 workers): every
+        [in, out] map transposed and COLUMN-BLOCKED over the launch's 32 workgroups -- [32][in][out / 32], a workgroup's slice of a
+        map is one contiguous run --, the gates' maps of y / of x as [32][3][D][D / 32] / [32][2][D][D / 32], the hidden heads as
+        [32][NCH][D][CH].  Fixed-address copies next to ``_rf`` (captured graphs read them); ``_rfg`` is None when the shape is not
+        the group kernel's (the per-worker kernel then runs the gated layout as before)."""
+        import ctypes
+        t = self.transformer
+        blk0 = t.transformer_blocks[0]
+        d = t.embed_dim
+        lib = etm_lib.load()
+        A = self.policy_branches[0].out_features
+        if not (self.rollout_group_kernel and self._rf is not None and blk0.use_gtrxl
+                and lib.etm_rollout_trxl_group_supported(d, t.num_heads, t.config["memory_length"], self.hidden_size, A, t.num_blocks, 1, 1)
+                and lib.etm_rollout_trxl_team(t.num_heads) == t.num_heads):
+            self._rfg = None
+            return
+        WG = lib.etm_rollout_trxl_group_grid()
+
+        def colblock(w_t):
+            """[K, OUT] (transposed weight) -> [32][K][OUT / 32]"""
+            k, out = w_t.shape
+            return w_t.reshape(k, WG, out // WG).permute(1, 0, 2)
+
+        cbh = 2 * self.hidden_size // WG
+        nch = (cbh + 15) // 16
+        with torch.no_grad():
+            heads_t = torch.cat((self.lin_policy.weight, self.lin_value.weight), dim=0).t()               # [D, 2 hid]
+            fresh = {"emb_t": colblock(t.linear_embedding.weight.t()),
+                     "heads_t": heads_t.reshape(d, WG, nch, cbh // nch).permute(1, 2, 0, 3)}              # [32][NCH][D][CH]
+            for i, blk in enumerate(t.transformer_blocks):
+                fresh[f"wq_t{i}"] = colblock(blk.attention.queries.weight.t())
+                fresh[f"wo_t{i}"] = colblock(blk.attention.fc_out.weight.t())
+                fresh[f"wfc_t{i}"] = colblock(blk.fc[0].weight.t())
+                for gi, gate in ((1, blk.gate1), (2, blk.gate2)):
+                    fresh[f"g{gi}wy_t{i}"] = torch.stack([colblock(getattr(gate, n).weight.t()) for n in ("Wr", "Wz", "Wg")], dim=1)
+                    fresh[f"g{gi}ux_t{i}"] = torch.stack([colblock(getattr(gate, n).weight.t()) for n in ("Ur", "Uz")], dim=1)
+                    fresh[f"g{gi}ug_t{i}"] = colblock(gate.Ug.weight.t())
+            rg = getattr(self, "_rfg", None)
+            if rg is None or rg["emb_t"].device != self.lin_policy.weight.device:
+                rg = {k: v.contiguous() for k, v in fresh.items()}
+                rg["emb_b"] = t.linear_embedding.bias
+                ptrs = []
+                for i, blk in enumerate(t.transformer_blocks):       # the 19 pointers per block of etm_rollout_trxl, group packings
+                    ptrs += [rg[f"wq_t{i}"], rg[f"wo_t{i}"], blk.attention.fc_out.bias, blk.norm1.weight, blk.norm1.bias,
+                             rg[f"wfc_t{i}"], blk.fc[0].bias, blk.norm2.weight, blk.norm2.bias]
+                    for gi, gname in ((1, "gate1"), (2, "gate2")):
+                        ptrs += [rg[f"g{gi}wy_t{i}"], rg[f"g{gi}ux_t{i}"], rg[f"g{gi}ug_t{i}"], getattr(blk, gname).bg]
+                    ptrs += [blk.norm_kv.weight, blk.norm_kv.bias] if blk.layer_norm == "pre" else [None, None]
+                rg["_keep"] = ptrs
+                rg["blocks"] = (ctypes.c_void_p * len(ptrs))(*[None if q is None else q.data_ptr() for q in ptrs])
+                rg["nb"], rg["H"], rg["eps"] = t.num_blocks, t.num_heads, blk0.norm1.eps
+                rg["pre_ln"], rg["gtrxl"], rg["group"] = int(blk0.layer_norm == "pre"), 1, True
+                self._rfg = rg
+            else:
+                for k, v in fresh.items():
+                    rg[k].copy_(v)
+            self._rfg["heads_b"] = self._b_heads
+            if "hid_t" in self._rf:
+                self._rfg["hid_t"] = self._rf["hid_t"]
 
     def _encode_fused(self, obs, obs_index=None, obs_rows=None, features_only=False):
         if getattr(self, "_w2p", None) is None or (not torch.cuda.is_current_stream_capturing()

@@ -466,7 +466,8 @@ class PPOTrainer:
             return g.stream.cuda_stream if own_stream else up
 
         early = use_graph and own_stream and all(getattr(g, "early", False) for g in groups)
-        direct_launch = bool(host_flag and self.config.get("direct_graph_launch", True))
+        # (CUDAGraph.raw_cuda_graph_exec exists in torch >= 2.8; without it the framework's replay() is used)
+        direct_launch = bool(host_flag and self.config.get("direct_graph_launch", True) and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"))
 
         def upload_state(g, t_next=0):
             """(episode step, slot) of the group's workers -> where the device finds them, after the host bookkeeping of the step."""
@@ -514,12 +515,18 @@ class PPOTrainer:
                     g.act_ready.record(main)
                     self._rollout_step_tail(g, carry)
 
+        pull = early and all(getattr(g, "pull", False) for g in groups)
+        # the native driver runs this rollout iff the captured steps hand over through the segment's go words (_native_rollout, decided
+        # at capture) AND the step is the single flag-hand-over graph on the group's own stream -- ONE predicate for "workers held
+        # spinning", "sequence restarted" and "etm_rollout_drive called" 
+        native = bool(use_graph and getattr(self, "_native_rollout", False) and host_flag and own_stream and not early and not pull
+                      and all(g.graphs[1] is None for g in groups))
         if use_graph and getattr(self, "_native_rollout", False):
             # the device's step counter restarts at 1: go = 0 on every group, acknowledged by every worker, BEFORE step 0 is launched;
-            # the workers then spin (no self-parking) until the rollout is over
-            self._shm_env.activate(hold=True)
+            # the workers then spin (no self-parking) until the rollout is over (native driver) or park when idle (host loop: the
+            # captured kernels still write the go words, the Python loop below steps the workers through the same sequence numbers)
+            self._shm_env.activate(hold=native)
             self._shm_env.restart_sequence()
-        pull = early and all(getattr(g, "pull", False) for g in groups)
         if pull:
             # the step graphs start with the pull kernel and are enqueued ONE STEP AHEAD: the rows of observation 0 are in pinned
             # memory already (flag value 1), the graphs of step 1 wait on the device for the flags of the first env.step
@@ -538,10 +545,11 @@ class PPOTrainer:
             for g in groups:
                 launch(g, 0)
         t_env = t_wait = t_launch = 0.0
-        native = (use_graph and getattr(self, "_native_rollout", False) and host_flag and own_stream and not early and not pull
-                  and all(g.graphs[1] is None for g in groups))
         if native:
-            t_wait, t_launch = self._drive_rollout_native(groups, episode_infos)
+            try:
+                t_wait, t_launch = self._drive_rollout_native(groups, episode_infos)
+            finally:
+                self._shm_env.park()          # whatever happened: no worker keeps spinning through the optimisation phase
         for t in (range(S) if not native else ()):
             for g in groups:
                 lo, hi = g.lo, g.hi
@@ -626,7 +634,7 @@ class PPOTrainer:
                         ops.rollout_trxl_clear_error(gg.rf_scratch)
                     gg.graphs = None
                 self.model.fused_rollout_block = False
-                self.model._rf = None
+                self.model._rf = self.model._rfg = None
                 self._step_graph = None
                 raise RuntimeError("fused rollout step: a team member timed out waiting for its partners; this rollout is void. The "
                                    "trainer has switched to the multi-launch step (fused_rollout_block: false) for the following rollouts")
@@ -738,8 +746,14 @@ class PPOTrainer:
         # (every team of the step kernel must be resident at once, and the groups' step kernels run concurrently: the workgroups
         # of ALL groups together must fit the 256 CUs -- one 512-thread workgroup per CU --, else the multi-launch path)
         n_conc = len(self._groups) if not g.full else 1
+        # round 5: GRU-gated layouts in groups of <= 8 workers take the GROUP form of the step kernel (weights once per group and
+        # step, 32 workgroups per launch; csrc/rollout_group.hip)
+        rfg_ = getattr(self.model, "_rfg", None) if rf_ is not None else None
+        g.group_kernel = bool(single and rfg_ is not None and self.config.get("rollout_group_kernel", True)
+                              and ops.rollout_trxl_group_ok(rfg_, g.W, self.memory_length, self.model.hidden_size, self.action_space_shape[0])
+                              and n_conc * etm_lib.load().etm_rollout_trxl_group_grid() <= 256)
         fused_step = (single and rf_ is not None and self.model.rollout_heads_fusable()
-                      and n_conc * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256)
+                      and (g.group_kernel or n_conc * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256))
         # the fused step kernel does the window lookup (and the cache reset of new episodes) itself: one launch fewer in the chain
         window_in_step = fused_step and self.config.get("window_in_step_kernel", True)
         # early_step_launch (opt-in; needs zero-copy state + the window lookup inside the step kernel + flag hand-over): the kernel
@@ -764,7 +778,7 @@ class PPOTrainer:
                 # post-LN blocks without gates: the transformer, the heads and the sampling are ONE launch -- one workgroup per
                 # worker walks the whole chain as matrix-vector products over the L2-resident weights (csrc/rollout_fused.hip);
                 # the step is then encoder (4 launches) + window lookup + this kernel instead of 26 dependent launches
-                rf = self.model._rf
+                rf = self.model._rfg if g.group_kernel else self.model._rf
                 h_bias = None
                 if obs_index is not None and "hid_t" in rf and self.config.get("split_hidden_product", True):
                     # lin_hidden as K-slice partial sums on 12 x 16 workgroups; the step kernel adds slices + bias + ReLU
@@ -791,13 +805,13 @@ class PPOTrainer:
                     h_in = self.model._encode(obs, obs_index, rows)
                 if getattr(g, "rf_scratch", None) is None:
                     t_ = self.model.transformer
-                    g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device)
+                    g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device, group=g.group_kernel)
                 # ... and, after the action hand-over, the memory-bank write and the K | V projection of the new items (the tail)
                 tail = None
                 if self.config.get("fused_rollout_tail", True) and getattr(self, "_kv_w_blocked", None) is not None:   # (pre-LN: the kernel applies norm_kv)
                     tail = (self._kv_w_blocked, self.model.transformer._pos(), g.step_l, g.slot_l, buf.bank)
                 g.tail_in_kernel = tail is not None
-                ops.rollout_trxl(h_in, self.model._rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
+                ops.rollout_trxl(h_in, rf, g.kv, win_t, mask_t, g.item, self.model.policy_branches[0], self.model.value,
                                  self._uniforms, self._forced_tab, g.t_dev, g.act_dev, st["actions"], st["log_probs"], st["values"],
                                  g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo,
                                  tail=tail, h_bias=h_bias,
@@ -949,7 +963,8 @@ class PPOTrainer:
         # words (the workers spin on them) instead of a private pinned word (decided here: the address is captured below)
         self._native_rollout = bool(self._shm_env is not None and self.config.get("native_rollout_driver", True) and so and hf
                                     and self._state_zero_copy and all(g.stream is not None for g in groups)
-                                    and not self.config.get("early_step_launch", False) and not self.config.get("pull_observations", False))
+                                    and not self.config.get("early_step_launch", False) and not self.config.get("pull_observations", False)
+                                    and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"))
         if self._native_rollout:
             for gi, g in enumerate(groups):
                 g.flag_pin = torch.from_numpy(self._shm_env.v["go"][gi, 0:1])

@@ -374,6 +374,32 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      const float *h_bias, int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                      int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
                      int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+/* The group form of the step for GRU-gated blocks (round 5, csrc/rollout_group.hip; replaces the same reference lines as
+ * etm_rollout_trxl: trainer.py:163-186 -> model.py:96-112 -> transformer.py:222-253 with the gates of :287-298): the W <= 8 workers of a
+ * group are the ROWS of every product and its columns are dealt to 32 workgroups, so every matrix leaves L2 / the Infinity Cache once
+ * per GROUP and step (the per-worker form streams 8.85 MB per worker and step at config 5).  Same arguments as etm_rollout_trxl with
+ * OTHER matrix packings: every [in = D, out] map (wemb_t, wq_t, wo_t, wfc_t, ug_t) transposed and COLUMN-BLOCKED [32][D][D / 32];
+ * wy_t = [32][3][D][D / 32] (Wr, Wz, Wg), ux_t = [32][2][D][D / 32] (Ur, Uz); wh_t = [32][NCH][D][CH], CH = 2 hid / 32 / NCH <= 16,
+ * NCH = ceil(2 hid / 32 / 16); wkv [nb][H][D][2 D / H] (per head: its K columns | its V columns); scratch:
+ * etm_rollout_trxl_group_scratch_bytes(nb) bytes, zeroed once.  Shapes: etm_rollout_trxl_group_supported (gtrxl != 0, W <= 8,
+ * W * H <= 32, D in {128, 384}, L <= 128); the launch is etm_rollout_trxl_group_grid() = 32 workgroups that must all be resident. */
+int etm_rollout_trxl_group_supported(int D, int H, int L, int hid, int A, int nb, int W, int gtrxl);
+int etm_rollout_trxl_group_grid(void);
+int64_t etm_rollout_trxl_group_scratch_bytes(int nb);
+int etm_rollout_trxl_group(const float *h_in, const float *wemb_t, const float *bemb, const void *const *blocks, int nb, float *kv,
+                     int64_t kv_worker_stride, int64_t kv_row_stride, const int64_t *win, const uint8_t *mask, float *items,
+                     const float *wh_t, const float *bh, const float *wp, const float *bp, const float *wv, const float *bv,
+                     const float *uniforms, const int64_t *forced, int64_t *t_dev, int64_t *actions, int64_t *st_actions,
+                     float *st_logp, float *st_values, int64_t *host_actions, int64_t *host_flag, int32_t *sync_counter, float ln_eps,
+                     void *scratch, int64_t scratch_bytes, const float *wkv, const float *pos, const int64_t *step_l,
+                     const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride,
+                     const float *h_bias, int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
+                     int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
+                     int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+/* Window pass (etm_window_*): 0 = load and multiply the window rows of fully masked waves too (A/B diagnostics; the results are
+ * bit-identical either way); default 1 = skip them.  Process-wide, read at launch. */
+int etm_window_set_skip_masked(int on);
+
 /* lin_hidden of a rollout step (model.py:94-100) as K-slice partial sums: part [splits, W, D], splits =
  * etm_rollout_hidden_splits(F) (<= 16), = the slice sums of x [W, F] @ wt [F, D] (wt = the weight TRANSPOSED, 16-byte aligned,
  * D % 32 == 0).  etm_rollout_trxl(h_in = part, h_bias = the layer's bias, h_splits = splits) adds the slices in slice order,

@@ -451,7 +451,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("cfg5", "pull_obs"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
-             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("img32", "conv12"), ("cfg3", "conv12"),
+             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("img32", "conv12"), ("cfg3", "conv12"),
              ("img32", "interleaved_bank"), ("cfg3", "interleaved_bank"), ("gtrxl", "interleaved_bank")]
 
 
@@ -548,12 +548,14 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         worst, worst_key, overall = movement_error(tr.model.state_dict(), z, tag, keys, prev)
         measured.update(move_all=overall, move_worst=worst, grad_all=g_all, grad_worst=g_worst)
         assert g_all <= bound["grad_all"] and g_worst <= bound["grad_tensor"], (g_all, g_worst, g_worst_key)
+        ratchet_violations = tf_ratchet(name, path, upd, measured)
         print(f"[teacher-forced {name}/{path} update {upd}] parameter-movement error: all tensors {overall:.2e}, worst tensor {worst:.2e} = {worst_key}")
         print(f"[teacher-forced {name}/{path} update {upd}] measured: " + ", ".join(f"{k} {v:.2e}" for k, v in measured.items()))
         if os.environ.get("ETM_TF_MEASURE_LOG"):
             with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
                 f.write(json.dumps({"case": name, "path": path, "update": upd, **measured}) + "\n")
         assert overall <= bound["move_all"] and worst <= bound["move_tensor"], (worst, worst_key, overall)
+        assert not ratchet_violations, f"{name}/{path} update {upd}: " + "; ".join(ratchet_violations)
     if name == "img32" and path == "default":
         assert tr._step_graph is not None and tr._stream_obs and len(tr._groups) == 2 and tr._train_graph is not None, \
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
@@ -612,12 +614,50 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 #       evaluation (cfg3 u0 step 1: lin_policy 2.1e-4; cfg2 u1 step 2: gate1.Wr 1.7e-3).  One flipped dense unit moves the
 #       tensors below it by 1e-5 .. 1e-3 of their norm, and AdamW (update lr * m_hat / (sqrt(v_hat) + eps): scale-free) turns that
 #       into sign changes of every element whose gradient is smaller -- measured 8.2e-4 / 4.6e-3 (cfg3), 1.4e-4 / 1.3e-3 (cfg2) in
-#       the first update where the flip-free cfg5 / img32 sit at 4e-5 .. 8e-5.  Bounds of this test at the BASELINE sizes therefore
+#       the first update where the flip-free paths of cfg5 (eager, kslice_hidden) and img32 sit at 4e-5 .. 8e-5.  Round 5: cfg5 on the
+#       DEFAULT rollout (conv3 + lin_hidden in one launch: 49 per-pixel partial rows instead of 16 K-slices) measures 1.37e-3 / 5.4e-3 --
+#       tools/parity_pair.py ran default, kslice_hidden and eager against each other: ONE unit, lin_policy unit 162 of the sample at
+#       sorted position 1672, float64 pre-activation +9.7e-8 with the default rollout's memory items and -3.3e-7 / -2.2e-7 with the
+#       other two; lin_policy.bias differs in that element only, lin_policy.weight by a rank-1 term in that row, the two flip-free
+#       paths agree to 1.9e-7 (profiles/r05/parity_pair_cfg5.txt).  Bounds of this test at the BASELINE sizes therefore
 #       stay at 2e-3 / 1e-2 (first update), 5e-3 / 2e-2 later; gradient of the first minibatch 2e-5 / 2e-3 of the norm (a flipped
 #       unit: cfg2 lin_hidden.weight 1.0e-3).  The TIGHT statement -- per tensor and per optimiser step against the float64
 #       evaluation, with bounds that are multiples of the floor of the same step -- is test_kink_free_update_vs_reference below, on
 #       minibatches from which the near-kink samples are removed: gradients <= 3 x the reference's own error (measured 0.24 - 1.9 x:
-#       1.3e-7 vs 5.4e-7 at cfg3), per tensor <= max(4 x, 5e-6), movement <= 3 x the twins' distance (measured 0.9 - 1.6 x).
+#       1.3e-7 vs 5.4e-7 at cfg3), per tensor <= max(4 x, 2e-6), movement <= 3 x the twins' distance (measured 0.9 - 1.6 x).
+#       And because these bounds cannot see a regression, every (case, path, update) is also held to 3 x its own recorded
+#       measurement (tf_ratchet below).
+# ---- The ratchet (round 5).  The bounds of tf_bounds at the BASELINE sizes are wide by necessity (a flipped ReLU unit is a
+# legitimate outcome there) -- wide enough that an 18 x shift of cfg5/default went through green in round 4.  So next to them every
+# (case, path, update) has its MEASURED values on record (tests/golden/tf_measured_baseline.json, written by tools/tf_ratchet.py from
+# the measurement log of a GPU suite run); a value that exceeds ratio (3) x max(record, floor) fails.  Recording a louder value is
+# only possible with a `known_flips` item that names the flipped unit, its pre-activation and the probe output
+# (tools/parity_pair.py): cfg2 -- unit 107 of linear_embedding; cfg3 -- one unit of lin_value; cfg5 default / pull_obs /
+# worker_processes -- unit 162 of lin_policy, pre-activation +9.7e-8 (profiles/r05/parity_pair_cfg5.txt).
+_RATCHET = None
+
+
+def tf_ratchet(name, path, upd, measured):
+    global _RATCHET
+    if _RATCHET is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_measured_baseline.json")) as f:
+            _RATCHET = json.load(f)
+    if os.environ.get("ETM_TF_RATCHET", "1") == "0":      # re-measuring after a deliberate change (tools/tf_ratchet.py update <log>)
+        return []
+    entry = _RATCHET["entries"].get(f"{name}/{path}/{upd}")
+    if entry is None:
+        return [f"no ratchet entry for {name}/{path}/{upd}: run the GPU suite with ETM_TF_MEASURE_LOG=<log> ETM_TF_RATCHET=0 and "
+                f"`python tools/tf_ratchet.py update <log>`"]
+    out = []
+    for f in ("move_all", "move_worst", "grad_all", "grad_worst"):
+        limit = float(_RATCHET["ratio"]) * max(float(entry[f]), float(_RATCHET["floors"][f]))
+        if measured[f] > limit:
+            out.append(f"{f} {measured[f]:.2e} exceeds {_RATCHET['ratio']} x the recorded {entry[f]:.2e} (tests/golden/tf_measured_baseline.json"
+                       f"{', known flip ' + entry['flip'] if entry.get('flip') else ''}): find the cause with tools/parity_pair.py {name} {path},eager "
+                       f"before recording a new value")
+    return out
+
+
 def tf_bounds(name, upd):
     big = name.startswith("cfg")
     return {"forward": 1e-4 if (big and upd > 0) else 5e-6,
@@ -640,15 +680,25 @@ def tf_bounds(name, upd):
 # the floor measured in the same step (the twins' distance), not free constants.
 _KF_GRAD_RATIO_ALL = 3.0       # HIP-vs-float64 gradient error over all tensors <= this x reference-vs-float64 (same step, same samples)
 _KF_GRAD_RATIO_TENSOR = 4.0    # ... per tensor (64-element samples scatter more), or the absolute floor below
-_KF_GRAD_ABS_TENSOR = (5e-6, 1e-5)   # per-tensor error / tensor norm that is accepted whatever the reference's own error is: first step
-#                                      (identical parameters; measured worst: 2.7e-6, one gate matrix of cfg5 on its 64 samples) / later steps (the parameters then differ from the fp32 twin's by the
+_KF_GRAD_ABS_TENSOR = (2e-6, 1e-5)   # per-tensor error / tensor norm that is accepted whatever the reference's own error is: first step
+#                                      (identical parameters) / later steps (the parameters then differ from the fp32 twin's by the
 #                                      movement error of the earlier steps, which the most sensitive tensors -- the query / key
-#                                      projections, whose gradients are the smallest -- answer with ~5e-6 of their norm: measured)
+#                                      projections, whose gradients are the smallest -- answer with ~5e-6 of their norm: measured).
+#                                      Round 5: the first-step floor is back at 2e-6 (round 4 had widened it to 5e-6 for one gate matrix of
+#                                      cfg5 at 2.7e-6 on its 64 samples).  The reference's own error of a tensor is now taken as the LARGER
+#                                      of its 64-sample estimate and its WHOLE-tensor value (`xgrad_err / xgrad_norm`, recorded by the
+#                                      generator): a 64-element sample of a 147,456-element matrix scatters by tens of per cent and the
+#                                      "4 x the reference" arm of the bound inherited that scatter.
 _KF_MOVE_RATIO = 3.0           # parameter movement error (vs either twin) <= this x the twins' own distance in the same step
 
 
+@pytest.mark.parametrize("mode", ["api", "graph"])
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg5"])
-def test_kink_free_update_vs_reference(golden_dir, name):
+def test_kink_free_update_vs_reference(golden_dir, name, mode):
+    """mode "api": the steps go through the upstream-API path (gathered minibatch -> `_train_mini_batch`, eager).  mode "graph"
+    (round 5): through `_train_step_graph` with SORTED indices -- the captured HIP graph of the optimisation step that bench.py and
+    `run_training` replay (two eager warm-up steps first, taken on a snapshot of the optimiser state that is restored before the
+    compared steps; the graph is re-captured when the kink-free minibatch changes its size)."""
     from trainer import PPOTrainer
     dev = _dev()
     z = load(golden_dir, f"rollout_{name}.npz")
@@ -665,6 +715,22 @@ def test_kink_free_update_vs_reference(golden_dir, name):
     params = dict(tr.model.named_parameters())
     assert list(params) == pnames
     init = {k: dg.sample(params[k].detach().cpu().numpy(), 64).astype(np.float64) for k in pnames}
+    if mode == "graph":
+        assert tr._use_train_graph and tr.config.get("sort_minibatch", True)
+        opt = tr.optimizer
+        arenas = (opt.flat_params, opt.exp_avg, opt.exp_avg_sq, opt.step_dev)
+        snap = [t.clone() for t in arenas]
+        idx0 = torch.as_tensor(z["kf/s0/idx"], device=dev, dtype=torch.long).sort().values
+        with torch.no_grad():
+            tr._bank_pos, tr._obs_train = tr._bank_with_positions(), tr._observations_channels_last()
+        for _ in range(2):                                   # the two eager warm-up steps every capture is preceded by
+            tr._train_step_graph(idx0, lr, clip, beta, False)
+        assert tr._train_graph is None and tr._train_warm == 2
+        with torch.no_grad():
+            for t, s0 in zip(arenas, snap):
+                t.copy_(s0)
+        for k in pnames:
+            assert np.array_equal(dg.sample(params[k].detach().cpu().numpy(), 64).astype(np.float64), init[k])
 
     def rows(key):
         a = z[key]
@@ -676,7 +742,7 @@ def test_kink_free_update_vs_reference(golden_dir, name):
         assert int(z[st + "dropped"]) + idx.size == (cfg["n_workers"] * cfg["worker_steps"]) // cfg["n_mini_batch"]
         # ---- gradient: HIP vs the float64 evaluation, beside the reference's fp32 gradient vs the same
         grads = tr.minibatch_gradients(idx, clip, beta)
-        xs, rs, xnorm = rows(st + "xgrad_samples"), rows(st + "grad_samples"), z[st + "xgrad_norm"]
+        xs, rs, xnorm, xerr = rows(st + "xgrad_samples"), rows(st + "grad_samples"), z[st + "xgrad_norm"], z[st + "xgrad_err"]
         num_h = num_r = den = 0.0
         worst = (0.0, "", 0.0)
         violations = []
@@ -686,19 +752,29 @@ def test_kink_free_update_vs_reference(golden_dir, name):
             eh, er = float(np.linalg.norm(got - xs[i])), float(np.linalg.norm(rs[i] - xs[i]))
             num_h, num_r, den = num_h + eh * eh, num_r + er * er, den + float(np.sum(xs[i] ** 2))
             if scale > 0:
-                allowed = max(_KF_GRAD_RATIO_TENSOR * er / scale, _KF_GRAD_ABS_TENSOR[min(s, 1)])
+                er_rel = max(er / scale, float(xerr[i]) / max(float(xnorm[i]), 1e-300))     # 64-sample estimate / whole tensor
+                allowed = max(_KF_GRAD_RATIO_TENSOR * er_rel, _KF_GRAD_ABS_TENSOR[min(s, 1)])
                 if eh / scale / allowed > worst[0]:
                     worst = (eh / scale / allowed, k, eh / scale)
                 if eh / scale > allowed:
                     violations.append(f"{k}: {eh / scale:.2e} of its norm from the float64 evaluation; the reference's fp32 gradient "
                                       f"is {er / scale:.2e} from it (bound {allowed:.2e})")
         hip_all, ref_all = (num_h / den) ** 0.5, (num_r / den) ** 0.5
-        print(f"[kink-free {name} step {s}] {idx.size} samples; gradient vs float64, all tensors: HIP {hip_all:.2e}, reference {ref_all:.2e} "
+        print(f"[kink-free {name}/{mode} step {s}] {idx.size} samples; gradient vs float64, all tensors: HIP {hip_all:.2e}, reference {ref_all:.2e} "
               f"(ratio {hip_all / ref_all:.2f}); tensor closest to its bound: {worst[1]} at {worst[2]:.2e} ({worst[0]:.2f} of the bound)")
         assert not violations, f"{name} kink-free step {s}: " + "; ".join(violations)
         assert hip_all <= _KF_GRAD_RATIO_ALL * ref_all, (hip_all, ref_all)
-        # ---- the step itself (the upstream-API path: gathered minibatch -> _train_mini_batch), then the parameter movement
-        tr._train_mini_batch(tr.buffer.gather(torch.as_tensor(idx, device=dev)), lr, clip, beta)
+        # ---- the step itself, then the parameter movement
+        if mode == "api":       # the upstream-API path: gathered minibatch -> _train_mini_batch
+            tr._train_mini_batch(tr.buffer.gather(torch.as_tensor(idx, device=dev)), lr, clip, beta)
+        else:                   # the captured optimisation step on sorted indices (what run_training / bench.py replay)
+            idx_t = torch.as_tensor(idx, device=dev, dtype=torch.long).sort().values
+            if getattr(tr, "_tg_idx", None) is not None and tr._tg_idx.numel() != idx_t.numel():
+                tr._train_graph, tr._tg_idx = None, None         # another minibatch size: capture again (workspaces are kept alive)
+            with torch.no_grad():
+                tr._bank_pos, tr._obs_train = tr._bank_with_positions(), tr._observations_channels_last()
+            tr._train_step_graph(idx_t, lr, clip, beta, False)
+            assert tr._train_graph is not None and tr._tg_idx.numel() == idx_t.numel(), "the step must have been a graph replay"
         a_rows, x_rows = rows(st + "sd_samples"), rows(st + "sd_exact_samples")
         num_a = num_x = num_f = den = 0.0
         for i, k in enumerate(pnames):
@@ -717,8 +793,9 @@ def test_kink_free_update_vs_reference(golden_dir, name):
               f"(whole tensors: {float(z[st + 'floor_move_all']):.2e})")
         if os.environ.get("ETM_TF_MEASURE_LOG"):
             with open(os.environ["ETM_TF_MEASURE_LOG"], "a") as f:
-                f.write(json.dumps({"case": name, "path": "kink_free", "step": s, "samples": int(idx.size), "grad_hip_vs_exact": hip_all,
-                                    "grad_ref_vs_exact": ref_all, "move_vs_ref": mv_a, "move_vs_exact": mv_x, "move_floor": floor}) + "\n")
+                f.write(json.dumps({"case": name, "path": "kink_free" if mode == "api" else "kink_free_graph", "step": s, "samples": int(idx.size), "grad_hip_vs_exact": hip_all,
+                                    "grad_ref_vs_exact": ref_all, "grad_tensor_nearest_bound": worst[1], "grad_tensor_err": worst[2],
+                                    "grad_tensor_frac_of_bound": worst[0], "move_vs_ref": mv_a, "move_vs_exact": mv_x, "move_floor": floor}) + "\n")
         assert mv_a <= _KF_MOVE_RATIO * floor and mv_x <= _KF_MOVE_RATIO * floor, (mv_a, mv_x, floor)
     tr.close()
 
@@ -1038,6 +1115,53 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
         if same == 1.0:
             for k in ("values", "log_probs", "mem"):
                 assert torch.allclose(a[k], m[k], atol=2e-5, rtol=1e-4), (D, ln, gtrxl, k, (a[k] - m[k]).abs().max())
+
+
+def test_group_rollout_step_kernel_vs_the_other_rollout_paths():
+    """etm_rollout_trxl_group (round 5, csrc/rollout_group.hip: GRU-gated blocks, the <= 8 workers of a group as the rows of every
+    product, columns over 32 workgroups, weights read once per group and step) against the per-worker step kernel
+    (etm_rollout_trxl, GEN instantiation) and the multi-launch path on the same weights, cache and observations: pre- and post-LN
+    gated layouts, D = 384 / H = 4 (config 5: L = 128, four blocks) and D = 128 / H = 1 (config 2), full and ragged groups
+    (W = 8, 6, 3), several groups side by side, 2 .. 5 actions."""
+    from trainer import PPOTrainer
+    dev = _dev()
+    for (D, H, L, nb, hid, A, W, groups, ln) in ((384, 4, 128, 4, 384, 4, 8, 1, "pre"), (384, 4, 64, 2, 384, 3, 6, 1, "pre"),
+                                                 (128, 1, 32, 4, 128, 2, 8, 1, "pre"), (384, 4, 40, 2, 384, 5, 8, 1, "post"),
+                                                 (128, 1, 32, 2, 128, 2, 3, 1, "pre"), (384, 4, 64, 2, 384, 3, 16, 2, "pre"),
+                                                 (128, 1, 16, 2, 256, 3, 16, 4, "post")):
+        cfg = dict(environment=dict(type="Synthetic", obs_shape=[7], num_actions=A, max_episode_steps=L + 5, seed=3, p_done=0.1, pool=4),
+                   gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=W, worker_steps=L + 12, n_mini_batch=1, value_loss_coefficient=0.5,
+                   hidden_layer_size=hid, max_grad_norm=0.5, rollout_groups=groups, rollout_min_group_size=2,
+                   transformer=dict(num_blocks=nb, embed_dim=D, num_heads=H, memory_length=L, positional_encoding="relative",
+                                    layer_norm=ln, gtrxl=True, gtrxl_bias=1.0),
+                   learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
+                   beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
+                   clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
+        snaps = []
+        for variant in (dict(), dict(rollout_group_kernel=False), dict(fused_rollout_block=False)):
+            c = {**json.loads(json.dumps(cfg)), **variant}
+            torch.manual_seed(23)
+            tr = PPOTrainer(c, run_id="groupstep", device=dev, tensorboard=False)
+            with torch.no_grad():
+                for prm in tr.model.parameters():          # non-trivial LayerNorm gains / biases / gate biases
+                    if prm.dim() == 1:
+                        prm.add_(0.1 * torch.randn_like(prm))
+            tr._sample_training_data()
+            used = [bool(getattr(g, "group_kernel", False)) for g in tr._groups]
+            assert all(used) == (not variant), (D, W, groups, variant, used)
+            assert len(tr._groups) == groups
+            tr.buffer.prepare_batch_dict()
+            b = tr.buffer
+            snaps.append({k: getattr(b, k).clone() for k in ("actions", "values", "log_probs", "memory_index")} | {"mem": b.memories.clone()})
+            tr.close()
+        grp, per_worker, multi = snaps
+        for other, what in ((per_worker, "per-worker step kernel"), (multi, "multi-launch path")):
+            assert torch.equal(grp["memory_index"], other["memory_index"])
+            same = (grp["actions"] == other["actions"]).float().mean().item()
+            assert same > 0.999, (D, W, ln, what, same)          # a different action only where a uniform sits on a CDF boundary
+            if same == 1.0:
+                for k in ("values", "log_probs", "mem"):
+                    assert torch.allclose(grp[k], other[k], atol=2e-5, rtol=1e-4), (D, W, ln, what, k, (grp[k] - other[k]).abs().max())
 
 
 def test_rollout_glue_riders_and_fused_policy():

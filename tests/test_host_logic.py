@@ -448,3 +448,67 @@ def test_worker_processes_step_a_python_environment():
         assert finished >= 4
     finally:
         env.close()
+
+
+def test_parity_ratchet_file_is_consistent_and_covers_every_teacher_forced_case():
+    """tests/golden/tf_measured_baseline.json (the ratchet under the teacher-forced GPU test): every entry that sits above the
+    quietest path of its (case, update) is covered by a known_flips item with an existing evidence file (tools/tf_ratchet.py
+    check), and every (case, path, update) the GPU test runs has an entry."""
+    import ast
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(here)
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "tf_ratchet.py"), "check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    doc = json.load(open(os.path.join(here, "golden", "tf_measured_baseline.json")))
+    # the case list of the GPU test, read from its source (importing the module would need nothing more, but keep this test free
+    # of the GPU test module's side effects)
+    tree = ast.parse(open(os.path.join(here, "test_gpu_parity.py")).read())
+    cases = None
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "_TF_CASES":
+            cases = ast.literal_eval(node.value)
+    assert cases
+    for name, path in cases:
+        z = np.load(os.path.join(here, "golden", f"rollout_{name}.npz"))
+        updates = json.loads(str(z["cfg_json"]))["cfg"]["updates"]
+        for u in range(updates):
+            assert f"{name}/{path}/{u}" in doc["entries"], f"no ratchet entry for {name}/{path}/{u}"
+
+
+def test_worker_processes_park_wake_protocol_has_no_missed_wakeups():
+    """ADVICE round 4 (environments/shm_env.py): (1) activate() issued exactly when a worker decides to park must still end with every
+    worker active AND holding -- the activation epoch is acknowledged by the worker, a worker seen PARKED later is woken again;
+    (2) reset() with the workers held active must not hang (held workers never read their pipe): the hold is dropped for the reset
+    and restored; (3) a host-driven step issued at the parking edge completes (wakes are re-sent while waiting)."""
+    import time
+    import numpy as np
+    from environments import shm_env
+    from environments.shm_env import ShmVecEnv
+    kw = dict(obs_shape=[2, 4, 4], num_actions=3, max_episode_steps=9, seed=5, p_done=0.08, p_reward=0.3, pool=4)
+    env = ShmVecEnv({"type": "Synthetic", **kw}, 4, groups=2, envs_per_proc=1, steps_per_rollout=8)
+    try:
+        env.reset()
+        a = np.zeros(4, dtype=np.int64)
+        for i in range(12):
+            env.activate(hold=False)
+            # land on the workers' parking decision (IDLE_PARK_S after their last activity), a little earlier / later each time
+            time.sleep(shm_env.IDLE_PARK_S + (i - 6) * 0.002)
+            if i % 2 == 0:
+                env.activate(hold=True)
+                time.sleep(2.5 * shm_env.IDLE_PARK_S)          # a worker that missed the hold would have parked by now
+                assert (env.v["state"][:, 0] == shm_env.ST_ACTIVE).all(), i
+                assert (env.v["state"][:, 1] == env.v["ctl"][2]).all(), i
+            env.step(a)                                            # at the edge (odd i) or under hold
+        # reset under hold: returns, and the hold is in force again afterwards
+        env.activate(hold=True)
+        t0 = time.perf_counter()
+        env.reset()
+        assert time.perf_counter() - t0 < 10.0
+        assert env.v["ctl"][1] == 1 and (env.v["state"][:, 0] == shm_env.ST_ACTIVE).all()
+        env.step(a)
+        env.park()
+    finally:
+        env.close()
