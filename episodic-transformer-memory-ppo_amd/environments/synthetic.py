@@ -19,6 +19,14 @@ a ring of ``pool`` frames at construction and then replayed (one frame per
 emitted observation), so that RNG cost -- which is not what the metric is about
 -- stays out of the timed region while every step still hands a fresh host
 buffer to the trainer.
+
+``pool: 0`` (round 5) is SURVEY section 8d to the letter: EVERY emitted observation is a fresh
+``default_rng(seed + worker_id).random(obs_shape, dtype=float32)`` draw, written straight into the
+output row (21,168 draws per env-step at 3x84x84: ~30 us of one host core); the (reward, done)
+uniforms then come from a second generator, ``default_rng((seed + worker_id, 1))``, so that both
+forms still produce identical streams whatever the order of their draws.  ``gen_threads`` > 1
+(vector form): the rows of a step are drawn by that many threads (numpy releases the GIL while it
+fills) -- what upstream's worker processes do with one process per environment.
 """
 from types import SimpleNamespace
 
@@ -45,7 +53,13 @@ class _WorkerStream:
 
     def __init__(self, worker_id, obs_shape, seed, pool):
         self.rng = np.random.default_rng(seed + worker_id)
-        self.frames = self.rng.random((pool,) + tuple(obs_shape), dtype=np.float32)
+        if pool > 0:
+            self.frames = self.rng.random((pool,) + tuple(obs_shape), dtype=np.float32)
+            self.rng_obs = None
+        else:                       # fresh draws: observations from default_rng(seed + worker_id), uniforms from a second stream
+            self.frames = None
+            self.rng_obs = self.rng
+            self.rng = np.random.default_rng((seed + worker_id, 1))
         self.u = None
         self.upos = _CHUNK
 
@@ -86,6 +100,8 @@ class SyntheticEnv:
         return self._T
 
     def _emit(self):
+        if self._pool == 0:
+            return self._s.rng_obs.random(self._shape, dtype=np.float32)
         frame = self._s.frames[self._cursor % self._pool]
         self._cursor += 1
         return frame
@@ -114,9 +130,11 @@ class SyntheticVecEnv:
     """Batched form of ``num_envs`` ``SyntheticEnv`` instances (same streams, auto-reset on done)."""
 
     def __init__(self, num_envs, obs_shape=(3, 84, 84), num_actions=3, max_episode_steps=96, seed=0,
-                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1, row_chunks=None, step_cost_us=0.0, min_chunked_envs=None):
+                 p_reward=0.05, p_done=0.02, pool=64, first_worker_id=0, copy_threads=1, row_chunks=None, step_cost_us=0.0, min_chunked_envs=None,
+                 gen_threads=1):
         """``copy_threads`` > 1: the observation rows of a step are written by that many threads (the kernel library's host
-        copier; the reference's workers write theirs in n_workers processes) instead of one numpy copy."""
+        copier; the reference's workers write theirs in n_workers processes) instead of one numpy copy.  ``pool`` = 0: every row is a
+        fresh draw of its worker's generator (module docstring); ``gen_threads`` > 1: drawn by that many threads."""
         self.num_envs = int(num_envs)
         # step_cost_us: a simulated simulator -- every environment of this front-end burns that much CPU time per step, one after
         # the other (what stepping real Python environments in one process costs; worker processes run them side by side)
@@ -136,7 +154,13 @@ class SyntheticVecEnv:
         self._rngs = [s.rng for s in streams]
         # [pool, W, *obs]: all cursors advance in lock-step, so the observations of one step are ONE contiguous block
         # (a single memcpy per step / per row chunk instead of W strided ones)
-        self._frames = np.ascontiguousarray(np.stack([s.frames for s in streams], axis=1))
+        self._frames = np.ascontiguousarray(np.stack([s.frames for s in streams], axis=1)) if pool > 0 else None
+        self._rngs_obs = [s.rng_obs for s in streams]
+        self._gen_pool = None
+        if pool == 0 and int(gen_threads) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._gen_pool = ThreadPoolExecutor(max_workers=int(gen_threads))
+            self._gen_threads = int(gen_threads)
         self._u = np.empty((self.num_envs, _CHUNK, 2))
         self._upos = _CHUNK
         self._cursor = 0
@@ -151,7 +175,36 @@ class SyntheticVecEnv:
     ROW_CHUNKS = 2   # on_rows granularity (vec_env protocol); 2 measured best: every upload call costs ~9 us of host time
     MIN_CHUNKED_ENVS = 16   # fewer environments (a small worker group): one notification for all rows
 
+    def _draw_rows(self, out, lo, hi):
+        for w in range(lo, hi):
+            self._rngs_obs[w].random(dtype=np.float32, out=out[w])
+
+    def _emit_fresh(self, out, on_rows):
+        """pool = 0: every row of the step is drawn now, by its worker's own generator, into the output row."""
+        if out is None:
+            out = np.empty((self.num_envs,) + self.observation_space_shape, dtype=np.float32)
+        if not (out.flags.c_contiguous and out.dtype == np.float32):
+            raise ValueError("fresh observations are drawn in place: a C-contiguous float32 output buffer is needed")
+        chunks = (self.ROW_CHUNKS if self.num_envs >= self.MIN_CHUNKED_ENVS else 1) if on_rows is not None else 1
+        step = max(1, -(-self.num_envs // chunks))
+        for lo in range(0, self.num_envs, step):
+            hi = min(lo + step, self.num_envs)
+            if self._gen_pool is not None and hi - lo > 1:
+                k = min(self._gen_threads, hi - lo)
+                per = -(-(hi - lo) // k)
+                futs = [self._gen_pool.submit(self._draw_rows, out, a, min(a + per, hi)) for a in range(lo + per, hi, per)]
+                self._draw_rows(out, lo, min(lo + per, hi))         # this thread takes the first share
+                for f in futs:
+                    f.result()
+            else:
+                self._draw_rows(out, lo, hi)
+            if on_rows is not None:
+                on_rows(lo, hi)
+        return out
+
     def _emit(self, out, on_rows=None):
+        if self._pool == 0:
+            return self._emit_fresh(out, on_rows)
         frame = self._frames[self._cursor % self._pool]
         self._cursor += 1
         if out is None:
@@ -242,4 +295,7 @@ class SyntheticVecEnv:
         return obs, rewards, dones, infos
 
     def close(self):
+        if getattr(self, "_gen_pool", None) is not None:
+            self._gen_pool.shutdown(wait=False)
+            self._gen_pool = None
         return None

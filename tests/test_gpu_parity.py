@@ -1128,7 +1128,7 @@ def test_group_rollout_step_kernel_vs_the_other_rollout_paths():
     for (D, H, L, nb, hid, A, W, groups, ln) in ((384, 4, 128, 4, 384, 4, 8, 1, "pre"), (384, 4, 64, 2, 384, 3, 6, 1, "pre"),
                                                  (128, 1, 32, 4, 128, 2, 8, 1, "pre"), (384, 4, 40, 2, 384, 5, 8, 1, "post"),
                                                  (128, 1, 32, 2, 128, 2, 3, 1, "pre"), (384, 4, 64, 2, 384, 3, 16, 2, "pre"),
-                                                 (128, 1, 16, 2, 256, 3, 16, 4, "post")):
+                                                 (128, 1, 16, 2, 128, 3, 16, 4, "post")):
         cfg = dict(environment=dict(type="Synthetic", obs_shape=[7], num_actions=A, max_episode_steps=L + 5, seed=3, p_done=0.1, pool=4),
                    gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=W, worker_steps=L + 12, n_mini_batch=1, value_loss_coefficient=0.5,
                    hidden_layer_size=hid, max_grad_norm=0.5, rollout_groups=groups, rollout_min_group_size=2,
