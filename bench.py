@@ -202,6 +202,11 @@ def main():
                     help="environments in worker processes over shared memory + the native rollout driver (config: what the YAML says)")
     ap.add_argument("--envs-per-process", type=int, default=None, help="environments per worker process (with worker processes)")
     ap.add_argument("--rollout-groups", default=None, help="override rollout_groups (auto, 1, 2, 4, 8)")
+    ap.add_argument("--env-pool", type=int, default=None,
+                    help="frames per worker in the synthetic environment's ring (default: the YAML's, 64); 0 = SURVEY 8d to the letter: every "
+                         "observation is a fresh default_rng(seed + worker).random([3, 84, 84]) draw inside the timed region")
+    ap.add_argument("--gen-threads", type=int, default=None,
+                    help="with --env-pool 0 and in-process environments: host threads that draw a step's observations (numpy releases the GIL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -260,6 +265,10 @@ def main():
         cfg["worker_processes"] = args.worker_processes == "on"
     if args.envs_per_process is not None:
         cfg["envs_per_process"] = args.envs_per_process
+    if args.env_pool is not None:
+        cfg["environment"]["pool"] = args.env_pool
+    if args.gen_threads is not None:
+        cfg["environment"]["gen_threads"] = args.gen_threads
     if args.rollout_groups is not None:
         cfg["rollout_groups"] = args.rollout_groups if args.rollout_groups == "auto" else int(args.rollout_groups)
         cfg["rollout_min_group_size"] = min(int(cfg.get("rollout_min_group_size", 8)), 4)
@@ -452,15 +461,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE config (3)/(4): configs/synthetic_minigrid.yaml -- per GPU n_workers=32 x worker_steps=512 "
                                    "= 16384 env steps per update, 5 epochs x 8 minibatches of 2048, TrXL 3 blocks D=384 H=4 L=64, "
-                                   "synthetic 3x84x84 observations: every worker replays a ring of 64 frames drawn once from U[0,1) "
-                                   "(numpy default_rng(seed + worker id)); rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); "
-                                   "environments stepped in-process on the host (part of the timed region); random-init weights",
+                                   "synthetic 3x84x84 observations: "
+                                   + ("every observation is a FRESH default_rng(seed + worker id).random([3, 84, 84]) float32 draw inside the timed "
+                                      "region (SURVEY 8d to the letter)" if cfg["environment"].get("pool", 64) == 0 else
+                                      f"every worker replays a ring of {cfg['environment'].get('pool', 64)} frames drawn once from U[0,1) "
+                                      "(numpy default_rng(seed + worker id))")
+                                   + "; rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); environments stepped "
+                                   + ("in worker processes" if cfg.get("worker_processes", False) else "in-process on the host")
+                                   + " (part of the timed region); random-init weights",
+                       "env_pool": cfg["environment"].get("pool", 64), "env_gen_threads": cfg["environment"].get("gen_threads", 1),
+                       "host_threads_busy": trainer._host_plan["busy_threads"], "host_cpu_plan": trainer._host_plan["reason"],
+                       "host_cpus_per_rank": trainer._host_plan["budget"]["per_rank"], "cgroup_cpu_quota": trainer._host_plan["budget"]["cgroup_quota"],
+                       "copy_threads": trainer._host_plan["copy_threads"],
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_team_placement": cfg.get("rollout_team_placement", "team_xcd"),
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": cfg.get("envs_per_process", 1) if cfg.get("worker_processes", False) else None,
+                       "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,
                        "native_rollout_driver": bool(getattr(trainer, "_native_rollout", False))},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},
             "roofline": roofline if roofline is not None else roofline_train,

@@ -24,13 +24,13 @@ struct Copier {
   std::atomic<int> pending{0};
   std::atomic<bool> stop{false};
   std::atomic<int> sleepers{0};
+  std::atomic<int> spin_pauses{40000};        // ~1 ms of _mm_pause before a helper goes to sleep (etm_host_copier_set_spin)
   std::mutex m;
   std::condition_variable cv;
   char *dst = nullptr;
   const char *src = nullptr;
   size_t bytes = 0;
 };
-constexpr int SPIN_PAUSES = 40000;            // ~1 ms of _mm_pause before a helper goes to sleep
 
 inline void chunk_of(const Copier &c, int i, size_t &lo, size_t &hi) {
   const size_t per = ((c.bytes + (size_t)c.n - 1) / (size_t)c.n + 63) & ~(size_t)63;   // cache-line multiples
@@ -42,7 +42,7 @@ void helper_main(Copier *c, int i) {
   for (;;) {
     int spins = 0;
     while (c->gen.load(std::memory_order_acquire) == last && !c->stop.load(std::memory_order_relaxed)) {
-      if (++spins < SPIN_PAUSES) { _mm_pause(); continue; }
+      if (++spins < c->spin_pauses.load(std::memory_order_relaxed)) { _mm_pause(); continue; }
       std::unique_lock<std::mutex> lk(c->m);
       c->sleepers.fetch_add(1);
       c->cv.wait(lk, [&] { return c->gen.load(std::memory_order_acquire) != last || c->stop.load(); });
@@ -70,6 +70,15 @@ extern "C" void *etm_host_copier_create(int threads) {
     c->n = (int)c->helpers.size() + 1;        // fewer helpers than asked for: still correct
   }
   return c;
+}
+
+// How long a helper spins after a job before it sleeps on the condition variable: `pauses` _mm_pause iterations (default 40,000 ~ 1 ms;
+// 0 = sleep at once -- for ranks whose CPU share does not cover spinning helpers, etm/hostcpu.py).
+extern "C" int etm_host_copier_set_spin(void *copier, int pauses) {
+  Copier *c = static_cast<Copier *>(copier);
+  if (!c || pauses < 0) return ETM_EINVAL;
+  c->spin_pauses.store(pauses, std::memory_order_relaxed);
+  return ETM_OK;
 }
 
 extern "C" void etm_host_copier_destroy(void *copier) {

@@ -50,7 +50,7 @@ class ShmLayout:
         row = int(np.prod(self.obs_shape))
         fields = [("obs", np.float32, (W,) + self.obs_shape), ("act", np.int64, (W, B)), ("go", np.int64, (G, LINE)),
                   ("ready", np.int64, (P, LINE)), ("rows", np.int64, (P, LINE)), ("state", np.int64, (P, LINE)), ("err", np.int64, (P, LINE)),
-                  ("ctl", np.int64, (LINE,)),                                    # [0] abort, [1] hold (no self-parking), [2] activation epoch
+                  ("ctl", np.int64, (LINE,)),                                    # [0] abort, [1] hold (no self-parking), [2] activation epoch, [3] back off (sleep between polls)
                   #                                                                (state[p]: [0] ST_*, [1] the last activation epoch process p has SEEN while active)
                   ("rewards", np.float32, (S, W)), ("dones", np.uint8, (S, W)), ("info_reward", np.float64, (S, W)),
                   ("info_length", np.int64, (S, W)), ("info_success", np.int8, (S, W)),
@@ -75,7 +75,7 @@ def _make_part(env_config, n, first_worker_id):
     """The environments of one worker process as a small in-process vector environment."""
     if env_config["type"] == "Synthetic":
         from environments.synthetic import SyntheticVecEnv
-        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool", "step_cost_us")
+        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool", "step_cost_us", "gen_threads")
         kw = {k: env_config[k] for k in keys if k in env_config}
         if "obs_shape" in kw:
             kw["obs_shape"] = tuple(kw["obs_shape"])
@@ -168,6 +168,7 @@ def worker_main(argv):
             state[1] = int(ctl[2])
             idle_since = time.perf_counter()
             spins = 0
+            backoff = ctl[3] != 0
             while True:
                 n = int(go[0])
                 if n != last:
@@ -180,7 +181,10 @@ def worker_main(argv):
                     spins = 0
                     continue
                 spins += 1
+                if backoff and spins & 63 == 0:
+                    time.sleep(20e-6)             # the rank's CPU share does not cover spinning workers (etm/hostcpu.py)
                 if spins & 1023 == 0:
+                    backoff = ctl[3] != 0
                     if ctl[0] != 0:
                         break
                     if state[1] != ctl[2]:
@@ -254,7 +258,7 @@ class ShmVecEnv:
     ``steps_per_rollout``: rows of the per-step result arrays (the trainer's ``worker_steps``)."""
 
     def __init__(self, env_config: dict, num_envs: int, first_worker_id: int = 0, groups: int = 1, envs_per_proc: int = 1,
-                 steps_per_rollout: int = 1, num_branches: int = 1):
+                 steps_per_rollout: int = 1, num_branches: int = 1, spin: bool = True):
         shape, n_act, T = _probe_env(env_config)
         self.observation_space_shape, self.num_actions, self.max_episode_steps = tuple(shape), int(n_act), int(T)
         W, G = int(num_envs), int(groups)
@@ -272,6 +276,7 @@ class ShmVecEnv:
         self.v = self.layout.views(self.shm.buf)
         for a in self.v.values():
             a[...] = 0
+        self.v["ctl"][3] = 0 if spin else 1        # workers sleep 20 us every 64 polls instead of spinning flat out
         self.bounds = [(g * per_group, (g + 1) * per_group) for g in range(G)]
         self.parts = [_ShmGroup(self, g, lo, hi) for g, (lo, hi) in enumerate(self.bounds)]
         self.proc_group = [p // self.procs_per_group for p in range(P)]

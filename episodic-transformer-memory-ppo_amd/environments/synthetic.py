@@ -34,6 +34,15 @@ import numpy as np
 
 _CHUNK = 4096
 _copiers = {}   # threads -> (library, copier handle): one pool of helper threads per process, shared by all front-ends
+_copier_spin = None   # None: the library's default (helpers spin ~1 ms between jobs); False: they sleep at once (etm/hostcpu.py)
+
+
+def set_copier_spin(spin):
+    """Do the copier's helper threads spin between jobs (default) or sleep at once?  Applies to existing and future copiers."""
+    global _copier_spin
+    _copier_spin = None if spin else False
+    for lib, handle in _copiers.values():
+        lib.etm_host_copier_set_spin(handle, 40000 if spin else 0)
 
 
 def _copier(threads):
@@ -44,6 +53,8 @@ def _copier(threads):
         handle = lib.etm_host_copier_create(int(threads))
         if not handle:
             raise RuntimeError(f"etm_host_copier_create({threads}) failed")
+        if _copier_spin is False:
+            lib.etm_host_copier_set_spin(handle, 0)
         _copiers[threads] = (lib, handle)
     return _copiers[threads]
 

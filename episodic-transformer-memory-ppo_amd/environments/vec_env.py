@@ -176,7 +176,7 @@ def make_vec_env(env_config: dict, num_envs: int, first_worker_id: int = 0, grou
         return CompositeVecEnv([make_vec_env(env_config, per, first_worker_id + g * per) for g in range(groups)])
     if env_config["type"] == "Synthetic":
         from environments.synthetic import SyntheticVecEnv
-        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool", "copy_threads", "row_chunks", "step_cost_us")
+        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool", "copy_threads", "row_chunks", "step_cost_us", "gen_threads")
         kw = {k: env_config[k] for k in keys if k in env_config}
         if "obs_shape" in kw:
             kw["obs_shape"] = tuple(kw["obs_shape"])

@@ -57,6 +57,7 @@ SIGNATURES = {
     "etm_relu_bwd_colsum": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_host_copier_create": (_P, [_I]),
     "etm_host_copier_destroy": (None, [_P]),
+    "etm_host_copier_set_spin": (_I, [_P, _I]),
     "etm_host_copy": (_I, [_P, _P, _P, _L]),
     "etm_rollout_trxl_team": (_I, [_I]),
     "etm_rollout_trxl_set_placement": (_I, [_I]),

@@ -173,16 +173,39 @@ class PPOTrainer:
         if config.get("rollout_groups", "auto") == "auto" and os.environ.get("ETM_QUIET") != "1":
             print(f"[etm] rollout worker groups: {n_groups} (rollout_groups: auto; hardware queues the HIP runtime is known to have been "
                   f"started with: {_HW_QUEUES_AT_IMPORT or 'runtime default (4)'})", file=sys.stderr, flush=True)
+        # round 5: the rank's host CPU share (affinity mask, cgroup CPU quota, ranks per node) against the threads a rollout keeps
+        # busy -- trainer thread on the action flag, observation-copier helpers, worker processes (etm/hostcpu.py).  With room to
+        # spare nothing changes; without it the helpers sleep between jobs, the copier / the worker processes shrink to what fits and
+        # the trainer thread sleeps through most of the expected device time before it spins.  `host_cpu_plan: false` keeps the
+        # configured values whatever the host looks like.
+        from etm import hostcpu
+        env_cfg = dict(config["environment"])
+        self._host_plan = hostcpu.plan_host_threads(copy_threads=int(env_cfg.get("copy_threads", 1)) if env_cfg.get("type") == "Synthetic" else 1,
+                                                    worker_processes=bool(env is None and config.get("worker_processes", False)),
+                                                    num_envs=self.num_workers, envs_per_process=int(config.get("envs_per_process", 1)),
+                                                    groups=n_groups, quiet=not config.get("host_cpu_plan", True))
+        if not config.get("host_cpu_plan", True):
+            self._host_plan.update(copy_threads=int(env_cfg.get("copy_threads", 1)), copier_spin=True, polite_wait=False,
+                                   envs_per_process=int(config.get("envs_per_process", 1)), worker_spin=True, reason="host_cpu_plan: false")
+        if env_cfg.get("type") == "Synthetic" and "copy_threads" in env_cfg:
+            env_cfg["copy_threads"] = self._host_plan["copy_threads"]
+        if not self._host_plan["copier_spin"]:
+            from environments import synthetic as _syn
+            _syn.set_copier_spin(False)
+        if self._host_plan["polite_wait"]:
+            hostcpu.set_timer_slack_ns(1000)
+        self._flag_wait_ema = 0.0
         # worker_processes (round 4; upstream trainer.py:62-66, worker.py): the environments live in worker PROCESSES over one shared,
         # HIP-registered segment (environments/shm_env.py): they take their actions straight from the device and step concurrently;
         # the per-step host loop is then the native driver of the kernel library (etm_rollout_drive) -- see _sample_training_data
         self._shm_env = None
         if env is None and config.get("worker_processes", False):
             from environments.shm_env import ShmVecEnv
-            self._shm_env = ShmVecEnv(config["environment"], self.num_workers, first_worker_id, groups=n_groups,
-                                      envs_per_proc=int(config.get("envs_per_process", 1)), steps_per_rollout=config["worker_steps"])
+            self._shm_env = ShmVecEnv(env_cfg, self.num_workers, first_worker_id, groups=n_groups,
+                                      envs_per_proc=self._host_plan["envs_per_process"], steps_per_rollout=config["worker_steps"],
+                                      spin=self._host_plan["worker_spin"])
             env = self._shm_env
-        self.env = env if env is not None else make_vec_env(config["environment"], self.num_workers, first_worker_id, groups=n_groups)
+        self.env = env if env is not None else make_vec_env(env_cfg, self.num_workers, first_worker_id, groups=n_groups)
         W = self.num_workers
         obs_shape = tuple(self.env.observation_space_shape)
         self.observation_space = type("Space", (), {"shape": obs_shape})()
@@ -468,6 +491,7 @@ class PPOTrainer:
         early = use_graph and own_stream and all(getattr(g, "early", False) for g in groups)
         # (CUDAGraph.raw_cuda_graph_exec exists in torch >= 2.8; without it the framework's replay() is used)
         direct_launch = bool(host_flag and self.config.get("direct_graph_launch", True) and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"))
+        polite = bool(self._host_plan["polite_wait"])
 
         def upload_state(g, t_next=0):
             """(episode step, slot) of the group's workers -> where the device finds them, after the host bookkeeping of the step."""
@@ -557,6 +581,10 @@ class PPOTrainer:
                 if host_flag:
                     # the sampling kernel stored the actions and then step t + 1 into pinned memory: spin on the counter
                     flag, target, spins, t_wait0 = g.flag_np, t + 1, 0, time.perf_counter()
+                    if polite and flag[0] != target and self._flag_wait_ema > 80e-6:
+                        # not enough CPUs for a spinning trainer thread (etm/hostcpu.py): sleep through most of the wait this flag
+                        # usually takes (an average of the earlier waits), spin for the rest
+                        time.sleep(0.7 * self._flag_wait_ema)
                     while flag[0] != target:
                         spins += 1
                         if spins % 4096 == 0 and time.perf_counter() - t_wait0 > 30.0:
@@ -565,6 +593,8 @@ class PPOTrainer:
                     g.act_ready.synchronize()
                 te = time.perf_counter()
                 t_wait += te - tw
+                if polite:
+                    self._flag_wait_ema += 0.1 * ((te - tw) - self._flag_wait_ema)
                 if pull:
                     flags = g.row_flags_np
 

@@ -451,6 +451,10 @@ int etm_gather_rows(const void *const *src, void *const *dst, const int64_t *row
  *   bytes are written; one job at a time per copier. */
 void *etm_host_copier_create(int threads);
 void etm_host_copier_destroy(void *copier);
+/* Spin budget of the copier's helper threads between jobs in _mm_pause iterations (default 40,000 ~ 1 ms; 0: sleep on the condition
+ * variable at once).  The trainer lowers it to 0 when the rank's CPU share (affinity mask, cgroup quota, ranks per node) does not
+ * cover spinning helpers (etm/hostcpu.py). */
+int etm_host_copier_set_spin(void *copier, int pauses);
 int etm_host_copy(void *copier, void *dst, const void *src, int64_t bytes);
 
 /* Rollout-only encoder convolution with fused bias + ReLU (one `relu(conv2d(x))` of model.py:90-92; forward, no grad):

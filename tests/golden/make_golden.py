@@ -448,9 +448,15 @@ KINK_MARGIN = 1e-5      # |pre-activation| below this (float64 forward) marks a 
 _RELU_SITES = ("conv1", "conv2", "conv3", "lin_hidden", "lin_policy", "lin_value", "transformer.linear_embedding")
 
 
-def _relu_margins(model64, samples64):
+def _relu_margins(model64, samples64, clip=None):
     """min |pre-activation| over every ReLU input of the reference's forward pass (model.py:90-106, transformer.py:115, :234), per
-    sample, from a float64 forward pass of ``samples64`` through ``model64`` (forward hooks on the modules in front of the ReLUs)."""
+    sample, from a float64 forward pass of ``samples64`` through ``model64`` (forward hooks on the modules in front of the ReLUs).
+    Round 5, ``clip`` given: the kinks of the PPO loss itself count too (trainer.py:290-298) -- a sample whose probability ratio is
+    within the margin of 1 - c or 1 + c (``clamp``), whose value moved within the margin of -c or +c from the old value (``clamp``), or
+    whose two squared value errors tie while they are different branches (``max``) has a gradient that two correct fp32 evaluations
+    may take from different sides.  In step 0 none exist (ratio = 1, V = V_old); from the second step on they were what made the
+    reference's own fp32 gradient 2 - 4 x noisier than in step 0 (cfg2 step 2: 1.2e-6 against 3.2e-7) and concentrated the noise in
+    the policy head."""
     n = samples64["obs"].shape[0]
     margin = torch.full((n,), float("inf"), dtype=torch.float64)
     counts = {}
@@ -470,7 +476,22 @@ def _relu_margins(model64, samples64):
     try:
         with torch.no_grad():
             memory = ref_utils.batched_index_select(samples64["memories"], 1, samples64["memory_indices"])
-            model64(samples64["obs"], memory, samples64["memory_mask"], samples64["memory_indices"])
+            pi, value, _ = model64(samples64["obs"], memory, samples64["memory_mask"], samples64["memory_indices"])
+            if clip is not None:
+                c = float(clip)
+                logp = pi[0].log_prob(samples64["actions"][:, 0])                      # one action branch (trainer.py:47)
+                ratio = torch.exp(logp - samples64["log_probs"][:, 0])
+                m_ratio = torch.minimum((ratio - (1.0 - c)).abs(), (ratio - (1.0 + c)).abs())
+                v_old = samples64["values"]
+                dv = value - v_old
+                m_v = torch.minimum((dv - c).abs(), (dv + c).abs()) / torch.clamp(v_old.abs(), min=1.0)
+                ret = v_old + samples64["advantages"]
+                e1, e2 = (value - ret) ** 2, (v_old + dv.clamp(-c, c) - ret) ** 2
+                m_tie = torch.where(dv.abs() > c, (e1 - e2).abs() / torch.clamp(torch.maximum(e1, e2), min=1e-300),
+                                    torch.full_like(e1, float("inf")))
+                m_loss = torch.minimum(torch.minimum(m_ratio, m_v), m_tie)
+                counts["ppo_loss_kinks"] = int((m_loss < KINK_MARGIN).sum())
+                margin.copy_(torch.minimum(margin, m_loss))
     finally:
         for h in hooks:
             h.remove()
@@ -509,7 +530,7 @@ def _kink_free_run(tr, cfg, lr, clip, beta, first_minibatch, steps):
 
     init = {n: p.detach().clone() for n, p in A.named_parameters()}
     for s_i in range(steps):
-        margin, counts = _relu_margins(copy.deepcopy(A).double(), samples_of(cand, True))
+        margin, counts = _relu_margins(copy.deepcopy(A).double(), samples_of(cand, True), clip=clip)
         keep = cand[margin >= KINK_MARGIN]
         st = f"kf/s{s_i}/"
         out[st + "idx"] = keep.clone()
@@ -549,6 +570,11 @@ def _kink_free_run(tr, cfg, lr, clip, beta, first_minibatch, steps):
         out[st + "xgrad_samples"] = _pack(x_at_a, pnames, dtype=np.float64)
         out[st + "xgrad_norm"] = np.array([float(x_at_a[k].norm()) for k in pnames])
         out[st + "xgrad_err"] = np.array([float((g32[k].double() - x_at_a[k]).norm()) for k in pnames])      # whole tensors
+        # round 5: how far the float64 gradient moves when it is evaluated at the OTHER twin's parameters (whole tensors): the two
+        # twins' parameters differ by the movement noise of the earlier steps (zero in step 0), so this is the per-tensor
+        # sensitivity of the gradient to exactly the kind of parameter noise a third correct implementation carries into the step --
+        # the floor under the per-tensor gradient bound of the later steps (tests/test_gpu_parity.py: was a free constant, 1e-5)
+        out[st + "xgrad_twin_shift"] = np.array([float((x_at_a[k] - x_at_x[k]).norm()) for k in pnames])
         out[st + "sd_samples"] = _pack({k: v.detach() for k, v in pa.items()}, pnames)
         out[st + "sd_exact_samples"] = _pack({k: v.detach() for k, v in px.items()}, pnames)
         errs = np.array([float((pa[k].detach().double() - px[k].detach().double()).norm()) for k in pnames])

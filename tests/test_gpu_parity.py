@@ -680,10 +680,13 @@ def tf_bounds(name, upd):
 # the floor measured in the same step (the twins' distance), not free constants.
 _KF_GRAD_RATIO_ALL = 3.0       # HIP-vs-float64 gradient error over all tensors <= this x reference-vs-float64 (same step, same samples)
 _KF_GRAD_RATIO_TENSOR = 4.0    # ... per tensor (64-element samples scatter more), or the absolute floor below
-_KF_GRAD_ABS_TENSOR = (2e-6, 1e-5)   # per-tensor error / tensor norm that is accepted whatever the reference's own error is: first step
-#                                      (identical parameters) / later steps (the parameters then differ from the fp32 twin's by the
-#                                      movement error of the earlier steps, which the most sensitive tensors -- the query / key
-#                                      projections, whose gradients are the smallest -- answer with ~5e-6 of their norm: measured).
+_KF_GRAD_ABS_TENSOR = 2e-6           # per-tensor error / tensor norm that is accepted whatever the reference's own error is.  In the later
+#                                      steps the parameters differ from the fp32 twin's by the movement error of the earlier steps;
+#                                      what that does to a tensor's gradient is MEASURED by the generator (round 5, `xgrad_twin_shift`:
+#                                      the float64 gradient at the fp32 twin's parameters minus the float64 gradient at the
+#                                      float64-gradient twin's, whole tensors) and enters the bound as _KF_MOVE_RATIO x that shift --
+#                                      the HIP trainer's parameters may be _KF_MOVE_RATIO x the twins' distance away (asserted below).
+#                                      It replaces round 4's free constant 1e-5 for the later steps.
 #                                      Round 5: the first-step floor is back at 2e-6 (round 4 had widened it to 5e-6 for one gate matrix of
 #                                      cfg5 at 2.7e-6 on its 64 samples).  The reference's own error of a tensor is now taken as the LARGER
 #                                      of its 64-sample estimate and its WHOLE-tensor value (`xgrad_err / xgrad_norm`, recorded by the
@@ -743,6 +746,7 @@ def test_kink_free_update_vs_reference(golden_dir, name, mode):
         # ---- gradient: HIP vs the float64 evaluation, beside the reference's fp32 gradient vs the same
         grads = tr.minibatch_gradients(idx, clip, beta)
         xs, rs, xnorm, xerr = rows(st + "xgrad_samples"), rows(st + "grad_samples"), z[st + "xgrad_norm"], z[st + "xgrad_err"]
+        xshift = z[st + "xgrad_twin_shift"]          # zero in step 0 (the twins start from the same parameters)
         num_h = num_r = den = 0.0
         worst = (0.0, "", 0.0)
         violations = []
@@ -753,7 +757,7 @@ def test_kink_free_update_vs_reference(golden_dir, name, mode):
             num_h, num_r, den = num_h + eh * eh, num_r + er * er, den + float(np.sum(xs[i] ** 2))
             if scale > 0:
                 er_rel = max(er / scale, float(xerr[i]) / max(float(xnorm[i]), 1e-300))     # 64-sample estimate / whole tensor
-                allowed = max(_KF_GRAD_RATIO_TENSOR * er_rel, _KF_GRAD_ABS_TENSOR[min(s, 1)])
+                allowed = max(_KF_GRAD_RATIO_TENSOR * er_rel, _KF_GRAD_ABS_TENSOR) + _KF_MOVE_RATIO * float(xshift[i]) / max(float(xnorm[i]), 1e-300)
                 if eh / scale / allowed > worst[0]:
                     worst = (eh / scale / allowed, k, eh / scale)
                 if eh / scale > allowed:

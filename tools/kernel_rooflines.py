@@ -268,11 +268,28 @@ def grouped_dw(dev, launches=20, N=2048, D=384, H=4, nb=3, hid=384):
                  replaces="the dW GEMMs of these layers, one library launch each (15 us x 19 at config 3, 0.26 of the peak)")
 
 
-def rollout_step_model(cfg, W, hidden_features):
+def rollout_step_model(cfg, W, hidden_features, group=False):
     """What one launch of the rollout step kernel (csrc/rollout_fused.hip) moves and how long its dependency chain is.
     Every worker's team streams every matrix of the chain once (weights are shared by all workers, but a team serves ONE worker:
-    matrix-VECTOR products), plus the worker's K | V cache columns of the window; the tail streams the K | V projection."""
+    matrix-VECTOR products), plus the worker's K | V cache columns of the window; the tail streams the K | V projection.
+    ``group``: the group form (csrc/rollout_group.hip, gated layouts): the chain's matrices once per GROUP; the tail (a unit projects its
+    own worker's items onto its head's K | V columns) still once per worker; every exchange is an all-gather of [8, D] activations."""
     t = cfg["transformer"]
+    if group:
+        D, nb, L, H = t["embed_dim"], t["num_blocks"], t["memory_length"], t["num_heads"]
+        hid = cfg["hidden_layer_size"]
+        w_chain = D * D + nb * 15 * D * D + D * 2 * hid
+        w_tail = nb * D * 2 * D
+        kv = nb * L * 2 * D
+        exchanges = 8 * nb + 3
+        piece = 8 * (D // 32)                                   # floats a workgroup publishes per exchange; 16-byte packets carry 2 each
+        ex_written, ex_read = exchanges * 32 * piece * 8, exchanges * 32 * 32 * piece * 8      # bytes (one polling pass over every piece)
+        return dict(weight_bytes_chain_once_per_group=4 * w_chain, weight_bytes_per_worker_tail=4 * w_tail, kv_bytes_per_worker=4 * kv,
+                    bytes_per_launch=4 * (w_chain + W * (w_tail + kv)), bytes_per_launch_to_handover=4 * (w_chain + W * kv),
+                    exchange_bytes_written=ex_written, exchange_bytes_read_one_pass=ex_read,
+                    unique_weight_bytes=4 * (w_chain + w_tail), unique_bytes_per_launch=4 * (w_chain + w_tail + W * kv),
+                    dependent_products=2 + 9 * nb, team_exchanges=exchanges, dependent_phases=2 + 9 * nb + exchanges + nb * 2 + 1, workers=W,
+                    workgroups=32, form="group (csrc/rollout_group.hip)")
     D, nb, L, H = t["embed_dim"], t["num_blocks"], t["memory_length"], t["num_heads"]
     hid = cfg["hidden_layer_size"]
     gates = 2 * 6 * D * D if t.get("gtrxl") else 0
@@ -312,7 +329,7 @@ def rollout_step(trainer, launches=40):
     res["step_sum_us"] = sum(v[0] * 1e3 * v[1] / launches for v in t.values())
     if "rollout_trxl_kernel" in t:
         feats = trainer.model.lin_hidden.in_features
-        m = rollout_step_model(trainer.config, g.W, feats)
+        m = rollout_step_model(trainer.config, g.W, feats, group=bool(getattr(g, "group_kernel", False)))
         us = t["rollout_trxl_kernel"][0] * 1e3
         gbs = m["bytes_per_launch"] / (us * 1e-6) / 1e9
         res["rollout_trxl_kernel"] = dict(kernel="rollout_trxl_kernel", bound="latency (dependent chain of matrix-vector products; bytes are L2 / "
@@ -350,10 +367,10 @@ def _bench_trainer(dev, overrides=()):
     """A PPOTrainer on BASELINE config 3 that has run one rollout (graphs captured): the fixture of the rollout_step target."""
     from yaml_parser import YamlParser
     from trainer import PPOTrainer
-    cfg = YamlParser(os.path.join(PKG, "configs", "synthetic_minigrid.yaml")).get_config()
+    cfg = YamlParser(os.path.join(PKG, "configs", os.environ.get("ETM_PROFILE_CONFIG", "synthetic_minigrid") + ".yaml")).get_config()
     for kv in overrides:
         k, v = kv.split("=")
-        cfg[k] = int(v) if v.lstrip("-").isdigit() else v
+        cfg[k] = (v == "1") if isinstance(cfg.get(k, None), bool) or k in ("rollout_group_kernel",) else (int(v) if v.lstrip("-").isdigit() else v)
     torch.manual_seed(0)
     tr = PPOTrainer(cfg, run_id="roofline", device=dev, tensorboard=False)
     tr._sample_training_data()

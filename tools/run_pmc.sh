@@ -10,7 +10,12 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_${ROUND:-r03}
 TARGETS=${@:-window_cold window_train window_sorted window_cold128 mfma3 gae ppo encoder rollout_step}
 for target in $TARGETS; do
-  if [ $target = conv ]; then cmd="python $ROOT/tools/conv_time.py"; else cmd="python $ROOT/tools/kernel_rooflines.py $target 6"; fi
+  # rollout_step5 / rollout_step2: the rollout_step target on BASELINE config 5 / 2 (group form of the step kernel); rollout_step5pw: per-worker form
+  if [ $target = conv ]; then cmd="python $ROOT/tools/conv_time.py";
+  elif [ $target = rollout_step5 ]; then cmd="env ETM_PROFILE_CONFIG=synthetic_mortar_gtrxl python $ROOT/tools/kernel_rooflines.py rollout_step 6";
+  elif [ $target = rollout_step5pw ]; then cmd="env ETM_PROFILE_CONFIG=synthetic_mortar_gtrxl python $ROOT/tools/kernel_rooflines.py rollout_step 6 rollout_group_kernel=0";
+  elif [ $target = rollout_step2 ]; then cmd="env ETM_PROFILE_CONFIG=synthetic_cartpole python $ROOT/tools/kernel_rooflines.py rollout_step 6";
+  else cmd="python $ROOT/tools/kernel_rooflines.py $target 6"; fi
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
     rm -rf /tmp/pmc_run
