@@ -15,7 +15,8 @@ runs, and nothing else can.  This tool shows which it is, without the reference:
      element's share of the squared error of the bias tensors (one-hot test),
   4. each path's gradient against the float64 evaluation of the reference's own loss code held by the fixture (64-element samples).
 
-    python tools/parity_pair.py cfg5 default,kslice_hidden,eager   -> gpurun_out/parity/pair_<case>.txt / .json
+    python tools/parity_pair.py cfg5 default,kslice_hidden,eager [--step=k]   -> gpurun_out/parity/pair_<case>[_stepk].txt / .json
+(--step=k: the update's first k optimiser steps are taken first -- eagerly, on the fixture's minibatches -- and the gradient of step k is probed)
 """
 import json
 import os
@@ -46,6 +47,9 @@ def say(*a):
     line = " ".join(str(x) for x in a)
     OUT.append(line)
     print(line, flush=True)
+
+
+STEP = 0      # optimiser steps of the update taken (eagerly, on the fixture's minibatches) before the probed gradient: --step k
 
 
 def run(name, path):
@@ -85,16 +89,24 @@ def run(name, path):
         return real_heads(h, lin_policy, lin_value, *a, **k)
 
     ops.linear_relu, ops.heads_ppo_loss = rec_linear_relu, rec_heads
+    n_mb = cfg["n_mini_batch"]
+    p0 = {k: v.detach().double().cpu().clone() for k, v in tr.model.named_parameters()}
+    for st in range(STEP):          # the update's first STEP optimiser steps, in the fixture's minibatch order
+        perm = z["u0/perms"][st // n_mb]
+        idx = torch.as_tensor(perm[(st % n_mb) * mbs: (st % n_mb + 1) * mbs], device=tr.device, dtype=torch.long).sort().values
+        tr._train_mini_batch(tr.buffer.gather(idx), lr, clip, beta)
+    probe_perm = z["u0/perms"][STEP // n_mb][(STEP % n_mb) * mbs: (STEP % n_mb + 1) * mbs]
     try:
-        grads = tr.minibatch_gradients(z["u0/perms"][0][:mbs], clip, beta)
+        grads = tr.minibatch_gradients(probe_perm, clip, beta)
     finally:
         ops.linear_relu, ops.heads_ppo_loss = real_lr, real_heads
     b = tr.buffer
     fields = {f: getattr(b, f).detach().double().cpu().numpy() for f in ("values", "log_probs", "advantages")}
-    res = {"grads": {k: g.detach().double().cpu() for k, g in grads.items()}, "rec": rec, "fields": fields}
+    res = {"grads": {k: g.detach().double().cpu() for k, g in grads.items()}, "rec": rec, "fields": fields,
+           "params": {k: v.detach().double().cpu().clone() for k, v in tr.model.named_parameters()}, "params0": p0}
     # against the float64 evaluation of the reference's loss code (fixture samples of step 0 of update 0)
     pnames = [str(k) for k in z["param_keys"]]
-    xs, rs, xnorm = z["u0/s0/xgrad_samples"], z["u0/s0/grad_samples"], z["u0/s0/xgrad_norm"]
+    xs, rs, xnorm = z[f"u0/s{STEP}/xgrad_samples"], z[f"u0/s{STEP}/grad_samples"], z[f"u0/s{STEP}/xgrad_norm"]
     num_h = num_r = den = 0.0
     rows = []
     for i, k in enumerate(pnames):
@@ -106,7 +118,7 @@ def run(name, path):
         rows.append((k, eh / max(scale, 1e-300), er / max(scale, 1e-300)))
         num_h, num_r, den = num_h + eh * eh, num_r + er * er, den + float(np.sum(x ** 2))
     res["vs_exact"] = {"hip": (num_h / den) ** 0.5, "ref": (num_r / den) ** 0.5, "rows": rows}
-    say(f"[{name}/{path}] first-minibatch gradient vs the float64 evaluation (fixture samples): HIP {res['vs_exact']['hip']:.2e}, "
+    say(f"[{name}/{path}] gradient of optimiser step {STEP} vs the float64 evaluation AT THE REFERENCE'S parameters of that step (fixture samples): HIP {res['vs_exact']['hip']:.2e}, "
         f"reference {res['vs_exact']['ref']:.2e}")
     for k, eh, er in sorted(rows, key=lambda t: -t[1])[:5]:
         say(f"      {k:56s} HIP {eh:.2e}   reference {er:.2e}")
@@ -119,6 +131,10 @@ def compare(name, pa, ra, pb, rb):
     for f in ("values", "log_probs", "advantages"):
         d = np.abs(ra["fields"][f] - rb["fields"][f])
         say(f"  buffer.{f}: max |A - B| {d.max():.2e}, rms {np.sqrt((d ** 2).mean()):.2e}")
+    if STEP:
+        num = sum(float((ra["params"][k] - rb["params"][k]).norm()) ** 2 for k in ra["params"])
+        den = sum(float((ra["params"][k] - ra["params0"][k]).norm()) ** 2 for k in ra["params"])
+        say(f"  parameters after {STEP} optimiser step(s): ||A - B|| / ||A - initial|| = {(num / max(den, 1e-300)) ** 0.5:.2e} (whole tensors)")
     flips = []
     for lname in ra["rec"]:
         A, B = ra["rec"][lname], rb["rec"].get(lname)
@@ -161,15 +177,20 @@ def compare(name, pa, ra, pb, rb):
 
 
 if __name__ == "__main__":
-    name = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
-    paths = (sys.argv[2] if len(sys.argv) > 2 else "default,kslice_hidden,eager").split(",")
+    args = [a for a in sys.argv[1:] if not a.startswith("--step")]
+    for a in sys.argv[1:]:
+        if a.startswith("--step="):
+            STEP = int(a.split("=")[1])
+    name = args[0] if args else "cfg5"
+    paths = (args[1] if len(args) > 1 else "default,kslice_hidden,eager").split(",")
     results = {p: run(name, p) for p in paths}
     summary = [compare(name, paths[0], results[paths[0]], p, results[p]) for p in paths[1:]]
     if len(paths) > 2:
         summary.append(compare(name, paths[1], results[paths[1]], paths[2], results[paths[2]]))
     os.makedirs(os.path.join(REPO, "gpurun_out", "parity"), exist_ok=True)
-    with open(os.path.join(REPO, "gpurun_out", "parity", f"pair_{name}.txt"), "w") as f:
+    tag = f"{name}_step{STEP}" if STEP else name
+    with open(os.path.join(REPO, "gpurun_out", "parity", f"pair_{tag}.txt"), "w") as f:
         f.write("\n".join(OUT) + "\n")
-    with open(os.path.join(REPO, "gpurun_out", "parity", f"pair_{name}.json"), "w") as f:
+    with open(os.path.join(REPO, "gpurun_out", "parity", f"pair_{tag}.json"), "w") as f:
         json.dump({"case": name, "vs_exact": {p: {"hip": r["vs_exact"]["hip"], "ref": r["vs_exact"]["ref"]} for p, r in results.items()},
                    "pairs": summary}, f)

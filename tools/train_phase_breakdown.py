@@ -10,7 +10,7 @@ import csv, sqlite3, sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if "rollout_trxl_kernel" in r[0] or "rollout_policy_kernel" in r[0]]
+marks = [i for i, r in enumerate(rows) if "rollout_trxl_kernel" in r[0] or "rollout_group_kernel" in r[0] or "rollout_policy_kernel" in r[0]]
 gaps = [(rows[b][1] - rows[a][2], a, b) for a, b in zip(marks, marks[1:]) if rows[b][1] - rows[a][2] > 30e6]
 if not gaps:
     sys.exit("no optimisation phase found between rollouts")
