@@ -492,7 +492,7 @@ int check_common(const void *bank, const void *win, const void *mask, const void
 extern "C" int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
                               const int64_t *pidx, const uint8_t *mask, const float *pos, const float *ln_g, const float *ln_b,
                               float ln_eps, const float *u, int64_t u_head_stride, int64_t u_sample_stride, float *att, float *z,
-                              int64_t z_head_stride, int64_t z_sample_stride, float *ln_stats, int N, int L, int D, int H,
+                              int64_t z_head_stride, int64_t z_sample_stride, float *ln_stats, int stats_ready, int N, int L, int D, int H,
                               void *stream) {
   (void)hipGetLastError();
   int rc = check_common(bank, win, mask, pos, pidx, ln_g, ln_b, ln_stats, N, L, D, H);
@@ -500,7 +500,7 @@ extern "C" int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_
   if (!u || !att || !z) return ETM_EINVAL;
   if (u_head_stride % 2 || u_sample_stride % 2 || z_head_stride % 2 || z_sample_stride % 2) return ETM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (ln_g) {
+  if (ln_g && !stats_ready) {     // (stats_ready: the caller filled ln_stats itself, e.g. gathered from per-bank-row statistics -- etm_ln_row_stats)
     rc = etm_launch_ln_stats(bank, ep_stride, row_stride, ep, win, pidx, pos, ln_eps, ln_stats, N, L, D, st);
     if (rc) return rc;
   }

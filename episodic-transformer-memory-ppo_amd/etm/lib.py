@@ -120,7 +120,10 @@ SIGNATURES = {
     "etm_heads_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "etm_heads_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _D, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _L,
                             _I, _I, _I, _P]),
-    "etm_window_fwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _P]),
+    "etm_window_fwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P]),
+    "etm_window_ln_grad_rows": (_I, [_I]),
+    "etm_window_ln_grad": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _P]),
+    "etm_ln_row_stats": (_I, [_P, _F, _P, _L, _I, _P]),
     "etm_window_bwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
     "etm_window_dx": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_profile_enable": (_I, [_I]),

@@ -65,7 +65,8 @@ class WindowSpec:
     bank_ptr/ep_stride/row_stride/block_stride are in float32 elements.  ``ep`` may be None (ep[n] = n).
     """
 
-    __slots__ = ("bank", "ep_stride", "row_stride", "block_stride", "ep", "win", "pidx", "mask", "N", "L", "pos_included")
+    __slots__ = ("bank", "ep_stride", "row_stride", "block_stride", "ep", "win", "pidx", "mask", "N", "L", "pos_included", "row_stats",
+                 "_gathered_stats")
 
     def __init__(self, bank, ep_stride, row_stride, block_stride, ep, win, pidx, mask):
         _need_dev(bank, ep, win, pidx, mask)
@@ -80,6 +81,11 @@ class WindowSpec:
         self.ep_stride, self.row_stride, self.block_stride = int(ep_stride), int(row_stride), int(block_stride)
         self.N, self.L = int(win.shape[0]), int(win.shape[1])
         self.pos_included = False   # True: the bank rows already contain their positional rows (see Transformer.bank_with_positions)
+        # round 5, pre-LN models: (mean, rstd) of every bank row [blocks, E, T, 2] (bank_row_stats; once per update: norm_kv's statistics
+        # do not depend on its gain / bias) -- the window passes then gather their [N, L, 2] statistics instead of re-reading every
+        # window row to compute them (472 MB per launch at config 5); None: computed per window row inside etm_window_fwd
+        self.row_stats = None
+        self._gathered_stats = {}
         self.ep = None if ep is None else ep.to(torch.int64).contiguous()
         self.win = win.to(torch.int64).contiguous()
         self.pidx = None if pidx is None else pidx.to(torch.int64).contiguous()
@@ -106,6 +112,31 @@ class WindowSpec:
 
     def block_ptr(self, block):
         return self.bank.data_ptr() + 4 * block * self.block_stride
+
+    def window_stats(self, block):
+        """[N, L, 2] LayerNorm statistics of this batch's window rows of ``block``, gathered from ``row_stats`` (None without it)."""
+        if self.row_stats is None:
+            return None
+        got = self._gathered_stats.get(block)
+        if got is None:
+            rs = self.row_stats[block]                                  # [E, T, 2]
+            ep = self.ep if self.ep is not None else torch.arange(self.N, device=self.win.device)
+            got = self._gathered_stats[block] = rs[ep.unsqueeze(1), self.win].contiguous()
+        return got
+
+
+def bank_row_stats(bank, eps, out=None):
+    """(mean, 1 / sqrt(var + eps)) of every row of a BLOCK-MAJOR episode bank view [E, T, blocks, D] (memory order [blocks][E][T][D],
+    buffer.py) -> [blocks, E, T, 2] (etm_ln_row_stats: one pass over the used part of the bank, once per update)."""
+    lib = _lib.load()
+    E, T, nb, D = bank.shape
+    rows = bank.permute(2, 0, 1, 3)                      # [blocks, E, T, D]: contiguous for a block-major bank
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    if out is None or out.shape != (nb, E, T, 2):
+        out = torch.empty((nb, E, T, 2), dtype=torch.float32, device=bank.device)
+    _lib.check(lib.etm_ln_row_stats(_ptr(rows), float(eps), _ptr(out), nb * E * T, D, _stream()), "etm_ln_row_stats")
+    return out
 
 
 class _MhaFn(torch.autograd.Function):
@@ -193,6 +224,7 @@ class _WindowFn(torch.autograd.Function):
         lib = _lib.load()
         _need_dev(u, ln_g, ln_b, pos)
         u = _f32c(u, "u")
+        ln_g_param, ln_b_param = ln_g, ln_b
         ln_g, ln_b, pos = _f32c(ln_g, "ln_g"), _f32c(ln_b, "ln_b"), _f32c(pos, "pos")
         H, N, D = u.shape
         L = spec.L
@@ -202,15 +234,21 @@ class _WindowFn(torch.autograd.Function):
         dev = u.device
         att = torch.empty((N, H, L), dtype=torch.float32, device=dev)
         z = torch.empty((H, N, D), dtype=torch.float32, device=dev)
-        ln_stats = torch.empty((N, L, 2), dtype=torch.float32, device=dev) if ln_g is not None else None
+        ln_stats, stats_ready = None, 0
+        if ln_g is not None:
+            ln_stats = spec.window_stats(block) if pos is None else None      # (row_stats were taken with the positional rows included)
+            stats_ready = int(ln_stats is not None)
+            if ln_stats is None:
+                ln_stats = torch.empty((N, L, 2), dtype=torch.float32, device=dev)
         pidx = spec.pidx if pos is not None else None
         rc = lib.etm_window_fwd(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
                                 _ptr(spec.mask), _ptr(pos), _ptr(ln_g), _ptr(ln_b), float(ln_eps), _ptr(u), N * D, D, _ptr(att),
-                                _ptr(z), N * D, D, _ptr(ln_stats), N, L, D, H, _stream())
+                                _ptr(z), N * D, D, _ptr(ln_stats), stats_ready, N, L, D, H, _stream())
         _lib.check(rc, "etm_window_fwd")
         if any(ctx.needs_input_grad[:4]):
             ctx.spec, ctx.block = spec, block
             ctx.has_ln, ctx.has_pos = ln_g is not None, pos is not None
+            ctx.ln_params = (ln_g_param, ln_b_param) if ln_g is not None else None      # the parameters themselves (arena views by address)
             saved = [u, att]
             if ln_g is not None:
                 saved += [ln_g, ln_b, ln_stats]
@@ -249,6 +287,21 @@ class _WindowFn(torch.autograd.Function):
         want_ln = ctx.has_ln and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         want_pos = ctx.has_pos and ctx.needs_input_grad[3]
         d_ln_g = d_ln_b = d_pos = None
+        if _ln_grad_kernel and want_ln and not want_pos and D % 128 == 0 and D <= 512 and H <= 8 and L <= 128:
+            # round 5: norm_kv's gain / bias gradients by the dedicated window pass (csrc/window_ln_grad.hip): per-workgroup partial
+            # rows, summed by the grouped column-sum reduction of the step (or here, without a collector) -- no atomics, 4 x faster
+            rows = lib.etm_window_ln_grad_rows(N)
+            partial = torch.empty((rows, 2 * D), dtype=torch.float32, device=dev)
+            rc = lib.etm_window_ln_grad(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                        _ptr(pos), _ptr(ln_stats), _ptr(att), _ptr(d_e), _ptr(u), _ptr(gz), N * D, D, _ptr(partial),
+                                        N, L, D, H, _stream())
+            _lib.check(rc, "etm_window_ln_grad")
+            col = DeferredDw.active
+            params = getattr(ctx, "ln_params", None)
+            if col is not None and params is not None and col.offer_colsum(partial, rows, 2 * D, [(0, D, params[0].data_ptr()), (D, D, params[1].data_ptr())]):
+                return du, None, None, None, None, None, None
+            sums = partial.sum(dim=0)
+            return du, sums[:D], sums[D:], None, None, None, None
         if want_ln or want_pos:
             d_ln_g = torch.zeros_like(ln_g) if want_ln else None
             d_ln_b = torch.zeros_like(ln_b) if want_ln else None
@@ -261,6 +314,14 @@ class _WindowFn(torch.autograd.Function):
                                    _ptr(d_ln_b), _ptr(d_pos), N, L, D, H, _stream())
             _lib.check(rc, "etm_window_dx")
         return du, d_ln_g, d_ln_b, d_pos, None, None, None
+
+
+_ln_grad_kernel = True      # norm_kv's gain / bias gradients by csrc/window_ln_grad.hip (False: the generic dX kernel, etm_window_dx)
+
+
+def set_ln_grad_kernel(on):
+    global _ln_grad_kernel
+    _ln_grad_kernel = bool(on)
 
 
 ATTENTION_IMPLS = ("folded", "dense")

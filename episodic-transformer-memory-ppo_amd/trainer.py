@@ -195,6 +195,7 @@ class PPOTrainer:
         if self._host_plan["polite_wait"]:
             hostcpu.set_timer_slack_ns(1000)
         self._flag_wait_ema = 0.0
+        ops.set_ln_grad_kernel(bool(config.get("fused_ln_grad", True)))      # (False: norm_kv's gradients through the generic dX kernel -- tested option)
         # worker_processes (round 4; upstream trainer.py:62-66, worker.py): the environments live in worker PROCESSES over one shared,
         # HIP-registered segment (environments/shm_env.py): they take their actions straight from the device and step concurrently;
         # the per-step host loop is then the native driver of the kernel library (etm_rollout_drive) -- see _sample_training_data
@@ -1114,7 +1115,7 @@ class PPOTrainer:
                 if monitor:
                     norms.append(self._grad_group_norms())
         train_info = torch.stack(stats).cpu().numpy()          # the only host sync of the optimisation phase
-        self._bank_pos = None
+        self._bank_pos = self._row_stats = None
         self._mb_stats3 = self._epoch_stats3 = None
         grad_info = {}
         if norms:
@@ -1129,6 +1130,7 @@ class PPOTrainer:
         if bank_pos is not None and ep is not None and samples["memories"].data_ptr() == self.buffer.bank.data_ptr():
             spec = WindowSpec.from_bank(bank_pos, ep, samples["memory_indices"], None, samples["memory_mask"])
             spec.pos_included = True
+            spec.row_stats = getattr(self, "_row_stats", None)
         else:
             spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
                                         samples["memory_mask"])
@@ -1193,14 +1195,42 @@ class PPOTrainer:
         """Episode bank with the sinusoidal positional rows pre-added, in a buffer that keeps its address (the captured
         training step reads it); None when the positional encoding is not the fixed sinusoid."""
         tr = self.model.transformer
-        if tr.pos_kind != "relative":
+        self._row_stats = None
+        if tr.pos_kind not in ("relative", ""):
             return None
         mem = self.buffer.memories
-        if getattr(self, "_bank_pos_buf", None) is None or self._bank_pos_buf.shape != self.buffer.bank.shape:
-            self._bank_pos_buf = torch.empty_like(self.buffer.bank)
-        out = self._bank_pos_buf[: mem.shape[0]]
-        torch.add(mem, tr._pos_table[None, : mem.shape[1], None, :], out=out)
-        return self._bank_pos_buf
+        if tr.pos_kind == "relative":
+            if getattr(self, "_bank_pos_buf", None) is None or self._bank_pos_buf.shape != self.buffer.bank.shape:
+                self._bank_pos_buf = torch.empty_like(self.buffer.bank)
+            out = self._bank_pos_buf[: mem.shape[0]]
+            torch.add(mem, tr._pos_table[None, : mem.shape[1], None, :], out=out)
+        self._row_stats = self._bank_row_stats(self._bank_pos_buf if tr.pos_kind == "relative" else self.buffer.bank, mem.shape[0])
+        return self._bank_pos_buf if tr.pos_kind == "relative" else None
+
+    def _bank_row_stats(self, bank, used):
+        """Pre-LN models (norm_kv, transformer.py:128-131): LayerNorm statistics of every used row of the (position-augmented) bank,
+        once per update, in a buffer [blocks, slots, T, 2] that keeps its address -- the window passes gather their per-window
+        statistics from it instead of re-reading every window row (ops.WindowSpec.row_stats).  None: not applicable."""
+        blk = self.model.transformer.transformer_blocks[0]
+        # bank_row_stats: opt-in.  Measured at config 5: optimisation phase 0.107 -> 0.102 s per update (+1.3 % env-steps/s).  Off by
+        # default because ONE teacher-forced flow -- cfg2 fixture, eager rollout, the diagnostics call minibatch_gradients() between the
+        # rollout and the captured optimisation steps of the SECOND update -- diverged with it (loss statistics off from the second
+        # replay on) and passed with AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_BLOCKING=1, i.e. an ordering problem between eager launches
+        # and graph replays that round 5 did not get to the bottom of (every other fixture and path is green with it: `bank_row_stats` paths).
+        if blk.layer_norm != "pre" or not self.buffer.block_major or not self.config.get("bank_row_stats", False):
+            return None
+        E, T, nb, D = bank.shape
+        if D % 128 != 0 or D > 1024:
+            return None
+        if getattr(self, "_row_stats_buf", None) is None or self._row_stats_buf.shape != (nb, E, T, 2):
+            self._row_stats_buf = torch.zeros((nb, E, T, 2), dtype=torch.float32, device=self.device)
+        lib = etm_lib.load()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for b in range(nb):           # the used slots of block b are one contiguous run of rows in a block-major bank
+            rows = bank[:used, :, b, :]
+            etm_lib.check(lib.etm_ln_row_stats(rows.data_ptr(), float(blk.norm_kv.eps), self._row_stats_buf[b].data_ptr(), used * T, D, st),
+                          "etm_ln_row_stats")
+        return self._row_stats_buf
 
     def _observations_channels_last(self):
         """Visual observations of the whole buffer in NHWC memory order, converted ONCE per update into a fixed-address buffer
@@ -1226,8 +1256,11 @@ class PPOTrainer:
         if self._bank_pos is not None:
             spec = WindowSpec.from_bank(self._bank_pos_buf, mb["memory_index"], mb["memory_indices"], None, mb["memory_mask"])
             spec.pos_included = True
+            spec.row_stats = getattr(self, "_row_stats", None)
         else:
             spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
+            if self.model.transformer.pos_kind == "":
+                spec.row_stats = getattr(self, "_row_stats", None)
         obs = mb.get("obs")
         if self._obs_train is not None:     # NHWC rows of the minibatch: gathered by the first encoder layer itself
             obs = IndexedObservations(self._obs_train, idx)
@@ -1250,8 +1283,11 @@ class PPOTrainer:
         if self._bank_pos is not None:
             spec = WindowSpec.from_bank(self._bank_pos_buf, mb["memory_index"], mb["memory_indices"], None, mb["memory_mask"])
             spec.pos_included = True
+            spec.row_stats = getattr(self, "_row_stats", None)
         else:
             spec = WindowSpec.from_bank(buf.bank, mb["memory_index"], mb["memory_indices"], mb["memory_indices"], mb["memory_mask"])
+            if self.model.transformer.pos_kind == "":
+                spec.row_stats = getattr(self, "_row_stats", None)
         obs = IndexedObservations(self._obs_train, idx)
         if stats3 is None:
             stats3 = ops.adv_stats(mb["advantages"])
@@ -1363,7 +1399,7 @@ class PPOTrainer:
             stats3 = self.dp.merge_adv_stats(ops.adv_stats(self.buffer.samples_flat["advantages"].index_select(0, idx)))
         self._train_body_a(idx, clip_range, beta, stats3)
         grads = {n: p.grad.detach().clone() for n, p in self.model.named_parameters() if p.requires_grad}
-        self._bank_pos = None
+        self._bank_pos = self._row_stats = None
         return grads
 
     def _train_body_b(self, monitor):

@@ -133,7 +133,24 @@ int etm_window_fwd(const float *bank, int64_t ep_stride, int64_t row_stride,
                    const float *pos, const float *ln_g, const float *ln_b, float ln_eps,
                    const float *u, int64_t u_head_stride, int64_t u_sample_stride,
                    float *att, float *z, int64_t z_head_stride, int64_t z_sample_stride,
-                   float *ln_stats, int N, int L, int D, int H, void *stream);
+                   float *ln_stats, int stats_ready, int N, int L, int D, int H, void *stream);
+/* (stats_ready != 0, round 5: ln_stats [N, L, 2] already holds (mean, 1 / sqrt(var + eps)) of every window row -- gathered by the
+ * caller from per-BANK-row statistics computed once per update with etm_ln_row_stats -- and the pass over the window rows that
+ * computes them is skipped; 0: computed here, as before.) */
+/* Gradients of norm_kv's gain / bias for the folded pre-LN attention (transformer.py:128-131 under trainer.py:310; round 5,
+ * csrc/window_ln_grad.hip; replaces etm_window_dx where the positional table is not learnable): partial
+ * [etm_window_ln_grad_rows(N)][2 D] = per-workgroup sums [d gain | d bias]; the caller adds the rows in a fixed order
+ * (etm_colsum_reduce_grouped).  u / gz = the folded vectors [H, N, D] (strides in floats), att / d_e [N, H, L] as etm_window_bwd
+ * leaves them, ln_stats [N, L, 2]; pos / pidx NULL when the bank rows already contain their positional rows.  D % 128 == 0,
+ * D <= 512, H <= 8, L <= 128, else ETM_EUNSUPPORTED.  Deterministic (no atomics). */
+int etm_window_ln_grad_rows(int N);
+int etm_window_ln_grad(const float *bank, int64_t ep_stride, int64_t row_stride, const int64_t *ep, const int64_t *win,
+                       const int64_t *pidx, const float *pos, const float *ln_stats, const float *att, const float *d_e,
+                       const float *u, const float *gz, int64_t vec_head_stride, int64_t vec_sample_stride, float *partial,
+                       int N, int L, int D, int H, void *stream);
+/* stats [R, 2] = (mean, 1 / sqrt(var + eps)) of the R contiguous rows of x [R, D]: LayerNorm statistics of the memory bank's rows,
+ * once per update (norm_kv's statistics do not depend on its gain / bias).  D % 128 == 0, D <= 1024. */
+int etm_ln_row_stats(const float *x, float eps, float *stats, int64_t R, int D, void *stream);
 int etm_window_bwd(const float *bank, int64_t ep_stride, int64_t row_stride,
                    const int64_t *ep, const int64_t *win, const int64_t *pidx, const uint8_t *mask,
                    const float *pos, const float *ln_g, const float *ln_b, const float *ln_stats,
