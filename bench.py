@@ -92,7 +92,7 @@ def pmc_traffic(kernel):
     symbol = PMC_SYMBOL.get(kernel, kernel)
     try:
         doc = path = None
-        for cand in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel
+        for cand in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel
             path = os.path.join(REPO, "profiles", cand)
             if not os.path.exists(path):
                 continue

@@ -3,7 +3,7 @@
 #   [SUITE=1] bash tools/collect_evidence.sh r03 [pmc targets...]      (SUITE=1: the GPU test suite first, its summary line -> gpu_suite.txt)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${1:-r03}; shift
+ROUND=${1:-r05}; shift
 TARGETS=${@:-encoder grouped_dw rollout_step window_sorted}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
