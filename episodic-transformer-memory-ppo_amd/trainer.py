@@ -1215,8 +1215,12 @@ class PPOTrainer:
         # bank_row_stats: opt-in.  Measured at config 5: optimisation phase 0.107 -> 0.102 s per update (+1.3 % env-steps/s).  Off by
         # default because ONE teacher-forced flow -- cfg2 fixture, eager rollout, the diagnostics call minibatch_gradients() between the
         # rollout and the captured optimisation steps of the SECOND update -- diverged with it (loss statistics off from the second
-        # replay on) and passed with AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_BLOCKING=1, i.e. an ordering problem between eager launches
-        # and graph replays that round 5 did not get to the bottom of (every other fixture and path is green with it: `bank_row_stats` paths).
+        # replay on).  What round 5 established: it needs eager rollouts AND this option AND the fused norm_kv gradient pass AND the
+        # test's host-side reads around the call (holding the returned gradient clones, reading the state dict after the first update);
+        # it passes with AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_BLOCKING=1, without the grouped column-sum offer as well as with it, and in
+        # a script that replays the same trainer calls without those reads -- i.e. it depends on the caching allocator's state, which
+        # points at a buffer of the captured step that is not owned by the graph's pool; not found (every other fixture and path is
+        # green with the option: `bank_row_stats` paths of the teacher-forced test).
         if blk.layer_norm != "pre" or not self.buffer.block_major or not self.config.get("bank_row_stats", False):
             return None
         E, T, nb, D = bank.shape
