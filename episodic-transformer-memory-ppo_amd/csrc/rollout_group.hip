@@ -45,11 +45,12 @@ struct Grp {
 };
 __device__ __forceinline__ float *rg_piece(const Grp &t, int ex, int wg) { return t.slots + ((long long)ex * RG_WG + wg) * (2 * RG_PIECE); }
 
-// n payload floats (LDS, n even) -> my piece of exchange ex
-__device__ __forceinline__ void rg_publish(const Grp &t, int ex, const float *src, int n) {
-  float *dst = rg_piece(t, ex, t.me);
-  const float tagf = __int_as_float(t.base + ex + 1);
-  for (int i = threadIdx.x; 2 * i < n; i += RF_T) packet_store(dst + 4 * i, tagf, src[2 * i], src[2 * i + 1]);
+// Publish: thread t < n holds payload float t (n even) of my piece of exchange ex; even threads take their neighbour's value by a lane shift and
+// store the packet -- no staging in LDS, no barrier between the epilogue and the publish.  Call from all threads.
+__device__ __forceinline__ void rg_publish_reg(const Grp &t, int ex, float v, int n) {
+  const float nxt = __shfl_down(v, 1, 64);
+  const int tid = threadIdx.x;
+  if (tid < n && !(tid & 1)) packet_store(rg_piece(t, ex, t.me) + 2 * tid, __int_as_float(t.base + ex + 1), v, nxt);
 }
 
 // NP packets per thread requested TOGETHER (one round trip per polling pass, not NP)
@@ -176,7 +177,6 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   __shared__ long long off_s[128];
   __shared__ long long ss_s[2];
   __shared__ unsigned char mask_s[128];
-  __shared__ float pub_s[2 * RG_PIECE];
   __shared__ float h2_s[RG_G * 48];
   __shared__ float out_s[RG_G * 16];
   __shared__ int dead_s;
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   // ---- transformer input.  lin_hidden as partial rows (h_splits > 0): unit (g, h) adds worker g's columns of head h in slice order
   // (+ bias, ReLU: model.py:97) and the units' pieces are gathered; else every workgroup reads the [W, D] input itself.
   if (p.h_splits > 0) {
+    float xin0 = 0.f;
     if (unit && tid < hd) {
       float part[RF_MAXSPLIT];
 #pragma unroll
@@ -253,10 +254,9 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       float v = 0.f;
 #pragma unroll
       for (int s = 0; s < RF_MAXSPLIT; ++s) v += part[s];
-      pub_s[tid] = fmaxf(v + p.h_bias[d0 + tid], 0.f);
+      xin0 = fmaxf(v + p.h_bias[d0 + tid], 0.f);
     }
-    rf_sync();
-    if (unit) rg_publish(grp, ex, pub_s, hd);
+    if (unit) rg_publish_reg(grp, ex, xin0, hd);
     {
       const int ppp = hd >> 1;
       rg_collect<NPK>(grp, ex, W * H * ppp,
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   af_load<KM>(af, A_s, Dp);
   chunk_mfma<KM>(af, wfA[0], part_s, 0);
   rf_sync();
-  if (eact) pub_s[tid] = fmaxf(chunk_sum(part_s, 0, eg, ec) + bemb_r, 0.f);
+  rg_publish_reg(grp, ex, eact ? fmaxf(chunk_sum(part_s, 0, eg, ec) + bemb_r, 0.f) : 0.f, RG_G * CB);      // (published from registers, before the
+  // next slices are requested: the pieces leave first)
   // the first block's slices: A = [q, Ur, Uz] (the gate's maps of x read the block input), B = [fc_out]
   my = p.blk[0].wq_t + (long long)wg * cblk;
   wf_issue<KM>(wfA[0], my, D, CB);
@@ -288,8 +289,6 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   wf_issue<KM>(wfA[1], my, D, CB);
   wf_issue<KM>(wfA[2], my + cblk, D, CB);
   wf_issue<KM>(wfB[0], p.blk[0].wo_t + (long long)wg * cblk, D, CB);
-  rf_sync();
-  rg_publish(grp, ex, pub_s, RG_G * CB);
   auto gather_cols = [&](float *dst_s) {                            // every workgroup's [8][CB] piece -> dst_s [8][Dp]
     const int ppp = 4 * CB;
     rg_collect<NPK>(grp, ex, RG_WG * ppp,
@@ -396,13 +395,13 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
     }
     rf_sync();
     float br = 0.f, bz = 0.f;
-    if (eact) { pub_s[tid] = chunk_sum(part_s, 0, eg, ec); br = chunk_sum(part_s, 1, eg, ec); bz = chunk_sum(part_s, 2, eg, ec); }
+    float pv = 0.f;
+    if (eact) { pv = chunk_sum(part_s, 0, eg, ec); br = chunk_sum(part_s, 1, eg, ec); bz = chunk_sum(part_s, 2, eg, ec); }
+    rg_publish_reg(grp, ex, pv, RG_G * CB);
     my = B.gate1.wy + (long long)wg * 3 * cblk;
     wf_issue<KM>(wfA[0], my, D, CB);
     wf_issue<KM>(wfA[1], my + cblk, D, CB);
     wf_issue<KM>(wfA[2], my + 2 * cblk, D, CB);
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     // ---- E1 (scatter): unit (g, h) takes row g of the pieces that hold its head's columns
     if (unit) {
       const int ppr = CB >> 1, per_head = hd / CB, first = d0 / CB;           // packets per piece row, pieces per head
@@ -463,14 +462,11 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
         }
         if (vg < vgroups) *reinterpret_cast<f32x4 *>(&part_s[vg * hd + vc4 * 4]) = acc;
         rf_sync();
-        if (tid < hd) {
-          float sacc = 0.f;
+        float sacc = 0.f;
+        if (tid < hd)
           for (int gg = 0; gg < vgroups; ++gg) sacc += part_s[gg * hd + tid];
-          pub_s[tid] = sacc;
-        }
-        rf_sync();
+        rg_publish_reg(grp, ex, sacc, hd);
       }
-      rg_publish(grp, ex, pub_s, hd);
     }
     // ---- E2: the units' context columns -> R_s (full rows)
     {
@@ -485,10 +481,8 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
     af_load<KM>(af, R_s, Dp);
     chunk_mfma<KM>(af, wfB[0], part_s, 0);
     rf_sync();
-    if (eact) pub_s[tid] = chunk_sum(part_s, 0, eg, ec) + bo_r;
+    rg_publish_reg(grp, ex, eact ? chunk_sum(part_s, 0, eg, ec) + bo_r : 0.f, RG_G * CB);
     wf_issue<KM>(wfB[0], B.gate1.ugx + (long long)wg * cblk, D, CB);
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     gather_cols(A_s);                                                // E3
     // ---- P3: gate 1, maps of y = a: r = sigmoid(Wr y + Ur x), z = sigmoid(Wz y + Uz x - bg) (transformer.py:294-295); publish r * x
     af_load<KM>(af, A_s, Dp);
@@ -503,14 +497,13 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       xm = X_s[eg * Dp + ecol];
       const float r = sigmoidf_(ar + br);
       zz = sigmoidf_(az + bz - bg1_r);
-      pub_s[tid] = r * xm;
+      pv = r * xm;
     }
+    rg_publish_reg(grp, ex, pv, RG_G * CB);
     my = B.gate2.ux + (long long)wg * 2 * cblk;
     wf_issue<KM>(wfA[0], my, D, CB);
     wf_issue<KM>(wfA[1], my + cblk, D, CB);
     wf_issue<KM>(wfA[2], B.wfc_t + (long long)wg * cblk, D, CB);
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     gather_cols(R_s);                                                // E4
     // ---- P4: h1 = (1 - z) x + z tanh(Wg y + Ug (r x)) (transformer.py:296-297)
     af_load<KM>(af, R_s, Dp);
@@ -518,11 +511,10 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
     rf_sync();
     if (eact) {
       const float hh = tanhf(ag + chunk_sum(part_s, 0, eg, ec));
-      pub_s[tid] = (1.0f - zz) * xm + zz * hh;
+      pv = (1.0f - zz) * xm + zz * hh;
     }
+    rg_publish_reg(grp, ex, pv, RG_G * CB);
     wf_issue<KM>(wfB[0], B.gate2.ugx + (long long)wg * cblk, D, CB);
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     gather_cols(H1_s);                                               // E5
     if (!p.pre_ln) {                                                 // post-LN: norm1 of the gate's output (transformer.py:143-149)
       ln_rows<NC>(H1_s, N_s, D, Dp, p.eps, g1s, b1s);
@@ -546,14 +538,13 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
     if (eact) {
       br = chunk_sum(part_s, 0, eg, ec);
       bz = chunk_sum(part_s, 1, eg, ec);
-      pub_s[tid] = fmaxf(chunk_sum(part_s, 2, eg, ec) + bfc_r, 0.f);
+      pv = fmaxf(chunk_sum(part_s, 2, eg, ec) + bfc_r, 0.f);
     }
+    rg_publish_reg(grp, ex, pv, RG_G * CB);
     my = B.gate2.wy + (long long)wg * 3 * cblk;
     wf_issue<KM>(wfA[0], my, D, CB);
     wf_issue<KM>(wfA[1], my + cblk, D, CB);
     wf_issue<KM>(wfA[2], my + 2 * cblk, D, CB);
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     gather_cols(A_s);                                                // E6
     // ---- P6: gate 2, maps of y = f; publish r * h1
     af_load<KM>(af, A_s, Dp);
@@ -567,8 +558,9 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       xm = H1_s[eg * Dp + ecol];
       const float r = sigmoidf_(ar + br);
       zz = sigmoidf_(az + bz - bg2_r);
-      pub_s[tid] = r * xm;
+      pv = r * xm;
     }
+    rg_publish_reg(grp, ex, pv, RG_G * CB);
     if (!last) {                                                     // the next block's [q, Ur, Uz]
       my = p.blk[b + 1].wq_t + (long long)wg * cblk;
       wf_issue<KM>(wfA[0], my, D, CB);
@@ -576,8 +568,6 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       wf_issue<KM>(wfA[1], my, D, CB);
       wf_issue<KM>(wfA[2], my + cblk, D, CB);
     }
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     gather_cols(R_s);                                                // E7
     // ---- P7: out = gate2(h1, f)
     af_load<KM>(af, R_s, Dp);
@@ -585,11 +575,10 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
     rf_sync();
     if (eact) {
       const float hh = tanhf(ag + chunk_sum(part_s, 0, eg, ec));
-      pub_s[tid] = (1.0f - zz) * xm + zz * hh;
+      pv = (1.0f - zz) * xm + zz * hh;
     }
+    rg_publish_reg(grp, ex, pv, RG_G * CB);
     if (!last) wf_issue<KM>(wfB[0], p.blk[b + 1].wo_t + (long long)wg * cblk, D, CB);
-    rf_sync();
-    rg_publish(grp, ex, pub_s, RG_G * CB);
     gather_cols(X_s);                                                // E8
     if (!p.pre_ln) {                                                 // post-LN: norm2 of the block's output (transformer.py:164-170)
       ln_rows<NC>(X_s, N_s, D, Dp, p.eps, g2s, b2s);
@@ -618,6 +607,7 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   }
   rf_sync();
   const int AO = A + 1, npub = RG_G * AO + ((RG_G * AO) & 1);
+  float hv_pub = 0.f;
   if (tid < npub) {
     float s = 0.f;
     if (tid < RG_G * AO) {
@@ -628,10 +618,9 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
         else if (col >= p.hid) s += h2_s[gg * 48 + cc] * p.wv[col - p.hid];
       }
     }
-    pub_s[tid] = s;
+    hv_pub = s;
   }
-  rf_sync();
-  rg_publish(grp, ex, pub_s, npub);
+  rg_publish_reg(grp, ex, hv_pub, npub);
   if (wg == 0) {
     const int ppp = npub >> 1;
     rg_collect<4>(grp, ex, RG_WG * ppp,
