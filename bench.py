@@ -48,9 +48,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 HBM_PEAK_GBS = 8000.0
 
 
+CONFIG_NAME = "synthetic_minigrid"      # --config: another YAML of configs/ (synthetic_mortar_gtrxl = BASELINE config 5's shape, synthetic_cartpole = config 2's)
+
+
 def load_config():
     from yaml_parser import YamlParser
-    return YamlParser(os.path.join(PKG, "configs", "synthetic_minigrid.yaml")).get_config()
+    return YamlParser(os.path.join(PKG, "configs", CONFIG_NAME + ".yaml")).get_config()
 
 
 def kernel_work(name, N, L, D, H):
@@ -92,7 +95,8 @@ def pmc_traffic(kernel):
     symbol = PMC_SYMBOL.get(kernel, kernel)
     try:
         doc = path = None
-        for cand in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel
+        for cand in (os.path.join("r05", "pmc_rollout_step_config5.json"), "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
+                     "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel (the group step kernel: its own config-5 passes)
             path = os.path.join(REPO, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -202,12 +206,17 @@ def main():
                     help="environments in worker processes over shared memory + the native rollout driver (config: what the YAML says)")
     ap.add_argument("--envs-per-process", type=int, default=None, help="environments per worker process (with worker processes)")
     ap.add_argument("--rollout-groups", default=None, help="override rollout_groups (auto, 1, 2, 4, 8)")
+    ap.add_argument("--config", default="synthetic_minigrid",
+                    help="YAML of configs/ to time (default: BASELINE config 3 = the driver's line; synthetic_mortar_gtrxl / synthetic_cartpole: the "
+                         "shapes of BASELINE configs 5 / 2 -- gated pre-LN blocks, the group form of the rollout step kernel)")
     ap.add_argument("--env-pool", type=int, default=None,
                     help="frames per worker in the synthetic environment's ring (default: the YAML's, 64); 0 = SURVEY 8d to the letter: every "
                          "observation is a fresh default_rng(seed + worker).random([3, 84, 84]) draw inside the timed region")
     ap.add_argument("--gen-threads", type=int, default=None,
                     help="with --env-pool 0 and in-process environments: host threads that draw a step's observations (numpy releases the GIL)")
     args = ap.parse_args()
+    global CONFIG_NAME
+    CONFIG_NAME = args.config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -414,7 +423,17 @@ def main():
                                 "K | V window columns, served by L2 / the Infinity Cache (unique bytes: model.unique_weight_bytes); "
                                 "timed eagerly after the timed region (graph replays take no per-kernel events).  The dominant kernel of "
                                 "the optimisation phase is in roofline_train."}
-            tr_pmc = pmc_traffic("rollout_trxl_kernel")
+            grouped = bool(getattr(trainer._groups[0], "group_kernel", False))
+            if grouped:
+                roofline["kernel"] = "rollout_group_kernel"
+                roofline["note"] = ("dominant kernel of ALL GPU time: the GROUP form of the rollout step kernel (csrc/rollout_group.hip, gated layouts): the "
+                                    "workers of a group are the rows of every product, 32 workgroups own its columns, every matrix is read once per group "
+                                    "and step; bytes_per_launch = every matrix of the chain once + per worker the tail's K | V projection and the K | V "
+                                    "window columns.  A dependency chain (82 phases at config 5: products -> all-gather of tagged packets -> ...), bound by "
+                                    "the exchange latency, not by a roofline; timed eagerly after the timed region.")
+            # (PMC passes exist for the config-3 step kernel and for the group kernel at config 5's shape only)
+            tr_pmc = (pmc_traffic("rollout_group_kernel") if CONFIG_NAME == "synthetic_mortar_gtrxl" else None) if grouped else \
+                (pmc_traffic("rollout_trxl_kernel") if CONFIG_NAME == "synthetic_minigrid" else None)
             if tr_pmc:
                 roofline["traffic"], roofline["traffic_source"] = tr_pmc["bytes_per_launch"], tr_pmc["source"]
                 roofline["hbm_side_frac"] = tr_pmc["bytes_per_launch"] / (rs["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -459,9 +478,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config (3)/(4): configs/synthetic_minigrid.yaml -- per GPU n_workers=32 x worker_steps=512 "
-                                   "= 16384 env steps per update, 5 epochs x 8 minibatches of 2048, TrXL 3 blocks D=384 H=4 L=64, "
-                                   "synthetic 3x84x84 observations: "
+            "config": {"workload": (("BASELINE config (3)/(4)" if CONFIG_NAME == "synthetic_minigrid" else
+                                     "shape of BASELINE config (5)" if CONFIG_NAME == "synthetic_mortar_gtrxl" else
+                                     "shape of BASELINE config (2)" if CONFIG_NAME == "synthetic_cartpole" else "config")
+                                    + f": configs/{CONFIG_NAME}.yaml -- per GPU n_workers={W} x worker_steps={S} "
+                                    f"= {W * S} env steps per update, {cfg['epochs']} epochs x {cfg['n_mini_batch']} minibatches of {N}, "
+                                    f"{'GTrXL' if cfg['transformer'].get('gtrxl') else 'TrXL'} ({cfg['transformer'].get('layer_norm') or 'no'}-LN) "
+                                    f"{cfg['transformer']['num_blocks']} blocks D={cfg['transformer']['embed_dim']} H={cfg['transformer']['num_heads']} "
+                                    f"L={cfg['transformer']['memory_length']}, synthetic {'x'.join(str(x) for x in cfg['environment']['obs_shape'])} observations: ")
                                    + ("every observation is a FRESH default_rng(seed + worker id).random([3, 84, 84]) float32 draw inside the timed "
                                       "region (SURVEY 8d to the letter)" if cfg["environment"].get("pool", 64) == 0 else
                                       f"every worker replays a ring of {cfg['environment'].get('pool', 64)} frames drawn once from U[0,1) "
