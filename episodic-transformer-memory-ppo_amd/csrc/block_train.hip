@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
 // Several column-sum reductions in one launch (the second stage of every LayerNorm / bias gradient of a backward pass, deferred to
 // its end): problem i adds the P[i] rows of `partial[i]` (row stride ld[i] floats) over C[i] columns into out[i]; same summation
 // tree as colsum_reduce_kernel, so the results are bit-identical to the per-call reductions.
-constexpr int CS_MAX = 24;
+constexpr int CS_MAX = 64;
 struct ColsumGroup {
   const float *partial[CS_MAX];
   float *out[CS_MAX];

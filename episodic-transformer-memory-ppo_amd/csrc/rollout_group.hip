@@ -21,12 +21,14 @@
 //     no cache byte is written by one workgroup and read by another within a launch, and the bank / staging / window rows of worker
 //     g are written by workgroup (g, 0);
 //   * workgroup 0 samples all workers of the group and hands the actions over.
-// Per gated block: 9 product phases and 8 exchanges (q scatter, ctx, a, r.x, h1, f, r.x, out) where the per-worker form has 15 products
+// Per gated block: 8 product phases and 7 exchanges (q scatter, ctx, r.x, h1, f, r.x, out) where the per-worker form has 15 products
 // and 6 exchanges -- the products are now small (latency of one L2 round trip, requested ahead), the exchanges are what is left.
-// Only summation order differs from the other rollout paths.
+// fc_out is folded into the first gate's maps of y (W (Wo ctx + bo) = (W Wo) ctx + W bo; the caller folds in float64 once per update):
+// apart from that association only summation order differs from the other rollout paths.
 //
 // Matrix layouts the caller packs for THIS kernel (etm_rollout_trxl_group; etm/model.py keeps them next to the per-worker ones):
-// every [in = D, out] map transposed and column-blocked [32][D][CB]; gate maps of y as [32][3][D][CB] (Wr, Wz, Wg), of x as
+// every [in = D, out] map transposed and column-blocked [32][D][CB]; gate maps of y as [32][3][D][CB] (Wr, Wz, Wg; the FIRST gate's folded
+// with fc_out -- (Wo^T W^T) column-blocked -- and followed by the three bias rows [3][D] = W bo; wo_t / bo are not read), of x as
 // [32][2][D][CB] (Ur, Uz); hidden heads [32][NCH][D][CH] with NCH * CH = 2 hid / 32 (CH <= 16); wkv per block and HEAD [nb][H][D][2 hd]
 // = [the head's K columns | the head's V columns] (what the per-worker kernel calls member-blocked, with P = H).
 #include "rollout_shared.h"
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   my = p.blk[0].gate1.ux + (long long)wg * 2 * cblk;
   wf_issue<KM>(wfA[1], my, D, CB);
   wf_issue<KM>(wfA[2], my + cblk, D, CB);
-  wf_issue<KM>(wfB[0], p.blk[0].wo_t + (long long)wg * cblk, D, CB);
+  wf_issue<KM>(wfB[0], p.blk[0].gate1.ugx + (long long)wg * cblk, D, CB);
   auto gather_cols = [&](float *dst_s) {                            // every workgroup's [8][CB] piece -> dst_s [8][Dp]
     const int ppp = 4 * CB;
     rg_collect<NPK>(grp, ex, RG_WG * ppp,
@@ -357,8 +359,12 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       if (tid < D) items_s[b * D + tid] = X_s[g * Dp + tid];
     }
     const float *g1s = ln_s + (b * 4 + 0) * D, *b1s = g1s + D, *g2s = b1s + D, *b2s = g2s + D;    // this block's LayerNorm gains / biases
-    float bo_r = 0.f, bfc_r = 0.f, bg1_r = 0.f, bg2_r = 0.f;
-    if (eact) { bo_r = B.bo[ecol]; bfc_r = B.bfc[ecol]; bg1_r = B.gate1.bg[ecol]; bg2_r = B.gate2.bg[ecol]; }
+    float bfc_r = 0.f, bg1_r = 0.f, bg2_r = 0.f, fb_r = 0.f, fb_z = 0.f, fb_g = 0.f;
+    if (eact) {
+      bfc_r = B.bfc[ecol]; bg1_r = B.gate1.bg[ecol]; bg2_r = B.gate2.bg[ecol];
+      const float *fb = B.gate1.wy + 3LL * D * D;                    // [3][D] = Wr bo, Wz bo, Wg bo behind the folded maps
+      fb_r = fb[ecol]; fb_z = fb[D + ecol]; fb_g = fb[2 * D + ecol];
+    }
     // ---- P1: q = Wq (pre-LN: norm1(h)) and the first gate's maps of x = h
     const float *qsrc = X_s;
     if (p.pre_ln) {
@@ -477,23 +483,19 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       ++ex;
       rf_sync();
     }
-    // ---- P2: a = Wo ctx + bo (transformer.py:83), my columns
+    // ---- P3: gate 1, maps of y = a = Wo ctx + bo (transformer.py:83): r = sigmoid(Wr y + Ur x), z = sigmoid(Wz y + Uz x - bg)
+    // (transformer.py:294-295).  The first gate's maps of y arrive FOLDED with fc_out -- W a = (W Wo) ctx + W bo, folded in float64 once per
+    // update by the caller (etm/model.py) -- so the attention output is never assembled: one product and one all-gather fewer per block
+    // (a is read by nothing else).  Publish r * x.
     af_load<KM>(af, R_s, Dp);
-    chunk_mfma<KM>(af, wfB[0], part_s, 0);
-    rf_sync();
-    rg_publish_reg(grp, ex, eact ? chunk_sum(part_s, 0, eg, ec) + bo_r : 0.f, RG_G * CB);
-    wf_issue<KM>(wfB[0], B.gate1.ugx + (long long)wg * cblk, D, CB);
-    gather_cols(A_s);                                                // E3
-    // ---- P3: gate 1, maps of y = a: r = sigmoid(Wr y + Ur x), z = sigmoid(Wz y + Uz x - bg) (transformer.py:294-295); publish r * x
-    af_load<KM>(af, A_s, Dp);
     chunk_mfma<KM>(af, wfA[0], part_s, 0);
     chunk_mfma<KM>(af, wfA[1], part_s, 1);
     chunk_mfma<KM>(af, wfA[2], part_s, 2);
     rf_sync();
     float zz = 0.f, ag = 0.f, xm = 0.f;
     if (eact) {
-      const float ar = chunk_sum(part_s, 0, eg, ec), az = chunk_sum(part_s, 1, eg, ec);
-      ag = chunk_sum(part_s, 2, eg, ec);
+      const float ar = chunk_sum(part_s, 0, eg, ec) + fb_r, az = chunk_sum(part_s, 1, eg, ec) + fb_z;
+      ag = chunk_sum(part_s, 2, eg, ec) + fb_g;
       xm = X_s[eg * Dp + ecol];
       const float r = sigmoidf_(ar + br);
       zz = sigmoidf_(az + bz - bg1_r);
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
       pv = (1.0f - zz) * xm + zz * hh;
     }
     rg_publish_reg(grp, ex, pv, RG_G * CB);
-    if (!last) wf_issue<KM>(wfB[0], p.blk[b + 1].wo_t + (long long)wg * cblk, D, CB);
+    if (!last) wf_issue<KM>(wfB[0], p.blk[b + 1].gate1.ugx + (long long)wg * cblk, D, CB);
     gather_cols(X_s);                                                // E8
     if (!p.pre_ln) {                                                 // post-LN: norm2 of the block's output (transformer.py:164-170)
       ln_rows<NC>(X_s, N_s, D, Dp, p.eps, g2s, b2s);
@@ -732,7 +734,7 @@ extern "C" int etm_rollout_trxl_group_supported(int D, int H, int L, int hid, in
 extern "C" int etm_rollout_trxl_group_grid(void) { return RG_WG; }
 extern "C" int64_t etm_rollout_trxl_group_scratch_bytes(int nb) {
   if (nb <= 0) return 0;
-  const int64_t n_ex = 8 * (int64_t)nb + 4;                          // exchanges per launch: 8 per gated block + input, embedding, heads
+  const int64_t n_ex = 7 * (int64_t)nb + 4;                          // exchanges per launch: 7 per gated block + input, embedding, heads
   return 64 + n_ex * RG_WG * 2 * RG_PIECE * (int64_t)sizeof(float);
 }
 

@@ -289,7 +289,9 @@ class _WindowFn(torch.autograd.Function):
         d_ln_g = d_ln_b = d_pos = None
         if _ln_grad_kernel and want_ln and not want_pos and D % 128 == 0 and D <= 512 and H <= 8 and L <= 128:
             # round 5: norm_kv's gain / bias gradients by the dedicated window pass (csrc/window_ln_grad.hip): per-workgroup partial
-            # rows, summed by the grouped column-sum reduction of the step (or here, without a collector) -- no atomics, 4 x faster
+            # rows, summed by the grouped column-sum reduction of the step, or -- without a collector / once it is full -- by the
+            # same kernel launched here.  NOT by torch's column sum: its two-stage reduction (a memset node for its semaphore + the
+            # reduce kernel) returns wrong sums in some replays of a captured graph on this runtime (profiles/r05/graph_reduce_hazard.txt).
             rows = lib.etm_window_ln_grad_rows(N)
             partial = torch.empty((rows, 2 * D), dtype=torch.float32, device=dev)
             rc = lib.etm_window_ln_grad(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
@@ -300,7 +302,7 @@ class _WindowFn(torch.autograd.Function):
             params = getattr(ctx, "ln_params", None)
             if col is not None and params is not None and col.offer_colsum(partial, rows, 2 * D, [(0, D, params[0].data_ptr()), (D, D, params[1].data_ptr())]):
                 return du, None, None, None, None, None, None
-            sums = partial.sum(dim=0)
+            sums = colsum_rows(partial, rows, 2 * D)
             return du, sums[:D], sums[D:], None, None, None, None
         if want_ln or want_pos:
             d_ln_g = torch.zeros_like(ln_g) if want_ln else None
@@ -314,6 +316,18 @@ class _WindowFn(torch.autograd.Function):
                                    _ptr(d_ln_b), _ptr(d_pos), N, L, D, H, _stream())
             _lib.check(rc, "etm_window_dx")
         return du, d_ln_g, d_ln_b, d_pos, None, None, None
+
+
+def colsum_rows(partial, P, C):
+    """Column sums of the first ``C`` columns of ``partial`` [P, ld] by the library's fixed-order reduction (the summation tree of the
+    grouped launch a ``DeferredDw`` collector would have used: same bits with and without a collector)."""
+    import ctypes
+    out = torch.empty(C, dtype=torch.float32, device=partial.device)
+    one = lambda t, v: (t * 1)(v)
+    _lib.check(_lib.load().etm_colsum_reduce_grouped(one(ctypes.c_void_p, _ptr(partial)), one(ctypes.c_int32, P), one(ctypes.c_int32, C),
+                                                     one(ctypes.c_int32, partial.stride(0)), one(ctypes.c_void_p, _ptr(out)), 1, _stream()),
+               "etm_colsum_reduce_grouped")
+    return out
 
 
 _ln_grad_kernel = True      # norm_kv's gain / bias gradients by csrc/window_ln_grad.hip (False: the generic dX kernel, etm_window_dx)

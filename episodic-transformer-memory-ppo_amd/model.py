@@ -232,8 +232,18 @@ class ActorCriticModel(nn.Module):
                 fresh[f"wq_t{i}"] = colblock(blk.attention.queries.weight.t())
                 fresh[f"wo_t{i}"] = colblock(blk.attention.fc_out.weight.t())
                 fresh[f"wfc_t{i}"] = colblock(blk.fc[0].weight.t())
+                # the first gate's maps of y read a = fc_out(ctx) and nothing else does: W a = (W Wo) ctx + W bo.  Folded here, in
+                # float64, once per refresh; the kernel multiplies the context rows with the folded maps and adds the folded bias rows
+                # (one product and one all-gather fewer per block)
+                wo64, bo64 = blk.attention.fc_out.weight.double(), blk.attention.fc_out.bias.double()
                 for gi, gate in ((1, blk.gate1), (2, blk.gate2)):
-                    fresh[f"g{gi}wy_t{i}"] = torch.stack([colblock(getattr(gate, n).weight.t()) for n in ("Wr", "Wz", "Wg")], dim=1)
+                    maps = [getattr(gate, n).weight for n in ("Wr", "Wz", "Wg")]
+                    if gi == 1:
+                        folded = torch.stack([colblock((m.double() @ wo64).float().t()) for m in maps], dim=1)          # [32][3][D][CB]
+                        bias = torch.stack([(m.double() @ bo64).float() for m in maps])                               # [3][D]
+                        fresh[f"g{gi}wy_t{i}"] = torch.cat((folded.reshape(-1), bias.reshape(-1)))
+                    else:
+                        fresh[f"g{gi}wy_t{i}"] = torch.stack([colblock(m.t()) for m in maps], dim=1)
                     fresh[f"g{gi}ux_t{i}"] = torch.stack([colblock(getattr(gate, n).weight.t()) for n in ("Ur", "Uz")], dim=1)
                     fresh[f"g{gi}ug_t{i}"] = colblock(gate.Ug.weight.t())
             rg = getattr(self, "_rfg", None)

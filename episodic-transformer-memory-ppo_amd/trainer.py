@@ -1212,16 +1212,11 @@ class PPOTrainer:
         once per update, in a buffer [blocks, slots, T, 2] that keeps its address -- the window passes gather their per-window
         statistics from it instead of re-reading every window row (ops.WindowSpec.row_stats).  None: not applicable."""
         blk = self.model.transformer.transformer_blocks[0]
-        # bank_row_stats: opt-in.  Measured at config 5: optimisation phase 0.107 -> 0.102 s per update (+1.3 % env-steps/s).  Off by
-        # default because ONE teacher-forced flow -- cfg2 fixture, eager rollout, the diagnostics call minibatch_gradients() between the
-        # rollout and the captured optimisation steps of the SECOND update -- diverged with it (loss statistics off from the second
-        # replay on).  What round 5 established: it needs eager rollouts AND this option AND the fused norm_kv gradient pass AND the
-        # test's host-side reads around the call (holding the returned gradient clones, reading the state dict after the first update);
-        # it passes with AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_BLOCKING=1, without the grouped column-sum offer as well as with it, and in
-        # a script that replays the same trainer calls without those reads -- i.e. it depends on the caching allocator's state, which
-        # points at a buffer of the captured step that is not owned by the graph's pool; not found (every other fixture and path is
-        # green with the option: `bank_row_stats` paths of the teacher-forced test).
-        if blk.layer_norm != "pre" or not self.buffer.block_major or not self.config.get("bank_row_stats", False):
+        # bank_row_stats (default on; False: every window pass computes the statistics of its own rows).  Measured at config 5:
+        # optimisation phase 0.107 -> 0.102 s per update.  (It was opt-in for part of round 5: one teacher-forced flow diverged with it.
+        # The cause was elsewhere -- torch's column sum in the norm_kv gradient pass's fallback inside the captured step,
+        # profiles/r05/graph_reduce_hazard.txt; this option merely changed the graph enough to expose it.)
+        if blk.layer_norm != "pre" or not self.buffer.block_major or not self.config.get("bank_row_stats", True):
             return None
         E, T, nb, D = bank.shape
         if D % 128 != 0 or D > 1024:

@@ -1,0 +1,65 @@
+"""A column sum inside a captured HIP graph, replayed 2,000 times: torch's own reduction against the library's (round 5).
+
+Why this exists: the optimisation step is one captured graph (trainer.py:_train_step_graph).  Its only torch reduction -- the
+fallback `partial.sum(dim=0)` of the norm_kv gradient pass when the grouped column-sum launch was full -- produced garbage
+gradients for ONE tensor in SOME replays (cfg2 teacher-forced fixture, second update), depending on the node count of the graph and
+on the caching allocator's state at capture time.  torch sums a tall [rows, C] matrix in two stages: a 4-byte memset of a semaphore
+(a MEMSET node in the graph) and a reduce kernel whose last-arriving workgroup adds the staged partial sums.  This script holds
+nothing of the framework: a [1024, 256] matrix is refilled from one of 64 random sources, summed over its rows inside a captured
+graph (between two matrix products), and every replay is compared with a float64 sum.  On ROCm 7.2 / gfx950 with the runtime's
+default AQL packet capture, a large share of the replays returns wrong sums; with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 none does, and
+the library's fixed-order reduction (etm_colsum_reduce_grouped: no semaphore, no memset node) is exact in both modes.
+
+    python tools/graph_reduce_hazard.py                                  # both reductions, the runtime's default graph launch
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python tools/graph_reduce_hazard.py # the same with packet capture off
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "episodic-transformer-memory-ppo_amd"))
+from etm import ops  # noqa: E402
+
+
+def run(kind, replays=2000, rows=1024, C=256):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    src = torch.randn(64, rows, C, device=dev)
+    partial = torch.empty(rows, C, device=dev)
+    idx = torch.zeros((), dtype=torch.long, device=dev)
+    out = torch.empty(C, device=dev)
+    pre = torch.randn(512, 512, device=dev)
+    reduce = (lambda p: p.sum(dim=0)) if kind == "torch" else (lambda p: ops.colsum_rows(p, rows, C))
+
+    def body():
+        y = pre @ pre
+        partial.copy_(src.index_select(0, idx.view(1))[0])
+        out.copy_(reduce(partial))
+        return y @ pre
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    bad = []
+    for it in range(replays):
+        idx.fill_(it % 64)
+        g.replay()
+        err = float((out.double() - src[it % 64].double().sum(dim=0)).abs().max())
+        if err > 1e-3:                      # (fp32 sums of 1,024 unit normals: ~1e-5)
+            bad.append(it)
+    return bad
+
+
+if __name__ == "__main__":
+    mode = "DEBUG_CLR_GRAPH_PACKET_CAPTURE=" + os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "<unset>")
+    print(f"torch {torch.__version__}, hip {torch.version.hip}, {torch.cuda.get_device_name(0)}, {mode}")
+    for kind in ("torch", "library"):
+        bad = run(kind)
+        print(f"{kind:8s} column sum inside a captured graph: {len(bad)} of 2000 replays wrong; first {bad[:6]}, last {bad[-3:]}")

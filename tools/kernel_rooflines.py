@@ -278,17 +278,17 @@ def rollout_step_model(cfg, W, hidden_features, group=False):
     if group:
         D, nb, L, H = t["embed_dim"], t["num_blocks"], t["memory_length"], t["num_heads"]
         hid = cfg["hidden_layer_size"]
-        w_chain = D * D + nb * 15 * D * D + D * 2 * hid
+        w_chain = D * D + nb * 14 * D * D + D * 2 * hid        # (fc_out is folded into the first gate's maps of y: 14 maps per block)
         w_tail = nb * D * 2 * D
         kv = nb * L * 2 * D
-        exchanges = 8 * nb + 3
+        exchanges = 7 * nb + 3
         piece = 8 * (D // 32)                                   # floats a workgroup publishes per exchange; 16-byte packets carry 2 each
         ex_written, ex_read = exchanges * 32 * piece * 8, exchanges * 32 * 32 * piece * 8      # bytes (one polling pass over every piece)
         return dict(weight_bytes_chain_once_per_group=4 * w_chain, weight_bytes_per_worker_tail=4 * w_tail, kv_bytes_per_worker=4 * kv,
                     bytes_per_launch=4 * (w_chain + W * (w_tail + kv)), bytes_per_launch_to_handover=4 * (w_chain + W * kv),
                     exchange_bytes_written=ex_written, exchange_bytes_read_one_pass=ex_read,
                     unique_weight_bytes=4 * (w_chain + w_tail), unique_bytes_per_launch=4 * (w_chain + w_tail + W * kv),
-                    dependent_products=2 + 9 * nb, team_exchanges=exchanges, dependent_phases=2 + 9 * nb + exchanges + nb * 2 + 1, workers=W,
+                    dependent_products=2 + 8 * nb, team_exchanges=exchanges, dependent_phases=2 + 8 * nb + exchanges + nb * 2 + 1, workers=W,
                     workgroups=32, form="group (csrc/rollout_group.hip)")
     D, nb, L, H = t["embed_dim"], t["num_blocks"], t["memory_length"], t["num_heads"]
     hid = cfg["hidden_layer_size"]
