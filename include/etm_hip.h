@@ -396,7 +396,10 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
  * group are the ROWS of every product and its columns are dealt to 32 workgroups, so every matrix leaves L2 / the Infinity Cache once
  * per GROUP and step (the per-worker form streams 8.85 MB per worker and step at config 5).  Same arguments as etm_rollout_trxl with
  * OTHER matrix packings: every [in = D, out] map (wemb_t, wq_t, wo_t, wfc_t, ug_t) transposed and COLUMN-BLOCKED [32][D][D / 32];
- * wy_t = [32][3][D][D / 32] (Wr, Wz, Wg), ux_t = [32][2][D][D / 32] (Ur, Uz); wh_t = [32][NCH][D][CH], CH = 2 hid / 32 / NCH <= 16,
+ * wy_t = [32][3][D][D / 32] (Wr, Wz, Wg), ux_t = [32][2][D][D / 32] (Ur, Uz) -- EXCEPT gate 1 (the attention gate), whose wy_t
+ * holds the products with fc_out folded in, (Wr Wo, Wz Wo, Wg Wo) rounded once from float64, followed by the three bias rows
+ * [3][D] = (Wr bo, Wz bo, Wg bo): the kernel never multiplies by wo_t / adds bo (one product and one exchange fewer per block;
+ * both pointers are still passed and ignored); wh_t = [32][NCH][D][CH], CH = 2 hid / 32 / NCH <= 16,
  * NCH = ceil(2 hid / 32 / 16); wkv [nb][H][D][2 D / H] (per head: its K columns | its V columns); scratch:
  * etm_rollout_trxl_group_scratch_bytes(nb) bytes, zeroed once.  Shapes: etm_rollout_trxl_group_supported (gtrxl != 0, W <= 8,
  * W * H <= 32, D in {128, 384}, L <= 128); the launch is etm_rollout_trxl_group_grid() = 32 workgroups that must all be resident. */
