@@ -15,11 +15,16 @@ for target in $TARGETS; do
   elif [ $target = rollout_step5 ]; then cmd="env ETM_PROFILE_CONFIG=synthetic_mortar_gtrxl python $ROOT/tools/kernel_rooflines.py rollout_step 6";
   elif [ $target = rollout_step5pw ]; then cmd="env ETM_PROFILE_CONFIG=synthetic_mortar_gtrxl python $ROOT/tools/kernel_rooflines.py rollout_step 6 rollout_group_kernel=0";
   elif [ $target = rollout_step2 ]; then cmd="env ETM_PROFILE_CONFIG=synthetic_cartpole python $ROOT/tools/kernel_rooflines.py rollout_step 6";
+  elif [ $target = bench_dense ]; then cmd="python $ROOT/bench.py --attention dense --steps 1 --warmup 2 --no-cpu-baseline --no-profile --no-rooflines";
   else cmd="python $ROOT/tools/kernel_rooflines.py $target 6"; fi
+  # bench_dense (round 5): the dense MFMA attention kernels INSIDE the whole path (rollout + captured optimisation steps), counters of
+  # those kernels only -- the rest of the process runs uninstrumented
+  filter=""; if [ $target = bench_dense ]; then filter="--kernel-include-regex mha_fwd_kernel|bwd_dw_kernel|bwd_scores_kernel|bwd_uw_kernel|bwd_dx_kernel"; fi
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    if [ $target = bench_dense ] && [ "$pass" = "WRITE_SIZE" ]; then continue; fi
     tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
     rm -rf /tmp/pmc_run
-    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_run -o pmc -- $cmd > /tmp/pmc_run.log 2>&1
+    timeout 400 rocprofv3 --pmc $pass $filter --kernel-trace --output-format csv -d /tmp/pmc_run -o pmc -- $cmd > /tmp/pmc_run.log 2>&1
     mkdir -p $OUT/$target/$tag
     for f in $(find /tmp/pmc_run -name "*counter_collection.csv"); do
       # keep the rows of this build's kernels only (the csv of a whole process is tens of MB)
