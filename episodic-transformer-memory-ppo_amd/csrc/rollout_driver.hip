@@ -7,8 +7,9 @@
 //     wait for the group's `ready` words  ->  episode bookkeeping (step counter, memory slot of a new episode)
 //     ->  (episode step, slot) words where the step kernel reads them  ->  enqueue the observation upload + the step graph
 // and that is this function: one blocking call per rollout from the trainer thread (ctypes releases the GIL), no Python between
-// two steps.  Groups are served round-robin in the (step, group) order of the Python loop it replaces, so the slot numbering --
-// upstream's `len(self.buffer.memories) - 1`, :211 -- is identical.  No device code in this file.
+// two steps.  Groups are served as they become ready (round 5; etm_rollout_drive_set_order), with the one ordering constraint that
+// keeps the slot numbering -- upstream's `len(self.buffer.memories) - 1`, :211 -- identical to the (step, group) order of the Python
+// loop this replaces.  No device code in this file.
 #include "etm_common.h"
 
 #include <chrono>
@@ -42,111 +43,140 @@ extern "C" int etm_host_unregister(void *ptr) {
   return (int)hipHostUnregister(ptr);
 }
 
+// Service order of the worker groups within a step (process-wide; results do not depend on it): 1 (default) = ready-first -- a group is
+// served as soon as all its worker processes have published the step, whatever the other groups do, EXCEPT a group that has an
+// episode end in this step, which waits until every lower-numbered group has been served: new memory slots are numbered in
+// (step, group) order (upstream's `len(self.buffer.memories) - 1`, trainer.py:211) and a slot number must be final when the group's
+// next step is launched.  0 = strict round-robin (rounds 4 - 5a: a late group stalls the groups behind it).
+static int g_drive_ready_first = 1;
+extern "C" int etm_rollout_drive_set_order(int ready_first) { g_drive_ready_first = ready_first ? 1 : 0; return ETM_OK; }
+
 extern "C" int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,
                                  const uint8_t *dones, int64_t *ep_step, int64_t *slot, int64_t *next_slot, int64_t capacity,
                                  int64_t *events, int64_t max_events, int64_t *n_events, const volatile int64_t *abort_words,
                                  int n_abort_words, int abort_stride, double timeout_s, double *timing, double *chain_log) {
   if (!groups || G <= 0 || S <= 0 || W <= 0 || !dones || !ep_step || !slot || !next_slot || !events || !n_events) return ETM_EINVAL;
-  double t_wait = 0.0, t_work = 0.0;
+  constexpr int MAXG = 16, MAXP = 64;
+  if (G > MAXG) return ETM_EINVAL;
+  for (int gi = 0; gi < G; ++gi)
+    if (groups[gi].n_procs > MAXP) return ETM_EINVAL;
+  const bool ready_first = g_drive_ready_first != 0;
+  double t_work = 0.0;
+  const double t_begin = now_s();
   int64_t ne = *n_events;
+  static thread_local int sent[MAXG][MAXP];
   for (int t = t_first; t < S; ++t) {
+    const int64_t target = (int64_t)t + 1;
+    const uint8_t *d = dones + (int64_t)t * W;
+    bool served[MAXG], ready[MAXG], early[MAXG];
+    int left[MAXG];
     for (int gi = 0; gi < G; ++gi) {
       const etm_rollout_group &g = groups[gi];
-      const int Wg = g.hi - g.lo;
-      const int64_t target = (int64_t)t + 1;
-      if (g.n_procs > 64) return ETM_EINVAL;
-      // ---- observation rows of step t + 1: uploaded piece by piece while the workers still write them (row progress words)
-      const double tw = now_s();
-      hipStream_t st = (hipStream_t)g.stream;
-      const bool early_rows = g.rows && g.rows_per_proc > 0 && t + 1 < S;
-      if (early_rows) {
-        const int k = g.rows_per_proc;
-        int sent[64];
-        int left = 0;
-        for (int p = 0; p < g.n_procs && p < 64; ++p) { sent[p] = 0; left += k; }
-        uint32_t spins = 0;
-        while (left > 0) {
-          for (int p = 0; p < g.n_procs && p < 64; ++p) {
-            if (sent[p] >= k) continue;
+      served[gi] = ready[gi] = false;
+      // observation rows of step t + 1 go up piece by piece while the workers still write them (row progress words)
+      early[gi] = g.rows && g.rows_per_proc > 0 && t + 1 < S;
+      left[gi] = early[gi] ? g.n_procs * g.rows_per_proc : 0;
+      for (int p = 0; p < g.n_procs; ++p) sent[gi][p] = 0;
+    }
+    const double tw = now_s();
+    int n_served = 0;
+    uint32_t spins = 0;
+    while (n_served < G) {
+      bool progress = false;
+      for (int gi = 0; gi < G; ++gi) {
+        if (served[gi]) continue;
+        if (!ready_first && gi > 0 && !served[gi - 1]) break;          // strict round-robin: nothing behind an unserved group moves
+        const etm_rollout_group &g = groups[gi];
+        const int Wg = g.hi - g.lo;
+        hipStream_t st = (hipStream_t)g.stream;
+        if (left[gi] > 0) {
+          const int k = g.rows_per_proc;
+          for (int p = 0; p < g.n_procs; ++p) {
+            if (sent[gi][p] >= k) continue;
             const int64_t v = __atomic_load_n(g.rows + (int64_t)p * g.ready_stride, __ATOMIC_ACQUIRE);
             if ((v >> 16) != target) continue;
             const int avail = (int)(v & 0xffff);
-            if (avail > sent[p]) {
-              const int64_t off = ((int64_t)p * k + sent[p]) * row_bytes;
+            if (avail > sent[gi][p]) {
+              const int64_t off = ((int64_t)p * k + sent[gi][p]) * row_bytes;
               hipError_t e = hipMemcpyAsync((char *)g.stage_dst + (int64_t)(t + 1) * stage_step_bytes + off, (const char *)g.obs_src + off,
-                                            (size_t)(avail - sent[p]) * (size_t)row_bytes, hipMemcpyHostToDevice, st);
+                                            (size_t)(avail - sent[gi][p]) * (size_t)row_bytes, hipMemcpyHostToDevice, st);
               if (e != hipSuccess) { *n_events = ne; return (int)e; }
-              left -= avail - sent[p];
-              sent[p] = avail;
-              spins = 0;
+              left[gi] -= avail - sent[gi][p];
+              sent[gi][p] = avail;
+              progress = true;
             }
           }
-          _mm_pause();
-          if ((++spins & 0xffff) == 0) {
-            for (int a = 0; a < n_abort_words; ++a)
-              if (abort_words && abort_words[(int64_t)a * abort_stride] != 0) { *n_events = ne; return ETM_EABORTED; }
-            if (now_s() - tw > timeout_s) { *n_events = ne; return ETM_ETIMEOUT; }
+          if (left[gi] > 0) continue;
+        }
+        // ---- every worker process of the group has published step t (observation rows, reward, done are final)?
+        if (!ready[gi]) {
+          bool all = true;
+          for (int p = 0; p < g.n_procs && all; ++p)
+            all = __atomic_load_n(g.ready + (int64_t)p * g.ready_stride, __ATOMIC_ACQUIRE) == target;
+          if (!all) continue;
+          ready[gi] = true;
+        }
+        bool has_done = false;
+        for (int w = g.lo; w < g.hi; ++w) has_done |= d[w] != 0;
+        if (has_done) {                                                  // slot numbers follow (step, group) order
+          bool lower = true;
+          for (int gj = 0; gj < gi; ++gj) lower &= served[gj];
+          if (!lower) continue;
+        }
+        const double te = now_s();
+        // ---- episode bookkeeping (upstream trainer.py:195-213): step counters, a fresh memory slot for every new episode
+        for (int w = g.lo; w < g.hi; ++w) {
+          if (d[w]) {
+            ep_step[w] = 0;
+            if (*next_slot >= capacity) { *n_events = ne; return ETM_EWORKSPACE; }
+            if (ne >= max_events) { *n_events = ne; return ETM_EWORKSPACE; }
+            const int64_t s = (*next_slot)++;
+            slot[w] = s;
+            events[3 * ne] = t; events[3 * ne + 1] = w; events[3 * ne + 2] = s;
+            ++ne;
+          } else {
+            ep_step[w] += 1;
           }
         }
-      }
-      // ---- wait: every worker process of the group has published step t (observation rows, reward, done are final)
-      for (int p = 0; p < g.n_procs; ++p) {
-        const volatile int64_t *r = g.ready + (int64_t)p * g.ready_stride;
-        uint32_t spins = 0;
-        while (__atomic_load_n(r, __ATOMIC_ACQUIRE) != target) {
-          _mm_pause();
-          if ((++spins & 0xffff) == 0) {
-            for (int a = 0; a < n_abort_words; ++a)
-              if (abort_words && abort_words[(int64_t)a * abort_stride] != 0) { *n_events = ne; return ETM_EABORTED; }
-            if (now_s() - tw > timeout_s) { *n_events = ne; return ETM_ETIMEOUT; }
+        if (t + 1 < S) {
+          // ---- (episode step, slot) of the group where the step kernel of step t + 1 reads them (pinned, in place)
+          if (g.tagged) {
+            const int64_t tag = ((int64_t)t + 2) << 32;
+            for (int i = 0; i < Wg; ++i) {
+              __atomic_store_n(g.ss_dst + i, ep_step[g.lo + i] | tag, __ATOMIC_RELEASE);
+              __atomic_store_n(g.ss_dst + Wg + i, slot[g.lo + i] | tag, __ATOMIC_RELEASE);
+            }
+          } else {
+            std::memcpy(g.ss_dst, ep_step + g.lo, sizeof(int64_t) * (size_t)Wg);
+            std::memcpy(g.ss_dst + Wg, slot + g.lo, sizeof(int64_t) * (size_t)Wg);
           }
+          // ---- observation rows of step t + 1 -> their row of the time-major staging array (unless they went piece by piece above),
+          // then the step: both on the group's stream
+          hipError_t e = hipSuccess;
+          if (!early[gi])
+            e = hipMemcpyAsync((char *)g.stage_dst + (int64_t)(t + 1) * stage_step_bytes, g.obs_src, (size_t)Wg * (size_t)row_bytes,
+                               hipMemcpyHostToDevice, st);
+          if (e != hipSuccess) { *n_events = ne; return (int)e; }
+          e = hipGraphLaunch((hipGraphExec_t)g.graph_exec, st);
+          if (e != hipSuccess) { *n_events = ne; return (int)e; }
         }
+        const double tl = now_s();
+        t_work += tl - te;
+        if (chain_log && gi == 0) { chain_log[4 * t] = tw; chain_log[4 * t + 1] = te; chain_log[4 * t + 2] = te; chain_log[4 * t + 3] = tl; }
+        served[gi] = true;
+        ++n_served;
+        progress = true;
       }
-      const double te = now_s();
-      t_wait += te - tw;
-      // ---- episode bookkeeping (upstream trainer.py:195-213): step counters, a fresh memory slot for every new episode
-      const uint8_t *d = dones + (int64_t)t * W;
-      for (int w = g.lo; w < g.hi; ++w) {
-        if (d[w]) {
-          ep_step[w] = 0;
-          if (*next_slot >= capacity) { *n_events = ne; return ETM_EWORKSPACE; }
-          if (ne >= max_events) { *n_events = ne; return ETM_EWORKSPACE; }
-          const int64_t s = (*next_slot)++;
-          slot[w] = s;
-          events[3 * ne] = t; events[3 * ne + 1] = w; events[3 * ne + 2] = s;
-          ++ne;
-        } else {
-          ep_step[w] += 1;
-        }
+      if (progress) { spins = 0; continue; }
+      _mm_pause();
+      if ((++spins & 0xffff) == 0) {
+        for (int a = 0; a < n_abort_words; ++a)
+          if (abort_words && abort_words[(int64_t)a * abort_stride] != 0) { *n_events = ne; return ETM_EABORTED; }
+        if (now_s() - tw > timeout_s) { *n_events = ne; return ETM_ETIMEOUT; }
       }
-      if (t + 1 < S) {
-        // ---- (episode step, slot) of the group where the step kernel of step t + 1 reads them (pinned, in place)
-        if (g.tagged) {
-          const int64_t tag = ((int64_t)t + 2) << 32;
-          for (int i = 0; i < Wg; ++i) {
-            __atomic_store_n(g.ss_dst + i, ep_step[g.lo + i] | tag, __ATOMIC_RELEASE);
-            __atomic_store_n(g.ss_dst + Wg + i, slot[g.lo + i] | tag, __ATOMIC_RELEASE);
-          }
-        } else {
-          std::memcpy(g.ss_dst, ep_step + g.lo, sizeof(int64_t) * (size_t)Wg);
-          std::memcpy(g.ss_dst + Wg, slot + g.lo, sizeof(int64_t) * (size_t)Wg);
-        }
-        // ---- observation rows of step t + 1 -> their row of the time-major staging array (unless they went piece by piece above),
-        // then the step: both on the group's stream
-        hipError_t e = hipSuccess;
-        if (!early_rows)
-          e = hipMemcpyAsync((char *)g.stage_dst + (int64_t)(t + 1) * stage_step_bytes, g.obs_src, (size_t)Wg * (size_t)row_bytes,
-                             hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) { *n_events = ne; return (int)e; }
-        e = hipGraphLaunch((hipGraphExec_t)g.graph_exec, st);
-        if (e != hipSuccess) { *n_events = ne; return (int)e; }
-      }
-      const double tl = now_s();
-      t_work += tl - te;
-      if (chain_log && gi == 0) { chain_log[4 * t] = tw; chain_log[4 * t + 1] = te; chain_log[4 * t + 2] = te; chain_log[4 * t + 3] = tl; }
     }
   }
   *n_events = ne;
-  if (timing) { timing[0] = t_wait; timing[1] = t_work; }
+  if (timing) { timing[1] = t_work; timing[0] = (now_s() - t_begin) - t_work; }
   return ETM_OK;
 }

@@ -720,6 +720,12 @@ class PPOTrainer:
         if self._chain_log is not None:
             chain = np.zeros((S, 4), dtype=np.float64)
         abort = env.v["err"]          # the workers' error words (one cache line apart) ...
+        # rollout_drive_order: "ready_first" (default: a group is served as soon as its worker processes have published the step;
+        # slot numbers stay in (step, group) order -- csrc/rollout_driver.hip) or "round_robin" (rounds 4 / 5a)
+        order = str(self.config.get("rollout_drive_order", "ready_first"))
+        if order not in ("ready_first", "round_robin"):
+            raise ValueError(f"rollout_drive_order must be 'ready_first' or 'round_robin', got {order!r}")
+        lib.etm_rollout_drive_set_order(1 if order == "ready_first" else 0)
         rc = lib.etm_rollout_drive(ctypes.cast(arr, ctypes.c_void_p), G, 0, S, W, row_bytes, W * row_bytes,
                                    env.v["dones"].ctypes.data, self._ss_pin[0].data_ptr(), self._ss_pin[1].data_ptr(),
                                    ctr.ctypes.data, int(buf.bank.shape[0]), self._drive_events.ctypes.data, self._drive_events.shape[0],

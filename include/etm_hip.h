@@ -558,8 +558,10 @@ int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
  * etm_host_register / etm_host_unregister: hipHostRegister (portable | mapped) of the shared segment, so that the device can
  *   write the action / sequence words and the copy engine can read the observation rows.  The kernels are handed HOST addresses:
  *   ETM_EUNSUPPORTED if the device address of the registered range differs from the host address.
- * etm_rollout_drive: for t = t_first .. S - 1 and every group in order (the (step, group) order of the loop it replaces, so the
- *   slot numbering is upstream's `len(self.buffer.memories) - 1`, trainer.py:211):
+ * etm_rollout_drive: for t = t_first .. S - 1 and every group -- in the order in which the groups become ready (default; G <= 16,
+ *   n_procs <= 64), except that a group with an episode end in step t is served after every lower-numbered group: memory slots
+ *   are numbered in the (step, group) order of the loop this replaces (upstream's `len(self.buffer.memories) - 1`, trainer.py:211),
+ *   so the results do not depend on the service order; etm_rollout_drive_set_order(0) selects strict round-robin (rounds 4 / 5a):
  *     wait until the group's n_procs `ready` words (ready_stride int64 apart) equal t + 1;
  *     bookkeeping of upstream :195-213 over dones[t, lo..hi): ep_step += 1, or (done) ep_step = 0 and slot = (*next_slot)++ with
  *       an event (t, worker, slot) appended to `events` [max_events][3] / *n_events (ETM_EWORKSPACE when the bank -- `capacity`
@@ -572,7 +574,7 @@ int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
  *   Blocking; returns when the bookkeeping of step S - 1 is done (the last launched step may still run).  abort_words: n words,
  *   abort_stride int64 apart (the workers' error words + the segment's abort word), polled while waiting -> ETM_EABORTED;
  *   ETM_ETIMEOUT after timeout_s without progress.  timing (optional): [0] seconds waiting for workers, [1] seconds of
- *   bookkeeping + enqueueing; chain_log (optional, [S][4] doubles): wait start / ready seen / ready seen / launched, group 0. */
+ *   bookkeeping + enqueueing; chain_log (optional, [S][4] doubles): step start / group 0's service start (twice) / launched. */
 typedef struct etm_rollout_group {
   void *graph_exec;               /* hipGraphExec_t of the group's captured rollout step */
   void *stream;                   /* hipStream_t of the group (step graph and observation upload) */
@@ -591,6 +593,7 @@ typedef struct etm_rollout_group {
 int etm_graph_launch(void *graph_exec, void *stream);
 int etm_host_register(void *ptr, int64_t bytes);
 int etm_host_unregister(void *ptr);
+int etm_rollout_drive_set_order(int ready_first);   /* process-wide; 1 (default) = ready-first, 0 = round-robin */
 int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,
                       const uint8_t *dones, int64_t *ep_step, int64_t *slot, int64_t *next_slot, int64_t capacity, int64_t *events,
                       int64_t max_events, int64_t *n_events, const volatile int64_t *abort_words, int n_abort_words, int abort_stride,

@@ -442,6 +442,7 @@ _ROLLOUT_PATHS = {
     "worker_processes": {"worker_processes": True},
     "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
     "worker_processes_eager": {"worker_processes": True, "envs_per_process": 2, "hip_graph_rollout": False},
+    "worker_processes_round_robin": {"worker_processes": True, "rollout_drive_order": "round_robin"},   # (default since round 5: ready-first)
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
@@ -455,6 +456,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("cfg5", "pull_obs"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
+             ("img32", "worker_processes_round_robin"), ("cfg3", "worker_processes_round_robin"),
              ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("cfg2", "window_row_stats"), ("cfg2", "generic_ln_grad"), ("cfg5", "window_row_stats"), ("img32", "conv12"), ("cfg3", "conv12"),
              ("img32", "interleaved_bank"), ("cfg3", "interleaved_bank"), ("gtrxl", "interleaved_bank")]
 
@@ -1772,6 +1774,135 @@ def test_grouped_column_sums_bit_identical_to_per_call_reductions(N, D):
     # float64: d n2.bias = column sums of the upstream gradient
     want = gout.double().sum(0)
     assert float((views[3].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())) * max(1.0, N ** 0.5)
+
+
+@pytest.mark.parametrize("order", ["ready_first", "round_robin"])
+def test_rollout_driver_service_order(order):
+    """csrc/rollout_driver.hip without a trainer: two fake worker groups (their `ready` words published by a thread of this test,
+    group 1 BEFORE group 0 in every step).  Ready-first: group 1 is served while group 0 is still stepping -- unless it has an episode
+    end in that step, then it waits for group 0, so that the slot numbers (upstream trainer.py:211) come out in (step, group) order.
+    Round-robin: group 1 is never served first.  Both: step counters, slots and the event list equal the Python loop they replace."""
+    import ctypes
+    import threading
+    import time
+    from etm import lib as etm_lib
+    if not hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"):
+        pytest.skip("needs CUDAGraph.raw_cuda_graph_exec")
+    dev = _dev()
+    lib = etm_lib.load()
+    G, Wg, S, row = 2, 2, 8, 16
+    W = G * Wg
+    rng = np.random.default_rng(11)
+    dones = (rng.random((S, W)) < 0.3).astype(np.uint8)
+    dones[1, 2] = 1; dones[1, :2] = 0            # step 1: group 1 has an episode end, group 0 has none
+    dones[2, :] = 0                              # step 2: nobody
+    dones[3, 0] = dones[3, 3] = 1                # step 3: both
+    ready = np.zeros((G, 8), dtype=np.int64)     # one cache line per process
+    ss = [np.zeros((2, Wg), dtype=np.int64) for _ in range(G)]
+    obs = np.zeros((W, row // 4), dtype=np.float32)
+    stage = torch.zeros((S + 1, W, row // 4), device=dev)
+    xs = [torch.zeros(8, device=dev) for _ in range(G)]
+    streams = [torch.cuda.Stream() for _ in range(G)]
+    graphs = []
+    for st, x in zip(streams, xs):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            x.add_(1.0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            x.add_(1.0)
+        graphs.append(g)
+    torch.cuda.synchronize()
+    arr = (etm_lib.RolloutGroup * G)()
+    for gi in range(G):
+        a = arr[gi]
+        a.graph_exec, a.stream = graphs[gi].raw_cuda_graph_exec(), streams[gi].cuda_stream
+        a.ready, a.n_procs, a.ready_stride = ready[gi:].ctypes.data, 1, ready.shape[1]
+        a.lo, a.hi = gi * Wg, (gi + 1) * Wg
+        a.obs_src, a.stage_dst, a.ss_dst = obs[gi * Wg:].ctypes.data, stage.data_ptr() + gi * Wg * row, ss[gi].ctypes.data
+        a.tagged, a.rows_per_proc, a.rows = 1, 0, None
+    ep_step, slot = np.zeros(W, dtype=np.int64), np.arange(W, dtype=np.int64)
+    ctr = np.array([W, 0], dtype=np.int64)
+    events = np.zeros((W * S, 3), dtype=np.int64)
+    abort = np.zeros((1, 8), dtype=np.int64)
+    served_first = []                            # per step: was group 1 served while group 0 had not published?
+
+    def workers():
+        for t in range(S):
+            ready[1, 0] = t + 1
+            seen, t0 = False, time.time()
+            while t + 1 < S and time.time() - t0 < 0.25 and not seen:
+                seen = int(ss[1][0, 0]) >> 32 == t + 2          # the driver wrote group 1's (step, slot) words of step t + 1
+                time.sleep(0.002)
+            served_first.append(seen)
+            ready[0, 0] = t + 1
+            t0 = time.time()
+            while t + 1 < S and time.time() - t0 < 5.0 and int(ss[0][0, 0]) >> 32 != t + 2:
+                time.sleep(0.001)
+
+    th = threading.Thread(target=workers)
+    lib.etm_rollout_drive_set_order(1 if order == "ready_first" else 0)
+    th.start()
+    try:
+        rc = lib.etm_rollout_drive(ctypes.cast(arr, ctypes.c_void_p), G, 0, S, W, row, W * row, dones.ctypes.data, ep_step.ctypes.data,
+                                   slot.ctypes.data, ctr.ctypes.data, 1000, events.ctypes.data, events.shape[0], ctr[1:].ctypes.data,
+                                   abort.ctypes.data, 1, abort.shape[1], 20.0, None, None)
+    finally:
+        th.join()
+        lib.etm_rollout_drive_set_order(1)
+    torch.cuda.synchronize()
+    assert rc == 0
+    # the loop it replaces (upstream trainer.py:195-213 in (step, group) order)
+    e_ref, s_ref, nxt, ev = np.zeros(W, dtype=np.int64), np.arange(W, dtype=np.int64), W, []
+    for t in range(S):
+        for w in range(W):
+            if dones[t, w]:
+                e_ref[w], s_ref[w] = 0, nxt
+                ev.append((t, w, nxt))
+                nxt += 1
+            else:
+                e_ref[w] += 1
+    assert np.array_equal(ep_step, e_ref) and np.array_equal(slot, s_ref) and ctr[0] == nxt and ctr[1] == len(ev)
+    assert np.array_equal(events[: len(ev)], np.asarray(ev, dtype=np.int64).reshape(-1, 3))
+    assert all(float(x[0]) == S for x in xs)                    # every group's step graph was launched S - 1 times (+ 1 warm-up)
+    if order == "round_robin":
+        assert not any(served_first), served_first
+    else:
+        for t in range(S - 1):
+            assert served_first[t] == (not dones[t, Wg:].any()), (t, served_first, dones[t])
+
+
+def test_grouped_column_sums_full_problem_table():
+    """etm_colsum_reduce_grouped with etm_colsum_reduce_max_problems() (64 since round 5: every model here fits one launch) ragged
+    problems -- different row counts, column counts (not multiples of 64), row strides, first columns -- against one launch per
+    problem (bit-identical) and float64; one problem more is refused (ETM_EINVAL), not truncated."""
+    import ctypes
+    from etm import lib as etm_lib, ops
+    dev = _dev()
+    lib = etm_lib.load()
+    n = lib.etm_colsum_reduce_max_problems()
+    assert n == 64
+    rng = np.random.default_rng(5)
+    parts, outs, P, C, LD, C0 = [], [], [], [], [], []
+    for i in range(n + 1):
+        p_, c_ = int(rng.integers(1, 300)), int(rng.integers(1, 500))
+        c0, pad = int(rng.integers(0, 9)), int(rng.integers(0, 70))
+        parts.append(torch.randn((p_, c0 + c_ + pad), device=dev))
+        outs.append(torch.full((c_,), float("nan"), device=dev))
+        P.append(p_); C.append(c_); LD.append(c0 + c_ + pad); C0.append(c0)
+    arr = lambda t, v: (t * len(v))(*v)
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda k: lib.etm_colsum_reduce_grouped(arr(ctypes.c_void_p, [parts[i].data_ptr() + 4 * C0[i] for i in range(k)]), arr(ctypes.c_int32, P[:k]),
+                                                   arr(ctypes.c_int32, C[:k]), arr(ctypes.c_int32, LD[:k]),
+                                                   arr(ctypes.c_void_p, [outs[i].data_ptr() for i in range(k)]), k, st)
+    assert call(n + 1) == -1          # ETM_EINVAL (include/etm_hip.h)
+    assert all(bool(torch.isnan(o).all()) for o in outs)
+    assert call(n) == 0
+    for i in range(n):
+        want = parts[i][:, C0[i]: C0[i] + C[i]].double().sum(0)
+        assert float((outs[i].double() - want).abs().max()) <= 1e-5 * max(1.0, P[i] ** 0.5), i
+        single = ops.colsum_rows(parts[i][:, C0[i]:], P[i], C[i])
+        assert torch.equal(single, outs[i]), i
 
 
 @pytest.mark.parametrize("N", [512, 601, 2048])

@@ -41,3 +41,4 @@ steps = cfg["n_workers"] * cfg["worker_steps"]
 print(f"{name}: {steps * n_upd / (r + t):.0f} env-steps/s  (rollout {r / n_upd:.3f} s, train {t / n_upd:.3f} s per update of {steps} steps; "
       f"D={cfg['transformer']['embed_dim']} L={cfg['transformer']['memory_length']} blocks={cfg['transformer']['num_blocks']} "
       f"gtrxl={cfg['transformer']['gtrxl']} ln={cfg['transformer']['layer_norm']!r})")
+tr.close()                          # (worker processes: stops them and unlinks the shared segment)
