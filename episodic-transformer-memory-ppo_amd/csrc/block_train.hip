@@ -427,7 +427,7 @@ extern "C" int64_t etm_gate_train_bwd_workspace_bytes(int N, int D) {
 extern "C" int etm_gate_train_bwd1(const float *dout, const float *z, const float *hh, const float *x, float *dA, float *dB, float *dx1,
                                    float *dbg, float *workspace, int64_t workspace_bytes, int N, int D, void *stream) {
   (void)hipGetLastError();
-  if (!dout || !z || !hh || !x || !dA || !dB || !dx1 || !dbg || !workspace || N <= 0 || D <= 0) return ETM_EINVAL;
+  if (!dout || !z || !hh || !x || !dA || !dB || !dx1 || !workspace || N <= 0 || D <= 0) return ETM_EINVAL;
   if (workspace_bytes < etm_gate_train_bwd_workspace_bytes(N, D)) return ETM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int rows = 8, P = (N + rows - 1) / rows;
@@ -439,11 +439,12 @@ extern "C" int etm_gate_train_bwd1(const float *dout, const float *z, const floa
       return etm_launch_status();
     });
   }
-  if (rc) return rc;
+  if (rc || !dbg) return rc;                            // no destination: the partial rows are reduced later (etm_colsum_reduce_grouped)
   EtmProfScope prof(ETM_K_COLSUM, st);
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, st, workspace, P, D, dbg);
   return etm_launch_status();
 }
+extern "C" int etm_gate_train_bwd_partial_rows(int N) { return N > 0 ? (N + 7) / 8 : 0; }
 
 extern "C" int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const float *dx1, float *dA, float *dB, float *dx2, int N,
                                    int D, void *stream) {

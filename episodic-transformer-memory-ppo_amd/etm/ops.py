@@ -117,12 +117,11 @@ class WindowSpec:
         """[N, L, 2] LayerNorm statistics of this batch's window rows of ``block``, gathered from ``row_stats`` (None without it)."""
         if self.row_stats is None:
             return None
-        got = self._gathered_stats.get(block)
-        if got is None:
-            rs = self.row_stats[block]                                  # [E, T, 2]
+        got = self._gathered_stats.get("all")
+        if got is None:                     # one gather for all blocks (the window indices are the same): 2 launches per step, not 2 per block
             ep = self.ep if self.ep is not None else torch.arange(self.N, device=self.win.device)
-            got = self._gathered_stats[block] = rs[ep.unsqueeze(1), self.win].contiguous()
-        return got
+            got = self._gathered_stats["all"] = self.row_stats[:, ep.unsqueeze(1), self.win].contiguous()       # [blocks, N, L, 2]
+        return got[block]
 
 
 def bank_row_stats(bank, eps, out=None):
@@ -991,13 +990,14 @@ class _GruGateFn(torch.autograd.Function):
     column-sum kernel for d bg) backward, instead of six small GEMMs + ~10 element-wise launches forward and twice that backward."""
 
     @staticmethod
-    def forward(ctx, x, y, wr, ur, wz, uz, wg, ug, bg):
+    def forward(ctx, x, y, wr, ur, wz, uz, wg, ug, bg, wy=None, ux=None):
         lib = _lib.load()
         _need_dev(x, y, wr, ur, wz, uz, wg, ug, bg)
         x, y = _f32c(x, "x"), _f32c(y, "y")
         N, D = x.shape
-        wy = torch.cat((wr, wz, wg), dim=0)            # [3D, D]
-        ux = torch.cat((ur, uz), dim=0)                # [2D, D]
+        if wy is None or ux is None:                   # (the caller may hand the concatenations over: transformer.py:_pack_gate_weights)
+            wy = torch.cat((wr, wz, wg), dim=0)        # [3D, D]
+            ux = torch.cat((ur, uz), dim=0)            # [2D, D]
         A = torch.mm(y, wy.t())
         B = torch.mm(x, ux.t())
         r, z, rx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
@@ -1008,6 +1008,7 @@ class _GruGateFn(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, y, r, z, rx, hh, wy, ux, ug)
             ctx.gate_weights = (wr, ur, wz, uz, wg)      # (the parameters themselves: DeferredDw looks their arena views up by address)
+            ctx.bg_ptr = bg.data_ptr()
         return out
 
     @staticmethod
@@ -1019,9 +1020,15 @@ class _GruGateFn(torch.autograd.Function):
         dev = x.device
         dA = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
         dB = torch.empty((N, 2 * D), dtype=torch.float32, device=dev)
-        dx1, dbg = torch.empty_like(x), torch.empty((D,), dtype=torch.float32, device=dev)
+        dx1, dbg = torch.empty_like(x), None
         nbytes = lib.etm_gate_train_bwd_workspace_bytes(N, D)
-        ws = workspace(nbytes, dev, "gate_bwd")
+        col = DeferredDw.active
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=dev) if col is not None else None
+        if col is not None and col.offer_colsum(part, lib.etm_gate_train_bwd_partial_rows(N), D, [(0, D, ctx.bg_ptr)]):
+            ws = part                                   # d bg's second stage rides in the collector's one reduction launch
+        else:
+            dbg = torch.empty((D,), dtype=torch.float32, device=dev)
+            ws = workspace(nbytes, dev, "gate_bwd")
         _lib.check(lib.etm_gate_train_bwd1(_ptr(dout), _ptr(z), _ptr(hh), _ptr(x), _ptr(dA), _ptr(dB), _ptr(dx1), _ptr(dbg), _ptr(ws), nbytes,
                                            N, D, _stream()), "etm_gate_train_bwd1")
         dC = dA[:, 2 * D:]                              # d pre_h, a strided view (row stride 3D): GEMM operand in place
@@ -1030,7 +1037,7 @@ class _GruGateFn(torch.autograd.Function):
         _lib.check(lib.etm_gate_train_bwd2(_ptr(drx), _ptr(x), _ptr(r), _ptr(dx1), _ptr(dA), _ptr(dB), _ptr(dx2), N, D, _stream()),
                    "etm_gate_train_bwd2")
         dy = torch.mm(dA, wy)
-        dx = torch.addmm(dx2, dB, ux)
+        dx = dx2.addmm_(dB, ux)                         # (in place: the out-of-place form first copies dx2, a 3 MB device copy per gate)
         # Weight gradients.  Round 5: with a DeferredDw collector active (the trainer's backward pass) the six D x D products go to the
         # grouped fp32-MFMA launch (csrc/grouped_dw.hip) like every other dense layer's -- column blocks of dA / dB as the left
         # operands (a_col0), written straight into the arena views.  Two reasons: 24 library GEMMs fewer per minibatch step at
@@ -1044,12 +1051,14 @@ class _GruGateFn(torch.autograd.Function):
         dux = torch.mm(dB.t(), x) if not (took[1] and took[3]) else None                 # [2D, D] = d [Ur; Uz]
         pick = lambda t, full, lo: None if t else full[lo: lo + D]
         return (dx, dy, pick(took[0], dwy, 0), pick(took[1], dux, 0), pick(took[2], dwy, D), pick(took[3], dux, D),
-                pick(took[4], dwy, 2 * D), None if took[5] else torch.mm(dC.t(), rx), dbg)
+                pick(took[4], dwy, 2 * D), None if took[5] else torch.mm(dC.t(), rx), dbg, None, None)
 
 
-def gru_gate_train(gate, x, y):
-    """Differentiable GTrXL gate of ``gate`` (a transformer.GRUGate) on [N, D] inputs."""
-    return _GruGateFn.apply(x, y, gate.Wr.weight, gate.Ur.weight, gate.Wz.weight, gate.Uz.weight, gate.Wg.weight, gate.Ug.weight, gate.bg)
+def gru_gate_train(gate, x, y, packed=None):
+    """Differentiable GTrXL gate of ``gate`` (a transformer.GRUGate) on [N, D] inputs.  ``packed``: ([Wr; Wz; Wg], [Ur; Uz]) of the
+    gate's CURRENT weights when the caller has them concatenated already."""
+    wy, ux = packed if packed is not None else (None, None)
+    return _GruGateFn.apply(x, y, gate.Wr.weight, gate.Ur.weight, gate.Wz.weight, gate.Uz.weight, gate.Wg.weight, gate.Ug.weight, gate.bg, wy, ux)
 
 
 def conv_pack_weights(weight2d):
@@ -1298,6 +1307,50 @@ class _LinearReluFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _offer_dw(gm, x, weight):
             dw = gm.t().mm(x)
         return dx, dw, db
+
+
+class _LinearBiasFn(torch.autograd.Function):
+    """y = x W^T + b (transformer.py:29 fc_out on the paths that keep its bias: pre-LN / gated blocks).  nn.Linear's backward leaves
+    the bias gradient to the framework's column sum -- two stages with a semaphore, which this runtime does not replay reliably from a
+    captured graph (profiles/r05/graph_reduce_hazard.txt) and which costs two launches; here it is etm_relu_bwd_colsum without a mask,
+    its second stage in the collector's one reduction launch; the weight gradient goes to the grouped launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.bias_ptr = bias.data_ptr()
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        lib = _lib.load()
+        g = _f32c(g, "grad")
+        n, c = g.shape
+        db = None
+        if ctx.needs_input_grad[2]:
+            nbytes = lib.etm_relu_bwd_colsum_workspace_bytes(n, c)
+            col = DeferredDw.active
+            part = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device) if col is not None else None
+            if col is not None and col.offer_colsum(part, lib.etm_relu_bwd_colsum_partial_rows(n), c, [(0, c, ctx.bias_ptr)]):
+                _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), None, None, None, _ptr(part), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+            else:
+                db = torch.empty(c, dtype=torch.float32, device=g.device)
+                ws = workspace(nbytes, g.device, "relu_bwd")
+                _lib.check(lib.etm_relu_bwd_colsum(_ptr(g), None, None, _ptr(db), _ptr(ws), nbytes, n, c, _stream()), "etm_relu_bwd_colsum")
+        dx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _offer_dw(g, x, weight):
+            dw = g.t().mm(x)
+        return dx, dw, db
+
+
+def linear_bias(lin, x):
+    """``lin(x)`` (an nn.Linear with bias) for 2-D fp32 device tensors under autograd: library GEMMs for y and dx, the bias gradient by
+    the library's column sums, both parameter gradients deferrable (see DeferredDw).  Anything else: ``lin(x)``."""
+    if (torch.is_grad_enabled() and lin.bias is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()):
+        return _LinearBiasFn.apply(x, lin.weight, lin.bias)
+    return lin(x)
 
 
 class _LinearReluNhwcFn(torch.autograd.Function):

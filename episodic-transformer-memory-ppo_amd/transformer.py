@@ -45,7 +45,7 @@ class MultiHeadAttention(nn.Module):
         ctx, att = ops.mha(q, self.keys.weight, self.values.weight, spec, block, self.num_heads, ln_g, ln_b, pos, eps)
         if raw:
             return ops.linear_nobias(ctx, self.fc_out.weight), att
-        return self.fc_out(ctx), att
+        return ops.linear_bias(self.fc_out, ctx), att
 
     def forward(self, values, keys, queries, mask):
         """Upstream signature: values/keys [N, L, D], queries [N, 1, D], mask [N, L] -> ([N, 1, D], [N, H, 1, L])."""
@@ -94,7 +94,10 @@ class GRUGate(nn.Module):
                 self.refresh_rollout_weights()       # weights moved since the copies were made (optimizer step, load)
             return ops.gru_gate(x, y, self._wy, self._ux, self.Ug.weight, self.bg)
         if torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.shape[1] <= 1024:
-            return ops.gru_gate_train(self, x, y)       # training: concatenated GEMMs + fused forward / backward kernels
+            # training: concatenated GEMMs + fused forward / backward kernels; the concatenations come packed (one launch for all
+            # gates of the model, Transformer._pack_gate_weights) when the enclosing forward pass made them, else from two cat launches
+            packed, self._train_cat = getattr(self, "_train_cat", None), None
+            return ops.gru_gate_train(self, x, y, packed)
         r = torch.sigmoid(self.Wr(y) + self.Ur(x))
         z = torch.sigmoid(self.Wz(y) + self.Uz(x) - self.bg)
         cand = torch.tanh(self.Wg(y) + self.Ug(r * x))
@@ -224,9 +227,30 @@ class Transformer(nn.Module):
             return self.pos_embedding
         return None
 
+    def _pack_gate_weights(self):
+        """[Wr; Wz; Wg] and [Ur; Uz] of every GRU gate (transformer.py:287-298: the operands of the gates' concatenated GEMMs) into
+        buffers that keep their address, by ONE multi-tensor copy for the whole model -- 2 cat launches per gate and step otherwise
+        (16 at BASELINE config 5).  The buffers are saved for backward: a second forward pass before the backward pass of the first
+        would overwrite them, which autograd reports (version counter) instead of computing with the wrong operands."""
+        gates = [g for blk in self.transformer_blocks if blk.use_gtrxl for g in (blk.gate1, blk.gate2)]
+        if not gates:
+            return
+        D, dev = self.embed_dim, gates[0].Wr.weight.device
+        buf = getattr(self, "_gate_cat", None)
+        if buf is None or buf.device != dev or buf.shape[0] != len(gates):
+            buf = self._gate_cat = torch.empty((len(gates), 5 * D, D), dtype=torch.float32, device=dev)
+            self._gate_cat_views = [v for i, _ in enumerate(gates) for v in (buf[i, :D], buf[i, D: 2 * D], buf[i, 2 * D: 3 * D],
+                                                                             buf[i, 3 * D: 4 * D], buf[i, 4 * D:])]
+        with torch.no_grad():
+            torch._foreach_copy_(self._gate_cat_views, [m.weight for g in gates for m in (g.Wr, g.Wz, g.Wg, g.Ur, g.Uz)])
+        for i, g in enumerate(gates):
+            g._train_cat = (buf[i, : 3 * D], buf[i, 3 * D:])
+
     def forward_window(self, h, spec: WindowSpec, want_items=True):
         """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D]) -- the items
         are None with ``want_items=False`` (the optimisation phase never stores them)."""
+        if torch.is_grad_enabled() and h.is_cuda and h.dim() == 2:
+            self._pack_gate_weights()
         h = ops.linear_relu(self.linear_embedding, h)
         pos = None if spec.pos_included else self._pos()
         items = []

@@ -1872,6 +1872,32 @@ def test_rollout_driver_service_order(order):
             assert served_first[t] == (not dones[t, Wg:].any()), (t, served_first, dones[t])
 
 
+def test_captured_graphs_hold_no_memset_nodes(tmp_path):
+    """No framework reduction inside a captured graph (tools/graph_reduce_hazard.py): torch's tall column sums
+    show up as a MEMSET node (their semaphore) in front of a reduce kernel, and that pair is not replay-safe on this runtime.  A
+    subprocess with DEBUG_HIP_GRAPH_DOT_PRINT=1 runs one update of a small post-LN TrXL and of a small pre-LN GTrXL trainer (the two
+    block layouts; visual and vector observations) and every graph the runtime dumps is scanned."""
+    import subprocess
+    import sys
+    script = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import __graft_entry__ as ge
+ge.smoke()
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "episodic-transformer-memory-ppo_amd"))
+    env = dict(os.environ, DEBUG_HIP_GRAPH_DOT_PRINT="1")
+    res = subprocess.run([sys.executable, "-c", script], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    dumps = sorted(p for p in os.listdir(tmp_path) if p.startswith("graph_"))
+    assert len(dumps) >= 4, dumps                  # two rollout step graphs + two optimisation step graphs at least
+    sizes = []
+    for name in dumps:
+        text = open(os.path.join(tmp_path, name)).read()
+        sizes.append(text.count("StreamId"))
+        assert "MEMSET" not in text, f"{name}: a memset node (a framework reduction's semaphore?) inside a captured graph"
+    assert max(sizes) > 40, sizes                  # the optimisation steps were among them
+
+
 def test_grouped_column_sums_full_problem_table():
     """etm_colsum_reduce_grouped with etm_colsum_reduce_max_problems() (64 since round 5: every model here fits one launch) ragged
     problems -- different row counts, column counts (not multiples of 64), row strides, first columns -- against one launch per
