@@ -1836,8 +1836,8 @@ def test_rollout_driver_service_order(order):
                 time.sleep(0.002)
             served_first.append(seen)
             ready[0, 0] = t + 1
-            t0 = time.time()
-            while t + 1 < S and time.time() - t0 < 5.0 and int(ss[0][0, 0]) >> 32 != t + 2:
+            t0 = time.time()       # (real workers cannot publish step t + 1 before the driver has launched it: wait for both groups' words)
+            while t + 1 < S and time.time() - t0 < 10.0 and (int(ss[0][0, 0]) >> 32 != t + 2 or int(ss[1][0, 0]) >> 32 != t + 2):
                 time.sleep(0.001)
 
     th = threading.Thread(target=workers)
