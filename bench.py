@@ -95,8 +95,11 @@ def pmc_traffic(kernel):
     symbol = PMC_SYMBOL.get(kernel, kernel)
     try:
         doc = path = None
-        for cand in (os.path.join("r05", "pmc_rollout_step_config5.json"), "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
-                     "r02_pmc_summary.json", "r01_pmc_summary.json"):      # newest round that has the kernel (the group step kernel: its own config-5 passes)
+        # newest round that has the kernel; the group step kernel has its own passes at config 5's shape (that file also holds the
+        # per-worker kernel at config 5's shape -- not the config-3 instantiation the other lines are about)
+        own = (os.path.join("r05", "pmc_rollout_step_config5_fold.json"), os.path.join("r05", "pmc_rollout_step_config5.json")) \
+            if kernel == "rollout_group_kernel" else ()         # (_fold: after fc_out was folded into the gate products; the other: before)
+        for cand in own + ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             path = os.path.join(REPO, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -116,8 +119,8 @@ def pmc_traffic(kernel):
             symbol = next(n for n in doc if n.startswith(symbol))
         k = doc[symbol]
         return {"bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"]["mean"] + 1024 * k["WRITE_SIZE"]["mean"],
-                "source": f"profiles/{os.path.basename(path)}, {('target ' + target + ', ') if target else ''}kernel symbol {symbol} "
-                          "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at the config-3 shape"
+                "source": f"profiles/{os.path.relpath(path, os.path.join(REPO, 'profiles'))}, {('target ' + target + ', ') if target else ''}kernel symbol {symbol} "
+                          f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at the {'config-5' if own else 'config-3'} shape"
                           + ("; forward and backward launches of the window pass averaged)" if symbol.startswith("window") else ")"),
                 "mfma_busy_fraction_pmc": k.get("derived", {}).get("mfma_busy_fraction")}
     except Exception:
