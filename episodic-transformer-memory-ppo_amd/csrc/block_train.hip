@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gate_out_train_kernel(const float *__rest
 // d out -> dA[:, 2D:3D] = d pre_h = dout z (1 - h^2);  d pre_z = dout (h - x) z (1 - z) -> dA[:, D:2D], dB[:, D:2D];
 // dx1 = dout (1 - z);  partial[wg][D] = column sums of -d pre_z (the gate bias enters the z gate with a minus sign).
 template <int NJ>
-__global__ __launch_bounds__(256) void gate_bwd1_kernel(const float *__restrict__ dout, const float *__restrict__ z,
+__global__ __launch_bounds__(256) void gate_bwd1_kernel(const float *__restrict__ dout, const float *__restrict__ dout2, const float *__restrict__ z,
                                                         const float *__restrict__ hh, const float *__restrict__ x,
                                                         float *__restrict__ dA, float *__restrict__ dB, float *__restrict__ dx1,
                                                         float *__restrict__ partial, int N, int D, int rows_per_wg) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gate_bwd1_kernel(const float *__restrict_
       const int c = lane + 64 * j;
       if (c < D) {
         const long long o = (long long)row * D + c;
-        const float g = dout[o], zz = z[o], h = hh[o], xv = x[o];
+        const float g = dout2 ? dout[o] + dout2[o] : dout[o], zz = z[o], h = hh[o], xv = x[o];   // (forked output: its two consumers' gradients)
         const float dph = g * zz * (1.0f - h * h);
         const float dpz = g * (h - xv) * zz * (1.0f - zz);
         dA[(long long)row * 3 * D + 2 * D + c] = dph;
@@ -424,7 +424,7 @@ extern "C" int64_t etm_gate_train_bwd_workspace_bytes(int N, int D) {
   return (int64_t)((N + rows - 1) / rows) * D * sizeof(float);
 }
 
-extern "C" int etm_gate_train_bwd1(const float *dout, const float *z, const float *hh, const float *x, float *dA, float *dB, float *dx1,
+extern "C" int etm_gate_train_bwd1(const float *dout, const float *dout2, const float *z, const float *hh, const float *x, float *dA, float *dB, float *dx1,
                                    float *dbg, float *workspace, int64_t workspace_bytes, int N, int D, void *stream) {
   (void)hipGetLastError();
   if (!dout || !z || !hh || !x || !dA || !dB || !dx1 || !workspace || N <= 0 || D <= 0) return ETM_EINVAL;
@@ -435,7 +435,7 @@ extern "C" int etm_gate_train_bwd1(const float *dout, const float *z, const floa
   {
     EtmProfScope prof(ETM_K_GATE_TRAIN, st);
     rc = dispatch_nj(D, [&](auto nj) {
-      hipLaunchKernelGGL((gate_bwd1_kernel<decltype(nj)::value>), dim3((unsigned)P), dim3(256), 0, st, dout, z, hh, x, dA, dB, dx1, workspace, N, D, rows);
+      hipLaunchKernelGGL((gate_bwd1_kernel<decltype(nj)::value>), dim3((unsigned)P), dim3(256), 0, st, dout, dout2, z, hh, x, dA, dB, dx1, workspace, N, D, rows);
       return etm_launch_status();
     });
   }

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 _lib = None
 
@@ -96,7 +96,7 @@ SIGNATURES = {
     "etm_gate_train_out": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_gate_train_bwd_workspace_bytes": (_L, [_I, _I]),
     "etm_gate_train_bwd_partial_rows": (_I, [_I]),
-    "etm_gate_train_bwd1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "etm_gate_train_bwd1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "etm_gate_train_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "etm_conv_train_fwd": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_train_set_fwd_lds": (_I, [_I]),

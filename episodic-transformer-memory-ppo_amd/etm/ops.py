@@ -990,7 +990,7 @@ class _GruGateFn(torch.autograd.Function):
     column-sum kernel for d bg) backward, instead of six small GEMMs + ~10 element-wise launches forward and twice that backward."""
 
     @staticmethod
-    def forward(ctx, x, y, wr, ur, wz, uz, wg, ug, bg, wy=None, ux=None):
+    def forward(ctx, x, y, wr, ur, wz, uz, wg, ug, bg, wy=None, ux=None, fork=False):
         lib = _lib.load()
         _need_dev(x, y, wr, ur, wz, uz, wg, ug, bg)
         x, y = _f32c(x, "x"), _f32c(y, "y")
@@ -1009,13 +1009,21 @@ class _GruGateFn(torch.autograd.Function):
             ctx.save_for_backward(x, y, r, z, rx, hh, wy, ux, ug)
             ctx.gate_weights = (wr, ur, wz, uz, wg)      # (the parameters themselves: DeferredDw looks their arena views up by address)
             ctx.bg_ptr = bg.data_ptr()
+        if fork:         # the output twice (one storage) for its two consumers (pre-LN blocks: the next LayerNorm and the next gate's
+            ctx.set_materialize_grads(False)   # residual input): their gradients arrive separately and gate_bwd1 adds them on load
+            return out, out.detach()
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
         lib = _lib.load()
         x, y, r, z, rx, hh, wy, ux, ug = ctx.saved_tensors
+        if dout is None:
+            dout, dout2 = dout2, None
+        if dout is None:
+            return (None,) * 12
         dout = _f32c(dout, "dout")
+        dout2 = _f32c(dout2, "dout2")
         N, D = x.shape
         dev = x.device
         dA = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
@@ -1029,7 +1037,7 @@ class _GruGateFn(torch.autograd.Function):
         else:
             dbg = torch.empty((D,), dtype=torch.float32, device=dev)
             ws = workspace(nbytes, dev, "gate_bwd")
-        _lib.check(lib.etm_gate_train_bwd1(_ptr(dout), _ptr(z), _ptr(hh), _ptr(x), _ptr(dA), _ptr(dB), _ptr(dx1), _ptr(dbg), _ptr(ws), nbytes,
+        _lib.check(lib.etm_gate_train_bwd1(_ptr(dout), _ptr(dout2), _ptr(z), _ptr(hh), _ptr(x), _ptr(dA), _ptr(dB), _ptr(dx1), _ptr(dbg), _ptr(ws), nbytes,
                                            N, D, _stream()), "etm_gate_train_bwd1")
         dC = dA[:, 2 * D:]                              # d pre_h, a strided view (row stride 3D): GEMM operand in place
         drx = torch.mm(dC, ug)
@@ -1051,14 +1059,16 @@ class _GruGateFn(torch.autograd.Function):
         dux = torch.mm(dB.t(), x) if not (took[1] and took[3]) else None                 # [2D, D] = d [Ur; Uz]
         pick = lambda t, full, lo: None if t else full[lo: lo + D]
         return (dx, dy, pick(took[0], dwy, 0), pick(took[1], dux, 0), pick(took[2], dwy, D), pick(took[3], dux, D),
-                pick(took[4], dwy, 2 * D), None if took[5] else torch.mm(dC.t(), rx), dbg, None, None)
+                pick(took[4], dwy, 2 * D), None if took[5] else torch.mm(dC.t(), rx), dbg, None, None, None)
 
 
-def gru_gate_train(gate, x, y, packed=None):
+def gru_gate_train(gate, x, y, packed=None, fork=False):
     """Differentiable GTrXL gate of ``gate`` (a transformer.GRUGate) on [N, D] inputs.  ``packed``: ([Wr; Wz; Wg], [Ur; Uz]) of the
-    gate's CURRENT weights when the caller has them concatenated already."""
+    gate's CURRENT weights when the caller has them concatenated already.  ``fork``: returns the result TWICE (two tensors, one
+    storage) for its two consumers; their gradients are added by the gate's backward kernel on load instead of by an extra launch."""
     wy, ux = packed if packed is not None else (None, None)
-    return _GruGateFn.apply(x, y, gate.Wr.weight, gate.Ur.weight, gate.Wz.weight, gate.Uz.weight, gate.Wg.weight, gate.Ug.weight, gate.bg, wy, ux)
+    return _GruGateFn.apply(x, y, gate.Wr.weight, gate.Ur.weight, gate.Wz.weight, gate.Uz.weight, gate.Wg.weight, gate.Ug.weight, gate.bg, wy, ux,
+                            fork)
 
 
 def conv_pack_weights(weight2d):

@@ -88,7 +88,8 @@ class GRUGate(nn.Module):
     def _versions(self):
         return tuple(m.weight._version for m in (self.Wr, self.Wz, self.Wg, self.Ur, self.Uz))
 
-    def forward(self, x, y):
+    def forward(self, x, y, fork=False):
+        """``fork`` (fused training path only): the result twice -- see ops.gru_gate_train."""
         if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and getattr(self, "_wy", None) is not None:
             if not torch.cuda.is_current_stream_capturing() and self._wver != self._versions():
                 self.refresh_rollout_weights()       # weights moved since the copies were made (optimizer step, load)
@@ -97,11 +98,12 @@ class GRUGate(nn.Module):
             # training: concatenated GEMMs + fused forward / backward kernels; the concatenations come packed (one launch for all
             # gates of the model, Transformer._pack_gate_weights) when the enclosing forward pass made them, else from two cat launches
             packed, self._train_cat = getattr(self, "_train_cat", None), None
-            return ops.gru_gate_train(self, x, y, packed)
+            return ops.gru_gate_train(self, x, y, packed, fork)
         r = torch.sigmoid(self.Wr(y) + self.Ur(x))
         z = torch.sigmoid(self.Wz(y) + self.Uz(x) - self.bg)
         cand = torch.tanh(self.Wg(y) + self.Ug(r * x))
-        return (1 - z) * x + z * cand
+        out = (1 - z) * x + z * cand
+        return (out, out) if fork else out
 
 
 class TransformerBlock(Module):
@@ -121,8 +123,9 @@ class TransformerBlock(Module):
 
     def forward_window(self, h, spec: WindowSpec, block=0, pos=None, h_res=None, fork=False):
         """h [N, D] query state; returns (new state [N, D], attention [N, H, L]).  ``h_res``: the second copy of ``h`` for the
-        residual branch when the producer forked it (ops.fused_layernorm); ``fork``: return the new state forked for the next
-        block, (state, attention, state for the residual) -- both only on the fused post-LN training path."""
+        residual branch when the producer forked it (ops.fused_layernorm / ops.gru_gate_train); ``fork``: return the new state forked
+        for the next block, (state, attention, state for the residual) -- both only on the fused training paths (post-LN without
+        gates, pre-LN with gates; the other layouts return None for the third element)."""
         pre = self.layer_norm == "pre"
         fused = self._fused_train(h)
         q_in = (ops.fused_layernorm(h, self.norm1) if fused else self.norm1(h)) if pre else h
@@ -140,7 +143,16 @@ class TransformerBlock(Module):
                 return out, att_w, out_res
             return ops.fused_layernorm(f_raw, self.norm2, bias=fc.bias, res=x_res, relu=True), att_w
         att_out, att_w = self.attention.attend(q_in, spec, block, pos, self.norm_kv if pre else None)
-        out = self._after_attention(h, att_out)
+        if fused and pre and self.use_gtrxl:
+            # training, pre-LN + gates: a gate's output feeds the next LayerNorm AND the next gate's residual input (transformer.py:
+            # 143-149, :160-170 with :287-298) -- forked, the two gradients are added by the gate's backward kernel on load
+            x, x_res = self.gate1(h if h_res is None else h_res, att_out, fork=True)
+            f = ops.linear_relu(self.fc[0], ops.fused_layernorm(x, self.norm2))
+            if fork:
+                out, out_res = self.gate2(x_res, f, fork=True)
+                return out, att_w, out_res
+            return self.gate2(x_res, f), att_w
+        out = self._after_attention(h if h_res is None else h_res, att_out)
         return (out, att_w, None) if fork else (out, att_w)
 
     @staticmethod

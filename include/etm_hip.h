@@ -236,7 +236,8 @@ int etm_gru_gate_out(const float *a, const float *c, const float *z, const float
  *                     C = (r x) Ug^T [N,D]:
  *       rz  : r = sigmoid(A_r + B_r), z = sigmoid(A_z + B_z - bg), rx = r x              (writes r, z, rx)
  *       out : hh = tanh(A_g + C), out = (1 - z) x + z hh                                  (writes hh, out)
- *       bwd1: dout -> dA[:, 2D:3D] = dout z (1 - hh^2); dA[:, D:2D] = dB[:, D:2D] = dout (hh - x) z (1 - z);
+ *       bwd1: dout (+ dout2 when not NULL: the gate's output fed two consumers and their gradients arrive separately)
+ *             -> dA[:, 2D:3D] = dout z (1 - hh^2); dA[:, D:2D] = dB[:, D:2D] = dout (hh - x) z (1 - z);
  *             dx1 = dout (1 - z); dbg [D] = - column sums of dA[:, D:2D]   (then the caller forms drx = dA[:, 2D:3D] Ug);
  *             dbg == NULL: `workspace` keeps etm_gate_train_bwd_partial_rows(N) rows of D partial sums for etm_colsum_reduce_grouped
  *       bwd2: drx -> dA[:, 0:D] = dB[:, 0:D] = drx x r (1 - r); dx2 = dx1 + drx r
@@ -259,7 +260,7 @@ int etm_gate_train_rz(const float *A, const float *B, const float *bg, const flo
 int etm_gate_train_out(const float *A, const float *C, const float *z, const float *x, float *hh, float *out, int N, int D, void *stream);
 int64_t etm_gate_train_bwd_workspace_bytes(int N, int D);
 int etm_gate_train_bwd_partial_rows(int N);
-int etm_gate_train_bwd1(const float *dout, const float *z, const float *hh, const float *x, float *dA, float *dB, float *dx1, float *dbg,
+int etm_gate_train_bwd1(const float *dout, const float *dout2, const float *z, const float *hh, const float *x, float *dA, float *dB, float *dx1, float *dbg,
                         float *workspace, int64_t workspace_bytes, int N, int D, void *stream);
 int etm_gate_train_bwd2(const float *drx, const float *x, const float *r, const float *dx1, float *dA, float *dB, float *dx2, int N, int D,
                         void *stream);
