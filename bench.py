@@ -469,7 +469,11 @@ def main():
                                     "rooflines.window.cold_hbm for the same kernel with every byte coming from HBM")
         rollout_k = {name: {"launches": cnt, "avg_ms": ms / cnt} for (tag, name), (ms, cnt) in prof.items() if tag == 0}
         out = {
-            "metric": "env-steps/sec (whole node) MinigridMemory 3x84x84",
+            # (BASELINE.json's metric is quoted on configs (3)/(4): the default line; --config lines name their own shape)
+            "metric": ("env-steps/sec (whole node) MinigridMemory 3x84x84" if CONFIG_NAME == "synthetic_minigrid" else
+                       "env-steps/sec (whole node), shape of BASELINE config (5) MortarMayhem-Grid GTrXL 3x84x84" if CONFIG_NAME == "synthetic_mortar_gtrxl" else
+                       "env-steps/sec (whole node), shape of BASELINE config (2) CartPole-masked-velocity GTrXL" if CONFIG_NAME == "synthetic_cartpole" else
+                       f"env-steps/sec (whole node), configs/{CONFIG_NAME}.yaml"),
             "value": total_env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
