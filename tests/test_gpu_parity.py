@@ -1872,6 +1872,19 @@ def test_rollout_driver_service_order(order):
             assert served_first[t] == (not dones[t, Wg:].any()), (t, served_first, dones[t])
 
 
+@pytest.mark.parametrize("layout", ["trxl_post", "gtrxl_pre"])
+def test_every_replay_of_the_captured_step_equals_its_eager_evaluation(layout):
+    """tools/graph_replay_soak.py, short: 60 updates = 238 replays of the captured optimisation step, each compared tensor by tensor
+    with an eager evaluation of the same minibatch at the same parameters.  A node that is not replay-safe (round 5: torch's column
+    sum) shows as a tensor that is wrong in some replays; rounding-level otherwise (measured <= 2.1e-7)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import graph_replay_soak as soak
+    r = soak.run(layout, 60, quiet=True)
+    assert r["replays"] >= 230
+    assert r["loud"] == 0 and r["worst"] < 1e-5, r
+
+
 def test_captured_graphs_hold_no_memset_nodes(tmp_path):
     """No framework reduction inside a captured graph (tools/graph_reduce_hazard.py): torch's tall column sums
     show up as a MEMSET node (their semaphore) in front of a reduce kernel, and that pair is not replay-safe on this runtime.  A
