@@ -25,7 +25,7 @@ namespace {
 constexpr int GD_MT = 3, GD_NT = 4;                 // 32-row tiles along Ma (96) and along Nb (128) per workgroup
 constexpr int GD_TM = 32 * GD_MT, GD_TN = 32 * GD_NT;
 constexpr int GD_PD = 6;                            // k-steps (2 rows each) in flight per wave
-constexpr int GD_MAXP = 56;                         // problems per launch (kernel-argument table)
+constexpr int GD_MAXP = 84;                         // problems per launch (kernel-argument table: 84 x 48 + 12 bytes of the 4 KB a launch may carry)
 
 struct GdProblem {
   const float *A, *B;
@@ -38,6 +38,8 @@ struct GdParams {
   GdProblem p[GD_MAXP];
   int n_problems, n_tiles, N;
 };
+
+static_assert(sizeof(GdParams) <= 4096, "kernel arguments of one launch");
 
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
