@@ -450,7 +450,7 @@ class DeferredDw:
         if not self.items:
             return
         lib = _lib.load()
-        cap = lib.etm_grouped_dw_max_problems()          # problems per launch (the kernel-argument table): gated models need two launches
+        cap = lib.etm_grouped_dw_max_problems()          # problems per launch (the kernel-argument table: 84)
         for lo in range(0, len(self.items), cap):
             items = self.items[lo: lo + cap]
             k = len(items)
