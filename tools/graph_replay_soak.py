@@ -7,7 +7,9 @@ of the replayed step are restored and training goes on.  Same kernels in the sam
 GEMMs may pick another algorithm outside capture) unless a node of the graph is not replay-safe -- DESIGN.md section 4: torch's
 column sum was not, from replay ~300 on, and returned garbage for one tensor.
 
-    python tools/graph_replay_soak.py [updates] [layout ...]        layouts: trxl_post (visual), gtrxl_pre (vector), gtrxl_pre_visual
+    python tools/graph_replay_soak.py [updates] [layout ...]        layouts: trxl_post (visual), gtrxl_pre (vector), gtrxl_pre_visual,
+                                                                    or the name of a configs/*.yaml (synthetic_minigrid = BASELINE config 3,
+                                                                    synthetic_mortar_gtrxl = config 5's shape, synthetic_cartpole = config 2's)
     python tools/graph_replay_soak.py 120 gtrxl_pre --framework-bias-grad
         positive control: fc_out as a plain nn.Linear again (its bias gradient = torch's column sum inside the captured step) on
         minibatches of 1,024 samples -- the check must report the replays in which that one tensor is wrong
@@ -43,7 +45,12 @@ LAYOUTS = {
 def run(layout, updates, quiet=False, framework_bias_grad=False):
     from trainer import PPOTrainer
     dev = torch.device("cuda", 0)
-    cfg = dict(BASE, **LAYOUTS[layout])
+    if layout in LAYOUTS:
+        cfg = dict(BASE, **LAYOUTS[layout])
+    else:
+        from yaml_parser import YamlParser
+        cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", layout + ".yaml")).get_config()
+        cfg["tunable_gemm"] = False
     if framework_bias_grad:
         from etm import ops
         ops.linear_bias = lambda lin, x: lin(x)
@@ -66,7 +73,7 @@ def run(layout, updates, quiet=False, framework_bias_grad=False):
             for idx in perm:
                 before = [p.detach().clone() for p in tr.params]
                 was_captured = tr._train_graph is not None
-                tr._train_step_graph(idx, 3e-4, 0.1, 1e-3, True)
+                tr._train_step_graph(idx, 3e-4, 0.1, 1e-3, bool(cfg.get("monitor_gradients", True)))
                 if not was_captured:
                     continue                                    # an eager warm-up step or the capture itself
                 replays += 1
@@ -98,7 +105,7 @@ def run(layout, updates, quiet=False, framework_bias_grad=False):
 if __name__ == "__main__":
     args = sys.argv[1:]
     updates = int(args[0]) if args and args[0].isdigit() else 150
-    layouts = [a for a in args if a in LAYOUTS] or list(LAYOUTS)
+    layouts = [a for a in args if a in LAYOUTS or a.startswith("synthetic_")] or list(LAYOUTS)
     control = "--framework-bias-grad" in args
     for layout in layouts:
         r = run(layout, updates, framework_bias_grad=control)
