@@ -1885,6 +1885,61 @@ def test_every_replay_of_the_captured_step_equals_its_eager_evaluation(layout):
     assert r["loud"] == 0 and r["worst"] < 1e-5, r
 
 
+@pytest.mark.parametrize("N,D", [(2048, 384), (601, 128)])
+def test_linear_bias_and_forked_gate_vs_plain_autograd(N, D):
+    """Round 5: ops.linear_bias (fc_out of the pre-LN / gated blocks: bias gradient by the library's column sums, weight gradient
+    deferrable) against nn.Linear under plain autograd in float64, with and without a DeferredDw collector (bit-identical to each
+    other); ops.gru_gate_train(fork=True) (the output twice, gradients added by gate_bwd1 on load) against the un-forked gate fed
+    the sum of the two gradients (bit-identical)."""
+    from etm import ops
+    import transformer as tfm
+    dev = _dev()
+    torch.manual_seed(N + D)
+    lin = torch.nn.Linear(D, D).to(dev)
+    x = torch.randn((N, D), device=dev, requires_grad=True)
+    g = torch.randn((N, D), device=dev)
+    (ops.linear_bias(lin, x) * g).sum().backward()
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin64 = torch.nn.Linear(D, D).to(dev).double()
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    (lin64(x64) * g.double()).sum().backward()
+    for a, b, what in zip(got, (x64.grad, lin64.weight.grad, lin64.bias.grad), ("dx", "dW", "db")):
+        err = float((a.double() - b).norm() / b.norm())
+        assert err < 2e-6, (what, err)
+    # through a collector: the same bits (the grouped launches use the per-call summation trees)
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    views = {lin.weight.data_ptr(): torch.full_like(lin.weight, float("nan")), lin.bias.data_ptr(): torch.full_like(lin.bias, float("nan"))}
+    with ops.DeferredDw(views) as col:
+        (ops.linear_bias(lin, x) * g).sum().backward()
+    assert lin.bias.data_ptr() in col.written and lin.bias.grad is None
+    assert torch.equal(views[lin.bias.data_ptr()], got[2]) and torch.equal(x.grad, got[0])
+    dw = views[lin.weight.data_ptr()] if lin.weight.data_ptr() in col.written else lin.weight.grad
+    assert float((dw.double() - lin64.weight.grad).norm() / lin64.weight.grad.norm()) < 2e-6
+
+    gate = tfm.GRUGate(D, 0.1).to(dev)
+    xg = torch.randn((N, D), device=dev, requires_grad=True)
+    yg = torch.randn((N, D), device=dev, requires_grad=True)
+    g1, g2 = torch.randn((N, D), device=dev), torch.randn((N, D), device=dev)
+    params = [xg, yg] + list(gate.parameters())
+    out = ops.gru_gate_train(gate, xg, yg)
+    (out * (g1 + g2)).sum().backward()
+    ref = [t.grad.clone() for t in params]
+    for t in params:
+        t.grad = None
+    a, b = ops.gru_gate_train(gate, xg, yg, fork=True)
+    assert a.data_ptr() == b.data_ptr() and torch.equal(a, out)
+    ((a * g1).sum() + (b * g2).sum()).backward()
+    for t, r in zip(params, ref):
+        assert torch.equal(t.grad, r), float((t.grad - r).abs().max())
+    for t in params:
+        t.grad = None
+    a, b = ops.gru_gate_train(gate, xg, yg, fork=True)          # only one consumer has a gradient
+    (b * g2).sum().backward()
+    out = ops.gru_gate_train(gate, xg.detach().requires_grad_(True), yg)
+    assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) for t in params)
+
+
 def test_captured_graphs_hold_no_memset_nodes(tmp_path):
     """No framework reduction inside a captured graph (tools/graph_reduce_hazard.py): torch's tall column sums
     show up as a MEMSET node (their semaphore) in front of a reduce kernel, and that pair is not replay-safe on this runtime.  A
