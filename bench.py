@@ -168,10 +168,123 @@ def cpu_baseline(cfg, seed=0):
     except Exception:
         pass
     return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "cgroup_cpu_quota": quota,
+            "sample_short": f"oracle trainer, 1 update of {c['n_workers']}x{c['worker_steps']} env steps, {c['epochs']} epochs x 1 minibatch of {steps}; {dt:.1f} s "
+                            f"on {threads} torch threads of {cores} host cores",
             "sample": f"1 update of {c['n_workers']} workers x {c['worker_steps']} steps (= {steps} env steps) with {c['epochs']} epochs x 1 "
                       f"minibatch of {steps} samples: same per-env-step work as the full config (minibatch 2048, 5 epochs); "
                       f"{dt:.1f} s (rollout {split['rollout_s']:.1f} s on {roll_threads} torch threads, train {split['train_s']:.1f} s on "
                       f"{threads}) of {cores} host cores"}
+
+LINE_LIMIT = 8000      # bytes of the ONE stdout line (the driver's parser dropped round 5's 20,013-character line); the full record goes to --full-json
+
+
+def _num(x, sig=6):
+    """Floats to ``sig`` significant digits (the line is a summary: the full-precision record is the side file)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _num(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, sig) for v in x]
+    return float(x) if hasattr(x, "__float__") else str(x)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "avg_launch_ms", "launches", "bytes_per_launch",
+                 "flops_per_launch", "unique_bytes_per_launch", "frac_unique", "hbm_side_frac", "mfma_busy_fraction_pmc", "est_region_ms",
+                 "us_per_dependent_phase", "dtype")
+
+
+def _flat_rooflines(r, prefix="", out=None):
+    """Micro-benchmark tree -> {path: [avg_launch_ms, frac]} (one entry per kernel line)."""
+    out = {} if out is None else out
+    if not isinstance(r, dict):
+        return out
+    if "frac" in r and ("avg_launch_ms" in r or "ms" in r):
+        out[prefix.rstrip(".")] = [r.get("avg_launch_ms", r.get("ms")), r["frac"]]
+    for k, v in r.items():
+        if isinstance(v, dict) and k not in ("shape", "model"):
+            _flat_rooflines(v, prefix + k + ".", out)
+    return out
+
+
+def fresh_obs_run(cfg, device, lib, updates=3, warmup=1):
+    """The same update on SURVEY 8d's environment as written: pool 0 (every observation a fresh default_rng draw inside the timed
+    region) with the environments in worker processes (the reference's workers step concurrently, worker.py:36-48)."""
+    from trainer import PPOTrainer
+    cfg["environment"]["pool"] = 0
+    cfg["worker_processes"] = True
+    torch.manual_seed(0)
+    np.random.seed(0)
+    tr = PPOTrainer(cfg, run_id="bench_fresh", device=device, tensorboard=False)
+    try:
+        lib.etm_profile_enable(0)
+        phases = np.zeros(2)
+        for i in range(warmup + updates):
+            if i == warmup:
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                phases[:] = 0
+            lr, beta, clip = tr.schedules(i)
+            ta = time.perf_counter()
+            tr._sample_training_data()
+            tr.buffer.prepare_batch_dict()
+            torch.cuda.synchronize(device)
+            tb = time.perf_counter()
+            tr._train_epochs(lr, clip, beta)
+            torch.cuda.synchronize(device)
+            phases += (tb - ta, time.perf_counter() - tb)
+        dt = time.perf_counter() - t0
+        return {"value": cfg["n_workers"] * cfg["worker_steps"] * updates / dt, "unit": "env-steps/s", "updates": updates, "warmup": warmup,
+                "phase_s_per_step": {"rollout": phases[0] / updates, "train": phases[1] / updates},
+                "envs_per_process": tr._host_plan["envs_per_process"], "env": "pool 0 (fresh U[0,1) draw per observation), worker processes"}
+    finally:
+        tr.close()
+
+
+def compact_line(full, full_path):
+    """The driver's line: the contract's keys, the roofline / cpu_baseline objects with numbers and one short note each, and
+    ONE {kernel: [avg_ms, frac]} summary of the micro-benchmarks.  Everything else (per-kernel tables, models, prose) is in
+    the side file ``full_path``."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data") if k in full}
+    cfgf = full["config"]
+    line["config"] = dict(_pick(cfgf, ("env_pool", "minibatch", "parallelism", "attention", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
+                                       "envs_per_process", "cgroup_cpu_quota")), workload=cfgf["workload"][:300])
+    for k in ("value_fresh_obs", "phase_s_per_step", "speedup_vs_cpu_baseline"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    for k in ("roofline", "roofline_train"):
+        r = full.get(k)
+        if r:
+            line[k] = _pick(r, ROOFLINE_KEYS)
+            line[k].setdefault("traffic", None)
+            if r.get("note_short"):
+                line[k]["note"] = r["note_short"][:120]
+    if full.get("allreduce"):
+        line["allreduce"] = _pick(full["allreduce"], ("bytes", "avg_ms", "bus_gbs", "exposed_ms", "per_update", "overlap", "error"))
+    if isinstance(full.get("rooflines"), dict):
+        line["rooflines"] = {"error": full["rooflines"]["error"][:200]} if "error" in full["rooflines"] else _flat_rooflines(full["rooflines"])
+    if full.get("cpu_baseline"):
+        c = full["cpu_baseline"]
+        line["cpu_baseline"] = dict(_pick(c, ("value", "unit", "cores", "kind", "cgroup_cpu_quota")), sample=c.get("sample_short", c.get("sample", ""))[:200])
+    line["full_json"] = full_path
+    line = _num(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:         # never lose the headline: shed the optional summaries, largest first
+        for k in ("rooflines", "roofline_train", "allreduce"):
+            line.pop(k, None)
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
 
 
 def main():
@@ -215,6 +328,12 @@ def main():
     ap.add_argument("--env-pool", type=int, default=None,
                     help="frames per worker in the synthetic environment's ring (default: the YAML's, 64); 0 = SURVEY 8d to the letter: every "
                          "observation is a fresh default_rng(seed + worker).random([3, 84, 84]) draw inside the timed region")
+    ap.add_argument("--full-json", default=os.path.join(REPO, "bench_full.json"),
+                    help="side file for the FULL record (per-kernel tables, roofline models, micro-benchmark trees, prose): the stdout line "
+                         "is a < 8 KB summary of it")
+    ap.add_argument("--no-fresh-obs", action="store_true",
+                    help="skip the second measurement after the timed region (N == 1 only): the same update with SURVEY 8d's environment to the "
+                         "letter (--env-pool 0, worker processes), reported as value_fresh_obs")
     ap.add_argument("--gen-threads", type=int, default=None,
                     help="with --env-pool 0 and in-process environments: host threads that draw a step's observations (numpy releases the GIL)")
     args = ap.parse_args()
@@ -420,6 +539,7 @@ def main():
                         "launches": rs["launches"], "bytes_per_launch": rs["bytes_per_launch"], "dtype": "f32",
                         "unique_bytes_per_launch": rs.get("unique_bytes_per_launch"), "frac_unique": rs.get("frac_unique"),
                         "est_region_ms": est[dom_all], "us_per_dependent_phase": rs["us_per_dependent_phase"], "model": rs["model"],
+                        "note_short": "rollout step kernel: latency chain, bytes = streamed (L2-served) weights + K|V; frac_unique = once-only bytes",
                         "note": "dominant kernel of ALL GPU time (rollout: one launch per worker group and step).  It is a dependency "
                                 "chain (products -> exchange -> LayerNorm ...), bound by round-trip latency, not by a roofline: "
                                 "bytes_per_launch = workers x every matrix of the chain (each team streams them once for ONE worker) + the "
@@ -460,6 +580,7 @@ def main():
             if tr_pmc and kind == "mfma":
                 roofline_train["mfma_busy_fraction_pmc"] = tr_pmc.get("mfma_busy_fraction_pmc")
             roofline_train.update(extra)
+            roofline_train["note_short"] = ("dominant kernel of the optimisation phase, HIP events inside the timed region (every 8th minibatch eager)")
             if kind == "hbm":
                 roofline_train["extra_bytes_per_launch"] = N * 4.0 * (2 * H * D + H * L * (2 if dom.endswith("bwd_kernel") else 1))
                 roofline_train["note"] = ("bytes_per_launch = N*L*D*4, the un-deduplicated window read of SURVEY 8d; minibatches are sorted by "
@@ -488,18 +609,16 @@ def main():
             "config": {"workload": (("BASELINE config (3)/(4)" if CONFIG_NAME == "synthetic_minigrid" else
                                      "shape of BASELINE config (5)" if CONFIG_NAME == "synthetic_mortar_gtrxl" else
                                      "shape of BASELINE config (2)" if CONFIG_NAME == "synthetic_cartpole" else "config")
-                                    + f": configs/{CONFIG_NAME}.yaml -- per GPU n_workers={W} x worker_steps={S} "
-                                    f"= {W * S} env steps per update, {cfg['epochs']} epochs x {cfg['n_mini_batch']} minibatches of {N}, "
-                                    f"{'GTrXL' if cfg['transformer'].get('gtrxl') else 'TrXL'} ({cfg['transformer'].get('layer_norm') or 'no'}-LN) "
+                                    + f" configs/{CONFIG_NAME}.yaml: per GPU {W} workers x {S} steps, {cfg['epochs']} epochs x {cfg['n_mini_batch']} minibatches of {N}, "
+                                    f"{'GTrXL' if cfg['transformer'].get('gtrxl') else 'TrXL'} {cfg['transformer'].get('layer_norm') or 'no'}-LN "
                                     f"{cfg['transformer']['num_blocks']} blocks D={cfg['transformer']['embed_dim']} H={cfg['transformer']['num_heads']} "
-                                    f"L={cfg['transformer']['memory_length']}, synthetic {'x'.join(str(x) for x in cfg['environment']['obs_shape'])} observations: ")
-                                   + ("every observation is a FRESH default_rng(seed + worker id).random([3, 84, 84]) float32 draw inside the timed "
-                                      "region (SURVEY 8d to the letter)" if cfg["environment"].get("pool", 64) == 0 else
-                                      f"every worker replays a ring of {cfg['environment'].get('pool', 64)} frames drawn once from U[0,1) "
-                                      "(numpy default_rng(seed + worker id))")
-                                   + "; rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); environments stepped "
-                                   + ("in worker processes" if cfg.get("worker_processes", False) else "in-process on the host")
-                                   + " (part of the timed region); random-init weights",
+                                    f"L={cfg['transformer']['memory_length']}, synthetic {'x'.join(str(x) for x in cfg['environment']['obs_shape'])} obs: "
+                                    + ("fresh default_rng draw per observation (SURVEY 8d to the letter)" if cfg["environment"].get("pool", 64) == 0 else
+                                       f"{cfg['environment'].get('pool', 64)}-frame ring per worker drawn once from U[0,1)")
+                                    + (", envs in worker processes" if cfg.get("worker_processes", False) else ", in-process envs")
+                                    + " inside the timed region, random-init weights"),
+                       "workload_detail": "rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); numpy default_rng(seed + worker id); see value_fresh_obs "
+                                          "for the same build on --env-pool 0 with worker processes",
                        "env_pool": cfg["environment"].get("pool", 64), "env_gen_threads": cfg["environment"].get("gen_threads", 1),
                        "host_threads_busy": trainer._host_plan["busy_threads"], "host_cpu_plan": trainer._host_plan["reason"],
                        "host_cpus_per_rank": trainer._host_plan["budget"]["per_rank"], "cgroup_cpu_quota": trainer._host_plan["budget"]["cgroup_quota"],
@@ -530,10 +649,28 @@ def main():
             except Exception as exc:       # reporting only: never lose the throughput line over it
                 out["rooflines"] = {"error": repr(exc)}
             trainer = None
+        if world == 1 and not args.no_fresh_obs and CONFIG_NAME == "synthetic_minigrid" and cfg["environment"].get("pool", 64) != 0:
+            # SURVEY 8d's environment to the letter, after the timed region: every observation a fresh draw, environments in worker processes
+            try:
+                if trainer is not None:
+                    trainer.close()
+                    trainer = None
+                    torch.cuda.empty_cache()
+                out["fresh_obs"] = fresh_obs_run(load_config(), device, lib)
+                out["value_fresh_obs"] = out["fresh_obs"]["value"]
+            except Exception as exc:       # reporting only: never lose the throughput line over it
+                out["fresh_obs"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), file=json_out, flush=True)
+        full_path = args.full_json
+        try:
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1, default=float)
+            full_path = os.path.relpath(full_path, REPO)
+        except OSError as exc:
+            full_path = f"not written: {exc!r}"[:100]
+        print(compact_line(out, full_path), file=json_out, flush=True)
     if dp is not None:
         dp.barrier()            # rank 0 ran the kernel micro-benchmarks: leave together
     if trainer is not None:

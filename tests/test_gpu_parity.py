@@ -2504,15 +2504,30 @@ def test_poc_memory_env_learns():
 
 
 def test_bench_prints_one_json_line(tmp_path):
-    """bench.py's contract with the driver: rank 0 prints ONE JSON line on stdout and nothing else (trainer / library notes go to
-    stderr) -- a stray informational print in round 4 would have broken the driver's parsing."""
+    """bench.py's contract with the driver, on the DRIVER'S command shape (--gpus 1, micro-benchmarks, fresh-observation run and CPU
+    baseline all ON): rank 0 prints ONE strict-JSON line on stdout, shorter than 8 KB (round 5's 20,013-character line was dropped by
+    the driver's parser), carrying the headline, `roofline`, `cpu_baseline` and `config.workload`; the full record is the side file."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "1", "--warmup", "1", "--no-rooflines", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, cwd=repo)
+    full = tmp_path / "full.json"
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--full-json", str(full)],
+                         capture_output=True, text=True, timeout=1500, cwd=repo)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[:2000]
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 1 and rec["unit"] == "env-steps/s" and rec["value"] > 0 and "roofline" in rec
+    assert len(lines[0].encode()) < 8192, len(lines[0])
+
+    def no_constants(name):
+        raise AssertionError(f"non-strict JSON constant {name} on the line")
+
+    rec = json.loads(lines[0], parse_constant=no_constants)
+    assert rec["n_gpus"] == 1 and rec["unit"] == "env-steps/s" and rec["value"] > 0 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert abs(rec["ms_per_step"] * rec["steps"] * 1e-3 * rec["value"] - 2 * 32 * 512) < 0.01 * 2 * 32 * 512
+    assert 0 < rec["roofline"]["frac"] < 1.5 and rec["roofline"]["peak"] > 0 and "traffic" in rec["roofline"]
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1
+    assert "synthetic_minigrid" in rec["config"]["workload"] and len(rec["config"]["workload"]) <= 300
+    assert rec["rooflines"]["encoder.all_passes"][1] > 0.3
+    assert rec["value_fresh_obs"] > 0
+    side = json.loads(full.read_text())
+    assert side["value"] == pytest.approx(rec["value"], rel=1e-5) and "kernels_train" in side and "rooflines" in side

@@ -603,3 +603,44 @@ def test_two_ranks_on_four_cpus_do_not_slow_each_other_down_under_the_host_cpu_p
             break
     assert both[0]["copy_threads"] == 2, both
     assert best <= 1.3, (best, alone, both)
+
+
+def test_bench_line_summary_is_short_strict_json():
+    """bench.py's stdout line is a summary of the full record: < 8 KB of strict JSON with the contract's keys, `roofline`,
+    `cpu_baseline` and one {kernel: [avg_ms, frac]} table -- checked here on the committed full record of round 5 (20,013
+    characters, the line the driver's parser dropped), on a record with non-finite numbers, and on an oversized one."""
+    import importlib.util
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(repo, "profiles", "r05_bench.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 19000
+
+    def strict(text):
+        def bad(name):
+            raise AssertionError(name)
+        return json.loads(text, parse_constant=bad)
+
+    text = bench.compact_line(full, "bench_full.json")
+    assert "\n" not in text and len(text.encode()) < 8000
+    rec = strict(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert rec[key] == pytest.approx(full[key], rel=1e-5) if isinstance(full[key], float) else rec[key] == full[key], key
+    assert rec["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5) and rec["roofline"]["bound"] == "hbm"
+    assert rec["roofline"]["traffic"] == pytest.approx(full["roofline"]["traffic"], rel=1e-5)
+    assert rec["cpu_baseline"]["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-5) and rec["cpu_baseline"]["cores"] == 64
+    assert len(rec["config"]["workload"]) <= 300 and len(rec["cpu_baseline"]["sample"]) <= 200
+    assert rec["rooflines"]["encoder.all_passes"][1] == pytest.approx(full["rooflines"]["encoder"]["all_passes"]["frac"], rel=1e-5)
+    assert rec["full_json"] == "bench_full.json"
+    # non-finite numbers never reach the line (json.dumps would print NaN / Infinity, which strict parsers reject)
+    full["roofline"]["frac_unique"] = float("nan")
+    full["phase_s_per_step"]["rollout"] = float("inf")
+    rec = strict(bench.compact_line(full, "x"))
+    assert rec["roofline"].get("frac_unique") is None and rec["phase_s_per_step"]["rollout"] is None
+    # an oversized optional table is shed before the headline is
+    full["rooflines"] = {f"k{i}": {"avg_launch_ms": 1.0, "frac": 0.5} for i in range(2000)}
+    text = bench.compact_line(full, "x")
+    assert len(text.encode()) < 8000 and "rooflines" not in strict(text) and strict(text)["value"] > 0
