@@ -626,7 +626,6 @@ def main():
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
-                       "rollout_team_placement": cfg.get("rollout_team_placement", "team_xcd"),
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,
                        "native_rollout_driver": bool(getattr(trainer, "_native_rollout", False))},

@@ -63,8 +63,9 @@ class Buffer:
         # BLOCK-MAJOR in memory (round 4): [blocks][slots][T][D] -- the L window rows of a (sample, block) are one
         # contiguous run of L * D floats (upstream's [slots, T, blocks, D] order interleaves the blocks: a row every blocks * D floats).
         # ``bank`` keeps upstream's logical shape [slots, T, blocks, D] as a VIEW; every kernel addresses it through its strides
-        # (etm/ops.py:WindowSpec.from_bank, the tail of etm_rollout_trxl).  ``episode_bank_layout: interleaved`` restores round 3's order.
-        self.block_major = config.get("episode_bank_layout", "block_major") == "block_major"
+        # (etm/ops.py:WindowSpec.from_bank, the tail of etm_rollout_trxl).  (Round 3's interleaved order was an option until round 6:
+        # window passes 8 % slower at config 3)
+        self.block_major = True
         self.bank = self._new_bank(cap)
         self.num_episodes = W
         self.address_captured = False      # set by the trainer once a captured graph reads / writes the bank
@@ -72,8 +73,6 @@ class Buffer:
 
     def _new_bank(self, slots: int) -> torch.Tensor:
         shape = (slots, self.max_episode_length, self.num_blocks, self.embed_dim)
-        if not self.block_major:
-            return torch.zeros(shape, dtype=torch.float32, device=self.device)
         store = torch.zeros((self.num_blocks, slots, self.max_episode_length, self.embed_dim), dtype=torch.float32, device=self.device)
         return store.permute(1, 2, 0, 3)
 

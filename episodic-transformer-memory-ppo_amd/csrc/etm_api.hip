@@ -1,7 +1,7 @@
 // ABI version + error strings of libetm_hip.so.
 #include "etm_common.h"
 
-extern "C" int etm_abi_version(void) { return 42; }
+extern "C" int etm_abi_version(void) { return 43; }
 
 extern "C" const char *etm_error_string(int code) {
   switch (code) {
@@ -69,7 +69,7 @@ extern "C" const char *etm_profile_kernel_name(int kid) {
                                            "conv_train_fwd_kernel", "conv_train_dgrad_kernel", "conv_train_wgrad_kernel", "rollout_trxl_kernel",
                                            "conv_fwd_layer1", "conv_fwd_layer2", "conv_fwd_layer3", "conv_dgrad_layer2", "conv_dgrad_layer3",
                                            "conv_wgrad_layer1", "conv_wgrad_layer2", "conv_wgrad_layer3", "hidden_partial_kernel",
-                                           "relu_bwd_colsum_kernel", "gather_rows_kernel", "grouped_dw_kernel", "obs_pull_kernel"};
+                                           "relu_bwd_colsum_kernel", "gather_rows_kernel", "grouped_dw_kernel"};
   return (kid >= 0 && kid < ETM_K_COUNT) ? names[kid] : "?";
 }
 extern "C" int etm_profile_collect(double *total_ms, int64_t *count) {

@@ -64,7 +64,7 @@ enum EtmKernelId {
   ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_TRAIN_DGRAD, ETM_K_CONV_TRAIN_WGRAD, ETM_K_ROLLOUT_FUSED,
   // the encoder passes per layer (kernel size 8 / 4 / 3 = layers 1 / 2 / 3 of model.py:29-31; other geometries keep the ids above)
   ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3,
-  ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, ETM_K_HIDDEN_PARTIAL, ETM_K_RELU_BWD_COLSUM, ETM_K_GATHER_ROWS, ETM_K_GROUPED_DW, ETM_K_OBS_PULL,
+  ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, ETM_K_HIDDEN_PARTIAL, ETM_K_RELU_BWD_COLSUM, ETM_K_GATHER_ROWS, ETM_K_GROUPED_DW,
   ETM_K_COUNT
 };
 // profile id of an encoder pass by layer (kernel size), falling back to the pass's generic id

@@ -7,7 +7,7 @@
 //     wait for the group's `ready` words  ->  episode bookkeeping (step counter, memory slot of a new episode)
 //     ->  (episode step, slot) words where the step kernel reads them  ->  enqueue the observation upload + the step graph
 // and that is this function: one blocking call per rollout from the trainer thread (ctypes releases the GIL), no Python between
-// two steps.  Groups are served as they become ready (round 5; etm_rollout_drive_set_order), with the one ordering constraint that
+// two steps.  Groups are served as they become ready (round 5), with the one ordering constraint that
 // keeps the slot numbering -- upstream's `len(self.buffer.memories) - 1`, :211 -- identical to the (step, group) order of the Python
 // loop this replaces.  No device code in this file.
 #include "etm_common.h"
@@ -43,13 +43,11 @@ extern "C" int etm_host_unregister(void *ptr) {
   return (int)hipHostUnregister(ptr);
 }
 
-// Service order of the worker groups within a step (process-wide; results do not depend on it): 1 (default) = ready-first -- a group is
-// served as soon as all its worker processes have published the step, whatever the other groups do, EXCEPT a group that has an
-// episode end in this step, which waits until every lower-numbered group has been served: new memory slots are numbered in
-// (step, group) order (upstream's `len(self.buffer.memories) - 1`, trainer.py:211) and a slot number must be final when the group's
-// next step is launched.  0 = strict round-robin (rounds 4 - 5a: a late group stalls the groups behind it).
-static int g_drive_ready_first = 1;
-extern "C" int etm_rollout_drive_set_order(int ready_first) { g_drive_ready_first = ready_first ? 1 : 0; return ETM_OK; }
+// Service order of the worker groups within a step (results do not depend on it): ready-first -- a group is served as soon as all
+// its worker processes have published the step, whatever the other groups do, EXCEPT a group that has an episode end in this step,
+// which waits until every lower-numbered group has been served: new memory slots are numbered in (step, group) order (upstream's
+// `len(self.buffer.memories) - 1`, trainer.py:211) and a slot number must be final when the group's next step is launched.
+// (Strict round-robin -- rounds 4 / 5a: a late group stalls the groups behind it -- was an option until round 6.)
 
 extern "C" int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,
                                  const uint8_t *dones, int64_t *ep_step, int64_t *slot, int64_t *next_slot, int64_t capacity,
@@ -60,24 +58,14 @@ extern "C" int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_f
   if (G > MAXG) return ETM_EINVAL;
   for (int gi = 0; gi < G; ++gi)
     if (groups[gi].n_procs > MAXP) return ETM_EINVAL;
-  const bool ready_first = g_drive_ready_first != 0;
   double t_work = 0.0;
   const double t_begin = now_s();
   int64_t ne = *n_events;
-  static thread_local int sent[MAXG][MAXP];
   for (int t = t_first; t < S; ++t) {
     const int64_t target = (int64_t)t + 1;
     const uint8_t *d = dones + (int64_t)t * W;
-    bool served[MAXG], ready[MAXG], early[MAXG];
-    int left[MAXG];
-    for (int gi = 0; gi < G; ++gi) {
-      const etm_rollout_group &g = groups[gi];
-      served[gi] = ready[gi] = false;
-      // observation rows of step t + 1 go up piece by piece while the workers still write them (row progress words)
-      early[gi] = g.rows && g.rows_per_proc > 0 && t + 1 < S;
-      left[gi] = early[gi] ? g.n_procs * g.rows_per_proc : 0;
-      for (int p = 0; p < g.n_procs; ++p) sent[gi][p] = 0;
-    }
+    bool served[MAXG], ready[MAXG];
+    for (int gi = 0; gi < G; ++gi) served[gi] = ready[gi] = false;
     const double tw = now_s();
     int n_served = 0;
     uint32_t spins = 0;
@@ -85,29 +73,9 @@ extern "C" int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_f
       bool progress = false;
       for (int gi = 0; gi < G; ++gi) {
         if (served[gi]) continue;
-        if (!ready_first && gi > 0 && !served[gi - 1]) break;          // strict round-robin: nothing behind an unserved group moves
         const etm_rollout_group &g = groups[gi];
         const int Wg = g.hi - g.lo;
         hipStream_t st = (hipStream_t)g.stream;
-        if (left[gi] > 0) {
-          const int k = g.rows_per_proc;
-          for (int p = 0; p < g.n_procs; ++p) {
-            if (sent[gi][p] >= k) continue;
-            const int64_t v = __atomic_load_n(g.rows + (int64_t)p * g.ready_stride, __ATOMIC_ACQUIRE);
-            if ((v >> 16) != target) continue;
-            const int avail = (int)(v & 0xffff);
-            if (avail > sent[gi][p]) {
-              const int64_t off = ((int64_t)p * k + sent[gi][p]) * row_bytes;
-              hipError_t e = hipMemcpyAsync((char *)g.stage_dst + (int64_t)(t + 1) * stage_step_bytes + off, (const char *)g.obs_src + off,
-                                            (size_t)(avail - sent[gi][p]) * (size_t)row_bytes, hipMemcpyHostToDevice, st);
-              if (e != hipSuccess) { *n_events = ne; return (int)e; }
-              left[gi] -= avail - sent[gi][p];
-              sent[gi][p] = avail;
-              progress = true;
-            }
-          }
-          if (left[gi] > 0) continue;
-        }
         // ---- every worker process of the group has published step t (observation rows, reward, done are final)?
         if (!ready[gi]) {
           bool all = true;
@@ -140,21 +108,10 @@ extern "C" int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_f
         }
         if (t + 1 < S) {
           // ---- (episode step, slot) of the group where the step kernel of step t + 1 reads them (pinned, in place)
-          if (g.tagged) {
-            const int64_t tag = ((int64_t)t + 2) << 32;
-            for (int i = 0; i < Wg; ++i) {
-              __atomic_store_n(g.ss_dst + i, ep_step[g.lo + i] | tag, __ATOMIC_RELEASE);
-              __atomic_store_n(g.ss_dst + Wg + i, slot[g.lo + i] | tag, __ATOMIC_RELEASE);
-            }
-          } else {
-            std::memcpy(g.ss_dst, ep_step + g.lo, sizeof(int64_t) * (size_t)Wg);
-            std::memcpy(g.ss_dst + Wg, slot + g.lo, sizeof(int64_t) * (size_t)Wg);
-          }
-          // ---- observation rows of step t + 1 -> their row of the time-major staging array (unless they went piece by piece above),
-          // then the step: both on the group's stream
-          hipError_t e = hipSuccess;
-          if (!early[gi])
-            e = hipMemcpyAsync((char *)g.stage_dst + (int64_t)(t + 1) * stage_step_bytes, g.obs_src, (size_t)Wg * (size_t)row_bytes,
+          std::memcpy(g.ss_dst, ep_step + g.lo, sizeof(int64_t) * (size_t)Wg);
+          std::memcpy(g.ss_dst + Wg, slot + g.lo, sizeof(int64_t) * (size_t)Wg);
+          // ---- observation rows of step t + 1 -> their row of the time-major staging array, then the step: both on the group's stream
+          hipError_t e = hipMemcpyAsync((char *)g.stage_dst + (int64_t)(t + 1) * stage_step_bytes, g.obs_src, (size_t)Wg * (size_t)row_bytes,
                                hipMemcpyHostToDevice, st);
           if (e != hipSuccess) { *n_events = ne; return (int)e; }
           e = hipGraphLaunch((hipGraphExec_t)g.graph_exec, st);

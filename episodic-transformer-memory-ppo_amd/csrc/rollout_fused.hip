@@ -47,7 +47,6 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
   __shared__ float t_s[RF_T];                                     // LayerNorm inputs / pieces to publish
   __shared__ float e_s[8 * 128];
   __shared__ long long off_s[128];
-  __shared__ long long ss_s[2];
   __shared__ unsigned char mask_s[128];
   __shared__ float out_s[64];
   __shared__ float items_s[RF_MAXB * RF_T];                       // every block's input (the new memory items), for the tail
@@ -107,30 +106,10 @@ __global__ __launch_bounds__(RF_T) void rollout_trxl_kernel(const RfParams p) {
     x_s[tid] = v;
   }
   long long step_w = 0, slot_w = 0;
-  if (p.ss && p.ss_tagged) {
-    // The launch may have been enqueued BEFORE the host finished the bookkeeping of the previous step (it is issued as soon as the
-    // observation rows are on their way): the host then publishes (step, slot) as words tagged with step counter + 1 in the upper
-    // half -- value and "ready" in one read, like the exchange packets.  ONE lane of the workgroup polls its two words (bounded;
-    // system-scope loads are not combined across lanes: 512 pollers per workgroup would be 65,000 PCIe reads per step) and hands
-    // them to the others through LDS at the barrier below.
-    if (tid == 0) {
-      const long long want = t_now + 1;
-      long long a = 0, b = 0;
-      int spins = 0;
-      for (;;) {
-        a = __hip_atomic_load(p.ss + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        b = __hip_atomic_load(p.ss + p.W + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (((a >> 32) >= want && (b >> 32) >= want) || ++spins > (RF_SPIN_LIMIT >> 3)) break;   // (>=: tools replay steps against one published state)
-        __builtin_amdgcn_s_sleep(8);
-      }
-      if (spins > (RF_SPIN_LIMIT >> 3)) p.ctl[1] = 2;              // ~1 s: the host never published this step's state
-      ss_s[0] = a & 0xffffffffLL; ss_s[1] = b & 0xffffffffLL;
-    }
-  } else if (p.ss) { step_w = p.ss[w]; slot_w = p.ss[p.W + w]; }   // read in place (possibly from pinned host memory)
+  if (p.ss) { step_w = p.ss[w]; slot_w = p.ss[p.W + w]; }   // read in place (possibly from pinned host memory)
   else if (p.wkv) { step_w = p.step_l[w]; slot_w = p.slot_l[w]; }
   const float bemb_r = (tid < DS) ? p.bemb[d0 + tid] : 0.f;
   rf_sync();
-  if (p.ss && p.ss_tagged) { step_w = ss_s[0]; slot_w = ss_s[1]; }   // (published by thread 0 before the barrier)
   // E0: linear_embedding + ReLU, my columns; collect the full row
   gemv_finish<GR>(wr, p.wemb_t + mcol, D, x_s, part_s, 0, D, DS, 0, DS);
   gemv_issue<GR>(wr, p.blk[0].wq_t + mcol, D, 0, DS, 0, DS, 0);
@@ -810,7 +789,7 @@ static int rollout_trxl_impl(int group, const float *h_in, const float *wemb_t, 
                                 const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride, const float *h_bias,
                                 int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                                 int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                                int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
+                                int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
   (void)hipGetLastError();
   if (ss && (!mask_table || !index_table || !st_mask || !st_idx || !latch || !mask_t || !win_t || T <= 0)) return ETM_EINVAL;
   if (!ss && (!win || !mask)) return ETM_EINVAL;
@@ -832,7 +811,7 @@ static int rollout_trxl_impl(int group, const float *h_in, const float *wemb_t, 
   RfParams p{};
   p.ss = (const long long *)ss; p.mask_table = mask_table; p.index_table = (const long long *)index_table; p.st_mask = st_mask;
   p.st_idx = (long long *)st_idx; p.latch = (long long *)latch; p.t_row = (long long *)t_row; p.mask_t = mask_t; p.win_t = (long long *)win_t;
-  p.kv_init = kv_init; p.T = T; p.ss_tagged = ss ? ss_tagged : 0;
+  p.kv_init = kv_init; p.T = T;
   p.h_in = h_in; p.h_bias = h_bias; p.h_splits = h_splits; p.wemb_t = wemb_t; p.bemb = bemb; p.nb = nb;
   for (int b = 0; b < nb; ++b) {
     const float *const *q = reinterpret_cast<const float *const *>(blocks) + RF_BLOCK_PTRS * b;
@@ -888,11 +867,11 @@ extern "C" int etm_rollout_trxl(const float *h_in, const float *wemb_t, const fl
                                 const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride, const float *h_bias,
                                 int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                                 int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                                int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
+                                int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
   return rollout_trxl_impl(0, h_in, wemb_t, bemb, blocks, nb, kv, kv_worker_stride, kv_row_stride, win, mask, items, wh_t, bh, wp, bp, wv, bv, uniforms, forced, t_dev,
                           actions, st_actions, st_logp, st_values, host_actions, host_flag, sync_counter, ln_eps, scratch, scratch_bytes, wkv, pos, step_l,
                           slot_l, bank, bank_slot_stride, bank_row_stride, bank_block_stride, h_bias, h_splits, ss, mask_table, index_table, st_mask, st_idx,
-                          latch, t_row, mask_t, win_t, kv_init, T, ss_tagged, pre_ln, gtrxl, W, D, H, L, hid, A, stage_W, stream);
+                          latch, t_row, mask_t, win_t, kv_init, T, pre_ln, gtrxl, W, D, H, L, hid, A, stage_W, stream);
 }
 // The group form (csrc/rollout_group.hip): same arguments, other matrix packings (see there) and scratch size
 // (etm_rollout_trxl_group_scratch_bytes); W <= 8 workers, GRU-gated blocks -- etm_rollout_trxl_group_supported.
@@ -905,9 +884,9 @@ extern "C" int etm_rollout_trxl_group(const float *h_in, const float *wemb_t, co
                                 const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride, const float *h_bias,
                                 int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                                 int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                                int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
+                                int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream) {
   return rollout_trxl_impl(1, h_in, wemb_t, bemb, blocks, nb, kv, kv_worker_stride, kv_row_stride, win, mask, items, wh_t, bh, wp, bp, wv, bv, uniforms, forced, t_dev,
                           actions, st_actions, st_logp, st_values, host_actions, host_flag, sync_counter, ln_eps, scratch, scratch_bytes, wkv, pos, step_l,
                           slot_l, bank, bank_slot_stride, bank_row_stride, bank_block_stride, h_bias, h_splits, ss, mask_table, index_table, st_mask, st_idx,
-                          latch, t_row, mask_t, win_t, kv_init, T, ss_tagged, pre_ln, gtrxl, W, D, H, L, hid, A, stage_W, stream);
+                          latch, t_row, mask_t, win_t, kv_init, T, pre_ln, gtrxl, W, D, H, L, hid, A, stage_W, stream);
 }

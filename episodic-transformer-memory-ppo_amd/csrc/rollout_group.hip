@@ -177,7 +177,6 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float e_s[128];
   __shared__ long long off_s[128];
-  __shared__ long long ss_s[2];
   __shared__ unsigned char mask_s[128];
   __shared__ float h2_s[RG_G * 48];
   __shared__ float out_s[RG_G * 16];
@@ -224,26 +223,11 @@ __global__ __launch_bounds__(RF_T) void rollout_group_kernel(const RfParams p) {
   }
   long long step_w = 0, slot_w = 0;
   if (unit) {
-    if (p.ss && p.ss_tagged) {
-      if (tid == 0) {                                              // (see rollout_fused.hip: tagged (step, slot) words, one polling lane)
-        const long long want = t_now + 1;
-        long long a = 0, b = 0;
-        int spins = 0;
-        for (;;) {
-          a = __hip_atomic_load(p.ss + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          b = __hip_atomic_load(p.ss + W + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (((a >> 32) >= want && (b >> 32) >= want) || ++spins > (RF_SPIN_LIMIT >> 3)) break;
-          __builtin_amdgcn_s_sleep(8);
-        }
-        if (spins > (RF_SPIN_LIMIT >> 3)) p.ctl[1] = 2;
-        ss_s[0] = a & 0xffffffffLL; ss_s[1] = b & 0xffffffffLL;
-      }
-    } else if (p.ss) { step_w = p.ss[g]; slot_w = p.ss[W + g]; }
+    if (p.ss) { step_w = p.ss[g]; slot_w = p.ss[W + g]; }
     else if (p.wkv) { step_w = p.step_l[g]; slot_w = p.slot_l[g]; }
   }
   const float bemb_r = eact ? p.bemb[ecol] : 0.f;
   __syncthreads();
-  if (unit && p.ss && p.ss_tagged) { step_w = ss_s[0]; slot_w = ss_s[1]; }
 
   // ---- transformer input.  lin_hidden as partial rows (h_splits > 0): unit (g, h) adds worker g's columns of head h in slice order
   // (+ bias, ReLU: model.py:97) and the units' pieces are gathered; else every workgroup reads the [W, D] input itself.

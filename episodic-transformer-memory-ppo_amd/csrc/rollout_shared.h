@@ -36,7 +36,6 @@ struct RfParams {
   long long *st_idx, *win_t, *latch, *t_row;
   const float *kv_init;              // [T, nb, 2D]: cache rows of an episode that has not written them yet
   int T;
-  int ss_tagged;                     // ss words carry (step counter + 1) << 32: the launch may run ahead of the host's bookkeeping
   const float *wemb_t, *bemb;        // [D, D] transposed, [D]
   RfBlock blk[RF_MAXB];
   int nb;

@@ -55,14 +55,25 @@ def _cgroup_quota():
 
 def host_cpu_budget(local_world=None):
     """{"affinity": CPUs in this process's mask, "cgroup_quota": CPUs or None, "usable": what the rank's NODE share is made of,
-    "local_world": ranks sharing it, "per_rank": usable / local_world}.  ``local_world`` defaults to LOCAL_WORLD_SIZE / WORLD_SIZE
-    (one node) / 1."""
+    "local_world": ranks sharing it, "per_rank": usable / local_world}.  ``local_world`` defaults to LOCAL_WORLD_SIZE (torchrun sets
+    it); without it WORLD_SIZE counts only when the job is known to be one node (NNODES / GROUP_WORLD_SIZE == 1 or unset together
+    with a loopback MASTER_ADDR), else 1 -- a multi-node launch without torchrun must not divide the node's CPUs by the global
+    world size."""
     try:
         affinity = len(os.sched_getaffinity(0))
     except Exception:      # noqa: BLE001
         affinity = os.cpu_count() or 1
     if local_world is None:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+        if os.environ.get("LOCAL_WORLD_SIZE"):
+            local_world = int(os.environ["LOCAL_WORLD_SIZE"])
+        else:
+            nnodes = os.environ.get("NNODES") or os.environ.get("GROUP_WORLD_SIZE")
+            one_node = (nnodes == "1") if nnodes else os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1")
+            local_world = int(os.environ.get("WORLD_SIZE", "1") or 1) if one_node else 1
+            if not one_node and int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+                import sys
+                print("[etm] host CPU plan: LOCAL_WORLD_SIZE is not set and the job is not known to be one node: assuming ONE rank on "
+                      "this node (set LOCAL_WORLD_SIZE to the ranks per node)", file=sys.stderr, flush=True)
     local_world = max(1, int(local_world))
     quota = _cgroup_quota()
     # conservative: every local rank is assumed to share this mask (NUMA pinning gives the ranks of one node the same mask; ranks

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 _lib = None
 
@@ -21,8 +21,7 @@ class RolloutGroup(ctypes.Structure):
     """etm_rollout_group of include/etm_hip.h (one worker group of the native rollout driver)."""
     _fields_ = [("graph_exec", ctypes.c_void_p), ("stream", ctypes.c_void_p), ("ready", ctypes.c_void_p), ("n_procs", ctypes.c_int32),
                 ("ready_stride", ctypes.c_int32), ("lo", ctypes.c_int32), ("hi", ctypes.c_int32), ("obs_src", ctypes.c_void_p),
-                ("stage_dst", ctypes.c_void_p), ("ss_dst", ctypes.c_void_p), ("tagged", ctypes.c_int32), ("rows_per_proc", ctypes.c_int32),
-                ("rows", ctypes.c_void_p)]
+                ("stage_dst", ctypes.c_void_p), ("ss_dst", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/etm_hip.h one to one
@@ -43,9 +42,7 @@ SIGNATURES = {
     "etm_graph_launch": (_I, [_P, _P]),
     "etm_host_register": (_I, [_P, _L]),
     "etm_host_unregister": (_I, [_P]),
-    "etm_rollout_drive_set_order": (_I, [_I]),
     "etm_rollout_drive": (_I, [_P, _I, _I, _I, _I, _L, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _D, _P, _P]),
-    "etm_obs_pull": (_I, [_P, _P, _L, _L, _I, _P, _P, _P, _P]),
     "etm_comm_unique_id": (_I, [_P]),
     "etm_comm_init": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_void_p)]),
     "etm_allreduce_f32": (_I, [_P, _P, _P, _L, _P]),
@@ -68,18 +65,16 @@ SIGNATURES = {
     "etm_rollout_trxl_scratch_bytes": (_L, [_I, _I, _I, _I]),
     "etm_rollout_trxl": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                               _P, _L, _P, _P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
-                              _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+                              _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_rollout_trxl_group": (_I, [_P, _P, _P, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                                     _P, _L, _P, _P, _P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
-                                    _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+                                    _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_rollout_trxl_group_supported": (_I, [_I] * 8),
     "etm_rollout_trxl_group_grid": (_I, []),
     "etm_rollout_trxl_group_scratch_bytes": (_L, [_I]),
     "etm_window_set_skip_masked": (_I, [_I]),
     "etm_rollout_hidden_splits": (_I, [_I]),
     "etm_rollout_hidden_partial": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "etm_rollout_conv12_supported": (_I, [_I] * 11),
-    "etm_rollout_conv12": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_rollout_conv3_hidden_supported": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "etm_rollout_conv3_hidden": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "etm_rollout_heads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -693,8 +693,7 @@ def rollout_trxl_group_ok(fused_group, W, L, hid, A):
     this model?  ``fused_group``: ``ActorCriticModel._rfg`` (None: the model has no group packings)."""
     if fused_group is None:
         return False
-    D = fused_group["emb_t"].shape[1]
-    return bool(_lib.load().etm_rollout_trxl_group_supported(D, fused_group["H"], L, hid, A, fused_group["nb"], W, fused_group["gtrxl"]))
+    return bool(_lib.load().etm_rollout_trxl_group_supported(fused_group["D"], fused_group["H"], L, hid, A, fused_group["nb"], W, fused_group["gtrxl"]))
 
 
 def rollout_trxl_scratch(W, D, H, nb, device, group=False):
@@ -727,8 +726,7 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
     pointer table ``blocks``); ``kv`` the group's K | V cache [W, T, blocks, 2D]; ``scratch`` from ``rollout_trxl_scratch``; the
     staging arguments as in ``rollout_policy``.  ``window`` = (ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init):
     the launch does the step's window lookup (and the cache reset of workers at episode step 0) itself -- no ``rollout_window``
-    in front of it; a ninth element ``ss_tagged`` = True: the ss words are tagged with the step counter (include/etm_hip.h) and the
-    launch may be enqueued before the host has published them.  ``tail`` = (wkv [blocks, D, 2D], pos [T, D] or None, step_l [W], slot_l [W],
+    in front of it.  ``tail`` = (wkv [blocks, D, 2D], pos [T, D] or None, step_l [W], slot_l [W],
     bank [slots, T, blocks, D]): after the action hand-over the same launch writes the new memory items into
     ``bank[slot_l, step_l]`` and their K | V projection into ``kv[w, step_l]``."""
     lib = _lib.load()
@@ -739,14 +737,13 @@ def rollout_trxl(h_in, fused, kv, win_t, mask_t, items, policy_head, value_head,
         h_in_shape = h_in.shape[1:]
     else:
         h_in_shape = h_in.shape
-    w_args = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
-    if window is not None:        # (ss [2, W], mask_table, index_table, st_mask, st_idx, latch [2, W], t_row, kv_init or None[, ss_tagged])
-        ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init = window[:8]
-        ss_tagged = int(bool(window[8])) if len(window) > 8 else 0
+    w_args = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    if window is not None:        # (ss [2, W], mask_table, index_table, st_mask, st_idx, latch [2, W], t_row, kv_init or None)
+        ss, mask_table, index_table, st_mask, st_idx, latch, t_row, kv_init = window
         Lw = win_t.shape[1]
         w_args = (_ptr(ss), _ptr(mask_table), _ptr(index_table), st_mask.data_ptr() + w_off * Lw * st_mask.element_size(),
                   st_idx.data_ptr() + w_off * Lw * st_idx.element_size(), _ptr(latch), _ptr(t_row), _ptr(mask_t), _ptr(win_t),
-                  0 if kv_init is None else _ptr(kv_init), index_table.shape[0], ss_tagged)
+                  0 if kv_init is None else _ptr(kv_init), index_table.shape[0])
     t_args = (0, 0, 0, 0, 0, 0, 0, 0)
     if tail is not None:
         wkv, pos, step_l, slot_l, bank = tail
@@ -814,37 +811,6 @@ def rollout_hidden_partial(x, wt, out=None):
     if out is None:
         out = torch.empty((splits, W, D), dtype=torch.float32, device=x.device)
     _lib.check(lib.etm_rollout_hidden_partial(_ptr(x), _ptr(wt), _ptr(out), W, F, D, _stream()), "etm_rollout_hidden_partial")
-    return out
-
-
-def rollout_conv12_supported(conv1, conv2, h, w):
-    return bool(_lib.load().etm_rollout_conv12_supported(conv1.in_channels, h, w, conv1.out_channels, conv1.kernel_size[0], conv1.kernel_size[1],
-                                                         conv1.stride[0], conv2.out_channels, conv2.kernel_size[0], conv2.kernel_size[1],
-                                                         conv2.stride[0]))
-
-
-def rollout_conv12(x, w1k, b1, w2k, b2, C, H, W, index=None, rows=None):
-    """First two encoder layers of a rollout step in one launch (etm_rollout_conv12): ``x`` NCHW [N, C, H, W] or, with ``index``, a
-    time-major stack [S, N, C, H, W] of which row x[index] (images ``rows`` = (lo, hi)) is read -> NHWC [N, Ho2, Wo2, 64]."""
-    lib = _lib.load()
-    x = _f32c(x, "x")
-    stride = 0
-    if index is not None:
-        stride = x[0].numel()
-        N = x.shape[1]
-    else:
-        N = x.shape[0]
-    base = x.data_ptr()
-    if rows is not None:
-        if index is None:
-            raise TypeError("rollout_conv12: rows needs index (stacked input)")
-        lo, hi = rows
-        base += lo * x[0, 0].numel() * 4
-        N = hi - lo
-    h1, w1 = (H - 8) // 4 + 1, (W - 8) // 4 + 1
-    out = torch.empty((N, (h1 - 4) // 2 + 1, (w1 - 4) // 2 + 1, 64), dtype=torch.float32, device=x.device)
-    _lib.check(lib.etm_rollout_conv12(base, _ptr(index), stride, _ptr(w1k), _ptr(b1), _ptr(w2k), _ptr(b2), _ptr(out), N, C, H, W, _stream()),
-               "etm_rollout_conv12")
     return out
 
 
@@ -1253,18 +1219,6 @@ def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None):
     convolution weights and biases (observations need none)."""
     return _EncoderFn.apply(obs_nhwc, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias,
                             (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index)
-
-
-def obs_pull(src_pinned, stage, t_dev, row_flags, w_off=0, err=None):
-    """First node of a rollout step's graph: the device copies the group's observation rows from pinned host memory ``src_pinned``
-    [Wg, ...] into ``stage[*t_dev, w_off : w_off + Wg]`` (time-major staging [S, W, ...]), each row as soon as the host has set
-    ``row_flags[r]`` (pinned int64 [Wg]) to the step index + 1 (etm_obs_pull)."""
-    lib = _lib.load()
-    rows = src_pinned.shape[0]
-    row_bytes = src_pinned[0].numel() * 4
-    dst = stage.data_ptr() + w_off * row_bytes
-    _lib.check(lib.etm_obs_pull(src_pinned.data_ptr(), dst, stage[0].numel() * 4, row_bytes, rows, _ptr(t_dev), row_flags.data_ptr(),
-                                0 if err is None else _ptr(err), _stream()), "etm_obs_pull")
 
 
 def upload(dst, src_pinned, stream):

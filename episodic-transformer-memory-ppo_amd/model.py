@@ -33,12 +33,9 @@ class ActorCriticModel(nn.Module):
         self.observation_space_shape = tuple(observation_space.shape)
         self.max_episode_length = max_episode_length
         self.visual = len(self.observation_space_shape) > 1
-        self.channels_last = bool(config.get("encoder_channels_last", True))
+        self.channels_last = True          # visual observations are kept NHWC for the optimisation phase (trainer._observations_channels_last)
         self.fused_encoder = bool(config.get("fused_rollout_encoder", True))
         self.train_encoder = bool(config.get("fused_train_encoder", True))     # False: library convolutions in the optimisation phase
-        # rollout: conv1 + conv2 as one launch (csrc/conv12_fused.hip).  Measured (round 4) and OFF: the first layer on the vector
-        # ALU of one CU per (second-layer pixel, 4 images) costs more than the launch it saves -- step graph 112.6 vs 107.9 us
-        self.fused_conv12 = bool(config.get("fused_conv12", False))
         self.fused_rollout_block = bool(config.get("fused_rollout_block", True))   # False: one launch per GEMM / LayerNorm / attention
         # round 5: GRU-gated layouts -- the step kernel of a worker GROUP (csrc/rollout_group.hip: workers as the rows of every product,
         # every matrix read once per group and step); False keeps the per-worker teams of csrc/rollout_fused.hip
@@ -113,14 +110,6 @@ class ActorCriticModel(nn.Module):
                     setattr(self, name, perm.contiguous())
                 else:
                     buf.copy_(perm)
-            # the first two layers as [(c, ky, kx), c1] / [(ky, kx, c1), co]: the fused conv1 + conv2 launch of a rollout step (ops.rollout_conv12)
-            for name, w in (("_w1k", self.conv1.weight.permute(1, 2, 3, 0).reshape(-1, self.conv1.out_channels)),
-                            ("_w2k", self.conv2.weight.permute(2, 3, 1, 0).reshape(-1, self.conv2.out_channels))):
-                buf = getattr(self, name, None)
-                if buf is None or buf.shape != w.shape or buf.device != w.device:
-                    setattr(self, name, w.contiguous())
-                else:
-                    buf.copy_(w)
             # the last layer as [(ky, kx, c), co]: what the fused conv3 + lin_hidden launch of a rollout step reads (ops.rollout_conv3_hidden)
             w3k = self.conv3.weight.permute(2, 3, 1, 0).reshape(-1, self.conv3.out_channels)
             if getattr(self, "_w3k", None) is None or self._w3k.shape != w3k.shape or self._w3k.device != w3k.device:
@@ -210,7 +199,8 @@ class ActorCriticModel(nn.Module):
         d = t.embed_dim
         lib = etm_lib.load()
         A = self.policy_branches[0].out_features
-        if not (self.rollout_group_kernel and self._rf is not None and blk0.use_gtrxl
+        # (the kernel's [W, D] input rows and its D x D embedding slice assume linear_embedding.in_features == embed_dim)
+        if not (self.rollout_group_kernel and self._rf is not None and blk0.use_gtrxl and t.linear_embedding.in_features == d
                 and lib.etm_rollout_trxl_group_supported(d, t.num_heads, t.config["memory_length"], self.hidden_size, A, t.num_blocks, 1, 1)
                 and lib.etm_rollout_trxl_team(t.num_heads) == t.num_heads):
             self._rfg = None
@@ -259,7 +249,7 @@ class ActorCriticModel(nn.Module):
                     ptrs += [blk.norm_kv.weight, blk.norm_kv.bias] if blk.layer_norm == "pre" else [None, None]
                 rg["_keep"] = ptrs
                 rg["blocks"] = (ctypes.c_void_p * len(ptrs))(*[None if q is None else q.data_ptr() for q in ptrs])
-                rg["nb"], rg["H"], rg["eps"] = t.num_blocks, t.num_heads, blk0.norm1.eps
+                rg["nb"], rg["H"], rg["eps"], rg["D"] = t.num_blocks, t.num_heads, blk0.norm1.eps, d
                 rg["pre_ln"], rg["gtrxl"], rg["group"] = int(blk0.layer_norm == "pre"), 1, True
                 self._rfg = rg
             else:
@@ -277,9 +267,6 @@ class ActorCriticModel(nn.Module):
         n, c, hh, ww = obs.shape[-4:]      # with obs_index: obs is a stack [S, N, C, H, W] and the layer reads obs[obs_index]
         if obs_rows is not None:
             n = obs_rows[1] - obs_rows[0]
-        if features_only == "conv2" and self.fused_conv12 and ops.rollout_conv12_supported(self.conv1, self.conv2, hh, ww):
-            # round 4: the first two layers as ONE launch (csrc/conv12_fused.hip); the caller runs the last layer together with lin_hidden
-            return ops.rollout_conv12(obs, self._w1k, self.conv1.bias, self._w2k, self.conv2.bias, c, hh, ww, index=obs_index, rows=obs_rows)
         x = ops.conv_relu(obs, self._w1p, self.conv1.bias, c, hh, ww, 8, 8, 4, False, False, index=obs_index, rows=obs_rows)  # -> NHWC
         h1, w1 = x.shape[1], x.shape[2]
         x = ops.conv_relu(x, self._w2p, self.conv2.bias, 32, h1, w1, 4, 4, 2, True, False)

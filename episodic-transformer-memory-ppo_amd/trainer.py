@@ -137,11 +137,9 @@ class PPOTrainer:
             raise RuntimeError("PPOTrainer needs an MI355X (HIP) device: this build has no CPU training path "
                                "(the CPU restatement under oracle/ is test infrastructure only)")
         etm_lib.load()  # fail loudly if the kernels are not built
-        # placement of the rollout step kernel's workgroups: "team_xcd" (default) puts a worker's whole team on one XCD (its
-        # exchanges stay inside that XCD), "member_xcd" gives every XCD one member index (it then only touches that member's weight
-        # slices).  Measured equal (111.9 vs 112.2 us per step graph); results do not depend on it (parity test path member_xcd)
-        placement = {"team_xcd": 0, "member_xcd": 1}[config.get("rollout_team_placement", "team_xcd")]
-        etm_lib.check(etm_lib.load().etm_rollout_trxl_set_placement(placement), "etm_rollout_trxl_set_placement")
+        # (placement of the step kernel's workgroups: a worker's whole team on one XCD, the library's default; the member-per-XCD map
+        # measured equal -- 111.9 vs 112.2 us per step graph -- and is a kernel-level test only since round 6)
+        etm_lib.check(etm_lib.load().etm_rollout_trxl_set_placement(0), "etm_rollout_trxl_set_placement")
         self.config = config
         self.device = device
         self.run_id = run_id
@@ -226,8 +224,8 @@ class PPOTrainer:
                 # one results file per rank: data-parallel ranks tune independently and must not write the same file
                 rank_tag = "" if dp is None else f"_rank{dp.rank}"
                 tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"etm_tunableop_results{rank_tag}.csv"), True)
-                tunable.set_max_tuning_duration(int(config.get("tunable_gemm_duration_ms", os.environ.get("ETM_TUNABLE_MS", 30))))
-                tunable.set_max_tuning_iterations(int(config.get("tunable_gemm_iterations", os.environ.get("ETM_TUNABLE_ITERS", 20))))
+                tunable.set_max_tuning_duration(int(os.environ.get("ETM_TUNABLE_MS", 30)))
+                tunable.set_max_tuning_iterations(int(os.environ.get("ETM_TUNABLE_ITERS", 20)))
             except Exception as exc:        # an older / newer torch without this API: run with the default heuristics
                 print(f"[trainer] per-shape GEMM tuning not available ({exc})")
         self.buffer = Buffer(config, self.observation_space, self.action_space_shape, self.max_episode_length, device)
@@ -310,7 +308,6 @@ class PPOTrainer:
         self._flag_np = self._flag_pin.numpy()
         self._host_flag = False      # decided when the step graph is captured
         self._up_stream = torch.cuda.Stream(device=device)
-        self._state_zero_copy = bool(config.get("state_zero_copy", True))
         self._chain_log = None       # tools/rollout_profile.py: per-step host timestamps of the first group
         self._up_done = torch.cuda.Event()
         self._stream_obs = False     # decided when the step graph is captured
@@ -414,16 +411,6 @@ class PPOTrainer:
             g.stream = torch.cuda.Stream(device=dev)
         g.ss_np = g.ss_pin.numpy()
         g.flag_np = g.flag_pin.numpy()
-        # (episode step, slot) words tagged with the rollout step counter + 1 in their upper half: with early_step_launch the step's
-        # graph is enqueued as soon as the observation rows are on their way and the kernel polls these words (see _sample_training_data)
-        g.ss_tag_pin = torch.zeros((2, Wg), dtype=torch.int64).pin_memory()
-        g.ss_tag_np = g.ss_tag_pin.numpy()
-        # pull_observations: per-row "observation row of step t is final in pinned memory" flags (value t + 1) that the step graph's
-        # first kernel polls, and an error word for a flag that never arrives
-        g.row_flags_pin = torch.zeros((Wg,), dtype=torch.int64).pin_memory()
-        g.row_flags_np = g.row_flags_pin.numpy()
-        g.pull_err = torch.zeros((1,), dtype=torch.int64, device=dev)
-        g.pull = False
         g.step_dev, g.slot_dev = g.ss_dev[0], g.ss_dev[1]
         # (episode step, slot) as LATCHED by the head of a step for its tail: the host uploads the next step's block on the
         # upload stream while the tail (bank / cache writes under env.step) may still be running, and only the group's own
@@ -484,23 +471,19 @@ class PPOTrainer:
         # -- stream order alone puts them before the step that reads them -- and the step's window kernel reads the
         # (episode step, slot) block straight from pinned host memory: no upload of that block, no event between an upload
         # stream and the step (each of those was a few us on the critical path of every step).
-        own_stream = stream_obs and self._state_zero_copy and all(g.stream is not None for g in groups)
+        own_stream = stream_obs and all(g.stream is not None for g in groups)
 
         def obs_stream(g):
             return g.stream.cuda_stream if own_stream else up
 
-        early = use_graph and own_stream and all(getattr(g, "early", False) for g in groups)
         # (CUDAGraph.raw_cuda_graph_exec exists in torch >= 2.8; without it the framework's replay() is used)
-        direct_launch = bool(host_flag and self.config.get("direct_graph_launch", True) and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"))
+        direct_launch = bool(host_flag and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"))
         polite = bool(self._host_plan["polite_wait"])
 
-        def upload_state(g, t_next=0):
+        def upload_state(g):
             """(episode step, slot) of the group's workers -> where the device finds them, after the host bookkeeping of the step."""
             if not g.full:
                 g.ss_np[:] = ss_global[:, g.lo:g.hi]
-            if early:      # tagged words: value in the lower half, step counter + 1 in the upper -- the kernel of step t_next polls for them
-                np.bitwise_or(ss_global[:, g.lo:g.hi], (t_next + 1) << 32, out=g.ss_tag_np)
-                return
             if own_stream:
                 return
             lib.etm_upload(g.ss_dev.data_ptr(), g.ss_pin.data_ptr(), g.ss_pin.numel() * 8, up)
@@ -540,11 +523,10 @@ class PPOTrainer:
                     g.act_ready.record(main)
                     self._rollout_step_tail(g, carry)
 
-        pull = early and all(getattr(g, "pull", False) for g in groups)
         # the native driver runs this rollout iff the captured steps hand over through the segment's go words (_native_rollout, decided
         # at capture) AND the step is the single flag-hand-over graph on the group's own stream -- ONE predicate for "workers held
         # spinning", "sequence restarted" and "etm_rollout_drive called" 
-        native = bool(use_graph and getattr(self, "_native_rollout", False) and host_flag and own_stream and not early and not pull
+        native = bool(use_graph and getattr(self, "_native_rollout", False) and host_flag and own_stream
                       and all(g.graphs[1] is None for g in groups))
         if use_graph and getattr(self, "_native_rollout", False):
             # the device's step counter restarts at 1: go = 0 on every group, acknowledged by every worker, BEFORE step 0 is launched;
@@ -552,23 +534,12 @@ class PPOTrainer:
             # captured kernels still write the go words, the Python loop below steps the workers through the same sequence numbers)
             self._shm_env.activate(hold=native)
             self._shm_env.restart_sequence()
-        if pull:
-            # the step graphs start with the pull kernel and are enqueued ONE STEP AHEAD: the rows of observation 0 are in pinned
-            # memory already (flag value 1), the graphs of step 1 wait on the device for the flags of the first env.step
-            for g in groups:
-                g.row_flags_np[:] = 1
-                upload_state(g, 0)
-                launch(g, 0)
-            if S > 1:
-                for g in groups:
-                    launch(g, 1)
-        elif stream_obs:
+        if stream_obs:
             for g in groups:                       # observation 0 -> staging row 0
                 lib.etm_upload(stage_base + g.lo * row_bytes, src_base + g.lo * row_bytes, g.W * row_bytes, obs_stream(g))
-                upload_state(g, 0)
-        if not pull:
-            for g in groups:
-                launch(g, 0)
+                upload_state(g)
+        for g in groups:
+            launch(g, 0)
         t_env = t_wait = t_launch = 0.0
         if native:
             try:
@@ -596,27 +567,13 @@ class PPOTrainer:
                 t_wait += te - tw
                 if polite:
                     self._flag_wait_ema += 0.1 * ((te - tw) - self._flag_wait_ema)
-                if pull:
-                    flags = g.row_flags_np
-
-                    def rows_final(a, b, flags=flags, tag=t + 2):
-                        flags[a:b] = tag              # rows [a, b) of observation t + 1 are final: the waiting pull kernel takes them
-
-                    _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np, on_rows=rows_final)
-                    launched = True
-                elif stream_obs and t + 1 < S:
+                if stream_obs and t + 1 < S:
                     dst_base = stage_base + ((t + 1) * W + lo) * row_bytes
                     src_g = src_base + lo * row_bytes
                     up_g = obs_stream(g)
 
-                    launched = False
-
                     def rows_ready(a, b):
-                        nonlocal launched
                         lib.etm_upload(dst_base + a * row_bytes, src_g + a * row_bytes, (b - a) * row_bytes, up_g)
-                        if early and b == g.W and not launched:      # last rows of the group are on their way: the step's graph follows
-                            launch(g, t + 1)                          # them at once; its (step, slot) words are published below
-                            launched = True
 
                     _, rewards, dones, infos = g.env.step(g.acts_host, out=g.obs_np, on_rows=rows_ready)
                 else:
@@ -635,12 +592,8 @@ class PPOTrainer:
                 if t + 1 < S:
                     tl = time.perf_counter()
                     if stream_obs:
-                        upload_state(g, t + 1)       # bookkeeping of this step is final: (step, slot) follow the observation rows
-                    if pull:
-                        if t + 2 < S:
-                            launch(g, t + 2)         # one step ahead: the device never waits for a launch
-                    elif not (early and stream_obs and launched):
-                        launch(g, t + 1)
+                        upload_state(g)              # bookkeeping of this step is final: (step, slot) follow the observation rows
+                    launch(g, t + 1)
                     t_launch += time.perf_counter() - tl
                     if self._chain_log is not None and g is groups[0]:
                         self._chain_log.append((tw, te, tl, time.perf_counter()))
@@ -649,12 +602,6 @@ class PPOTrainer:
         for st_ in side_streams:
             main.wait_stream(st_)
         t_ = self.model.transformer
-        for g in groups:
-            if getattr(g, "pull", False):
-                g.row_flags_np[:] = 0
-                if int(g.pull_err.item()) != 0:
-                    g.pull_err.zero_()
-                    raise RuntimeError("pull_observations: a row flag did not arrive within the kernel's limit; this rollout is void")
         for g in groups + [self._group_all]:
             if g.rf_scratch is not None and int(ops.rollout_trxl_error(g.rf_scratch).item()) != 0:
                 # a team member gave up waiting for its partners (not all workgroups were resident): this rollout's data are
@@ -704,12 +651,6 @@ class PPOTrainer:
             a.obs_src = self._obs_pin.data_ptr() + g.lo * row_bytes
             a.stage_dst = stage.data_ptr() + g.lo * row_bytes
             a.ss_dst = g.ss_pin.data_ptr()
-            a.tagged = 0
-            # upload_rows_early (measured, round 4, off): the rows of a process uploaded one by one while it still writes -- four 85 KB copies
-            # instead of one 340 KB copy per group cost MORE device time than they hide (step cycle 166 -> 206 us)
-            early_rows = bool(self.config.get("upload_rows_early", False))
-            a.rows_per_proc = env.envs_per_proc if early_rows else 0
-            a.rows = env.v["rows"][first:].ctypes.data if early_rows else None
         if getattr(self, "_drive_events", None) is None:
             self._drive_events = np.zeros((W * S, 3), dtype=np.int64)
             self._drive_counters = np.zeros(2, dtype=np.int64)          # [next slot, number of events]
@@ -720,12 +661,8 @@ class PPOTrainer:
         if self._chain_log is not None:
             chain = np.zeros((S, 4), dtype=np.float64)
         abort = env.v["err"]          # the workers' error words (one cache line apart) ...
-        # rollout_drive_order: "ready_first" (default: a group is served as soon as its worker processes have published the step;
-        # slot numbers stay in (step, group) order -- csrc/rollout_driver.hip) or "round_robin" (rounds 4 / 5a)
-        order = str(self.config.get("rollout_drive_order", "ready_first"))
-        if order not in ("ready_first", "round_robin"):
-            raise ValueError(f"rollout_drive_order must be 'ready_first' or 'round_robin', got {order!r}")
-        lib.etm_rollout_drive_set_order(1 if order == "ready_first" else 0)
+        # (groups are served ready-first: as soon as a group's worker processes have published the step; slot numbers stay in
+        # (step, group) order -- csrc/rollout_driver.hip)
         rc = lib.etm_rollout_drive(ctypes.cast(arr, ctypes.c_void_p), G, 0, S, W, row_bytes, W * row_bytes,
                                    env.v["dones"].ctypes.data, self._ss_pin[0].data_ptr(), self._ss_pin[1].data_ptr(),
                                    ctr.ctypes.data, int(buf.bank.shape[0]), self._drive_events.ctypes.data, self._drive_events.shape[0],
@@ -761,11 +698,6 @@ class PPOTrainer:
         rows = None if g.full else (g.lo, g.hi)
         if stream_obs:      # the observation of this step is already in row t of the staging array (see _sample_training_data)
             obs, obs_index = st["obs"], g.t_dev
-            if self._pull_ok(g, host_flag):
-                # ... or gets there now: the device pulls the rows from pinned memory itself as the host marks them final (the graph
-                # is enqueued a step ahead: no runtime copy call and no graph launch between env.step and the device's start)
-                ops.obs_pull(g.obs_pin, st["obs"], g.t_dev, g.row_flags_pin, w_off=g.lo, err=g.pull_err)
-                g.pull = True
         else:
             g.obs_dev.copy_(g.obs_pin, non_blocking=True)
             obs, obs_index, rows = g.obs_dev, None, None
@@ -776,9 +708,8 @@ class PPOTrainer:
         # the sampling kernel) and resets the K/V cache of workers at episode step 0 (they start from the projection of an
         # empty memory)
         # streamed + pipelined mode: the (step, slot) block is read from pinned host memory (see _sample_training_data)
-        zero_copy = stream_obs and self._state_zero_copy and g.stream is not None
+        zero_copy = stream_obs and g.stream is not None
         ss_src = g.ss_pin if zero_copy else g.ss_dev
-        g.early = False
         rf_ = getattr(self.model, "_rf", None) if self._use_kv_cache else None
         # (every team of the step kernel must be resident at once, and the groups' step kernels run concurrently: the workgroups
         # of ALL groups together must fit the 256 CUs -- one 512-thread workgroup per CU --, else the multi-launch path)
@@ -792,18 +723,7 @@ class PPOTrainer:
         fused_step = (single and rf_ is not None and self.model.rollout_heads_fusable()
                       and (g.group_kernel or n_conc * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256))
         # the fused step kernel does the window lookup (and the cache reset of new episodes) itself: one launch fewer in the chain
-        window_in_step = fused_step and self.config.get("window_in_step_kernel", True)
-        # early_step_launch (opt-in; needs zero-copy state + the window lookup inside the step kernel + flag hand-over): the kernel
-        # reads TAGGED (step, slot) words and waits for the tag of its step, so the host may enqueue the step's graph as soon as the
-        # observation rows are on their way, before the bookkeeping of the previous step.  Measured (round 3, config 3): no gain --
-        # 178.2 vs 176.1 us per step: the graph then simply waits for the observation DMA (1.35 MB over PCIe, ~27 us) that the
-        # late launch overlaps with the host's bookkeeping, and the tag poll over PCIe costs ~4 us -- so it stays off.
-        if g.pull and not (zero_copy and window_in_step and host_flag):
-            raise RuntimeError("pull_observations needs the one-launch step kernel with its window lookup, zero-copy state and the flag hand-over")
-        if zero_copy and window_in_step and host_flag and (g.pull or self.config.get("early_step_launch", False)):
-            g.early = True
-            ss_src = g.ss_tag_pin
-        if not window_in_step:
+        if not fused_step:
             ops.rollout_window(ss_src[0], self._mask_table, self._index_table, g.t_dev, mask_t, win_t,
                                st["memory_mask"], st["memory_indices"], t_row=g.t_row,
                                reset=(g.kv, self._kv_init) if self._use_kv_cache else None, w_off=g.lo,
@@ -817,7 +737,7 @@ class PPOTrainer:
                 # the step is then encoder (4 launches) + window lookup + this kernel instead of 26 dependent launches
                 rf = self.model._rfg if g.group_kernel else self.model._rf
                 h_bias = None
-                if obs_index is not None and "hid_t" in rf and self.config.get("split_hidden_product", True):
+                if obs_index is not None and "hid_t" in rf:
                     # lin_hidden as K-slice partial sums on 12 x 16 workgroups; the step kernel adds slices + bias + ReLU
                     m_ = self.model
                     hh_, ww_ = m_.observation_space_shape[-2:]
@@ -840,9 +760,11 @@ class PPOTrainer:
                     h_bias = self.model.lin_hidden.bias
                 else:
                     h_in = self.model._encode(obs, obs_index, rows)
-                if getattr(g, "rf_scratch", None) is None:
+                if getattr(g, "rf_scratch", None) is None or getattr(g, "rf_scratch_kind", None) != g.group_kernel:
+                    # (the two forms of the kernel lay their scratch out differently: launch counter, tags and slots belong to one form)
                     t_ = self.model.transformer
                     g.rf_scratch = ops.rollout_trxl_scratch(g.W, t_.embed_dim, t_.num_heads, t_.num_blocks, self.device, group=g.group_kernel)
+                    g.rf_scratch_kind = g.group_kernel
                 # ... and, after the action hand-over, the memory-bank write and the K | V projection of the new items (the tail)
                 tail = None
                 if self.config.get("fused_rollout_tail", True) and getattr(self, "_kv_w_blocked", None) is not None:   # (pre-LN: the kernel applies norm_kv)
@@ -853,7 +775,7 @@ class PPOTrainer:
                                  g.rf_scratch, host_actions=g.act_pin, host_flag=g.flag_pin if host_flag else None, w_off=g.lo,
                                  tail=tail, h_bias=h_bias,
                                  window=(ss_src, self._mask_table, self._index_table, st["memory_mask"], st["memory_indices"],
-                                         g.ss_latch, g.t_row, self._kv_init, g.early) if window_in_step else None)
+                                         g.ss_latch, g.t_row, self._kv_init))
                 item = g.item
                 fused_policy = True
             elif single and self.model.rollout_heads_fusable():
@@ -904,29 +826,6 @@ class PPOTrainer:
         if item.data_ptr() != g.item.data_ptr():
             g.item.copy_(item)
         return g.item
-
-    def _pull_ok(self, g, host_flag):
-        """pull_observations (opt-in): streamed observations on the group's own stream, flag hand-over, one-launch step kernel.
-        Measured (round 3, config 3): no gain -- 181 vs 175 us per step.  The host's part of a step drops from 42 to 24 us (no
-        runtime copy calls, the graph launch off the path), but 1.35 MB per group and step cross PCIe either way: pulled by the
-        kernel that takes 37 us (36 GB/s), of which only the part under the host's row writes is hidden -- the copy engine's
-        transfer overlaps more of the host's work.  Kept as a tested option."""
-        if not (self.config.get("pull_observations", False) and host_flag and g.stream is not None and self._state_zero_copy and self._use_kv_cache):
-            return False
-        rf_ = getattr(self.model, "_rf", None)
-        return (rf_ is not None and len(self.action_space_shape) == 1 and self.config.get("window_in_step_kernel", True)
-                and len(self._groups) * etm_lib.load().etm_rollout_trxl_grid(g.W, rf_["H"]) <= 256)
-
-    def publish_for_replay(self, on=True):
-        """Tools that replay step graphs without the host loop (tools/rollout_profile.py, tools/kernel_rooflines.py): publish a state /
-        row-flag tag that every replayed step accepts (``on=False``: back to 'nothing published')."""
-        for g in self._groups:
-            if on:
-                np.bitwise_or(self._ss_pin.numpy()[:, g.lo:g.hi], 1 << 40, out=g.ss_tag_np)
-                g.row_flags_np[:] = 1 << 40
-            else:
-                g.ss_tag_np[:] = 0
-                g.row_flags_np[:] = 0
 
     def _rollout_step_tail(self, g, item, stream_obs=False):
         """What the host does NOT have to wait for before stepping the environments: memory-bank write (upstream :174),
@@ -998,9 +897,7 @@ class PPOTrainer:
         # native rollout driver (worker_processes): needs the flag hand-over, streamed observations on the groups' own streams and
         # the (step, slot) block read in place -- then the sampling kernels write the step's sequence number into the SEGMENT's go
         # words (the workers spin on them) instead of a private pinned word (decided here: the address is captured below)
-        self._native_rollout = bool(self._shm_env is not None and self.config.get("native_rollout_driver", True) and so and hf
-                                    and self._state_zero_copy and all(g.stream is not None for g in groups)
-                                    and not self.config.get("early_step_launch", False) and not self.config.get("pull_observations", False)
+        self._native_rollout = bool(self._shm_env is not None and so and hf and all(g.stream is not None for g in groups)
                                     and hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph_exec"))
         if self._native_rollout:
             for gi, g in enumerate(groups):
@@ -1024,13 +921,8 @@ class PPOTrainer:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side), torch.no_grad():
                 for i in range(3):
-                    # (early_step_launch / pull_observations: the kernels poll for words tagged with their step counter + 1; warm-up
-                    # run i is step i)
-                    np.bitwise_or(self._ss_pin.numpy()[:, g.lo:g.hi], (i + 1) << 32, out=g.ss_tag_np)
-                    g.row_flags_np[:] = i + 1
                     self._rollout_step_device(g, so, hf)
                     side.synchronize()
-                g.row_flags_np[:] = 0
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             pool = torch.cuda.graph_pool_handle()
@@ -1140,6 +1032,8 @@ class PPOTrainer:
         else:
             spec = WindowSpec.from_bank(samples["memories"], ep, samples["memory_indices"], samples["memory_indices"],
                                         samples["memory_mask"])
+            if ep is not None and self.model.transformer.pos_kind == "" and samples["memories"].data_ptr() == self.buffer.bank.data_ptr():
+                spec.row_stats = getattr(self, "_row_stats", None)       # (as the captured bodies do: same work on both paths)
         stats3 = getattr(self, "_mb_stats3", None)
         if stats3 is None:
             stats3 = ops.adv_stats(samples["advantages"])

@@ -242,39 +242,50 @@ class Transformer(nn.Module):
     def _pack_gate_weights(self):
         """[Wr; Wz; Wg] and [Ur; Uz] of every GRU gate (transformer.py:287-298: the operands of the gates' concatenated GEMMs) into
         buffers that keep their address, by ONE multi-tensor copy for the whole model -- 2 cat launches per gate and step otherwise
-        (16 at BASELINE config 5).  The buffers are saved for backward: a second forward pass before the backward pass of the first
-        would overwrite them, which autograd reports (version counter) instead of computing with the wrong operands."""
+        (16 at BASELINE config 5).  The buffers are saved for backward; TWO of them alternate, so a second grad-enabled forward pass
+        before the backward pass of the first (auxiliary loss, twin evaluation) computes with its own copy; a third one overwrites
+        the first's, which autograd reports (version counter) instead of computing with the wrong operands.  Returns the gates
+        whose ``_train_cat`` was set (``forward_window`` clears them again whatever happens in between)."""
         gates = [g for blk in self.transformer_blocks if blk.use_gtrxl for g in (blk.gate1, blk.gate2)]
         if not gates:
-            return
+            return gates
         D, dev = self.embed_dim, gates[0].Wr.weight.device
-        buf = getattr(self, "_gate_cat", None)
-        if buf is None or buf.device != dev or buf.shape[0] != len(gates):
-            buf = self._gate_cat = torch.empty((len(gates), 5 * D, D), dtype=torch.float32, device=dev)
-            self._gate_cat_views = [v for i, _ in enumerate(gates) for v in (buf[i, :D], buf[i, D: 2 * D], buf[i, 2 * D: 3 * D],
-                                                                             buf[i, 3 * D: 4 * D], buf[i, 4 * D:])]
+        bufs = getattr(self, "_gate_cat", None)
+        if bufs is None or bufs[0].device != dev or bufs[0].shape[0] != len(gates):
+            bufs = self._gate_cat = [torch.empty((len(gates), 5 * D, D), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._gate_cat_views = [[v for i, _ in enumerate(gates) for v in (b[i, :D], b[i, D: 2 * D], b[i, 2 * D: 3 * D],
+                                                                              b[i, 3 * D: 4 * D], b[i, 4 * D:])] for b in bufs]
+            self._gate_cat_turn = 0
+        k = self._gate_cat_turn = 1 - self._gate_cat_turn
+        buf = bufs[k]
         with torch.no_grad():
-            torch._foreach_copy_(self._gate_cat_views, [m.weight for g in gates for m in (g.Wr, g.Wz, g.Wg, g.Ur, g.Uz)])
+            torch._foreach_copy_(self._gate_cat_views[k], [m.weight for g in gates for m in (g.Wr, g.Wz, g.Wg, g.Ur, g.Uz)])
         for i, g in enumerate(gates):
             g._train_cat = (buf[i, : 3 * D], buf[i, 3 * D:])
+        return gates
 
     def forward_window(self, h, spec: WindowSpec, want_items=True):
         """h [N, input_dim]; windows addressed by ``spec``.  Returns (h [N, D], new memory items [N, blocks, D]) -- the items
         are None with ``want_items=False`` (the optimisation phase never stores them)."""
-        if torch.is_grad_enabled() and h.is_cuda and h.dim() == 2:
-            self._pack_gate_weights()
-        h = ops.linear_relu(self.linear_embedding, h)
-        pos = None if spec.pos_included else self._pos()
-        items = []
-        h_res = None
-        last = len(self.transformer_blocks) - 1
-        for i, blk in enumerate(self.transformer_blocks):
-            if want_items:
-                items.append(h.detach())
-            if i < last:       # the state forked for the next block's two consumers (fused post-LN training path; None otherwise)
-                h, _, h_res = blk.forward_window(h, spec, i, pos, h_res=h_res, fork=True)
-            else:
-                h, _ = blk.forward_window(h, spec, i, pos, h_res=h_res)
+        packed = self._pack_gate_weights() if (torch.is_grad_enabled() and h.is_cuda and h.dim() == 2) else []
+        try:
+            h = ops.linear_relu(self.linear_embedding, h)
+            pos = None if spec.pos_included else self._pos()
+            items = []
+            h_res = None
+            last = len(self.transformer_blocks) - 1
+            for i, blk in enumerate(self.transformer_blocks):
+                if want_items:
+                    items.append(h.detach())
+                if i < last:       # the state forked for the next block's two consumers (fused post-LN training path; None otherwise)
+                    h, _, h_res = blk.forward_window(h, spec, i, pos, h_res=h_res, fork=True)
+                else:
+                    h, _ = blk.forward_window(h, spec, i, pos, h_res=h_res)
+        finally:
+            # a gate that did not consume its packed operands (eager path at D > 1024, an exception above) must not find a pointer into
+            # the shared buffer in a later, non-window forward()
+            for g in packed:
+                g._train_cat = None
         return h, (torch.stack(items, dim=1) if want_items else None)
 
     def bank_with_positions(self, bank):

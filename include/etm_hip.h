@@ -363,9 +363,6 @@ int etm_rollout_policy(const float *h, const float *h_bias, const float *wp, con
  *           mask up in index_table [T, L] / mask_table [L, L] (trainer.py:165-169), member 0 also writes them to win_t / mask_t [W, L]
  *           and to row *t_dev of the staging arrays st_idx / st_mask [S, stage_W, L], latches ss into latch [2, W] and *t_dev into
  *           t_row; a worker at episode step 0 first gets its cache rows reset to kv_init [T, nb, 2D] (NULL: no reset);
- *           ss_tagged != 0: every ss word carries (*t_dev + 1) << 32 in its upper half and the value in its lower half -- the caller
- *           may enqueue the launch BEFORE it has finished the bookkeeping of the previous step (trainer.py:192-213) and publish the
- *           tagged words afterwards; the kernel polls its two words (bounded: error word 2 if they never arrive);
  *   h_splits > 0: h_in is [h_splits, W, D] from etm_rollout_hidden_partial and the input is relu(sum over slices + h_bias [D]);
  *   tail (wkv non-NULL; NULL = none): after the action hand-over the launch also writes bank[slot_l[w], step_l[w], b, :] = item_b
  *           (bank [slots, T, nb, D] with the given slot / row strides in floats) and kv[w, step_l[w], b, :] = (item_b +
@@ -393,7 +390,7 @@ int etm_rollout_trxl(const float *h_in, const float *wemb_t, const float *bemb, 
                      const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride,
                      const float *h_bias, int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                      int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                     int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+                     int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
 /* The group form of the step for GRU-gated blocks (round 5, csrc/rollout_group.hip; replaces the same reference lines as
  * etm_rollout_trxl: trainer.py:163-186 -> model.py:96-112 -> transformer.py:222-253 with the gates of :287-298): the W <= 8 workers of a
  * group are the ROWS of every product and its columns are dealt to 32 workgroups, so every matrix leaves L2 / the Infinity Cache once
@@ -418,7 +415,7 @@ int etm_rollout_trxl_group(const float *h_in, const float *wemb_t, const float *
                      const int64_t *slot_l, float *bank, int64_t bank_slot_stride, int64_t bank_row_stride, int64_t bank_block_stride,
                      const float *h_bias, int h_splits, const int64_t *ss, const uint8_t *mask_table, const int64_t *index_table, uint8_t *st_mask,
                      int64_t *st_idx, int64_t *latch, int64_t *t_row, uint8_t *mask_t, int64_t *win_t, const float *kv_init, int T,
-                     int ss_tagged, int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
+                     int pre_ln, int gtrxl, int W, int D, int H, int L, int hid, int A, int stage_W, void *stream);
 /* Window pass (etm_window_*): 0 = load and multiply the window rows of fully masked waves too (A/B diagnostics; the results are
  * bit-identical either way); default 1 = skip them.  Process-wide, read at launch. */
 int etm_window_set_skip_masked(int on);
@@ -434,12 +431,6 @@ int etm_rollout_hidden_partial(const float *x, const float *wt, float *part, int
  * 64 rows of lin_hidden^T.  x2 [W, Hi, Wi, 64] NHWC (output of the second etm_conv_relu), w3k [(ky, kx, c), co] = [576, 64],
  * hid_t [64 * Ho * Wo, D] (feature = co * Ho * Wo + pixel), part [Ho * Wo, W, D] -- the consumer (etm_rollout_trxl with
  * h_splits = Ho * Wo <= 64) adds the slices, the bias and the ReLU.  etm_rollout_conv3_hidden_supported: 1 for this geometry. */
-/* Rollout only: the first two encoder layers (model.py:90-91: Conv2d(C <= 3, 32, 8, 4) + ReLU, Conv2d(32, 64, 4, 2) + ReLU) as ONE launch,
- * one workgroup per output pixel of the second layer and four images (csrc/conv12_fused.hip).  in [W, C, H, Wd] NCHW (row *in_index of a
- * time-major stack when in_index != NULL, as etm_conv_relu), w1k [(c, ky, kx), 32], w2k [(ky, kx, c1), 64], out [W, Ho2, Wo2, 64] NHWC. */
-int etm_rollout_conv12_supported(int C, int H, int Wd, int C1, int K1h, int K1w, int S1, int C2, int K2h, int K2w, int S2);
-int etm_rollout_conv12(const float *in, const int64_t *in_index, int64_t in_index_stride, const float *w1k, const float *b1, const float *w2k,
-                       const float *b2, float *out, int W, int C, int H, int Wd, void *stream);
 int etm_rollout_conv3_hidden_supported(int C, int Hi, int Wi, int Cout, int KH, int KW, int S, int D);
 int etm_rollout_conv3_hidden(const float *x2, const float *w3k, const float *b3, const float *hid_t, float *part, int W, int Hi, int Wi,
                              int D, void *stream);
@@ -564,16 +555,14 @@ int etm_upload(void *dst, const void *src, int64_t bytes, void *stream);
  * etm_rollout_drive: for t = t_first .. S - 1 and every group -- in the order in which the groups become ready (default; G <= 16,
  *   n_procs <= 64), except that a group with an episode end in step t is served after every lower-numbered group: memory slots
  *   are numbered in the (step, group) order of the loop this replaces (upstream's `len(self.buffer.memories) - 1`, trainer.py:211),
- *   so the results do not depend on the service order; etm_rollout_drive_set_order(0) selects strict round-robin (rounds 4 / 5a):
+ *   so the results do not depend on the service order:
  *     wait until the group's n_procs `ready` words (ready_stride int64 apart) equal t + 1;
  *     bookkeeping of upstream :195-213 over dones[t, lo..hi): ep_step += 1, or (done) ep_step = 0 and slot = (*next_slot)++ with
  *       an event (t, worker, slot) appended to `events` [max_events][3] / *n_events (ETM_EWORKSPACE when the bank -- `capacity`
  *       slots -- or the event list is full);
- *     if t + 1 < S: (ep_step, slot) of the group -> ss_dst [2, Wg] (pinned; `tagged`: OR-ed with (t + 2) << 32, the
- *       early_step_launch protocol of etm_rollout_trxl), hipMemcpyAsync of the group's observation rows (obs_src, Wg * row_bytes)
- *       to stage_dst + (t + 1) * stage_step_bytes and hipGraphLaunch(graph_exec) -- both on the group's `stream`.  With row
- *       progress words (`rows`, rows_per_proc > 0) the rows are uploaded in pieces WHILE the workers still write (a piece = the
- *       rows of one process that became final since the last look), i.e. before `ready`; only the graph launch follows it.
+ *     if t + 1 < S: (ep_step, slot) of the group -> ss_dst [2, Wg] (pinned), hipMemcpyAsync of the group's observation rows
+ *       (obs_src, Wg * row_bytes) to stage_dst + (t + 1) * stage_step_bytes and hipGraphLaunch(graph_exec) -- both on the group's
+ *       `stream`.
  *   Blocking; returns when the bookkeeping of step S - 1 is done (the last launched step may still run).  abort_words: n words,
  *   abort_stride int64 apart (the workers' error words + the segment's abort word), polled while waiting -> ETM_EABORTED;
  *   ETM_ETIMEOUT after timeout_s without progress.  timing (optional): [0] seconds waiting for workers, [1] seconds of
@@ -587,28 +576,16 @@ typedef struct etm_rollout_group {
   const void *obs_src;            /* the group's observation rows in the shared segment */
   void *stage_dst;                /* device: staging row 0 of the group's first worker */
   int64_t *ss_dst;                /* pinned [2, hi - lo]: where the step kernel reads (episode step, slot) */
-  int32_t tagged;
-  int32_t rows_per_proc;          /* environments of one worker process (0: no row progress words, upload after `ready`) */
-  const volatile int64_t *rows;   /* first row-progress word of the group's processes (ready_stride apart): ((t + 1) << 16) | rows final */
 } etm_rollout_group;
 /* hipGraphLaunch(graph_exec, stream) without the framework's per-replay bookkeeping (stream switches, generator checks): the
  * in-process rollout loop launches a group's captured step with it (same call the native driver makes). */
 int etm_graph_launch(void *graph_exec, void *stream);
 int etm_host_register(void *ptr, int64_t bytes);
 int etm_host_unregister(void *ptr);
-int etm_rollout_drive_set_order(int ready_first);   /* process-wide; 1 (default) = ready-first, 0 = round-robin */
 int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,
                       const uint8_t *dones, int64_t *ep_step, int64_t *slot, int64_t *next_slot, int64_t capacity, int64_t *events,
                       int64_t max_events, int64_t *n_events, const volatile int64_t *abort_words, int n_abort_words, int abort_stride,
                       double timeout_s, double *timing, double *chain_log);
-
-/* Observation rows of a rollout step pulled by the device (trainer.py:163, :190-193), capturable as the first node of the step's
- * graph: row r of `src` (pinned host memory, `rows` rows of row_bytes, % 16 == 0) is copied to dst_base + (*t_dev) *
- * dst_step_stride_bytes + r * row_bytes as soon as row_flags[r] (pinned int64) >= *t_dev + 1 -- the host sets the flag when the
- * row is final; the launch itself may be enqueued long before (one step ahead).  err (optional device int64): 3 if a flag
- * never arrived within ~1 s. */
-int etm_obs_pull(const void *src, void *dst_base, int64_t dst_step_stride_bytes, int64_t row_bytes, int rows, const int64_t *t_dev,
-                 const int64_t *row_flags, int64_t *err, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel #2: generalized advantage estimation, replaces Buffer.calc_advantages (buffer.py:95-113).

@@ -421,20 +421,12 @@ _ROLLOUT_PATHS = {
     "library_convs": {"fused_train_encoder": False},          # optimisation phase on the library convolutions
     "multi_launch_blocks": {"fused_rollout_block": False},    # rollout: one launch per GEMM / attention / LayerNorm instead of one per step
     "launched_tail": {"fused_rollout_tail": False},           # bank write + K/V projection of the new items as separate launches
-    "library_hidden": {"split_hidden_product": False},        # lin_hidden of a rollout step by the library GEMM, not as K-slice sums
-    "window_launch": {"window_in_step_kernel": False},        # window lookup as its own launch in front of the encoder
-    "state_uploaded": {"state_zero_copy": False},             # (step, slot) and observations on the upload stream + event, not read in place
-    "member_xcd": {"rollout_team_placement": "member_xcd"},   # step kernel: one member index per XCD instead of a team per XCD
     "four_groups": {"rollout_groups": 4, "rollout_min_group_size": 2},          # four worker groups (correct with any number of hardware queues)
     "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False,    # heads / loss / weight gradients as separate ops (round-2 form),
                        "grouped_colsum_train": False},                          # every column-sum gradient reduced by its own launch
-    "pull_obs": {"pull_observations": True},                  # the device pulls the observation rows itself; step graphs enqueued one step ahead
-    "early_launch": {"early_step_launch": True},              # the step's graph is enqueued BEFORE the host bookkeeping (tagged state words)
     # round 4: environments in worker PROCESSES over a shared, HIP-registered segment; the per-step host loop is the library's native
     # driver (etm_rollout_drive) where the step is a flag-hand-over graph with streamed observations, else the host-driven protocol
     "kslice_hidden": {"fused_conv3_hidden": False},              # lin_hidden of a rollout step as 16 K-slice sums behind the third convolution (round 3)
-    "interleaved_bank": {"episode_bank_layout": "interleaved"},  # upstream's [slots, T, blocks, D] memory order (round 3) instead of block-major
-    "conv12": {"fused_conv12": True},                            # the first two encoder layers of a rollout step as ONE launch (measured, off by default)
     # round 5 (pre-LN models): norm_kv's statistics gathered from per-bank-row statistics taken once per update (opt-in) instead of per
     # window row inside etm_window_fwd; norm_kv's gain / bias gradients through the generic dX kernel instead of csrc/window_ln_grad.hip
     "window_row_stats": {"bank_row_stats": False},      # norm_kv statistics per window row inside the passes (default: once per bank row)
@@ -442,23 +434,18 @@ _ROLLOUT_PATHS = {
     "worker_processes": {"worker_processes": True},
     "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
     "worker_processes_eager": {"worker_processes": True, "envs_per_process": 2, "hip_graph_rollout": False},
-    "worker_processes_round_robin": {"worker_processes": True, "rollout_drive_order": "round_robin"},   # (default since round 5: ready-first)
 }
 _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl", "eager"), ("img", "default"), ("img", "eager"),
              ("img32", "default"), ("img32", "eager"), ("img32", "graph_one_group"), ("img32", "graph_unstreamed"),
              ("img32", "groups4"), ("img32", "event_handover"), ("img32", "eager_train"), ("img32", "library_convs"),
              ("img32", "multi_launch_blocks"), ("vec", "multi_launch_blocks"), ("img32", "launched_tail"), ("vec", "launched_tail"),
-             ("img32", "state_uploaded"), ("img32", "library_hidden"), ("img32", "window_launch"),
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
-             ("cfg3", "member_xcd"), ("cfg5", "default"), ("cfg5", "eager"), ("img32", "member_xcd"), ("img32", "early_launch"),
-             ("cfg3", "early_launch"), ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "pull_obs"), ("cfg3", "pull_obs"), ("img32", "four_groups"), ("cfg3", "four_groups"),
-             ("cfg5", "pull_obs"),
+             ("cfg5", "default"), ("cfg5", "eager"),
+             ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "four_groups"), ("cfg3", "four_groups"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
-             ("img32", "worker_processes_round_robin"), ("cfg3", "worker_processes_round_robin"),
-             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("cfg2", "window_row_stats"), ("cfg2", "generic_ln_grad"), ("cfg5", "window_row_stats"), ("img32", "conv12"), ("cfg3", "conv12"),
-             ("img32", "interleaved_bank"), ("cfg3", "interleaved_bank"), ("gtrxl", "interleaved_bank")]
+             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("cfg2", "window_row_stats"), ("cfg2", "generic_ln_grad"), ("cfg5", "window_row_stats")]
 
 
 def movement_error(sd, z, tag, keys, prev):
@@ -612,10 +599,6 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
             "img32/default must run the benchmarked configuration: graphs, observation streaming, two worker groups"
         assert tr.model._train_encoder_ok, "img32/default: the optimisation phase runs the hand-written encoder kernels"
         assert tr.model._rf is not None, "img32/default: transformer + heads + sampling of a rollout step are one launch"
-    if path == "pull_obs":
-        assert all(g.pull and g.early for g in tr._groups), "the step graphs start with the observation pull kernel"
-    if path == "early_launch":
-        assert all(g.early for g in tr._groups), "the step graphs are enqueued ahead of the host bookkeeping (tagged state words)"
     if name in ("cfg2", "cfg3", "cfg5") and path == "default":
         # the benchmarked instantiations ran: captured step graphs with the one-launch step kernel (teams of etm_rollout_trxl_team(H)
         # workgroups per worker: 4 at H = 4), captured optimisation step; visual configs: observation streaming, two worker groups,
@@ -639,8 +622,7 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
         assert bool(getattr(tr, "_native_rollout", False)) == (name != "vec" and path != "worker_processes_eager"), (name, path)
         if path == "worker_processes_k4":
             assert len(tr._groups) == 4
-    blk_major = path != "interleaved_bank"
-    assert tr.buffer.block_major == blk_major and (tr.buffer.bank.stride(2) > tr.buffer.bank.stride(0)) == blk_major   # [blocks][slots][T][D] in memory
+    assert tr.buffer.block_major and tr.buffer.bank.stride(2) > tr.buffer.bank.stride(0)   # [blocks][slots][T][D] in memory
     if path == "groups4":
         assert len(tr._groups) == 4
     if path == "event_handover":
@@ -670,12 +652,16 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 #       evaluation (cfg3 u0 step 1: lin_policy 2.1e-4; cfg2 u1 step 2: gate1.Wr 1.7e-3).  One flipped dense unit moves the
 #       tensors below it by 1e-5 .. 1e-3 of their norm, and AdamW (update lr * m_hat / (sqrt(v_hat) + eps): scale-free) turns that
 #       into sign changes of every element whose gradient is smaller -- measured 8.2e-4 / 4.6e-3 (cfg3), 1.4e-4 / 1.3e-3 (cfg2) in
-#       the first update where the flip-free paths of cfg5 (eager, kslice_hidden) and img32 sit at 4e-5 .. 8e-5.  Round 5: cfg5 on the
-#       DEFAULT rollout (conv3 + lin_hidden in one launch: 49 per-pixel partial rows instead of 16 K-slices) measures 1.37e-3 / 5.4e-3 --
-#       tools/parity_pair.py ran default, kslice_hidden and eager against each other: ONE unit, lin_policy unit 162 of the sample at
-#       sorted position 1672, float64 pre-activation +9.7e-8 with the default rollout's memory items and -3.3e-7 / -2.2e-7 with the
-#       other two; lin_policy.bias differs in that element only, lin_policy.weight by a rank-1 term in that row, the two flip-free
-#       paths agree to 1.9e-7 (profiles/r05/parity_pair_cfg5.txt).  Bounds of this test at the BASELINE sizes therefore
+#       the first update where the flip-free paths of cfg5 and img32 sit at 4e-5 .. 8e-5.  cfg5 has such a unit too: lin_policy unit 162
+#       of the sample at sorted position 1672, float64 pre-activation within 3.3e-7 of zero under EVERY rollout path's memory items, so
+#       which paths evaluate it as active is an accident of rounding and moves whenever a summation order upstream changes.  END STATE
+#       OF ROUND 5 (tests/golden/tf_measured_baseline.json, known_flips[2]; profiles/r05/parity_pair_cfg5_final.txt): after the group
+#       step kernel folded fc_out into the first gate's maps the pre-activation under the DEFAULT rollout went from +9.7e-8 to -6.2e-9,
+#       i.e. cfg5/default is QUIET (4.2e-5 / 1.6e-4, like eager and worker_processes) and the flip shows on kslice_hidden and
+#       window_row_stats (1.4e-3 / 5.4e-3; pre-activations +2.4e-7 / -8.4e-9).  (Mid round 5 it was the other way round -- default
+#       1.37e-3 / 5.4e-3 with the other paths quiet, profiles/r05/parity_pair_cfg5.txt: same unit, same signature.)  lin_policy.bias
+#       differs in element 162 only, lin_policy.weight by a rank-1 term in that row; paths on the same side agree to 1.5e-7 .. 1.9e-7.
+#       Bounds of this test at the BASELINE sizes therefore
 #       stay at 2e-3 / 1e-2 (first update), 5e-3 / 2e-2 later; gradient of the first minibatch 2e-5 / 2e-3 of the norm (a flipped
 #       unit: cfg2 lin_hidden.weight 1.0e-3).  The TIGHT statement -- per tensor and per optimiser step against the float64
 #       evaluation, with bounds that are multiples of the floor of the same step -- is test_kink_free_update_vs_reference below, on
@@ -688,8 +674,8 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
 # (case, path, update) has its MEASURED values on record (tests/golden/tf_measured_baseline.json, written by tools/tf_ratchet.py from
 # the measurement log of a GPU suite run); a value that exceeds ratio (3) x max(record, floor) fails.  Recording a louder value is
 # only possible with a `known_flips` item that names the flipped unit, its pre-activation and the probe output
-# (tools/parity_pair.py): cfg2 -- unit 107 of linear_embedding; cfg3 -- one unit of lin_value; cfg5 default / pull_obs /
-# worker_processes -- unit 162 of lin_policy, pre-activation +9.7e-8 (profiles/r05/parity_pair_cfg5.txt).
+# (tools/parity_pair.py): cfg2 -- unit 107 of linear_embedding; cfg3 -- one unit of lin_value; cfg5 kslice_hidden /
+# window_row_stats -- unit 162 of lin_policy (profiles/r05/parity_pair_cfg5_final.txt; cfg5/default, eager, worker_processes are quiet).
 _RATCHET = None
 
 
@@ -873,34 +859,6 @@ def test_kink_free_update_vs_reference(golden_dir, name, mode):
                                     "grad_tensor_frac_of_bound": worst[0], "move_vs_ref": mv_a, "move_vs_exact": mv_x, "move_floor": floor}) + "\n")
         assert mv_a <= _KF_MOVE_RATIO * floor and mv_x <= _KF_MOVE_RATIO * floor, (mv_a, mv_x, floor)
     tr.close()
-
-
-def test_rollout_conv12_vs_float64():
-    """csrc/conv12_fused.hip (round 4): the first two encoder layers of a rollout step in one launch against
-    relu(conv2d(relu(conv2d(x)))) in float64 (model.py:90-91): 84 x 84 and 36 x 36 inputs, ragged image counts, one and three input
-    channels, plain input and a row of a time-major stack restricted to a worker group."""
-    from etm import ops
-    dev = _dev()
-    torch.manual_seed(12)
-    for (N, C, H, W) in ((8, 3, 84, 84), (5, 3, 84, 84), (6, 1, 36, 36), (16, 3, 36, 36)):
-        c1, c2 = torch.nn.Conv2d(C, 32, 8, 4).to(dev), torch.nn.Conv2d(32, 64, 4, 2).to(dev)
-        assert ops.rollout_conv12_supported(c1, c2, H, W)
-        w1k = c1.weight.detach().permute(1, 2, 3, 0).reshape(-1, 32).contiguous()
-        w2k = c2.weight.detach().permute(2, 3, 1, 0).reshape(-1, 64).contiguous()
-        x = torch.rand((N, C, H, W), device=dev)
-        got = ops.rollout_conv12(x, w1k, c1.bias.detach(), w2k, c2.bias.detach(), C, H, W)
-        with torch.no_grad():
-            ref = torch.relu(torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(
-                x.double().cpu(), c1.weight.double().cpu(), c1.bias.double().cpu(), 4)), c2.weight.double().cpu(), c2.bias.double().cpu(), 2))
-        ref = ref.permute(0, 2, 3, 1)
-        assert tuple(got.shape) == tuple(ref.shape)
-        assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6, (N, C, H, W)
-        # row 2 of a time-major stack, images [1, N - 1) (a worker group)
-        stack = torch.rand((4, N, C, H, W), device=dev)
-        stack[2] = x
-        got2 = ops.rollout_conv12(stack, w1k, c1.bias.detach(), w2k, c2.bias.detach(), C, H, W,
-                                  index=torch.tensor(2, dtype=torch.int64, device=dev), rows=(1, N - 1))
-        assert torch.equal(got2, got[1:N - 1])
 
 
 def test_rollout_conv3_hidden_vs_float64():
@@ -1145,6 +1103,7 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
     """etm_rollout_trxl (transformer + heads + sampling of a rollout step in one launch) against the multi-launch path
     (library GEMMs, cached attention, residual + LayerNorm and policy kernels) on the same weights, cache and observations:
     memory items, values, log-probs and -- for every worker whose uniform is not within 1e-5 of a CDF boundary -- actions."""
+    from etm import lib as etm_lib
     from trainer import PPOTrainer
     dev = _dev()
     # teams of 4 / 2 / 1 workgroups; two heads per member with a window beyond 64 rows; D = 512 (the 32-row register slices)
@@ -1168,9 +1127,10 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
         for fused, placement in ((True, "team_xcd"), (True, "member_xcd"), (False, "team_xcd")):
             c = json.loads(json.dumps(cfg))
             c["fused_rollout_block"] = fused
-            c["rollout_team_placement"] = placement
             torch.manual_seed(17)
             tr = PPOTrainer(c, run_id="fusedstep", device=dev, tensorboard=False)
+            # (process-wide library switch, read at launch and by etm_rollout_trxl_grid; the trainer sets the default, team_xcd)
+            etm_lib.check(etm_lib.load().etm_rollout_trxl_set_placement(1 if placement == "member_xcd" else 0), "set_placement")
             with torch.no_grad():
                 for prm in tr.model.parameters():          # non-trivial LayerNorm gains / biases
                     if prm.dim() == 1:
@@ -1181,6 +1141,7 @@ def test_fused_rollout_step_kernel_vs_multi_launch_path():
             b = tr.buffer
             snaps.append({k: getattr(b, k).clone() for k in ("actions", "values", "log_probs", "memory_index")} | {"mem": b.memories.clone()})
             tr.close()
+            etm_lib.load().etm_rollout_trxl_set_placement(0)
         a, a2, m = snaps
         for k in ("actions", "values", "log_probs", "mem"):
             assert torch.equal(a[k], a2[k]), (D, ln, gtrxl, k, "the two placements of the step kernel must agree bit for bit")
@@ -1776,12 +1737,11 @@ def test_grouped_column_sums_bit_identical_to_per_call_reductions(N, D):
     assert float((views[3].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())) * max(1.0, N ** 0.5)
 
 
-@pytest.mark.parametrize("order", ["ready_first", "round_robin"])
-def test_rollout_driver_service_order(order):
+def test_rollout_driver_service_order():
     """csrc/rollout_driver.hip without a trainer: two fake worker groups (their `ready` words published by a thread of this test,
-    group 1 BEFORE group 0 in every step).  Ready-first: group 1 is served while group 0 is still stepping -- unless it has an episode
-    end in that step, then it waits for group 0, so that the slot numbers (upstream trainer.py:211) come out in (step, group) order.
-    Round-robin: group 1 is never served first.  Both: step counters, slots and the event list equal the Python loop they replace."""
+    group 1 BEFORE group 0 in every step).  Group 1 is served while group 0 is still stepping -- unless it has an episode end in
+    that step, then it waits for group 0, so that the slot numbers (upstream trainer.py:211) come out in (step, group) order.
+    Step counters, slots and the event list equal the Python loop the driver replaces."""
     import ctypes
     import threading
     import time
@@ -1820,7 +1780,6 @@ def test_rollout_driver_service_order(order):
         a.ready, a.n_procs, a.ready_stride = ready[gi:].ctypes.data, 1, ready.shape[1]
         a.lo, a.hi = gi * Wg, (gi + 1) * Wg
         a.obs_src, a.stage_dst, a.ss_dst = obs[gi * Wg:].ctypes.data, stage.data_ptr() + gi * Wg * row, ss[gi].ctypes.data
-        a.tagged, a.rows_per_proc, a.rows = 1, 0, None
     ep_step, slot = np.zeros(W, dtype=np.int64), np.arange(W, dtype=np.int64)
     ctr = np.array([W, 0], dtype=np.int64)
     events = np.zeros((W * S, 3), dtype=np.int64)
@@ -1829,19 +1788,19 @@ def test_rollout_driver_service_order(order):
 
     def workers():
         for t in range(S):
+            ss[0][0, 0] = ss[1][0, 0] = -1                      # (episode steps are >= 0: the driver's write of step t + 1's words shows)
             ready[1, 0] = t + 1
             seen, t0 = False, time.time()
             while t + 1 < S and time.time() - t0 < 0.25 and not seen:
-                seen = int(ss[1][0, 0]) >> 32 == t + 2          # the driver wrote group 1's (step, slot) words of step t + 1
+                seen = int(ss[1][0, 0]) != -1                   # the driver wrote group 1's (step, slot) words of step t + 1
                 time.sleep(0.002)
             served_first.append(seen)
             ready[0, 0] = t + 1
             t0 = time.time()       # (real workers cannot publish step t + 1 before the driver has launched it: wait for both groups' words)
-            while t + 1 < S and time.time() - t0 < 10.0 and (int(ss[0][0, 0]) >> 32 != t + 2 or int(ss[1][0, 0]) >> 32 != t + 2):
+            while t + 1 < S and time.time() - t0 < 10.0 and (int(ss[0][0, 0]) == -1 or int(ss[1][0, 0]) == -1):
                 time.sleep(0.001)
 
     th = threading.Thread(target=workers)
-    lib.etm_rollout_drive_set_order(1 if order == "ready_first" else 0)
     th.start()
     try:
         rc = lib.etm_rollout_drive(ctypes.cast(arr, ctypes.c_void_p), G, 0, S, W, row, W * row, dones.ctypes.data, ep_step.ctypes.data,
@@ -1849,7 +1808,6 @@ def test_rollout_driver_service_order(order):
                                    abort.ctypes.data, 1, abort.shape[1], 20.0, None, None)
     finally:
         th.join()
-        lib.etm_rollout_drive_set_order(1)
     torch.cuda.synchronize()
     assert rc == 0
     # the loop it replaces (upstream trainer.py:195-213 in (step, group) order)
@@ -1865,11 +1823,8 @@ def test_rollout_driver_service_order(order):
     assert np.array_equal(ep_step, e_ref) and np.array_equal(slot, s_ref) and ctr[0] == nxt and ctr[1] == len(ev)
     assert np.array_equal(events[: len(ev)], np.asarray(ev, dtype=np.int64).reshape(-1, 3))
     assert all(float(x[0]) == S for x in xs)                    # every group's step graph was launched S - 1 times (+ 1 warm-up)
-    if order == "round_robin":
-        assert not any(served_first), served_first
-    else:
-        for t in range(S - 1):
-            assert served_first[t] == (not dones[t, Wg:].any()), (t, served_first, dones[t])
+    for t in range(S - 1):
+        assert served_first[t] == (not dones[t, Wg:].any()), (t, served_first, dones[t])
 
 
 @pytest.mark.parametrize("layout", ["trxl_post", "gtrxl_pre"])

@@ -316,7 +316,6 @@ def rollout_step(trainer, launches=40):
     def step_fn():
         g.t_dev.zero_()
         g.flag_np[0] = 0
-        trainer.publish_for_replay(True)          # early_step_launch / pull_observations: a tag every replayed step accepts
         with torch.no_grad():
             trainer._rollout_step_device(g, so, hf)
 
@@ -324,7 +323,6 @@ def rollout_step(trainer, launches=40):
     with torch.cuda.stream(stream):
         t = _timed(step_fn, launches)
     torch.cuda.synchronize()
-    trainer.publish_for_replay(False)
     res = {"kernels": {k: dict(avg_us=v[0] * 1e3, launches_per_step=v[1] / launches) for k, v in t.items()}}
     res["step_sum_us"] = sum(v[0] * 1e3 * v[1] / launches for v in t.values())
     if "rollout_trxl_kernel" in t:
@@ -340,8 +338,7 @@ def rollout_step(trainer, launches=40):
                                           # + every worker's own K | V window columns) against the same time and peak
                                           unique_bytes_per_launch=m["unique_bytes_per_launch"],
                                           frac_unique=m["unique_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                          us_per_dependent_phase=us / m["dependent_phases"], model=m,
-                                          placement=trainer.config.get("rollout_team_placement", "team_xcd"))
+                                          us_per_dependent_phase=us / m["dependent_phases"], model=m, placement="team_xcd")
     return res
 
 

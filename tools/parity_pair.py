@@ -37,7 +37,6 @@ PATHS = {
     "default": {},
     "eager": {"hip_graph_rollout": False},
     "kslice_hidden": {"fused_conv3_hidden": False},
-    "library_hidden": {"split_hidden_product": False, "fused_conv3_hidden": False},
     "multi_launch_blocks": {"fused_rollout_block": False},
     "window_row_stats": {"bank_row_stats": False},      # (optimisation phase: norm_kv statistics per window row)
     "window_row_stats_eager": {"bank_row_stats": False, "hip_graph_rollout": False},

@@ -65,7 +65,6 @@ tr._chain_log = None
 # device time of the step graphs alone (no host work in between): head = critical path of a step, tail = under env.step
 if tr._step_graph is not None:
     g0 = tr._groups[0]                       # the first worker group's graphs (all workers when rollout_groups = 1)
-    tr.publish_for_replay(True)              # early_step_launch / pull_observations: the kernels poll for tags -- publish one every step accepts
     g0.t_dev.zero_(); torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     n = max(1, min(200, S - 8))          # the step counter must stay inside the staging arrays
