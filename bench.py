@@ -318,6 +318,9 @@ def main():
     ap.add_argument("--dp-overlap", choices=("on", "off"), default="off",
                     help="data-parallel runs: all-reduce of the head / transformer / lin_hidden gradient slice on a side stream under the "
                          "encoder's backward pass (bit-identical parameters; default off until a multi-GPU run has A/B-ed it)")
+    ap.add_argument("--dp-graph-collective", choices=("on", "off"), default="on",
+                    help="data-parallel runs with the library collective: capture the gradient all-reduce INSIDE the optimisation step's graph "
+                         "(one replay per minibatch; self-tested on every rank at start-up, else the three-call step) or keep it a host call")
     ap.add_argument("--worker-processes", choices=("config", "on", "off"), default="config",
                     help="environments in worker processes over shared memory + the native rollout driver (config: what the YAML says)")
     ap.add_argument("--envs-per-process", type=int, default=None, help="environments per worker process (with worker processes)")
@@ -392,6 +395,7 @@ def main():
 
     cfg = load_config()
     cfg["dp_overlap"] = args.dp_overlap == "on"
+    cfg["dp_graph_collective"] = args.dp_graph_collective == "on"
     if args.worker_processes != "config":
         cfg["worker_processes"] = args.worker_processes == "on"
     if args.envs_per_process is not None:
@@ -625,6 +629,7 @@ def main():
                        "copy_threads": trainer._host_plan["copy_threads"],
                        "env_steps_per_update_per_gpu": W * S, "minibatch": N, "parallelism": f"dp{world}",
                        "attention": args.attention, "dp_collective": dp.collective if dp is not None else None,
+                       "dp_step": (None if dp is None else "one_graph" if getattr(trainer, "_dp_one_graph", False) else "graph_a+allreduce+graph_b"),
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,

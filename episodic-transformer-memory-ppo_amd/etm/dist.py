@@ -64,6 +64,7 @@ class DataParallel:
         if self.collective not in ("torch", "etm"):
             raise ValueError(f"collective must be 'torch' or 'etm', got {self.collective!r}")
         self._comm = None
+        self._graph_collective = None      # can the library all-reduce be captured into a HIP graph? (decided by graph_collective_ok)
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,6 +210,78 @@ class DataParallel:
             watchdog.cancel()
         if not agreed:
             return self._use_torch_collective(why)
+        # step 4 (round 6): the same collective INSIDE a captured graph -- the optimisation step then is ONE graph per minibatch
+        # (forward, backward, all-reduce, clip + AdamW) instead of two replays around a host call.  Symmetric like the steps above:
+        # every rank captures and replays, then all agree; any failure leaves the three-call step in place.
+        watchdog = threading.Timer(limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            self._graph_collective = agree(self._graph_selftest())
+        finally:
+            watchdog.cancel()
+        if not self._graph_collective and self.rank == 0:
+            print("[etm.dist] the library all-reduce could not be captured into a HIP graph on every rank: the optimisation step stays "
+                  "graph A -> all-reduce -> graph B", flush=True)
+
+    def _graph_selftest(self):
+        """Library all-reduce of 4 floats captured into a HIP graph, replayed twice, results checked.  False on any failure."""
+        import ctypes  # noqa: F401
+        from . import lib as _lib
+        if os.environ.get("ETM_DP_GRAPH_COLLECTIVE", "1") == "0" or self._comm is None:
+            return False
+        dev = torch.device(self.device)
+        try:
+            with torch.cuda.device(dev):
+                src = torch.ones(4, dtype=torch.float32, device=dev)
+                buf = torch.zeros(4, dtype=torch.float32, device=dev)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        buf.copy_(src)
+                        _lib.check(_lib.load().etm_allreduce_f32(self._comm, buf.data_ptr(), buf.data_ptr(), 4,
+                                                                 torch.cuda.current_stream(dev).cuda_stream), "etm_allreduce_f32")
+                        buf.mul_(2.0)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                ok = True
+                for k in (1.0, 3.0):
+                    src.fill_(k)
+                    g.replay()
+                    torch.cuda.synchronize(dev)
+                    ok = ok and buf.tolist() == [2.0 * k * self.world] * 4      # (the communicator has self.world ranks)
+                return ok
+        except Exception as exc:       # noqa: BLE001 -- capture not supported here: the eager collective stays
+            print(f"[etm.dist] rank {self.rank}: graph capture of the library all-reduce failed ({exc!r})", flush=True)
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:          # noqa: BLE001
+                pass
+            return False
+
+    def agree(self, ok: bool) -> bool:
+        """Logical AND of ``ok`` over the ranks (one small torch.distributed all-reduce; every rank must call it)."""
+        if not self.active or not dist.is_initialized():
+            return bool(ok)
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def graph_collective_ok(self):
+        """True when the gradient all-reduce may be captured inside the optimisation step's graph: library communicator in use and
+        its captured form self-tested on every rank (multi-rank: at construction; world size 1 with the collective forced on --
+        tests --: here, on first use)."""
+        if self.collective != "etm":
+            return False
+        if self._graph_collective is None:
+            if self.world != 1:
+                return False              # (multi-rank runs decide in _start_etm_comm, together)
+            if self._comm is None:
+                self._comm = self._single_rank_comm()
+            self._graph_collective = self._graph_selftest()
+        return bool(self._graph_collective)
 
     def _use_torch_collective(self, why):
         if self.rank == 0 or why is not None:

@@ -1309,8 +1309,10 @@ class PPOTrainer:
 
     def _train_step_graph(self, idx, learning_rate, clip_range, beta, monitor):
         """Minibatch step through captured graphs (two eager warm-up steps first).  Single GPU: one graph.  Data parallel: the
-        merged advantage statistics are computed eagerly first, then graph A (through the packed gradients), the RCCL
-        all-reduce of the flat bucket, graph B (clip + AdamW).  Returns (stats[6], norms or None)."""
+        merged advantage statistics are computed eagerly first (one all-gather per epoch), then ONE graph that holds the packed
+        gradients' RCCL all-reduce between the backward pass and clip + AdamW (round 6; upstream insertion point trainer.py:310-311)
+        when the library collective's captured form passed its self-test on every rank (etm/dist.py: graph_collective_ok) --
+        otherwise graph A, the all-reduce as a host call, graph B.  Returns (stats[6], norms or None)."""
         dp = self.dp
         if getattr(self, "_tg_idx", None) is None:
             self._tg_idx = torch.empty_like(idx)
@@ -1330,6 +1332,8 @@ class PPOTrainer:
         sample_eager = self.profile_sample_every and self._mb_counter % self.profile_sample_every == 0
         key = (monitor, self._bank_pos is not None)
         overlap = self._dp_overlap_ready()
+        one_graph = bool(dp is not None and self.config.get("dp_graph_collective", True) and dp.graph_collective_ok()
+                         and not getattr(self, "_dp_one_graph_failed", False))
         if (self._train_graph is None and self._train_warm < 2) or sample_eager:
             self._train_warm += 1
             if overlap:
@@ -1345,26 +1349,33 @@ class PPOTrainer:
             return st.clone(), (nm.clone() if nm is not None else None)
         if self._train_graph is None or self._tg_key != key:
             torch.cuda.synchronize(self.device)
-            ga = torch.cuda.CUDAGraph()
-            gb = ga2 = None
-            # (one memory pool for the pieces of the overlapped step: part 2 reads tensors part 1 allocated)
-            pool = torch.cuda.graph_pool_handle() if overlap else None
-            with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+            ga, gb, ga2 = self._capture_one_graph_dp_step(clip_range, beta, monitor, overlap) if one_graph else None, None, None
+            one_graph = ga is not None
+            if dp is not None and dp.world > 1 and self.config.get("dp_graph_collective", True) and dp.graph_collective_ok():
+                # every rank must replay the same form: a rank whose capture failed takes everybody to the three-call step
+                if not dp.agree(one_graph):
+                    ga, one_graph, self._dp_one_graph_failed = None, False, True
+            if ga is None:
+                ga = torch.cuda.CUDAGraph()
+                # (one memory pool for the pieces of the overlapped step: part 2 reads tensors part 1 allocated)
+                pool = torch.cuda.graph_pool_handle() if overlap else None
+                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                    if overlap:
+                        self._tg_stats, self._tg_dfeats = self._train_body_a1(self._tg_idx, clip_range, beta, self._tg_stats3)
+                    else:
+                        self._tg_stats = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
+                    if dp is None:
+                        self._tg_norms = self._train_body_b(monitor)
                 if overlap:
-                    self._tg_stats, self._tg_dfeats = self._train_body_a1(self._tg_idx, clip_range, beta, self._tg_stats3)
-                else:
-                    self._tg_stats = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
-                if dp is None:
-                    self._tg_norms = self._train_body_b(monitor)
-            if overlap:
-                ga2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga2, pool=pool, capture_error_mode="thread_local"):
-                    self._train_body_a2(self._tg_dfeats)
-            if dp is not None:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
-                    self._tg_norms = self._train_body_b(monitor)
+                    ga2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga2, pool=pool, capture_error_mode="thread_local"):
+                        self._train_body_a2(self._tg_dfeats)
+                if dp is not None:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
+                        self._tg_norms = self._train_body_b(monitor)
             self._train_graph, self._tg_key, self._train_graph_a2 = (ga, gb), key, ga2
+            self._dp_one_graph = one_graph
             self.buffer.address_captured = True
             ops.freeze_workspaces(self.device)
         ga, gb = self._train_graph
@@ -1378,6 +1389,31 @@ class PPOTrainer:
                 dp.all_reduce_grads(average=False)
             gb.replay()
         return self._tg_stats.clone(), (self._tg_norms.clone() if monitor else None)
+
+    def _capture_one_graph_dp_step(self, clip_range, beta, monitor, overlap):
+        """Data-parallel minibatch step as ONE graph (round 6): gather, forward, loss, backward, the library's RCCL all-reduce of
+        the flat gradient arena (etm_allreduce_f32 enqueues on the capturing stream like every other entry; with dp_overlap the
+        two slices on the side stream, which joins the capture through the fork event and leaves it through the join event), clip +
+        AdamW.  Returns the captured graph or None (capture failed: the caller captures graph A / graph B around the host-side
+        collective instead)."""
+        ga = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                if overlap:
+                    self._tg_stats, dfe = self._train_body_a1(self._tg_idx, clip_range, beta, self._tg_stats3)
+                    self._allreduce_rest_async()
+                    self._train_body_a2(dfe)
+                    self._allreduce_conv_and_join()
+                else:
+                    self._tg_stats = self._train_body_a(self._tg_idx, clip_range, beta, self._tg_stats3)
+                    self.dp.all_reduce_grads(average=False)
+                self._tg_norms = self._train_body_b(monitor)
+            return ga
+        except Exception as exc:       # noqa: BLE001
+            print(f"[etm] one-graph data-parallel step not captured ({exc!r}); using graph A -> all-reduce -> graph B", file=sys.stderr, flush=True)
+            torch.cuda.synchronize(self.device)
+            self._dp_one_graph_failed = True
+            return None
 
     def _allreduce_rest_async(self):
         main = torch.cuda.current_stream(self.device)

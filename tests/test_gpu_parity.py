@@ -1488,9 +1488,11 @@ def test_graph_and_eager_optimisation_steps_agree():
 
 
 def test_dp_graph_step_single_rank(tmp_path):
-    """Data-parallel optimisation step (graph A -> RCCL all-reduce of the flat bucket -> graph B, advantage statistics merged
-    with an all-gather) on one device with the collectives really issued (world size 1, `active` forced): must train exactly
-    like the single-GPU captured step on the same seeds."""
+    """Data-parallel optimisation step on one device with the collectives really issued (world size 1, `active` forced), in both
+    forms: ONE graph holding the library's RCCL all-reduce between backward and clip + AdamW (round 6, the default with the library
+    collective) and graph A -> all-reduce as a host call -> graph B (torch's collective, or `dp_graph_collective: false`); advantage
+    statistics merged with an all-gather.  Both must train exactly like the single-GPU captured step on the same seeds, and the
+    two data-parallel forms bit-identically."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -1523,20 +1525,27 @@ rng = np.random.default_rng(0)
 acts = rng.integers(0, 3, size=(3, 6, 48))
 perms = [[rng.permutation(6 * 48) for _ in range(2)] for _ in range(3)]
 res = []
-for use_dp in (False, True):
-    dp = ForcedDP(dev) if use_dp else None
+for mode in ("single", "one_graph", "three_call", "torch_collective"):
+    dp = ForcedDP(dev, collective="torch" if mode == "torch_collective" else "etm") if mode != "single" else None
     torch.manual_seed(5)
-    tr = PPOTrainer(json.loads(json.dumps(cfg)), run_id="dpg", device=dev, dp=dp, tensorboard=False)
+    c = json.loads(json.dumps(cfg))
+    c["dp_graph_collective"] = mode != "three_call"
+    tr = PPOTrainer(c, run_id="dpg", device=dev, dp=dp, tensorboard=False)
     for u in range(3):
         lr, beta, clip = tr.schedules(u)
         tr._sample_training_data(forced_actions=acts[u])
         tr.buffer.prepare_batch_dict()
         tr._train_epochs(lr, clip, beta, perms=perms[u])
-    assert tr._train_graph is not None and (tr._train_graph[1] is not None) == use_dp
+    assert tr._train_graph is not None and (tr._train_graph[1] is not None) == (mode in ("three_call", "torch_collective")), mode
+    assert bool(getattr(tr, "_dp_one_graph", False)) == (mode == "one_graph"), mode
     res.append([p.detach().clone() for p in tr.model.parameters()])
     tr.close()
-for a, b in zip(*res):
-    assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), float((a - b).abs().max())
+for other in res[1:]:
+    for a, b in zip(res[0], other):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), float((a - b).abs().max())
+for other in res[2:]:
+    for a, b in zip(res[1], other):
+        assert torch.equal(a, b), float((a - b).abs().max())
 dist.destroy_process_group()
 print("dp-graph-ok")
 """
@@ -1547,8 +1556,9 @@ print("dp-graph-ok")
 def test_dp_overlapped_step_single_rank(tmp_path):
     """dp_overlap (round 4): the backward pass cut at the encoder output, the all-reduce of the head / transformer / lin_hidden slice
     on a side stream under the encoder's backward pass, the convolution slice after it -- on one device with the collectives really
-    issued (world size 1, library RCCL communicator): parameters BIT-IDENTICAL to the non-overlapped data-parallel step (the same
-    kernels in the same order per stream; only the all-reduce is split) and equal to the single-GPU step within rounding."""
+    issued (world size 1, library RCCL communicator), as host calls between graph replays and (round 6) captured with the whole step
+    in ONE graph (with and without the overlap): parameters BIT-IDENTICAL to the non-overlapped three-call data-parallel step (the
+    same kernels in the same order per stream; only the all-reduce is split / captured) and equal to the single-GPU step within rounding."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -1581,11 +1591,12 @@ rng = np.random.default_rng(0)
 acts = rng.integers(0, 3, size=(3, 8, 48))
 perms = [[rng.permutation(8 * 48) for _ in range(2)] for _ in range(3)]
 res = {{}}
-for mode in ("single", "dp", "dp_overlap"):
+for mode in ("single", "dp", "dp_overlap", "dp_one_graph", "dp_overlap_one_graph"):
     dp = ForcedDP(dev, collective="etm") if mode != "single" else None
     torch.manual_seed(5)
     c = json.loads(json.dumps(cfg))
-    c["dp_overlap"] = mode == "dp_overlap"
+    c["dp_overlap"] = "overlap" in mode
+    c["dp_graph_collective"] = "one_graph" in mode
     tr = PPOTrainer(c, run_id="dpo", device=dev, dp=dp, tensorboard=False)
     for u in range(3):
         lr, beta, clip = tr.schedules(u)
@@ -1594,10 +1605,12 @@ for mode in ("single", "dp", "dp_overlap"):
         tr._train_epochs(lr, clip, beta, perms=perms[u])
     assert tr._train_graph is not None and tr.model._train_encoder_ok
     assert (getattr(tr, "_train_graph_a2", None) is not None) == (mode == "dp_overlap"), mode
+    assert bool(getattr(tr, "_dp_one_graph", False)) == ("one_graph" in mode), mode
     res[mode] = [p.detach().clone() for p in tr.model.parameters()]
     tr.close()
-for a, b in zip(res["dp"], res["dp_overlap"]):
-    assert torch.equal(a, b), float((a - b).abs().max())
+for other in ("dp_overlap", "dp_one_graph", "dp_overlap_one_graph"):      # same kernels in the same order per stream: bit-identical parameters
+    for a, b in zip(res["dp"], res[other]):
+        assert torch.equal(a, b), (other, float((a - b).abs().max()))
 for a, b in zip(res["single"], res["dp_overlap"]):
     assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), float((a - b).abs().max())
 dist.destroy_process_group()
