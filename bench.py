@@ -215,15 +215,15 @@ def _flat_rooflines(r, prefix="", out=None):
     return out
 
 
-def fresh_obs_run(cfg, device, lib, updates=3, warmup=1):
-    """The same update on SURVEY 8d's environment as written: pool 0 (every observation a fresh default_rng draw inside the timed
-    region) with the environments in worker processes (the reference's workers step concurrently, worker.py:36-48)."""
+def worker_processes_run(cfg, device, lib, updates=3, warmup=1):
+    """The same update with the environments in worker PROCESSES over shared memory + the native rollout driver (the reference's
+    workers step concurrently, worker.py:36-48), every observation a fresh default_rng draw inside the timed region (pool 0)."""
     from trainer import PPOTrainer
     cfg["environment"]["pool"] = 0
     cfg["worker_processes"] = True
     torch.manual_seed(0)
     np.random.seed(0)
-    tr = PPOTrainer(cfg, run_id="bench_fresh", device=device, tensorboard=False)
+    tr = PPOTrainer(cfg, run_id="bench_wp", device=device, tensorboard=False)
     try:
         lib.etm_profile_enable(0)
         phases = np.zeros(2)
@@ -258,7 +258,7 @@ def compact_line(full, full_path):
     cfgf = full["config"]
     line["config"] = dict(_pick(cfgf, ("env_pool", "minibatch", "parallelism", "attention", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
                                        "envs_per_process", "cgroup_cpu_quota")), workload=cfgf["workload"][:300])
-    for k in ("value_fresh_obs", "phase_s_per_step", "speedup_vs_cpu_baseline"):
+    for k in ("value_worker_processes", "phase_s_per_step", "speedup_vs_cpu_baseline"):
         if full.get(k) is not None:
             line[k] = full[k]
     for k in ("roofline", "roofline_train"):
@@ -329,16 +329,16 @@ def main():
                     help="YAML of configs/ to time (default: BASELINE config 3 = the driver's line; synthetic_mortar_gtrxl / synthetic_cartpole: the "
                          "shapes of BASELINE configs 5 / 2 -- gated pre-LN blocks, the group form of the rollout step kernel)")
     ap.add_argument("--env-pool", type=int, default=None,
-                    help="frames per worker in the synthetic environment's ring (default: the YAML's, 64); 0 = SURVEY 8d to the letter: every "
-                         "observation is a fresh default_rng(seed + worker).random([3, 84, 84]) draw inside the timed region")
+                    help="default: the YAML's, 0 = SURVEY 8d to the letter: every observation is a fresh default_rng(seed + worker).random([3, 84, 84]) "
+                         "draw inside the timed region; n > 0: every worker replays a ring of n frames drawn once (rounds 1 - 5 timed 64)")
     ap.add_argument("--full-json", default=os.path.join(REPO, "bench_full.json"),
                     help="side file for the FULL record (per-kernel tables, roofline models, micro-benchmark trees, prose): the stdout line "
                          "is a < 8 KB summary of it")
-    ap.add_argument("--no-fresh-obs", action="store_true",
-                    help="skip the second measurement after the timed region (N == 1 only): the same update with SURVEY 8d's environment to the "
-                         "letter (--env-pool 0, worker processes), reported as value_fresh_obs")
+    ap.add_argument("--no-worker-processes-run", "--no-fresh-obs", dest="no_worker_processes_run", action="store_true",
+                    help="skip the second measurement after the timed region (N == 1 only): the same update with the environments in worker "
+                         "processes over shared memory (the reference's form), reported as value_worker_processes")
     ap.add_argument("--gen-threads", type=int, default=None,
-                    help="with --env-pool 0 and in-process environments: host threads that draw a step's observations (numpy releases the GIL)")
+                    help="pool 0, in-process environments: host threads that draw a step's observation rows (libetm_envgen.so's pool)")
     args = ap.parse_args()
     global CONFIG_NAME
     CONFIG_NAME = args.config
@@ -621,8 +621,9 @@ def main():
                                        f"{cfg['environment'].get('pool', 64)}-frame ring per worker drawn once from U[0,1)")
                                     + (", envs in worker processes" if cfg.get("worker_processes", False) else ", in-process envs")
                                     + " inside the timed region, random-init weights"),
-                       "workload_detail": "rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); numpy default_rng(seed + worker id); see value_fresh_obs "
-                                          "for the same build on --env-pool 0 with worker processes",
+                       "workload_detail": "rewards Bernoulli(0.05), done at 96 steps or Bernoulli(0.02); observations = numpy default_rng(seed + worker id)"
+                                          ".random([3, 84, 84], float32), drawn by libetm_envgen.so (the same stream bit for bit); value_worker_processes: "
+                                          "the same environments stepped in worker processes over shared memory",
                        "env_pool": cfg["environment"].get("pool", 64), "env_gen_threads": cfg["environment"].get("gen_threads", 1),
                        "host_threads_busy": trainer._host_plan["busy_threads"], "host_cpu_plan": trainer._host_plan["reason"],
                        "host_cpus_per_rank": trainer._host_plan["budget"]["per_rank"], "cgroup_cpu_quota": trainer._host_plan["budget"]["cgroup_quota"],
@@ -653,17 +654,17 @@ def main():
             except Exception as exc:       # reporting only: never lose the throughput line over it
                 out["rooflines"] = {"error": repr(exc)}
             trainer = None
-        if world == 1 and not args.no_fresh_obs and CONFIG_NAME == "synthetic_minigrid" and cfg["environment"].get("pool", 64) != 0:
-            # SURVEY 8d's environment to the letter, after the timed region: every observation a fresh draw, environments in worker processes
+        if world == 1 and not args.no_worker_processes_run and CONFIG_NAME == "synthetic_minigrid" and not cfg.get("worker_processes", False):
+            # the other environment form, after the timed region: the same fresh-draw environments stepped in worker processes
             try:
                 if trainer is not None:
                     trainer.close()
                     trainer = None
                     torch.cuda.empty_cache()
-                out["fresh_obs"] = fresh_obs_run(load_config(), device, lib)
-                out["value_fresh_obs"] = out["fresh_obs"]["value"]
+                out["worker_processes_run"] = worker_processes_run(load_config(), device, lib)
+                out["value_worker_processes"] = out["worker_processes_run"]["value"]
             except Exception as exc:       # reporting only: never lose the throughput line over it
-                out["fresh_obs"] = {"error": repr(exc)}
+                out["worker_processes_run"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

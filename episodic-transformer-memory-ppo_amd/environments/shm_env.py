@@ -75,7 +75,8 @@ def _make_part(env_config, n, first_worker_id):
     """The environments of one worker process as a small in-process vector environment."""
     if env_config["type"] == "Synthetic":
         from environments.synthetic import SyntheticVecEnv
-        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool", "step_cost_us", "gen_threads")
+        # (no gen_threads: the worker processes ARE the parallelism; a drawing pool per process would only add spinning threads)
+        keys = ("obs_shape", "num_actions", "max_episode_steps", "seed", "p_reward", "p_done", "pool", "step_cost_us")
         kw = {k: env_config[k] for k in keys if k in env_config}
         if "obs_shape" in kw:
             kw["obs_shape"] = tuple(kw["obs_shape"])

@@ -178,15 +178,17 @@ class PPOTrainer:
         # configured values whatever the host looks like.
         from etm import hostcpu
         env_cfg = dict(config["environment"])
-        self._host_plan = hostcpu.plan_host_threads(copy_threads=int(env_cfg.get("copy_threads", 1)) if env_cfg.get("type") == "Synthetic" else 1,
+        # the threads that write a step's observation rows: the copier's (frame ring) or the generator pool's (pool: 0, fresh draws)
+        row_threads = ("gen_threads" if int(env_cfg.get("pool", 64)) == 0 else "copy_threads") if env_cfg.get("type") == "Synthetic" else None
+        self._host_plan = hostcpu.plan_host_threads(copy_threads=int(env_cfg.get(row_threads, 1)) if row_threads else 1,
                                                     worker_processes=bool(env is None and config.get("worker_processes", False)),
                                                     num_envs=self.num_workers, envs_per_process=int(config.get("envs_per_process", 1)),
                                                     groups=n_groups, quiet=not config.get("host_cpu_plan", True))
         if not config.get("host_cpu_plan", True):
-            self._host_plan.update(copy_threads=int(env_cfg.get("copy_threads", 1)), copier_spin=True, polite_wait=False,
+            self._host_plan.update(copy_threads=int(env_cfg.get(row_threads, 1)) if row_threads else 1, copier_spin=True, polite_wait=False,
                                    envs_per_process=int(config.get("envs_per_process", 1)), worker_spin=True, reason="host_cpu_plan: false")
-        if env_cfg.get("type") == "Synthetic" and "copy_threads" in env_cfg:
-            env_cfg["copy_threads"] = self._host_plan["copy_threads"]
+        if row_threads and row_threads in env_cfg:
+            env_cfg[row_threads] = self._host_plan["copy_threads"]
         if not self._host_plan["copier_spin"]:
             from environments import synthetic as _syn
             _syn.set_copier_spin(False)

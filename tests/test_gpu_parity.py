@@ -2496,6 +2496,6 @@ def test_bench_prints_one_json_line(tmp_path):
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1
     assert "synthetic_minigrid" in rec["config"]["workload"] and len(rec["config"]["workload"]) <= 300
     assert rec["rooflines"]["encoder.all_passes"][1] > 0.3
-    assert rec["value_fresh_obs"] > 0
+    assert rec["value_worker_processes"] > 0 and rec["config"]["env_pool"] == 0          # the default environment draws every observation fresh
     side = json.loads(full.read_text())
     assert side["value"] == pytest.approx(rec["value"], rel=1e-5) and "kernels_train" in side and "rooflines" in side

@@ -644,3 +644,48 @@ def test_bench_line_summary_is_short_strict_json():
     full["rooflines"] = {f"k{i}": {"avg_launch_ms": 1.0, "frac": 0.5} for i in range(2000)}
     text = bench.compact_line(full, "x")
     assert len(text.encode()) < 8000 and "rooflines" not in strict(text) and strict(text)["value"] > 0
+
+
+def test_native_pcg64_stream_is_numpys():
+    """libetm_envgen.so (csrc/envgen.cc, include/etm_envgen.h): every symbol the header declares is exported, and the fill is numpy's
+    ``default_rng(seed).random(n, dtype=float32)`` bit for bit -- floats AND the generator state afterwards -- in the AVX-512 form (where
+    the host has it) and in the portable scalar form, over lengths around the lane counts, chained calls, several seeds; the
+    multi-threaded row fill equals the per-row fills."""
+    import ctypes
+    from environments import envgen
+    here = os.path.dirname(os.path.abspath(__file__))
+    header = open(os.path.join(here, "..", "include", "etm_envgen.h")).read()
+    declared = set(re.findall(r"\b(etm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(envgen.SIGNATURES), declared ^ set(envgen.SIGNATURES)
+    lib = envgen.load(required=True)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.etm_envgen_abi_version() == envgen.ABI_VERSION
+    assert lib.etm_pcg64_fill_f32(None, None, 4) != 0 and lib.etm_pcg64_fill_f32(np.zeros(4, np.uint64).ctypes.data, np.zeros(4, np.float32).ctypes.data, 3) != 0
+    try:
+        for vec in (1, 0):
+            lib.etm_envgen_set_vector(vec)
+            for seed in (0, 7, (5, 1), 2 ** 40 + 3):
+                for n in (0, 2, 14, 16, 18, 62, 64, 66, 126, 128, 130, 510, 1026, 2 * 5 * 5, 3 * 84 * 84):
+                    native, ref = np.random.default_rng(seed), np.random.default_rng(seed)
+                    st = envgen.state_of(native)
+                    for _ in range(3):
+                        out = np.full(n, -1.0, dtype=np.float32)
+                        assert lib.etm_pcg64_fill_f32(st.ctypes.data, out.ctypes.data, n) == 0
+                        assert np.array_equal(out, ref.random(n, dtype=np.float32)), (vec, seed, n)
+                        assert np.array_equal(st, envgen.state_of(ref)), (vec, seed, n)
+                    envgen.set_state(native, st)          # numpy continues where the native stream stands
+                    assert np.array_equal(native.random(9, dtype=np.float32), ref.random(9, dtype=np.float32))
+    finally:
+        lib.etm_envgen_set_vector(1)
+    # rows of a step side by side on the library's threads
+    pool = lib.etm_envgen_pool_create(3)
+    assert pool
+    gens = [np.random.default_rng(100 + w) for w in range(7)]
+    states = np.ascontiguousarray(np.stack([envgen.state_of(g) for g in gens]))
+    for _ in range(20):
+        out = np.empty((7, 3 * 84 * 84), dtype=np.float32)
+        assert lib.etm_pcg64_fill_rows_f32(pool, states.ctypes.data, out.ctypes.data, out.shape[1], 7) == 0
+        for w, g in enumerate(gens):
+            assert np.array_equal(out[w], g.random(out.shape[1], dtype=np.float32))
+    lib.etm_envgen_pool_destroy(pool)
