@@ -215,38 +215,27 @@ def _flat_rooflines(r, prefix="", out=None):
     return out
 
 
-def worker_processes_run(cfg, device, lib, updates=3, warmup=1):
+def worker_processes_run(updates=3, warmup=1):
     """The same update with the environments in worker PROCESSES over shared memory + the native rollout driver (the reference's
-    workers step concurrently, worker.py:36-48), every observation a fresh default_rng draw inside the timed region (pool 0)."""
-    from trainer import PPOTrainer
-    cfg["environment"]["pool"] = 0
-    cfg["worker_processes"] = True
-    torch.manual_seed(0)
-    np.random.seed(0)
-    tr = PPOTrainer(cfg, run_id="bench_wp", device=device, tensorboard=False)
-    try:
-        lib.etm_profile_enable(0)
-        phases = np.zeros(2)
-        for i in range(warmup + updates):
-            if i == warmup:
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                phases[:] = 0
-            lr, beta, clip = tr.schedules(i)
-            ta = time.perf_counter()
-            tr._sample_training_data()
-            tr.buffer.prepare_batch_dict()
-            torch.cuda.synchronize(device)
-            tb = time.perf_counter()
-            tr._train_epochs(lr, clip, beta)
-            torch.cuda.synchronize(device)
-            phases += (tb - ta, time.perf_counter() - tb)
-        dt = time.perf_counter() - t0
-        return {"value": cfg["n_workers"] * cfg["worker_steps"] * updates / dt, "unit": "env-steps/s", "updates": updates, "warmup": warmup,
-                "phase_s_per_step": {"rollout": phases[0] / updates, "train": phases[1] / updates},
-                "envs_per_process": tr._host_plan["envs_per_process"], "env": "pool 0 (fresh U[0,1) draw per observation), worker processes"}
-    finally:
-        tr.close()
+    workers step concurrently, worker.py:36-48), same fresh-draw environments.  Run as a fresh process of this script: the worker
+    groups' streams of a second trainer in THIS process would share hardware queues with the first one's (torch hands out pooled
+    streams; measured: rollout 0.161 s instead of 0.091 s per update)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(updates), "--warmup", str(warmup), "--worker-processes", "on",
+               "--config", CONFIG_NAME, "--no-rooflines", "--no-cpu-baseline", "--no-worker-processes-run", "--no-profile",
+               "--full-json", os.path.join(tmp, "wp.json")]
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"worker-process run failed (rc {r.returncode}): {r.stderr[-400:]}")
+        rec = json.loads(lines[-1])
+    return {"value": rec["value"], "unit": rec["unit"], "updates": updates, "warmup": warmup, "phase_s_per_step": rec.get("phase_s_per_step"),
+            "envs_per_process": rec["config"].get("envs_per_process"), "env": "pool 0 (fresh U[0,1) draw per observation), worker processes, own process"}
 
 
 def compact_line(full, full_path):
@@ -661,7 +650,7 @@ def main():
                     trainer.close()
                     trainer = None
                     torch.cuda.empty_cache()
-                out["worker_processes_run"] = worker_processes_run(load_config(), device, lib)
+                out["worker_processes_run"] = worker_processes_run()
                 out["value_worker_processes"] = out["worker_processes_run"]["value"]
             except Exception as exc:       # reporting only: never lose the throughput line over it
                 out["worker_processes_run"] = {"error": repr(exc)}
@@ -670,6 +659,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         full_path = args.full_json
         try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
             with open(full_path, "w") as f:
                 json.dump(out, f, indent=1, default=float)
             full_path = os.path.relpath(full_path, REPO)

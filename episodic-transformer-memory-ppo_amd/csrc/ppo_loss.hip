@@ -43,6 +43,69 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict
   }
 }
 
+// Large N (the scaled micro-benchmark, data-parallel epochs at many workers): the one-workgroup kernel above reads at 6 GB/s
+// (11 ms at 2^24 samples) -- here every workgroup takes a contiguous chunk, computes the chunk's own (count, mean, M2)
+// with the same two passes (the second one re-reads the chunk from L2), and a one-workgroup kernel merges the chunks in a fixed tree
+// (Chan et al.: M2 = sum M2_i + sum n_i (mean_i - mean)^2, in double).  Deterministic; N < ADV_STATS_SPLIT_MIN keeps the kernel above
+// (bit-identical results at the minibatch sizes of the configs).
+constexpr int ADV_STATS_CHUNK = 16384;
+__global__ __launch_bounds__(1024) void adv_stats_part_kernel(const float *__restrict__ adv, int N, int per, float *__restrict__ partials) {
+  __shared__ float red[16];
+  __shared__ float mean_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long lo = (long long)blockIdx.x * per;
+  const int n = (int)((lo + per <= N) ? per : (N > lo ? N - lo : 0));
+  const float *a = adv + lo;
+  float s = 0.f;
+  for (int i = tid; i < n; i += 1024) s += a[i];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    mean_s = n > 0 ? t / (float)n : 0.f;
+  }
+  __syncthreads();
+  const float mean = mean_s;
+  float m2 = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    const float d = a[i] - mean;
+    m2 += d * d;
+  }
+  m2 = wave_sum(m2);
+  __syncthreads();
+  if (lane == 0) red[wave] = m2;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    partials[3 * blockIdx.x] = (float)n;
+    partials[3 * blockIdx.x + 1] = mean;
+    partials[3 * blockIdx.x + 2] = t;
+  }
+}
+__global__ __launch_bounds__(1024) void adv_stats_merge_kernel(const float *__restrict__ partials, int nb, float *__restrict__ stats3) {
+  __shared__ double sn[1024], sm[1024];
+  const int tid = threadIdx.x;
+  const double n = tid < nb ? (double)partials[3 * tid] : 0.0, mu = tid < nb ? (double)partials[3 * tid + 1] : 0.0;
+  sn[tid] = n; sm[tid] = n * mu;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {                      // fixed tree: the same sums whatever the timing
+    if (tid < o) { sn[tid] += sn[tid + o]; sm[tid] += sm[tid + o]; }
+    __syncthreads();
+  }
+  const double N = sn[0], mean = sm[0] / sn[0];
+  __syncthreads();
+  sm[tid] = tid < nb ? (double)partials[3 * tid + 2] + n * (mu - mean) * (mu - mean) : 0.0;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) sm[tid] += sm[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) { stats3[0] = (float)N; stats3[1] = (float)mean; stats3[2] = (float)sm[0]; }
+}
+
 struct LossParams {
   const float *logits;
   const long long *actions;
@@ -212,6 +275,29 @@ extern "C" int etm_adv_stats(const float *adv, int N, float *stats3, void *strea
   if (!adv || !stats3 || N <= 0) return ETM_EINVAL;
   EtmProfScope prof(ETM_K_ADV_STATS, (hipStream_t)stream);
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, adv, N, stats3);
+  return etm_launch_status();
+}
+
+extern "C" int64_t etm_adv_stats_workspace_bytes(int N) {
+  if (N < ETM_ADV_STATS_SPLIT_MIN) return 0;
+  const int nb = (N + ADV_STATS_CHUNK - 1) / ADV_STATS_CHUNK;
+  return (int64_t)(nb < 1024 ? nb : 1024) * 3 * sizeof(float);
+}
+// As etm_adv_stats, over many workgroups when N >= ETM_ADV_STATS_SPLIT_MIN and a workspace of etm_adv_stats_workspace_bytes(N) bytes is
+// given (else the one-workgroup kernel: the same results as etm_adv_stats bit for bit).
+extern "C" int etm_adv_stats_ws(const float *adv, int N, float *stats3, void *workspace, int64_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();
+  if (!adv || !stats3 || N <= 0) return ETM_EINVAL;
+  const int64_t need = etm_adv_stats_workspace_bytes(N);
+  if (need == 0 || !workspace) return etm_adv_stats(adv, N, stats3, stream);
+  if (workspace_bytes < need) return ETM_EWORKSPACE;
+  int nb = (N + ADV_STATS_CHUNK - 1) / ADV_STATS_CHUNK;
+  if (nb > 1024) nb = 1024;
+  const int per = (int)((((long long)N + nb - 1) / nb + 3) & ~3LL);
+  nb = (int)(((long long)N + per - 1) / per);
+  EtmProfScope prof(ETM_K_ADV_STATS, (hipStream_t)stream);
+  hipLaunchKernelGGL(adv_stats_part_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, adv, N, per, (float *)workspace);
+  hipLaunchKernelGGL(adv_stats_merge_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float *)workspace, nb, stats3);
   return etm_launch_status();
 }
 

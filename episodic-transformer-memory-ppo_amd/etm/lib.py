@@ -111,6 +111,8 @@ SIGNATURES = {
     "etm_adamw_clip": (_I, [_P, _P, _P, _P, _L, _P, _I, _P, _P, _D, _D, _D, _D, _F, _F, _P, _P]),
     "etm_gae": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _P]),
     "etm_adv_stats": (_I, [_P, _I, _P, _P]),
+    "etm_adv_stats_workspace_bytes": (_L, [_I]),
+    "etm_adv_stats_ws": (_I, [_P, _I, _P, _P, _L, _P]),
     "etm_ppo_loss_workspace_bytes": (_L, [_I]),
     "etm_heads_loss_supported": (_I, [_I, _I, _I]),
     "etm_heads_loss_row_floats": (_I, [_I, _I]),

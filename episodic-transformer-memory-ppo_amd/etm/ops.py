@@ -1434,6 +1434,11 @@ def adv_stats(adv):
     _need_dev(adv)
     adv = _f32c(adv.reshape(-1), "adv")
     stats = torch.empty(3, dtype=torch.float32, device=adv.device)
+    ws_bytes = lib.etm_adv_stats_workspace_bytes(adv.numel())
+    if ws_bytes > 0:       # large N: per-chunk statistics on many workgroups + a fixed-order merge
+        ws = workspace(ws_bytes, adv.device, tag="adv_stats")
+        _lib.check(lib.etm_adv_stats_ws(_ptr(adv), adv.numel(), _ptr(stats), _ptr(ws), ws_bytes, _stream()), "etm_adv_stats_ws")
+        return stats
     _lib.check(lib.etm_adv_stats(_ptr(adv), adv.numel(), _ptr(stats), _stream()), "etm_adv_stats")
     return stats
 

@@ -621,6 +621,12 @@ int etm_gae(const float *rewards, const uint8_t *dones, const float *values, con
  *   partials : scratch of etm_ppo_loss_workspace_bytes(N) bytes
  */
 int etm_adv_stats(const float *adv, int N, float *stats3, void *stream);
+/* The same statistics over many workgroups for large N (>= ETM_ADV_STATS_SPLIT_MIN: per-chunk (count, mean, M2) + a fixed-order
+ * merge, Chan et al.; deterministic).  workspace: etm_adv_stats_workspace_bytes(N) bytes (0 for small N: then, and with a NULL
+ * workspace, this IS etm_adv_stats, bit for bit). */
+#define ETM_ADV_STATS_SPLIT_MIN 65536
+int64_t etm_adv_stats_workspace_bytes(int N);
+int etm_adv_stats_ws(const float *adv, int N, float *stats3, void *workspace, int64_t workspace_bytes, void *stream);
 
 int64_t etm_ppo_loss_workspace_bytes(int N);
 

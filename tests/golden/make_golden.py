@@ -498,9 +498,10 @@ def _relu_margins(model64, samples64, clip=None):
     return margin, counts
 
 
-def _kink_free_run(tr, cfg, lr, clip, beta, first_minibatch, steps):
+def _kink_free_run(tr, cfg, lr, clip, beta, candidates):
     """A short optimisation run from the trainer's CURRENT state (called before the update's `_train_epochs`, on copies) on
-    minibatches without near-kink samples: before every step the candidate samples (the update's first minibatch) are screened in
+    minibatches without near-kink samples: before every step the candidate samples (``candidates[step]``: the update's first
+    minibatch; round 6: also its SECOND minibatch and then the first one again -- a second minibatch and a second visit) are screened in
     float64 at the fp32 twin's current parameters and only samples whose every ReLU input keeps |x| >= KINK_MARGIN are used.  Two
     twins take the same steps through the reference's own `_train_mini_batch`: the fp32 one (= what the reference computes) and the
     "exact-gradient" one (float64 gradient rounded once to fp32, then the same fp32 clipping + AdamW).  On such minibatches every
@@ -515,7 +516,7 @@ def _kink_free_run(tr, cfg, lr, clip, beta, first_minibatch, steps):
     opt_x = torch.optim.AdamW(X.parameters(), lr=cfg["learning_rate_schedule"]["initial"])
     shim = types.SimpleNamespace(config=tr.config, action_space_shape=tr.action_space_shape)
     out = {}
-    cand = first_minibatch.clone()
+    steps = len(candidates)
 
     def samples_of(idx, double):
         mb = {}
@@ -530,6 +531,7 @@ def _kink_free_run(tr, cfg, lr, clip, beta, first_minibatch, steps):
 
     init = {n: p.detach().clone() for n, p in A.named_parameters()}
     for s_i in range(steps):
+        cand = candidates[s_i].clone()
         margin, counts = _relu_margins(copy.deepcopy(A).double(), samples_of(cand, True), clip=clip)
         keep = cand[margin >= KINK_MARGIN]
         st = f"kf/s{s_i}/"
@@ -722,8 +724,11 @@ def golden_rollout(only=None):
                 # its candidate samples are the update's first minibatch, so the update's permutation is drawn FIRST (and handed to
                 # the update's first epoch below) -- torch.randperm is called exactly as often as without this run
                 first_perm = real_randperm(b.batch_size)
-                kf_steps = {"cfg2": 3}.get(name, 2)
-                out.update(_kink_free_run(tr, cfg, lr, clip, beta, first_perm[: b.batch_size // b.n_mini_batches], kf_steps))
+                # steps 0 .. k - 1 on the first minibatch (rounds 4 / 5: k = 3 for cfg2, else 2), then the SECOND minibatch of the
+                # permutation, then the first one again (round 6: another minibatch and a revisit, as epochs do)
+                mbs_ = b.batch_size // b.n_mini_batches
+                mb0_, mb1_ = first_perm[:mbs_], first_perm[mbs_: 2 * mbs_]
+                out.update(_kink_free_run(tr, cfg, lr, clip, beta, [mb0_] * {"cfg2": 3}.get(name, 2) + [mb1_, mb0_]))
                 pending = [first_perm]
 
                 def rec_randperm(n, *a, _pending=pending, **k):      # noqa: F811 -- first call returns the permutation drawn above

@@ -379,6 +379,32 @@ def test_ppo_loss_multi_branch_vs_oracle():
     close(vd.grad, value.grad.numpy(), atol=1e-8, rtol=2e-3, what="gvalue")
 
 
+def test_adv_stats_many_workgroups_vs_float64():
+    """etm_adv_stats_ws (round 6): at N >= 65536 the (count, mean, M2) of the advantages come from per-chunk statistics on many
+    workgroups + a fixed-order merge (the one-workgroup kernel read 2^24 samples at 6 GB/s); against float64, for ragged sizes, twice
+    (deterministic); below the threshold `ops.adv_stats` is the old kernel, bit for bit."""
+    from etm import lib as etm_lib
+    from etm import ops
+    dev = _dev()
+    lib = etm_lib.load()
+    g = torch.Generator().manual_seed(4)
+    for N in (65536, 65537, 100003, 1 << 20, (1 << 24) + 12345):
+        adv = (torch.randn(N, generator=g) * 3.0 + 0.7).to(dev)
+        assert lib.etm_adv_stats_workspace_bytes(N) > 0
+        a, b = ops.adv_stats(adv), ops.adv_stats(adv)
+        assert torch.equal(a, b)
+        ref = adv.double().cpu()
+        mean, m2 = float(ref.mean()), float(((ref - ref.mean()) ** 2).sum())
+        got = a.double().cpu().tolist()
+        assert got[0] == float(np.float32(N)) and abs(got[1] - mean) <= 2e-6 * max(1.0, abs(mean)) and abs(got[2] - m2) <= 3e-6 * m2, (N, got, mean, m2)
+    for N in (7, 2048, 65535):
+        adv = torch.randn(N, generator=g).to(dev)
+        assert lib.etm_adv_stats_workspace_bytes(N) == 0
+        old = torch.empty(3, device=dev)
+        etm_lib.check(lib.etm_adv_stats(adv.data_ptr(), N, old.data_ptr(), torch.cuda.current_stream().cuda_stream), "etm_adv_stats")
+        assert torch.equal(ops.adv_stats(adv), old)
+
+
 def test_ppo_loss_vectorised_path_vs_oracle():
     """Large-batch form of the loss kernel (four samples per thread, 16-byte operand moves; taken from 65,536 samples with three
     actions) against the oracle's restatement of trainer.py:276-304, including ties of the clipping rules (exact 1.0 ratios)."""
@@ -693,8 +719,17 @@ def tf_ratchet(name, path, upd, measured):
     out = []
     for f in ("move_all", "move_worst", "grad_all", "grad_worst"):
         limit = float(_RATCHET["ratio"]) * max(float(entry[f]), float(_RATCHET["floors"][f]))
+        if entry.get("flip"):
+            # round 6: an entry that carries a known flip is dominated by ONE fixed rank-1 term (the flipped unit) that every path
+            # reproduces to four digits (profiles/r06: 8.221e-4 .. 8.225e-4 over nine cfg3 paths, the same on the boxes of two rounds),
+            # so ratio x the record would admit a regression as large as the flip itself.  What is held instead is the flip-free
+            # REMAINDER: an independent error e on top of the flip f shows as sqrt(f^2 + e^2), and e is bounded by ratio x the
+            # flip-free level of the BASELINE-size fixtures (the quiet cfg5 paths; x later_update_factor once the trajectories
+            # have parted).  cfg3 update 0: 8.22e-4 -> limit 8.32e-4 instead of 2.5e-3.
+            ff = float(_RATCHET["flip_free"][f]) * (float(_RATCHET["flip_free"]["later_update_factor"]) if upd > 0 else 1.0)
+            limit = 1.005 * (float(entry[f]) ** 2 + (float(_RATCHET["ratio"]) * max(ff, float(_RATCHET["floors"][f]))) ** 2) ** 0.5   # (0.5 %: the records' own scatter over boxes is 0.02 %)
         if measured[f] > limit:
-            out.append(f"{f} {measured[f]:.2e} exceeds {_RATCHET['ratio']} x the recorded {entry[f]:.2e} (tests/golden/tf_measured_baseline.json"
+            out.append(f"{f} {measured[f]:.3e} exceeds the limit {limit:.3e} from the recorded {entry[f]:.3e} (tests/golden/tf_measured_baseline.json"
                        f"{', known flip ' + entry['flip'] if entry.get('flip') else ''}): find the cause with tools/parity_pair.py {name} {path},eager "
                        f"before recording a new value")
     return out
@@ -1080,6 +1115,9 @@ def test_small_worker_groups_stress():
             snap = {k: getattr(b, k).clone() for k in ("values", "log_probs", "advantages", "memory_mask", "memory_indices", "memory_index")}
             snap["memories"] = b.memories.clone()
             snaps.append(snap)
+        # round 6: the bootstrap value of the last observation (get_last_value) is a graph replay from the third rollout on; the
+        # advantages compared below are its consumers, against the eager path's
+        assert (tr._lv.graph is not None) == ("rollout_groups" in over), over
         if "rollout_groups" in over:
             assert len(tr._groups) == 2 and tr._groups[0].W == 2 and tr._stream_obs
             assert bool(getattr(tr, "_native_rollout", False)) == bool(over.get("worker_processes")), over

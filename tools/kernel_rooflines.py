@@ -179,6 +179,12 @@ def ppo(dev, N, A=3, launches=20):
     res["adv_stats_kernel_ms"] = t["adv_stats_kernel"][0]
     res["adv_stats_gbs"] = 4 * N / (t["adv_stats_kernel"][0] * 1e-3) / 1e9
     res["ppo_finalize_kernel_ms"] = t["ppo_finalize_kernel"][0]
+    # the loss cannot run without the statistics pass in front of it and the finalize behind it: the three launches together
+    # against the bytes of all three (the advantages are read once more by the statistics pass)
+    total_ms = t["ppo_loss_kernel"][0] + t["adv_stats_kernel"][0] + t["ppo_finalize_kernel"][0]
+    nbytes = (28 + 8 * A + 4) * N
+    res["with_stats"] = dict(kernel="adv_stats + ppo_loss + ppo_finalize", bound="hbm", bytes_per_launch=nbytes, avg_launch_ms=total_ms,
+                             achieved=nbytes / (total_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=nbytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
     return res
 
 
