@@ -84,6 +84,13 @@ class Buffer:
 
     def begin_rollout(self, live_slots: torch.Tensor):
         """Start of an update: live episodes move to slots 0..W-1, every other used slot is cleared."""
+        # the pinned bookkeeping arrays (memory_index, rewards, done flags) are the sources of ASYNCHRONOUS uploads of the previous
+        # update (prepare_batch_dict, calc_advantages): the host must not rewrite them before those copies have run.  With an
+        # optimisation phase in between they long have; a caller that samples again at once (tests, tools) runs ahead of the device
+        # since round 6 (get_last_value is one graph launch instead of ~100 eager ones) and would hand the copy the NEW contents.
+        ev = getattr(self, "_host_arrays_uploaded", None)
+        if ev is not None:
+            ev.synchronize()
         W = self.n_workers
         live = self.bank.index_select(0, live_slots)
         self.bank[:W].copy_(live)
@@ -91,6 +98,12 @@ class Buffer:
             self.bank[W: self.num_episodes].zero_()
         self.num_episodes = W
         self.memory_index_host[:] = np.arange(W, dtype=np.int64)[:, None]
+
+    def _mark_host_arrays_uploaded(self):
+        if self.device.type == "cuda":
+            if getattr(self, "_host_arrays_uploaded", None) is None:
+                self._host_arrays_uploaded = torch.cuda.Event()
+            self._host_arrays_uploaded.record(torch.cuda.current_stream(self.device))
 
     def open_episode(self) -> int:
         """Reserve the next (zero-filled) slot and return its index; grows the bank if it is full."""
@@ -110,6 +123,7 @@ class Buffer:
     def prepare_batch_dict(self) -> None:
         """Upload the host-side bookkeeping and expose the samples flattened to [W*S, ...] (W-major, views)."""
         self.memory_index.copy_(self._memory_index_host, non_blocking=True)
+        self._mark_host_arrays_uploaded()
         samples = {
             "actions": self.actions, "values": self.values, "log_probs": self.log_probs, "advantages": self.advantages,
             "obs": self.obs, "memory_mask": self.memory_mask, "memory_index": self.memory_index,
@@ -148,4 +162,5 @@ class Buffer:
         """GAE over the [W, S] buffer on device (upstream buffer.py:95-113)."""
         self.rewards_dev.copy_(self._rewards_host, non_blocking=True)
         self.dones_dev.copy_(self._dones_host, non_blocking=True)
+        self._mark_host_arrays_uploaded()
         ops.gae(self.rewards_dev, self.dones_dev, self.values, last_value.detach(), gamma, lamda, out=self.advantages)

@@ -724,10 +724,12 @@ def golden_rollout(only=None):
                 # its candidate samples are the update's first minibatch, so the update's permutation is drawn FIRST (and handed to
                 # the update's first epoch below) -- torch.randperm is called exactly as often as without this run
                 first_perm = real_randperm(b.batch_size)
-                # steps 0 .. k - 1 on the first minibatch (rounds 4 / 5: k = 3 for cfg2, else 2), then the SECOND minibatch of the
-                # permutation, then the first one again (round 6: another minibatch and a revisit, as epochs do)
+                # steps 0 .. k - 1 on the first minibatch (rounds 4 / 5: k = 3 for cfg2, else 2), then ANOTHER minibatch -- the second
+                # one of the permutation, or (fixtures with one minibatch per epoch) the second half of the first -- and then the first
+                # one again (round 6: another sample set of another size and a revisit, as epochs do)
                 mbs_ = b.batch_size // b.n_mini_batches
-                mb0_, mb1_ = first_perm[:mbs_], first_perm[mbs_: 2 * mbs_]
+                mb0_ = first_perm[:mbs_]
+                mb1_ = first_perm[mbs_: 2 * mbs_] if b.n_mini_batches > 1 else first_perm[mbs_ // 2: mbs_]
                 out.update(_kink_free_run(tr, cfg, lr, clip, beta, [mb0_] * {"cfg2": 3}.get(name, 2) + [mb1_, mb0_]))
                 pending = [first_perm]
 
