@@ -245,7 +245,7 @@ def compact_line(full, full_path):
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data") if k in full}
     cfgf = full["config"]
-    line["config"] = dict(_pick(cfgf, ("env_pool", "minibatch", "parallelism", "attention", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
+    line["config"] = dict(_pick(cfgf, ("env_pool", "observation_rows", "minibatch", "parallelism", "attention", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
                                        "envs_per_process", "cgroup_cpu_quota")), workload=cfgf["workload"][:300])
     for k in ("value_worker_processes", "phase_s_per_step", "speedup_vs_cpu_baseline"):
         if full.get(k) is not None:
@@ -326,6 +326,9 @@ def main():
     ap.add_argument("--no-worker-processes-run", "--no-fresh-obs", dest="no_worker_processes_run", action="store_true",
                     help="skip the second measurement after the timed region (N == 1 only): the same update with the environments in worker "
                          "processes over shared memory (the reference's form), reported as value_worker_processes")
+    ap.add_argument("--direct-rows", choices=("on", "off"), default="on",
+                    help="in-process environments write the observation rows of a step straight into the staging array in device memory "
+                         "(large BAR; round 6) instead of pinned memory + a copy-engine transfer per worker group and step")
     ap.add_argument("--gen-threads", type=int, default=None,
                     help="pool 0, in-process environments: host threads that draw a step's observation rows (libetm_envgen.so's pool)")
     args = ap.parse_args()
@@ -384,6 +387,7 @@ def main():
 
     cfg = load_config()
     cfg["dp_overlap"] = args.dp_overlap == "on"
+    cfg["direct_observation_rows"] = args.direct_rows == "on"
     cfg["dp_graph_collective"] = args.dp_graph_collective == "on"
     if args.worker_processes != "config":
         cfg["worker_processes"] = args.worker_processes == "on"
@@ -622,6 +626,7 @@ def main():
                        "dp_step": (None if dp is None else "one_graph" if getattr(trainer, "_dp_one_graph", False) else "graph_a+allreduce+graph_b"),
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "observation_rows": "direct (host writes into device memory)" if getattr(trainer, "_direct_rows", False) else "pinned + upload",
                        "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,
                        "native_rollout_driver": bool(getattr(trainer, "_native_rollout", False))},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},

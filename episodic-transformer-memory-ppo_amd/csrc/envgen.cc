@@ -162,6 +162,7 @@ void work(Pool *p) {
     const int r = p->next.fetch_add(1, std::memory_order_relaxed);
     if (r >= p->rows) return;
     fill_f32(p->states + 4 * (int64_t)r, p->out + (int64_t)r * p->row_floats, p->row_floats);
+    _mm_sfence();        // the rows may be device memory behind a write-combining mapping: drained before completion is reported
   }
 }
 

@@ -54,6 +54,7 @@ void helper_main(Copier *c, int i) {
     size_t lo, hi;
     chunk_of(*c, i, lo, hi);
     if (hi > lo) std::memcpy(c->dst + lo, c->src + lo, hi - lo);
+    _mm_sfence();                              // (the destination may be device memory behind a write-combining mapping)
     c->pending.fetch_sub(1, std::memory_order_release);
   }
 }
@@ -114,5 +115,82 @@ extern "C" int etm_host_copy(void *copier, void *dst, const void *src, int64_t b
   chunk_of(*c, 0, lo, hi);
   if (hi > lo) std::memcpy(c->dst + lo, c->src + lo, hi - lo);
   while (c->pending.load(std::memory_order_acquire) != 0) _mm_pause();
+  return ETM_OK;
+}
+
+// ---- Observation rows written by the host STRAIGHT into device memory (round 6; upstream trainer.py:189-193 hands the workers'
+// observations to the model as a tensor built from host arrays: one host -> device transfer per step).  On large-BAR systems the
+// device's memory is mapped into the process (a hipMalloc pointer is a valid host address), so the environment front-end can
+// produce a step's rows in the staging array itself: no pinned intermediate, no copy-engine transfer (677 KB per worker group
+// and step at 3x84x84: ~20 us of the step's critical path), no runtime call.  What makes that safe:
+//   * the rows cross PCIe as posted writes; the doorbell of the step's launch is a later posted write to the same device and
+//     cannot pass them;
+//   * etm_host_store_fence() drains the calling core's write-combining buffers (sfence) and then writes the device's HDP flush
+//     register (HSA_AMD_AGENT_INFO_HDP_FLUSH, the register RCCL / MPI write after a NIC has written into device memory) -- one more
+//     posted write behind the rows: whatever the host data path still holds is in memory before the launch is seen;
+//   * helper threads that write rows fence themselves before they report completion (host copier above, libetm_envgen.so's pool).
+// etm_host_direct_write_init(device): 1 = usable (large BAR; the HDP flush register was found, or the device reports none),
+// 0 = not usable (the caller keeps pinned memory + etm_upload), < 0 error.
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+namespace {
+constexpr int MAXDEV = 64;
+volatile uint32_t *g_hdp_flush[MAXDEV];
+int g_direct_ok[MAXDEV];          // 0 unknown, 1 usable, -1 not usable
+
+struct HsaFns {
+  decltype(&hsa_init) init = nullptr;
+  decltype(&hsa_iterate_agents) iterate = nullptr;
+  decltype(&hsa_agent_get_info) info = nullptr;
+} g_hsa;
+struct FindCtx { uint32_t bdf, domain; volatile uint32_t *flush; bool found; };
+
+hsa_status_t find_agent(hsa_agent_t agent, void *data) {
+  FindCtx *c = static_cast<FindCtx *>(data);
+  hsa_device_type_t type;
+  if (g_hsa.info(agent, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+  uint32_t bdf = 0, domain = 0;
+  if (g_hsa.info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+  (void)g_hsa.info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+  if (bdf != c->bdf || domain != c->domain) return HSA_STATUS_SUCCESS;
+  hsa_amd_hdp_flush_t hdp{nullptr, nullptr};
+  if (g_hsa.info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp) == HSA_STATUS_SUCCESS) c->flush = hdp.HDP_MEM_FLUSH_CNTL;
+  c->found = true;
+  return HSA_STATUS_INFO_BREAK;
+}
+}  // namespace
+
+extern "C" int etm_host_direct_write_init(int device) {
+  if (device < 0 || device >= MAXDEV) return ETM_EINVAL;
+  if (g_direct_ok[device] != 0) return g_direct_ok[device] > 0 ? 1 : 0;
+  g_direct_ok[device] = -1;
+  int large_bar = 0;
+  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) return 0;
+  int dom = 0, bus = 0, dev = 0;
+  if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
+      hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
+      hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess) return 0;
+  void *h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return 0;
+  g_hsa.init = (decltype(g_hsa.init))dlsym(h, "hsa_init");
+  g_hsa.iterate = (decltype(g_hsa.iterate))dlsym(h, "hsa_iterate_agents");
+  g_hsa.info = (decltype(g_hsa.info))dlsym(h, "hsa_agent_get_info");
+  if (!g_hsa.init || !g_hsa.iterate || !g_hsa.info || g_hsa.init() != HSA_STATUS_SUCCESS) return 0;     // (reference-counted: the HIP runtime holds the first one)
+  FindCtx c{(uint32_t)((bus << 8) | (dev << 3)), (uint32_t)dom, nullptr, false};
+  (void)g_hsa.iterate(find_agent, &c);
+  if (!c.found) return 0;
+  g_hdp_flush[device] = c.flush;            // nullptr: the device has no host data path cache to flush (e.g. xGMI-attached hosts)
+  g_direct_ok[device] = 1;
+  return 1;
+}
+
+extern "C" int etm_host_store_fence(int device) {
+  _mm_sfence();
+  if (device >= 0 && device < MAXDEV && g_hdp_flush[device]) {
+    *g_hdp_flush[device] = 1u;
+    _mm_sfence();
+  }
   return ETM_OK;
 }

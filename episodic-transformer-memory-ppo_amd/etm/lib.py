@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 _lib = None
 
@@ -40,6 +40,8 @@ SIGNATURES = {
     "etm_conv_relu": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_upload": (_I, [_P, _P, _L, _P]),
     "etm_graph_launch": (_I, [_P, _P]),
+    "etm_host_direct_write_init": (_I, [_I]),
+    "etm_host_store_fence": (_I, [_I]),
     "etm_host_register": (_I, [_P, _L]),
     "etm_host_unregister": (_I, [_P]),
     "etm_rollout_drive": (_I, [_P, _I, _I, _I, _I, _L, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _D, _P, _P]),

@@ -1221,6 +1221,51 @@ def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None):
                             (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index)
 
 
+def host_view(t):
+    """numpy array over the memory of the contiguous float32 device tensor ``t`` at its HOST address (large-BAR systems map the
+    device's memory into the process: the pointer is the same) -- WRITE-ONLY use: host reads through the BAR are uncached and
+    slow, and the device's caches know nothing of them.  Call ``host_direct_write_ok`` first."""
+    import ctypes
+    import numpy as np
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError("host_view: a contiguous float32 device tensor is needed")
+    buf = (ctypes.c_float * t.numel()).from_address(t.data_ptr())
+    return np.ctypeslib.as_array(buf).reshape(tuple(t.shape))
+
+
+_direct_ok = {}
+
+
+def host_direct_write_ok(device):
+    """Can the host write rows straight into this device's memory (etm_host_direct_write_init: large BAR + HDP flush register),
+    and does a written pattern come back through the device (self-test, once per device)?"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _direct_ok:
+        ok = False
+        try:
+            lib = _lib.load()
+            if lib.etm_host_direct_write_init(idx) == 1:
+                import numpy as np
+                # 48 rounds of "host rewrites a small buffer whose lines the previous kernel has just read, a kernel reads it
+                # again": what a rollout does with its staging rows (tools/microbench/bar_stale.hip is the long form: 12,000
+                # plain launches and graph replays, none stale)
+                probe = torch.zeros(1024, dtype=torch.float32, device=device)
+                view = host_view(probe)
+                base = np.arange(1024, dtype=np.float32) * 0.5
+                seen = []
+                for k in range(48):
+                    torch.cuda.synchronize(device)
+                    view[:] = base + float(k + 1)
+                    lib.etm_host_store_fence(idx)
+                    seen.append(probe + 0.0)
+                got = torch.stack(seen).cpu().numpy()
+                ok = bool(all(np.array_equal(got[k], base + float(k + 1)) for k in range(48)))
+        except Exception:      # noqa: BLE001 -- anything odd: keep pinned memory + uploads
+            ok = False
+        _direct_ok[idx] = ok
+    return _direct_ok[idx]
+
+
 def upload(dst, src_pinned, stream):
     """Asynchronous pinned-host -> device copy of a contiguous block on ``stream`` (a torch.cuda.Stream)."""
     lib = _lib.load()

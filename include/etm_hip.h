@@ -580,6 +580,13 @@ typedef struct etm_rollout_group {
 /* hipGraphLaunch(graph_exec, stream) without the framework's per-replay bookkeeping (stream switches, generator checks): the
  * in-process rollout loop launches a group's captured step with it (same call the native driver makes). */
 int etm_graph_launch(void *graph_exec, void *stream);
+/* Observation rows written by the host straight into device memory (round 6, large-BAR systems; csrc/host_copy.hip): the staging
+ * row of the next step is the environment front-end's output buffer, no pinned intermediate and no copy-engine transfer.
+ * etm_host_direct_write_init(device): 1 usable, 0 not (the caller keeps pinned memory + etm_upload).  etm_host_store_fence(device):
+ * after the rows are written and before the step is launched -- drains the core's write-combining buffers and writes the
+ * device's HDP flush register (a posted write behind the rows). */
+int etm_host_direct_write_init(int device);
+int etm_host_store_fence(int device);
 int etm_host_register(void *ptr, int64_t bytes);
 int etm_host_unregister(void *ptr);
 int etm_rollout_drive(const etm_rollout_group *groups, int G, int t_first, int S, int W, int64_t row_bytes, int64_t stage_step_bytes,

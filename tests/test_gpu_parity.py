@@ -447,6 +447,7 @@ _ROLLOUT_PATHS = {
     "library_convs": {"fused_train_encoder": False},          # optimisation phase on the library convolutions
     "multi_launch_blocks": {"fused_rollout_block": False},    # rollout: one launch per GEMM / attention / LayerNorm instead of one per step
     "launched_tail": {"fused_rollout_tail": False},           # bank write + K/V projection of the new items as separate launches
+    "uploaded_rows": {"direct_observation_rows": False},      # observation rows through pinned memory + a copy-engine transfer (rounds 1 - 5) instead of host writes into device memory
     "four_groups": {"rollout_groups": 4, "rollout_min_group_size": 2},          # four worker groups (correct with any number of hardware queues)
     "separate_heads": {"fused_heads_loss": False, "grouped_dw_train": False,    # heads / loss / weight gradients as separate ops (round-2 form),
                        "grouped_colsum_train": False},                          # every column-sum gradient reduced by its own launch
@@ -468,7 +469,7 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              # BASELINE model sizes (round 3): the kernel instantiations bench.py / tools/config_bench.py time, pinned to the reference
              ("cfg2", "default"), ("cfg2", "eager"), ("cfg3", "default"), ("cfg3", "eager"), ("cfg3", "multi_launch_blocks"),
              ("cfg5", "default"), ("cfg5", "eager"),
-             ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "four_groups"), ("cfg3", "four_groups"),
+             ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "four_groups"), ("cfg3", "four_groups"), ("img32", "uploaded_rows"), ("cfg3", "uploaded_rows"), ("cfg5", "uploaded_rows"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
              ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("cfg2", "window_row_stats"), ("cfg2", "generic_ln_grad"), ("cfg5", "window_row_stats")]
@@ -651,6 +652,11 @@ def test_trainer_teacher_forced_vs_reference(golden_dir, name, path):
     assert tr.buffer.block_major and tr.buffer.bank.stride(2) > tr.buffer.bank.stride(0)   # [blocks][slots][T][D] in memory
     if path == "groups4":
         assert len(tr._groups) == 4
+    if name in ("img32", "cfg3", "cfg5") and path in ("default", "four_groups", "uploaded_rows"):
+        from etm import ops as etm_ops
+        # round 6: the in-process front-ends write their rows straight into the staging array in device memory where the host can
+        # (large BAR); the bit-exact observation comparison above is what checks every one of those writes
+        assert tr._direct_rows == (path != "uploaded_rows" and etm_ops.host_direct_write_ok(dev)), (name, path, tr._direct_rows)
     if path == "event_handover":
         assert not tr._host_flag
     tr.close()
@@ -823,7 +829,10 @@ def test_kink_free_update_vs_reference(golden_dir, name, mode):
     for s in range(int(z["kf/steps"])):
         st = f"kf/s{s}/"
         idx = z[st + "idx"]
-        assert int(z[st + "dropped"]) + idx.size == (cfg["n_workers"] * cfg["worker_steps"]) // cfg["n_mini_batch"]
+        mbs_kf = (cfg["n_workers"] * cfg["worker_steps"]) // cfg["n_mini_batch"]
+        # candidates: the update's first minibatch; round 6: one step on ANOTHER sample set (the second minibatch, or the second half of
+        # the first where an epoch has one minibatch) and a revisit of the first (tests/golden/make_golden.py:_kink_free_run)
+        assert int(z[st + "dropped"]) + idx.size in (mbs_kf, mbs_kf - mbs_kf // 2), (s, int(z[st + "dropped"]), idx.size)
         # ---- gradient: HIP vs the float64 evaluation, beside the reference's fp32 gradient vs the same
         grads = tr.minibatch_gradients(idx, clip, beta)
         xs, rs, xnorm, xerr = rows(st + "xgrad_samples"), rows(st + "grad_samples"), z[st + "xgrad_norm"], z[st + "xgrad_err"]
