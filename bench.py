@@ -424,10 +424,12 @@ def main():
     if not args.no_profile:
         etm_lib.profile_collect()
         lib.etm_profile_enable(1)
-        # the optimisation step is a captured graph (no per-kernel events inside a replay): every 8th minibatch of the timed
-        # region runs the identical step eagerly so that the dominant kernel is still timed live, inside the timed region
+        # the optimisation step is a captured graph (no per-kernel events inside a replay): ONE minibatch of every update of the timed
+        # region runs the identical step eagerly so that the dominant kernel is still timed live, inside the timed region (rounds 2 - 5
+        # sampled every 8th minibatch: an eager step costs ~0.9 ms more than a replay at config 3, five of them 3 % of the update --
+        # and 16 % at the launch-bound config 2; the per-kernel averages then come from `steps` launches instead of 5 x `steps`)
         if getattr(trainer, "_use_train_graph", False):
-            trainer.profile_sample_every = 8
+            trainer.profile_sample_every = max(8, cfg["epochs"] * cfg["n_mini_batch"])
     if dp is not None:
         dp.barrier()
     torch.cuda.synchronize(device)
@@ -577,7 +579,7 @@ def main():
             if tr_pmc and kind == "mfma":
                 roofline_train["mfma_busy_fraction_pmc"] = tr_pmc.get("mfma_busy_fraction_pmc")
             roofline_train.update(extra)
-            roofline_train["note_short"] = ("dominant kernel of the optimisation phase, HIP events inside the timed region (every 8th minibatch eager)")
+            roofline_train["note_short"] = ("dominant kernel of the optimisation phase, HIP events inside the timed region (1 eager minibatch per update)")
             if kind == "hbm":
                 roofline_train["extra_bytes_per_launch"] = N * 4.0 * (2 * H * D + H * L * (2 if dom.endswith("bwd_kernel") else 1))
                 roofline_train["note"] = ("bytes_per_launch = N*L*D*4, the un-deduplicated window read of SURVEY 8d; minibatches are sorted by "
