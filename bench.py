@@ -99,7 +99,7 @@ def pmc_traffic(kernel):
         # per-worker kernel at config 5's shape -- not the config-3 instantiation the other lines are about)
         own = (os.path.join("r05", "pmc_rollout_step_config5_fold.json"), os.path.join("r05", "pmc_rollout_step_config5.json")) \
             if kernel == "rollout_group_kernel" else ()         # (_fold: after fc_out was folded into the gate products; the other: before)
-        for cand in own + ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for cand in own + ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             path = os.path.join(REPO, "profiles", cand)
             if not os.path.exists(path):
                 continue
