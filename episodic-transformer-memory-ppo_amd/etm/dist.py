@@ -217,19 +217,25 @@ class DataParallel:
         watchdog.daemon = True
         watchdog.start()
         try:
-            self._graph_collective = agree(self._graph_selftest())
+            # two phases, each followed by an agreement: a rank whose CAPTURE fails issues no collective, so nobody may replay (= issue
+            # the captured all-reduce) before every rank is known to hold a graph
+            captured = self._graph_selftest_capture()
+            if agree(captured is not None):
+                self._graph_collective = agree(self._graph_selftest_replay(captured))
+            else:
+                self._graph_collective = False
         finally:
             watchdog.cancel()
         if not self._graph_collective and self.rank == 0:
             print("[etm.dist] the library all-reduce could not be captured into a HIP graph on every rank: the optimisation step stays "
                   "graph A -> all-reduce -> graph B", flush=True)
 
-    def _graph_selftest(self):
-        """Library all-reduce of 4 floats captured into a HIP graph, replayed twice, results checked.  False on any failure."""
-        import ctypes  # noqa: F401
+    def _graph_selftest_capture(self):
+        """Library all-reduce of 4 floats captured into a HIP graph (no communication happens during a capture).  -> (graph, src, buf) or
+        None on any failure."""
         from . import lib as _lib
         if os.environ.get("ETM_DP_GRAPH_COLLECTIVE", "1") == "0" or self._comm is None:
-            return False
+            return None
         dev = torch.device(self.device)
         try:
             with torch.cuda.device(dev):
@@ -245,20 +251,36 @@ class DataParallel:
                                                                  torch.cuda.current_stream(dev).cuda_stream), "etm_allreduce_f32")
                         buf.mul_(2.0)
                 torch.cuda.current_stream(dev).wait_stream(side)
-                ok = True
-                for k in (1.0, 3.0):
-                    src.fill_(k)
-                    g.replay()
-                    torch.cuda.synchronize(dev)
-                    ok = ok and buf.tolist() == [2.0 * k * self.world] * 4      # (the communicator has self.world ranks)
-                return ok
+                torch.cuda.synchronize(dev)
+                return g, src, buf
         except Exception as exc:       # noqa: BLE001 -- capture not supported here: the eager collective stays
             print(f"[etm.dist] rank {self.rank}: graph capture of the library all-reduce failed ({exc!r})", flush=True)
             try:
                 torch.cuda.synchronize(dev)
             except Exception:          # noqa: BLE001
                 pass
+            return None
+
+    def _graph_selftest_replay(self, captured):
+        """Two replays of the captured all-reduce with different inputs; every rank calls this (or none does)."""
+        g, src, buf = captured
+        dev = torch.device(self.device)
+        try:
+            ok = True
+            with torch.cuda.device(dev):
+                for k in (1.0, 3.0):
+                    src.fill_(k)
+                    g.replay()
+                    torch.cuda.synchronize(dev)
+                    ok = ok and buf.tolist() == [2.0 * k * self.world] * 4      # (the communicator has self.world ranks)
+            return ok
+        except Exception as exc:       # noqa: BLE001
+            print(f"[etm.dist] rank {self.rank}: replay of the captured all-reduce failed ({exc!r})", flush=True)
             return False
+
+    def _graph_selftest(self):
+        captured = self._graph_selftest_capture()
+        return captured is not None and self._graph_selftest_replay(captured)
 
     def agree(self, ok: bool) -> bool:
         """Logical AND of ``ok`` over the ranks (one small torch.distributed all-reduce; every rank must call it)."""
