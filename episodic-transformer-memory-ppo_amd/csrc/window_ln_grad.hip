@@ -143,6 +143,66 @@ __global__ __launch_bounds__(WG_T) void window_ln_grad_kernel(const LnGradParams
     p.partial[(long long)blockIdx.x * 2 * D + c] = ((red[c] + red[2 * D + c]) + red[4 * D + c]) + red[6 * D + c];
 }
 
+// ---- Round 6: the same two gradients WITHOUT a pass over the window rows.  With xfull = xhat g + b (what the window passes read):
+//     sum_l dY[l,c] xhat[l,c] = sum_h u[h,c] A[h,c] + gz[h,c] B[h,c],   A = sum_l dE[h,l] xhat[l,c],   B = sum_l att[h,l] xhat[l,c]
+// and the window passes have ALREADY formed both sums over the rows, with the affine rows:
+//     du[h,c] = sum_l dE[h,l] xfull[l,c] = g_c A + b_c sdE[h]        (the backward pass's output; sdE = sum_l dE[h,l], ~0)
+//     z[h,c]  = sum_l att[h,l] xfull[l,c] = g_c B + b_c satt[h]      (the forward pass's output; satt = sum_l att[h,l], ~1)
+// so  d gain[c] = (1 / g_c) sum_{n,h} u (du - b sdE) + gz (z - b satt),   d bias[c] = sum_{n,h} u sdE + gz satt:
+// an elementwise pass over four [H, N, D] tensors (50 MB at config 5) instead of a third read of the gathered window (402 MB).
+// One wave per sample at a time (lane = columns 2 lane + 128 j), per-lane running sums, the workgroup's four waves added in wave
+// order, the division by the gain per workgroup row (distributes over the fixed-order sum of the rows), partial rows as above.
+// The division is the price: a gain of exactly zero has no gradient through this identity (the rows-based kernel above stays for
+// that and as the cross-check of tests/test_gpu_parity.py); LayerNorm gains start at 1 and AdamW moves them by ~lr per step.
+struct LnOutParams {
+  const float *u, *gz, *du, *z, *att, *d_e, *ln_g, *ln_b;
+  long long vec_hs, vec_ns;
+  float *partial;
+  int N, L, D, H;
+};
+template <int NJ>
+__global__ __launch_bounds__(WG_T) void ln_grad_from_outputs_kernel(const LnOutParams p) {
+  __shared__ float red[WG_WAVES * 2 * 512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = p.L, D = p.D, H = p.H;
+  float2 dg[NJ], db[NJ], gb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    dg[j] = db[j] = float2{0.f, 0.f};
+    gb[j] = *reinterpret_cast<const float2 *>(p.ln_b + 2 * lane + 128 * j);
+  }
+  for (int n = blockIdx.x * WG_WAVES + wave; n < p.N; n += gridDim.x * WG_WAVES) {
+    for (int h = 0; h < H; ++h) {
+      const long long row = ((long long)n * H + h) * L;
+      float sde = 0.f, sat = 0.f;
+      for (int l = lane; l < L; l += 64) { sde += p.d_e[row + l]; sat += p.att[row + l]; }
+      sde = wave_sum(sde);
+      sat = wave_sum(sat);
+      const long long o = (long long)h * p.vec_hs + (long long)n * p.vec_ns + 2 * lane;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float2 u = *reinterpret_cast<const float2 *>(p.u + o + 128 * j), gz = *reinterpret_cast<const float2 *>(p.gz + o + 128 * j);
+        const float2 du = *reinterpret_cast<const float2 *>(p.du + o + 128 * j), z = *reinterpret_cast<const float2 *>(p.z + o + 128 * j);
+        dg[j].x += u.x * (du.x - gb[j].x * sde) + gz.x * (z.x - gb[j].x * sat);
+        dg[j].y += u.y * (du.y - gb[j].y * sde) + gz.y * (z.y - gb[j].y * sat);
+        db[j].x += u.x * sde + gz.x * sat;
+        db[j].y += u.y * sde + gz.y * sat;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    *reinterpret_cast<float2 *>(&red[wave * 2 * D + 2 * lane + 128 * j]) = dg[j];
+    *reinterpret_cast<float2 *>(&red[wave * 2 * D + D + 2 * lane + 128 * j]) = db[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < 2 * D; c += WG_T) {
+    float s = ((red[c] + red[2 * D + c]) + red[4 * D + c]) + red[6 * D + c];
+    if (c < D) s = s / p.ln_g[c];
+    p.partial[(long long)blockIdx.x * 2 * D + c] = s;
+  }
+}
+
 // one wave per row of a contiguous [R, D] matrix
 template <int NJ>
 __global__ __launch_bounds__(256) void ln_row_stats_kernel(const float *__restrict__ x, float eps, float *__restrict__ stats, long long R, int D) {
@@ -211,6 +271,28 @@ extern "C" int etm_window_ln_grad(const float *bank, int64_t ep_stride, int64_t 
     default: if (h4) LG_LAUNCH(4, 4); else LG_LAUNCH(4, 8); break;
   }
 #undef LG_LAUNCH
+  return etm_launch_status();
+}
+
+// The same partial rows from the window passes' OUTPUTS (see ln_grad_from_outputs_kernel): u / gz / du / z [H, N, D] with one pair of
+// strides, att / d_e [N, H, L], ln_g / ln_b [D] -- norm_kv's parameters as the passes used them.  No window row is read.
+extern "C" int etm_window_ln_grad_from_outputs(const float *u, const float *gz, const float *du, const float *z, const float *att,
+                                               const float *d_e, const float *ln_g, const float *ln_b, int64_t vec_head_stride,
+                                               int64_t vec_sample_stride, float *partial, int N, int L, int D, int H, void *stream) {
+  (void)hipGetLastError();
+  if (!u || !gz || !du || !z || !att || !d_e || !ln_g || !ln_b || !partial) return ETM_EINVAL;
+  if (N <= 0 || L <= 0 || D <= 0 || H <= 0) return ETM_EINVAL;
+  if (D % 128 != 0 || D > 512 || vec_head_stride % 2 || vec_sample_stride % 2) return ETM_EUNSUPPORTED;
+  LnOutParams p{u, gz, du, z, att, d_e, ln_g, ln_b, vec_head_stride, vec_sample_stride, partial, N, L, D, H};
+  const int grid = etm_window_ln_grad_rows(N);
+  hipStream_t st = (hipStream_t)stream;
+  EtmProfScope prof(ETM_K_BWD_DX, st);
+  switch (D / 128) {
+    case 1: hipLaunchKernelGGL((ln_grad_from_outputs_kernel<1>), dim3(grid), dim3(WG_T), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((ln_grad_from_outputs_kernel<2>), dim3(grid), dim3(WG_T), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((ln_grad_from_outputs_kernel<3>), dim3(grid), dim3(WG_T), 0, st, p); break;
+    default: hipLaunchKernelGGL((ln_grad_from_outputs_kernel<4>), dim3(grid), dim3(WG_T), 0, st, p); break;
+  }
   return etm_launch_status();
 }
 

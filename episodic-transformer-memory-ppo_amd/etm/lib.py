@@ -124,6 +124,7 @@ SIGNATURES = {
     "etm_window_fwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P]),
     "etm_window_ln_grad_rows": (_I, [_I]),
     "etm_window_ln_grad": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _P]),
+    "etm_window_ln_grad_from_outputs": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _P]),
     "etm_ln_row_stats": (_I, [_P, _F, _P, _L, _I, _P]),
     "etm_window_bwd": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
     "etm_window_dx": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

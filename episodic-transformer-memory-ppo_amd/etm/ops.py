@@ -250,7 +250,7 @@ class _WindowFn(torch.autograd.Function):
             ctx.ln_params = (ln_g_param, ln_b_param) if ln_g is not None else None      # the parameters themselves (arena views by address)
             saved = [u, att]
             if ln_g is not None:
-                saved += [ln_g, ln_b, ln_stats]
+                saved += [ln_g, ln_b, ln_stats, z]      # (z: norm_kv's gradients are formed from the passes' outputs, round 6)
             if pos is not None:
                 saved += [pos]
             ctx.save_for_backward(*saved)
@@ -267,9 +267,10 @@ class _WindowFn(torch.autograd.Function):
         u, att = saved[:2]
         rest = saved[2:]
         ln_g = ln_b = ln_stats = pos = None
+        z_fwd = None
         if ctx.has_ln:
-            ln_g, ln_b, ln_stats = rest[:3]
-            rest = rest[3:]
+            ln_g, ln_b, ln_stats, z_fwd = rest[:4]
+            rest = rest[4:]
         if ctx.has_pos:
             pos = rest[0]
         H, N, D = u.shape
@@ -287,16 +288,23 @@ class _WindowFn(torch.autograd.Function):
         want_pos = ctx.has_pos and ctx.needs_input_grad[3]
         d_ln_g = d_ln_b = d_pos = None
         if _ln_grad_kernel and want_ln and not want_pos and D % 128 == 0 and D <= 512 and H <= 8 and L <= 128:
-            # round 5: norm_kv's gain / bias gradients by the dedicated window pass (csrc/window_ln_grad.hip): per-workgroup partial
-            # rows, summed by the grouped column-sum reduction of the step, or -- without a collector / once it is full -- by the
-            # same kernel launched here.  NOT by torch's column sum: its two-stage reduction (a memset node for its semaphore + the
-            # reduce kernel) returns wrong sums in some replays of a captured graph on this runtime (profiles/r05/graph_reduce_hazard.txt).
+            # norm_kv's gain / bias gradients as per-workgroup partial rows (csrc/window_ln_grad.hip), summed by the grouped column-sum
+            # reduction of the step, or -- without a collector / once it is full -- by the same kernel launched here.  NOT by torch's
+            # column sum: its two-stage reduction (a memset node for its semaphore + the reduce kernel) returns wrong sums in some
+            # replays of a captured graph on this runtime (profiles/r05/graph_reduce_hazard.txt).
+            # Round 6 ("outputs", the default): from the window passes' OUTPUTS -- u, gz, du and the forward's z -- an elementwise
+            # pass over four [H, N, D] tensors; round 5 ("rows"): a third pass over the gathered window rows (8 x the bytes).
             rows = lib.etm_window_ln_grad_rows(N)
             partial = torch.empty((rows, 2 * D), dtype=torch.float32, device=dev)
-            rc = lib.etm_window_ln_grad(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
-                                        _ptr(pos), _ptr(ln_stats), _ptr(att), _ptr(d_e), _ptr(u), _ptr(gz), N * D, D, _ptr(partial),
-                                        N, L, D, H, _stream())
-            _lib.check(rc, "etm_window_ln_grad")
+            if _ln_grad_kernel == "rows":
+                rc = lib.etm_window_ln_grad(spec.block_ptr(block), spec.ep_stride, spec.row_stride, _ptr(spec.ep), _ptr(spec.win), _ptr(pidx),
+                                            _ptr(pos), _ptr(ln_stats), _ptr(att), _ptr(d_e), _ptr(u), _ptr(gz), N * D, D, _ptr(partial),
+                                            N, L, D, H, _stream())
+                _lib.check(rc, "etm_window_ln_grad")
+            else:
+                rc = lib.etm_window_ln_grad_from_outputs(_ptr(u), _ptr(gz), _ptr(du), _ptr(z_fwd), _ptr(att), _ptr(d_e), _ptr(ln_g), _ptr(ln_b),
+                                                         N * D, D, _ptr(partial), N, L, D, H, _stream())
+                _lib.check(rc, "etm_window_ln_grad_from_outputs")
             col = DeferredDw.active
             params = getattr(ctx, "ln_params", None)
             if col is not None and params is not None and col.offer_colsum(partial, rows, 2 * D, [(0, D, params[0].data_ptr()), (D, D, params[1].data_ptr())]):
@@ -329,12 +337,16 @@ def colsum_rows(partial, P, C):
     return out
 
 
-_ln_grad_kernel = True      # norm_kv's gain / bias gradients by csrc/window_ln_grad.hip (False: the generic dX kernel, etm_window_dx)
+_ln_grad_kernel = "outputs"      # norm_kv's gain / bias gradients by csrc/window_ln_grad.hip: "outputs" (from the passes' outputs,
+#                                    round 6) or "rows" (a pass over the window rows, round 5); False: the generic dX kernel, etm_window_dx
 
 
 def set_ln_grad_kernel(on):
+    """True / "outputs", "rows", or False (trainer.py: ``fused_ln_grad``)."""
     global _ln_grad_kernel
-    _ln_grad_kernel = bool(on)
+    if on not in (True, False, "outputs", "rows"):
+        raise ValueError(f"fused_ln_grad must be true, false, 'outputs' or 'rows', got {on!r}")
+    _ln_grad_kernel = "outputs" if on is True else on
 
 
 ATTENTION_IMPLS = ("folded", "dense")

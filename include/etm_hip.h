@@ -148,6 +148,13 @@ int etm_window_ln_grad(const float *bank, int64_t ep_stride, int64_t row_stride,
                        const int64_t *pidx, const float *pos, const float *ln_stats, const float *att, const float *d_e,
                        const float *u, const float *gz, int64_t vec_head_stride, int64_t vec_sample_stride, float *partial,
                        int N, int L, int D, int H, void *stream);
+/* Round 6: the same partial rows from the window passes' OUTPUTS, without reading a window row: with xfull = xhat g + b,
+ * d gain = (1 / g) sum_{n,h} u (du - b sdE) + gz (z - b satt) and d bias = sum_{n,h} u sdE + gz satt (sdE / satt: row sums of d_e / att;
+ * du = etm_window_bwd's output, z = etm_window_fwd's).  u / gz / du / z [H, N, D] (one pair of strides), att / d_e [N, H, L], ln_g / ln_b
+ * [D].  D % 128 == 0, D <= 512.  A gain of exactly zero has no gradient through this identity (etm_window_ln_grad reads the rows). */
+int etm_window_ln_grad_from_outputs(const float *u, const float *gz, const float *du, const float *z, const float *att, const float *d_e,
+                                    const float *ln_g, const float *ln_b, int64_t vec_head_stride, int64_t vec_sample_stride,
+                                    float *partial, int N, int L, int D, int H, void *stream);
 /* stats [R, 2] = (mean, 1 / sqrt(var + eps)) of the R contiguous rows of x [R, D]: LayerNorm statistics of the memory bank's rows,
  * once per update (norm_kv's statistics do not depend on its gain / bias).  D % 128 == 0, D <= 1024. */
 int etm_ln_row_stats(const float *x, float eps, float *stats, int64_t R, int D, void *stream);
