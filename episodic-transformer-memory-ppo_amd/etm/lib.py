@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 _lib = None
 
