@@ -1233,6 +1233,43 @@ def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None):
                             (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index)
 
 
+class ReplayAfterWarmup:
+    """``fn()`` -- device work on fixed-address operands without host synchronisation (a weight repacking, a cache refresh: dozens of
+    small launches once per update) -- run eagerly for its first ``warm`` calls and from a captured graph afterwards (round 6:
+    refresh_rollout_weights 2.3 -> 0.3 ms per update at config 5).  ``after``: host-side bookkeeping that must follow every execution,
+    captured or not.  A failed capture keeps the eager form for good; ``enabled`` False never captures."""
+
+    def __init__(self, fn, device, warm=2, after=None, enabled=True, what="refresh"):
+        self.fn, self.device, self.warm, self.after, self.enabled, self.what = fn, device, warm, after, enabled, what
+        self.calls, self.graph, self.failed = 0, None, False
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.calls += 1
+            capture = (self.enabled and not self.failed and self.calls > self.warm and torch.device(self.device).type == "cuda"
+                       and not torch.cuda.is_current_stream_capturing())
+            if capture:
+                try:
+                    torch.cuda.synchronize(self.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self.fn()
+                    self.graph = g
+                    g.replay()
+                except Exception as exc:       # noqa: BLE001
+                    import sys
+                    self.failed, self.graph = True, None
+                    torch.cuda.synchronize(self.device)
+                    print(f"[etm] {self.what} stays eager (capture failed: {exc!r})", file=sys.stderr, flush=True)
+                    self.fn()
+            else:
+                self.fn()
+        if self.after is not None:
+            self.after()
+
+
 def host_view(t):
     """numpy array over the memory of the contiguous float32 device tensor ``t`` at its HOST address (large-BAR systems map the
     device's memory into the process: the pointer is the same) -- WRITE-ONLY use: host reads through the BAR are uncached and

@@ -79,9 +79,26 @@ class ActorCriticModel(nn.Module):
         return ww % 4 == 0 and obs.shape[1] * 1 >= 1 and h1 >= 4 and w1 >= 4 and ((h1 - 4) // 2 + 1) >= 3 and ((w1 - 4) // 2 + 1) >= 3
 
     def refresh_rollout_weights(self):
-        """(Re)build the [Cout, KH*KW*C] weight copies the NHWC layers of the fused encoder read.  Buffers keep their address
-        (the captured rollout graph reads them); called by the trainer at the start of every rollout and lazily whenever a
-        weight's version counter moved."""
+        """(Re)build the weight copies / packings the rollout kernels read.  Buffers keep their address (the captured rollout graph
+        reads them); called by the trainer at the start of every rollout and lazily whenever a weight's version counter moved.
+        Round 6: dozens of small launches (2.3 ms per update for the gated layouts) -- from its third call on a graph replay when the
+        trainer set ``graph_refresh`` (ops.ReplayAfterWarmup); the version bookkeeping follows every execution."""
+        r = getattr(self, "_refresh_replay", None)
+        if r is None:
+            r = self._refresh_replay = ops.ReplayAfterWarmup(self._refresh_rollout_weights_now, self.lin_policy.weight.device,
+                                                             after=self._mark_weight_versions, enabled=bool(getattr(self, "graph_refresh", False)),
+                                                             what="refresh_rollout_weights")
+        r.enabled = bool(getattr(self, "graph_refresh", False)) and r.device == self.lin_policy.weight.device
+        r()
+
+    def _mark_weight_versions(self):
+        for mod in self.modules():
+            if mod is not self and hasattr(mod, "_versions"):
+                mod._wver = mod._versions()
+        if self.visual:
+            self._wver = (self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
+
+    def _refresh_rollout_weights_now(self):
         for mod in self.modules():
             if mod is not self and hasattr(mod, "refresh_rollout_weights"):
                 mod.refresh_rollout_weights()

@@ -234,6 +234,7 @@ class PPOTrainer(_DataParallelStep, _NativeRolloutDrive, _RunOutputs):
         self.buffer = Buffer(config, self.observation_space, self.action_space_shape, self.max_episode_length, device)
         self.model = ActorCriticModel(config, self.observation_space, self.action_space_shape, self.max_episode_length).to(device)
         self.model.train()
+        self.model.graph_refresh = bool(config.get("hip_graph_rollout", True))      # (refresh_rollout_weights as a graph replay from its third call on)
         if self.dp is not None:
             self.dp.broadcast_parameters(self.model)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
@@ -818,7 +819,16 @@ class PPOTrainer(_DataParallelStep, _NativeRolloutDrive, _RunOutputs):
     def _refresh_kv_cache(self):
         """Start of a rollout: re-project every live episode's memory with the CURRENT weights (they changed in the
         last optimisation phase) into the per-worker K/V cache [W, T, blocks, 2D]; rows that are not written yet hold the
-        projection of a zero item, which is also the initial state of every episode that starts during the rollout."""
+        projection of a zero item, which is also the initial state of every episode that starts during the rollout.
+        (Round 6: a graph replay from its third call on, ops.ReplayAfterWarmup -- with ``hip_graph_rollout``.)"""
+        r = getattr(self, "_kv_refresh_replay", None)
+        if r is None:
+            r = self._kv_refresh_replay = ops.ReplayAfterWarmup(self._refresh_kv_cache_now, self.device, what="_refresh_kv_cache",
+                                                                enabled=bool(self.config.get("hip_graph_rollout", True)))
+        r.enabled = bool(self.config.get("hip_graph_rollout", True)) and self.buffer.address_captured      # (the bank keeps its address from the first captured step on)
+        r()
+
+    def _refresh_kv_cache_now(self):
         W, T = self.num_workers, self.max_episode_length
         tr = self.model.transformer
         with torch.no_grad():

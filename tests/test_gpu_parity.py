@@ -1128,6 +1128,8 @@ def test_small_worker_groups_stress():
         # round 6: the bootstrap value of the last observation (get_last_value) is a graph replay from the third rollout on; the
         # advantages compared below are its consumers, against the eager path's
         assert (tr._lv.graph is not None) == ("rollout_groups" in over), over
+        # ... likewise the per-update weight repacking and the K | V cache refresh (ops.ReplayAfterWarmup)
+        assert (tr.model._refresh_replay.graph is not None) == ("rollout_groups" in over) and (tr._kv_refresh_replay.graph is not None) == ("rollout_groups" in over), over
         if "rollout_groups" in over:
             assert len(tr._groups) == 2 and tr._groups[0].W == 2 and tr._stream_obs
             assert bool(getattr(tr, "_native_rollout", False)) == bool(over.get("worker_processes")), over

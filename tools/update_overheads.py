@@ -1,7 +1,7 @@
 """Where the part of an update that is NOT rollout steps or minibatch steps goes (round 6): every piece of `_sample_training_data`
 around its step loop and of `_train_epochs` around its minibatch loop, timed with a device synchronisation on both sides.
 
-    python tools/update_overheads.py [updates]
+    python tools/update_overheads.py [updates] [config name]
 """
 import os
 import sys
@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from trainer import PPOTrainer  # noqa: E402
 from yaml_parser import YamlParser  # noqa: E402
 
-cfg = YamlParser(os.path.join(PKG, "configs", "synthetic_minigrid.yaml")).get_config()
+cfg = YamlParser(os.path.join(PKG, "configs", (sys.argv[2] if len(sys.argv) > 2 else "synthetic_minigrid") + ".yaml")).get_config()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="ovh", device=dev, tensorboard=False)
