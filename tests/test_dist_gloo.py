@@ -70,6 +70,10 @@ def _worker(rank, world, port, out_dir):
     assert abs(float(torch.sqrt(merged[2] / (merged[0] - 1))) - float(adv.std())) < 1e-5
 
     assert dp.max_over_ranks(float(rank + 1)) == float(world)
+    # round 6: the agreements around the one-graph data-parallel step -- a logical AND over the ranks (one "no" anywhere = "no" everywhere);
+    # over gloo the library collective is not in use, so the collective can never be captured inside the step's graph
+    assert dp.agree(True) is True and dp.agree(rank != 1) is False and dp.agree(False) is False
+    assert dp.collective == "torch" and dp.graph_collective_ok() is False
     dp.barrier()
     dp.close()
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
