@@ -1091,6 +1091,40 @@ def test_rollout_fast_paths_agree():
                              dict(stream_observations=False, rollout_groups=1), dict(hip_graph_rollout=False)])
 
 
+def test_fresh_observation_draws_reach_the_device_bit_for_bit():
+    """Round 6, the default environment path of the benchmark: every observation is a fresh draw of its worker's numpy stream
+    (`pool: 0`), made by libetm_envgen.so (or numpy without it) STRAIGHT into the staging array in device memory where the host can
+    write there (large BAR; else through pinned memory + uploads), over several rollouts of a pipelined trainer: `buffer.obs[w, t]` of
+    rollout r must be draw number r * S + t of `default_rng(seed + w)` -- regenerated here by numpy alone."""
+    from etm import ops
+    from trainer import PPOTrainer
+    dev = _dev()
+    W, S, R, shape, seed = 8, 24, 4, (3, 36, 36), 11
+    base = dict(environment=dict(type="Synthetic", obs_shape=list(shape), num_actions=3, max_episode_steps=9, seed=seed, p_done=0.1, pool=0, gen_threads=3),
+                gamma=0.99, lamda=0.95, updates=1, epochs=1, n_workers=W, worker_steps=S, n_mini_batch=2, value_loss_coefficient=0.5,
+                hidden_layer_size=32, max_grad_norm=0.5, rollout_groups=2, rollout_min_group_size=2,
+                transformer=dict(num_blocks=2, embed_dim=64, num_heads=2, memory_length=6, positional_encoding="relative",
+                                 layer_norm="post", gtrxl=False, gtrxl_bias=0.0),
+                learning_rate_schedule=dict(initial=3e-4, final=3e-4, power=1.0, max_decay_steps=10),
+                beta_schedule=dict(initial=1e-3, final=1e-3, power=1.0, max_decay_steps=10),
+                clip_range_schedule=dict(initial=0.1, final=0.1, power=1.0, max_decay_steps=10))
+    n = int(np.prod(shape))
+    want = np.stack([np.random.default_rng(seed + w).random((R * S + 1) * n, dtype=np.float32).reshape(R * S + 1, *shape) for w in range(W)])
+    for direct in (True, False):
+        cfg = json.loads(json.dumps(base))
+        cfg["direct_observation_rows"] = direct
+        torch.manual_seed(3)
+        tr = PPOTrainer(cfg, run_id="fresh", device=dev, tensorboard=False)
+        for r in range(R):
+            tr._sample_training_data()
+            tr.buffer.prepare_batch_dict()
+            got = tr.buffer.obs.cpu().numpy()                      # [W, S, ...]
+            assert np.array_equal(got, want[:, r * S:(r + 1) * S]), (direct, r)
+        assert len(tr._groups) == 2 and tr._stream_obs
+        assert tr._direct_rows == (direct and ops.host_direct_write_ok(dev))
+        tr.close()
+
+
 def test_small_worker_groups_stress():
     """Pipelined worker groups of TWO workers with a near-free environment (the host is back with the next step's (episode
     step, slot) block long before the tail of the current step has run): 12 teacher-forced rollouts of a gated (GTrXL) model
