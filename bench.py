@@ -628,7 +628,8 @@ def main():
                        "dp_step": (None if dp is None else "one_graph" if getattr(trainer, "_dp_one_graph", False) else "graph_a+allreduce+graph_b"),
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "observation_rows": "direct (host writes into device memory)" if getattr(trainer, "_direct_rows", False) else "pinned + upload",
+                       "observation_rows": ("direct (host writes into device memory" + (", HDP flush register written)" if etm_ops._direct_mode.get(device.index) == 2 else ")")
+                                            if getattr(trainer, "_direct_rows", False) else "pinned + upload"),
                        "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,
                        "native_rollout_driver": bool(getattr(trainer, "_native_rollout", False))},
             "phase_s_per_step": {"rollout": phase[0] / args.steps, "train": phase[1] / args.steps, "env_host": env_s / args.steps},

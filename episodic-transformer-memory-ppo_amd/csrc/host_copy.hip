@@ -129,8 +129,8 @@ extern "C" int etm_host_copy(void *copier, void *dst, const void *src, int64_t b
 //     register (HSA_AMD_AGENT_INFO_HDP_FLUSH, the register RCCL / MPI write after a NIC has written into device memory) -- one more
 //     posted write behind the rows: whatever the host data path still holds is in memory before the launch is seen;
 //   * helper threads that write rows fence themselves before they report completion (host copier above, libetm_envgen.so's pool).
-// etm_host_direct_write_init(device): 1 = usable (large BAR; the HDP flush register was found, or the device reports none),
-// 0 = not usable (the caller keeps pinned memory + etm_upload), < 0 error.
+// etm_host_direct_write_init(device): 2 = usable and etm_host_store_fence writes the device's HDP flush register, 1 = usable, the device
+// reports no such register (nothing to flush), 0 = not usable (the caller keeps pinned memory + etm_upload), < 0 error.
 #include <dlfcn.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -164,7 +164,7 @@ hsa_status_t find_agent(hsa_agent_t agent, void *data) {
 
 extern "C" int etm_host_direct_write_init(int device) {
   if (device < 0 || device >= MAXDEV) return ETM_EINVAL;
-  if (g_direct_ok[device] != 0) return g_direct_ok[device] > 0 ? 1 : 0;
+  if (g_direct_ok[device] != 0) return g_direct_ok[device] > 0 ? (g_hdp_flush[device] ? 2 : 1) : 0;
   g_direct_ok[device] = -1;
   int large_bar = 0;
   if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) return 0;
@@ -183,7 +183,7 @@ extern "C" int etm_host_direct_write_init(int device) {
   if (!c.found) return 0;
   g_hdp_flush[device] = c.flush;            // nullptr: the device has no host data path cache to flush (e.g. xGMI-attached hosts)
   g_direct_ok[device] = 1;
-  return 1;
+  return c.flush ? 2 : 1;
 }
 
 extern "C" int etm_host_store_fence(int device) {

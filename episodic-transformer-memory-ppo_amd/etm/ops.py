@@ -1283,6 +1283,7 @@ def host_view(t):
 
 
 _direct_ok = {}
+_direct_mode = {}      # device index -> etm_host_direct_write_init's answer (2: with an HDP flush register, 1: without, 0: not usable)
 
 
 def host_direct_write_ok(device):
@@ -1293,7 +1294,9 @@ def host_direct_write_ok(device):
         ok = False
         try:
             lib = _lib.load()
-            if lib.etm_host_direct_write_init(idx) == 1:
+            mode = lib.etm_host_direct_write_init(idx)
+            _direct_mode[idx] = mode
+            if mode >= 1:
                 import numpy as np
                 # 48 rounds of "host rewrites a small buffer whose lines the previous kernel has just read, a kernel reads it
                 # again": what a rollout does with its staging rows (tools/microbench/bar_stale.hip is the long form: 12,000

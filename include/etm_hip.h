@@ -589,7 +589,8 @@ typedef struct etm_rollout_group {
 int etm_graph_launch(void *graph_exec, void *stream);
 /* Observation rows written by the host straight into device memory (round 6, large-BAR systems; csrc/host_copy.hip): the staging
  * row of the next step is the environment front-end's output buffer, no pinned intermediate and no copy-engine transfer.
- * etm_host_direct_write_init(device): 1 usable, 0 not (the caller keeps pinned memory + etm_upload).  etm_host_store_fence(device):
+ * etm_host_direct_write_init(device): 2 usable + an HDP flush register to write, 1 usable (the device reports none), 0 not usable (the
+ * caller keeps pinned memory + etm_upload).  etm_host_store_fence(device):
  * after the rows are written and before the step is launched -- drains the core's write-combining buffers and writes the
  * device's HDP flush register (a posted write behind the rows). */
 int etm_host_direct_write_init(int device);
