@@ -1,0 +1,411 @@
+// Training-side encoder on the bf16 matrix pipe at fp32 accuracy (round 6; /root/reference model.py:40-56, :90-92 and their autograd
+// backward): forward of the three layers and backward-data of layers 2 / 3.
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector rate, 157 TFLOP/s; the bf16 pipe is 16 x faster.  Every fp32 operand is the
+// EXACT sum of three bf16 terms (a = a1 + a2 + a3, 3 x 8 significant bits, round-to-nearest at each level), and a product a.b is
+// accumulated in fp32 as the six bf16 products a1 b3 + a3 b1 + a2 b2 + a1 b2 + a2 b1 + a1 b1 (small terms first; the dropped terms
+// a2 b3, a3 b2, a3 b3 are <= 2^-23 |a b|): six instructions of 32 cycles in place of eight fp32 MFMAs of 64 cycles per 16 k, i.e. 0.375 of
+// the fp32 MFMA time -- at an error against float64 that is AT OR BELOW the fp32 MFMA chain's (tools/microbench/b3_gemm.hip, profiles/r06/
+// b3_gemm.txt: 3.6e-7 against 4.3e-7 of the result norm at K = 576; 344 fp32-equivalent TFLOP/s measured on register operands).
+//
+// All five passes are one kernel: a "forward-like" convolution over images that are RESIDENT IN LDS as three bf16 planes,
+//   * forward: the layer input (layer 1: the 84 x 84 x 3 observation, 127 KB; layer 2: one 20 x 20 x 32 image, its columns de-interleaved
+//     by parity so that the stride-2 windows of neighbouring output pixels are neighbours in LDS; layer 3: four 9 x 9 x 64 images);
+//   * backward-data: the gradient image, zero-bordered (rows share their border pixels: row stride = width + taps - 1), walked per
+//     stride-parity class as a dense T x T convolution -- the classes are more output-channel tiles of the same GEMM;
+//   * every input element crosses the memory system once per group as coalesced 16-byte fp32 loads (the NEXT group's are requested
+//     during the k loop into registers), is split once into its three bf16 terms (v_cvt_pk_bf16_f32, 5.5 vector-ALU operations per
+//     element) and written to the planes; pixel stride padded by 16 bytes (an odd number of 16-byte slots: the 32 pixels of a fragment
+//     read spread over the banks);
+//   * the MFMA computes D[channel][pixel] (A = weight fragment, B = image fragment): a lane ends up with 4 CONSECUTIVE channels of one
+//     pixel per accumulator quad, so bias + ReLU (forward) or the ReLU mask of the layer below (backward-data) and a 16-byte store
+//     follow straight from the registers -- no transposition through LDS;
+//   * weights: etm_conv_b3_pack splits and packs them once per optimiser step in fragment order ([k / 16][channel tile][plane][lane][8]
+//     bf16, 1 KB per fragment), the waves stream them from L2.
+// x, y, dy, dx are fp32 NHWC exactly as for etm_conv_train_fwd / _dgrad: the split is internal to the kernels.
+#include "etm_common.h"
+
+#include <utility>
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct B3Args {
+  const float *x;                 // forward: layer input NHWC; backward-data: gradient of the layer output NHWC
+  const long long *img_index;     // forward, optional (one image per group only): image n of the batch = x image img_index[n]
+  const unsigned short *wp;       // etm_conv_b3_pack
+  const float *bias;              // forward
+  const float *ymask;             // backward-data: output of the layer below (NULL: no mask)
+  float *out;
+  int N, n_groups;
+};
+
+__device__ __forceinline__ unsigned b3_cvt_pk(float a, float b) {        // two floats -> two bf16 (a in the low half), round to nearest even
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (a, b) -> the three bf16 terms of each, packed pairwise
+__device__ __forceinline__ void b3_split_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  h = b3_cvt_pk(a, b);
+  a -= __uint_as_float(h << 16); b -= __uint_as_float(h & 0xffff0000u);
+  m = b3_cvt_pk(a, b);
+  a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xffff0000u);
+  l = b3_cvt_pk(a, b);
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void b3_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void b3_for(F &&f) { b3_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Geometry of one pass.  DGRAD false: forward of Conv2d(C, COUT, KS, S) on HW x HW inputs.  DGRAD true: backward-data of that layer
+// (the LDS image is the gradient of its output, the result its input gradient).
+template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G_>
+struct B3Geo {
+  static constexpr int G = G_;
+  static constexpr int HOUT = (HW - KS) / S + 1;                 // output size of the layer
+  static constexpr int T = KS / S;                               // backward-data: taps per dimension and class
+  static constexpr int CI = DGRAD ? COUT : C;                    // channels of the LDS-resident image
+  static constexpr int HI = DGRAD ? HOUT : HW;                   // its size in memory
+  static constexpr bool THREE = CI == 3;                         // layer 1: 3 channels, the image stays in its memory order
+  static constexpr int RS = DGRAD ? HI + T - 1 : HI;             // LDS row stride in pixel slots
+  static constexpr int SLOTS = DGRAD ? (HI + 2 * (T - 1) - 1) * RS + HI + 2 * (T - 1) : HI * HI;
+  static constexpr int CPB = THREE ? 6 : (CI + 8) * 2;           // bytes per pixel slot and plane
+  static constexpr int IMGB = (SLOTS * CPB + 15) / 16 * 16;      // bytes per image and plane
+  static constexpr int PLANE = G * IMGB;
+  static constexpr int HO = DGRAD ? HI + T - 1 : HOUT;           // result pixels per row (backward-data: per class)
+  static constexpr int PIX = HO * HO, M = G * PIX, MT = (M + 31) / 32;
+  static constexpr int NOUT = DGRAD ? S * S * C : COUT;          // output channels of the GEMM (backward-data: class x channel)
+  static constexpr int NT = NOUT / 32, RP = NT >= 4 ? 1 : 4 / NT, TPW = (MT + RP - 1) / RP;
+  static constexpr int TAPS = DGRAD ? T : KS;                    // window size per dimension
+  static constexpr int K = TAPS * TAPS * CI, KSTEPS = K / 16;
+  static constexpr int KPT = THREE ? 1 : CI / 16;                // k steps per tap
+  static constexpr int Q_IMG = HI * HI * CI / 4;                 // float4 per image in memory
+  static constexpr int NQ = (G * Q_IMG + 255) / 256;             // float4 per thread and group
+  static constexpr int LPK = (NQ + KSTEPS - 1) / KSTEPS;         // next-group loads issued per k step
+  static constexpr int HRES = DGRAD ? S * HO : HO;               // result image size
+  static constexpr int CRES = DGRAD ? C : COUT;                  // result channels
+  static_assert(K % 16 == 0 && NOUT % 32 == 0 && (THREE || CI % 16 == 0) && (NT == 1 || NT == 2 || NT == 4), "layer geometry");
+  static_assert(!DGRAD || (HW % S == 0 && KS % S == 0 && HI + T - 1 == HW / S), "backward-data: class grids tile the input");
+
+  // pixel slot of memory pixel (y, x)
+  static constexpr int slot(int y, int x) {
+    if (DGRAD) return (y + T - 1) * RS + (x + T - 1);
+    if (S == 2) return y * HI + (x & 1) * (HI / 2) + (x >> 1);
+    return y * HI + x;
+  }
+  // byte offset (inside a plane's image) of k step ks relative to the window's first element (layers with CI % 16 == 0)
+  static constexpr int tap_bytes(int ks) {
+    const int tap = ks / KPT, cg = ks % KPT, ty = tap / TAPS, tx = tap % TAPS;
+    int so = ty * RS + tx;
+    if (!DGRAD && S == 2) so = ty * HI + (tx & 1) * (HI / 2) + (tx >> 1);
+    return so * CPB + cg * 32;
+  }
+};
+
+template <class L, bool DGRAD, int C, int S>
+__global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
+  constexpr int G = L::G, TPW = L::TPW, NT = L::NT, RP = L::RP, KSTEPS = L::KSTEPS, NQ = L::NQ, PD = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // three planes of [G] images
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave % NT, rp = wave / NT;
+
+  if (DGRAD) {                                             // the borders stay zero for the whole launch
+    for (int e = tid; e < 3 * L::PLANE / 16; e += 256) reinterpret_cast<u32x4 *>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
+
+  // ---- per tile: LDS byte offset of this lane's window (plane 0) and the lane's result pixel
+  int a_off[TPW], a_offb[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int m = min((rp + t * RP) * 32 + col, L::M - 1);
+    const int g = m / L::PIX, r = m - g * L::PIX, oy = r / L::HO, ox = r - oy * L::HO;
+    if (L::THREE) {
+      const int e0 = (oy * S * L::HI + ox * S) * 3;        // first element of the window
+      a_off[t] = g * L::IMGB + e0 * 2 + half * 16;         // k groups of 8 elements: (2 ks, 2 ks + 1) in the same window row ...
+      a_offb[t] = g * L::IMGB + e0 * 2 + half * ((L::HI * 3 - 16) * 2);      // ... or the second one at the start of the next row
+    } else {
+      const int q0 = DGRAD ? oy * L::RS + ox : (S == 2 ? (2 * oy) * L::HI + ox : (oy * S) * L::HI + ox * S);
+      a_off[t] = g * L::IMGB + q0 * L::CPB + half * 16;
+      a_offb[t] = 0;
+    }
+  }
+
+  // ---- fill: this thread's float4 u of a group -> LDS byte offset inside a plane
+  auto fill_dst = [&](int u) {
+    const int q = tid + u * 256;
+    const int g = q / L::Q_IMG, qi = q - g * L::Q_IMG;
+    if (L::THREE) return g * L::IMGB + qi * 8;
+    const int pix = qi / (L::CI / 4), c4 = qi - pix * (L::CI / 4), y = pix / L::HI, x = pix - y * L::HI;
+    return g * L::IMGB + L::slot(y, x) * L::CPB + c4 * 8;
+  };
+  // buffer descriptor of a group's images: the float4 it really has (ragged last group; a group that does not exist: none -- the loads
+  // are still issued and return zeros without touching memory)
+  auto group_rsrc = [&](int grp) {
+    const bool exists = grp < p.n_groups;
+    const int n0 = exists ? grp * G : 0;
+    const long long src = (G == 1 && p.img_index) ? p.img_index[n0] : (long long)n0;
+    const int images = exists ? min(G, p.N - n0) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + src * (L::Q_IMG * 4)), 0, images * L::Q_IMG * 16, 0x00020000);
+  };
+  f32x4 fill[NQ];
+  auto fill_to_lds = [&]() {
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      if (tid + u * 256 < G * L::Q_IMG) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        b3_split_pair(fill[u][0], fill[u][1], h0, m0, l0);
+        b3_split_pair(fill[u][2], fill[u][3], h1, m1, l1);
+        const int d = fill_dst(u);
+        *reinterpret_cast<u32x2 *>(lds + d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(lds + L::PLANE + d) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2 *>(lds + 2 * L::PLANE + d) = u32x2{l0, l1};
+      }
+    }
+  };
+  auto fill_load = [&](int u, __amdgpu_buffer_rsrc_t rx) {
+    fill[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, tid * 16, u * 4096, 0));
+  };
+
+  int grp = blockIdx.x;
+  {
+    const __amdgpu_buffer_rsrc_t rx = group_rsrc(grp);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) fill_load(u, rx);
+    fill_to_lds();
+  }
+  // bias of this lane's channels: accumulator quad j = channels ct * 32 + 8 j + 4 half + (0..3)
+  f32x4 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bias4[j] = DGRAD ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(p.bias + ct * 32 + 8 * j + 4 * half);
+  // weight fragment (ks, ct, plane): 1 KB at ((ks NT + ct) 3 + plane) 1024, 16 bytes per lane
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.wp, 0, KSTEPS * NT * 3 * 1024, 0x00020000);
+  const int w_lane = lane * 16, w_ct = ct * 3072;
+  auto w_load = [&](int ks, int pl) { return __builtin_amdgcn_raw_buffer_load_b128(rw, w_lane, w_ct + (ks * NT * 3 + pl) * 1024, 0); };
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)((long long)p.N * L::HRES * L::HRES * L::CRES * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ymask ? p.ymask : p.out), 0,
+                                                                       p.ymask ? (int)((long long)p.N * L::HRES * L::HRES * L::CRES * 4) : 0, 0x00020000);
+
+  for (; grp < p.n_groups; grp += gridDim.x) {
+    __syncthreads();                                       // the group's planes are in LDS
+    const __amdgpu_buffer_rsrc_t nrx = group_rsrc(grp + gridDim.x);
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    u32x4 b[PD][3];
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[s][pl] = w_load(s, pl);         // (beyond the last step: outside the descriptor, zeros)
+
+    // image fragment of (tile t, k step ks): three planes of 8 bf16
+    auto read_x = [&](u32x4(&xf)[3], int t, auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      if constexpr (L::THREE) {
+        constexpr int g8 = 2 * ks, ky = g8 / 3, o8 = g8 % 3;
+        constexpr bool cross = (ks % 3) == 1;
+        const int base = (cross ? a_offb[t] : a_off[t]) + (ky * L::HI * 3 + o8 * 8) * 2;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const u32x2 lo = *reinterpret_cast<const u32x2 *>(lds + pl * L::PLANE + base);
+          const u32x2 hi = *reinterpret_cast<const u32x2 *>(lds + pl * L::PLANE + base + 8);
+          xf[pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      } else {
+        constexpr int off = L::tap_bytes(ks);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[pl] = *reinterpret_cast<const u32x4 *>(lds + pl * L::PLANE + a_off[t] + off);
+      }
+    };
+
+    u32x4 xa[2][3];
+    read_x(xa[0], 0, std::integral_constant<int, 0>{});
+    b3_for<KSTEPS>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value, s = ks % PD;
+      b3_for<TPW>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, cur = (ks * TPW + t) & 1;
+        // the next step's fragments are requested in front of this step's products
+        if constexpr (t + 1 < TPW) read_x(xa[cur ^ 1], t + 1, std::integral_constant<int, ks>{});
+        else if constexpr (ks + 1 < KSTEPS) read_x(xa[cur ^ 1], 0, std::integral_constant<int, ks + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 w1 = __builtin_bit_cast(bf16x8, b[s][0]), w2 = __builtin_bit_cast(bf16x8, b[s][1]), w3 = __builtin_bit_cast(bf16x8, b[s][2]);
+        const bf16x8 x1 = __builtin_bit_cast(bf16x8, xa[cur][0]), x2 = __builtin_bit_cast(bf16x8, xa[cur][1]), x3 = __builtin_bit_cast(bf16x8, xa[cur][2]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // this step's weight registers are free: the fragments of step ks + PD; then the next group's images
+      if constexpr (ks + PD < KSTEPS) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[s][pl] = w_load(ks + PD, pl);
+      }
+#pragma unroll
+      for (int u = ks * L::LPK; u < (ks + 1) * L::LPK; ++u)
+        if (u < NQ) fill_load(u, nrx);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- results: accumulator quad j of tile t = 4 consecutive channels of pixel (tile, col)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int T_ = rp + t * RP;
+      const int m = T_ * 32 + col;
+      const int g = m / L::PIX, r = m - g * L::PIX;
+      const int n = grp * G + g;
+      if (T_ < L::MT && m < L::M && n < p.N) {
+        int o;                                             // byte offset of the lane's first quad
+        if (DGRAD) {
+          const int cls = ct / (C / 32), py = cls / S, px = cls - py * S;
+          const int cy = r / L::HO, cx = r - cy * L::HO;
+          o = ((((n * L::HRES + S * cy + py) * L::HRES + S * cx + px) * C + (ct % (C / 32)) * 32 + 4 * half)) * 4;
+        } else {
+          o = ((n * L::PIX + r) * L::CRES + ct * 32 + 4 * half) * 4;
+        }
+        f32x4 mk[4];
+        if (DGRAD && p.ymask) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mk[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, o + 32 * j, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v{acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]};
+          if (DGRAD) {
+            if (p.ymask) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = mk[j][q] > 0.f ? v[q] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] + bias4[j][q], 0.f);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o + 32 * j, 0, 0);
+        }
+      }
+    }
+
+    __syncthreads();                                       // every wave has read the planes: the next group's take their place
+    fill_to_lds();
+  }
+}
+
+template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G>
+int launch_b3(const B3Args &p0, hipStream_t st) {
+  using L = B3Geo<DGRAD, C, HW, KS, S, COUT, G>;
+  B3Args p = p0;
+  if (G > 1 && p.img_index) return ETM_EUNSUPPORTED;
+  if ((long long)p.N * L::HRES * L::HRES * L::CRES * 4 >= 0x7ffffff0ll) return ETM_EUNSUPPORTED;      // 32-bit byte offsets into the result
+  p.n_groups = (p.N + G - 1) / G;
+  constexpr size_t lds = 3 * (size_t)L::PLANE;
+  static_assert(lds <= 160 * 1024, "LDS of a CU");
+  auto kern = conv_b3_kernel<L, DGRAD, C, S>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  const int grid = p.n_groups < 256 ? p.n_groups : 256;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+  return etm_launch_status();
+}
+
+// ---- weight split + packing: one thread per (k, output channel) element
+constexpr int B3_MAXP = 8;
+struct B3Pack {
+  const float *w[B3_MAXP];
+  unsigned short *out[B3_MAXP];
+  int dgrad[B3_MAXP], Cout[B3_MAXP], C[B3_MAXP], KS[B3_MAXP], S[B3_MAXP], first_block[B3_MAXP + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void conv_b3_pack_kernel(const B3Pack g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;      // uniform
+  const float *__restrict__ w = g.w[i];
+  const int Cout = g.Cout[i], C = g.C[i], KS = g.KS[i], S = g.S[i];
+  const int total = Cout * C * KS * KS;
+  const int e = ((int)blockIdx.x - g.first_block[i]) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = e & 7, lane = (e >> 3) & 63, rest = e >> 9;
+  float v;
+  if (!g.dgrad[i]) {
+    const int NT = Cout >> 5, nt = rest % NT, ks = rest / NT;
+    const int co = nt * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
+    const int c = k % C, kx = (k / C) % KS, ky = k / (C * KS);
+    v = w[((co * C + c) * KS + ky) * KS + kx];
+  } else {
+    const int T = KS / S, NT = (S * S * C) >> 5, nt = rest % NT, ks = rest / NT;
+    const int n = nt * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
+    const int cls = n / C, c = n - cls * C, py = cls / S, px = cls - py * S;
+    const int tap = k / Cout, co = k - tap * Cout, ta = tap / T, tb = tap - ta * T;
+    v = w[((co * C + c) * KS + (py + S * (T - 1 - ta))) * KS + (px + S * (T - 1 - tb))];
+  }
+  unsigned h, m, l;
+  b3_split_pair(v, 0.f, h, m, l);
+  unsigned short *o = g.out[i] + ((size_t)rest * 3 * 64 + lane) * 8 + j;
+  o[0] = (unsigned short)h; o[64 * 8] = (unsigned short)m; o[2 * 64 * 8] = (unsigned short)l;
+}
+}  // namespace
+
+// w[i] [Cout, C, KS, KS] fp32 -> out[i]: 3 * Cout * C * KS * KS bf16 (the three planes of every fragment), for the forward pass
+// (dgrad[i] == 0) or the backward-data pass (dgrad[i] != 0) of layer i; n <= 8 entries, one launch.
+extern "C" int etm_conv_b3_pack(const float *const *w, uint16_t *const *out, const int *dgrad, const int *Cout, const int *C, const int *KS,
+                                const int *S, int n, void *stream) {
+  (void)hipGetLastError();
+  if (!w || !out || !dgrad || !Cout || !C || !KS || !S || n <= 0 || n > B3_MAXP) return ETM_EINVAL;
+  B3Pack g{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || !out[i] || Cout[i] <= 0 || C[i] <= 0 || KS[i] <= 0 || S[i] <= 0) return ETM_EINVAL;
+    if (!dgrad[i] && (Cout[i] % 32 != 0 || (KS[i] * KS[i] * C[i]) % 16 != 0)) return ETM_EUNSUPPORTED;
+    if (dgrad[i] && (KS[i] % S[i] != 0 || (S[i] * S[i] * C[i]) % 32 != 0 || C[i] % 32 != 0 || ((KS[i] / S[i]) * (KS[i] / S[i]) * Cout[i]) % 16 != 0))
+      return ETM_EUNSUPPORTED;
+    g.w[i] = w[i]; g.out[i] = out[i]; g.dgrad[i] = dgrad[i]; g.Cout[i] = Cout[i]; g.C[i] = C[i]; g.KS[i] = KS[i]; g.S[i] = S[i];
+    g.first_block[i] = blocks;
+    blocks += (Cout[i] * C[i] * KS[i] * KS[i] + 255) / 256;
+  }
+  g.first_block[n] = blocks;
+  g.n = n;
+  hipLaunchKernelGGL(conv_b3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  return etm_launch_status();
+}
+
+// y = relu(conv(x) + bias) for the three layers of model.py:29-31 on 84 x 84 observations (arguments as etm_conv_train_fwd, w_b3 from
+// etm_conv_b3_pack); ETM_EUNSUPPORTED for any other geometry.
+extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, int N, int C, int H,
+                               int W, int Cout, int KH, int KW, int S, void *stream) {
+  (void)hipGetLastError();
+  if (!x || !w_b3 || !bias || !y || N <= 0) return ETM_EINVAL;
+  if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)bias % 16) return ETM_EINVAL;
+  if (H != W || KH != KW) return ETM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, y, N, 0};
+  EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
+  if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1>(p, st);
+  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 1>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<false, 64, 9, 3, 1, 64, 4>(p, st);
+  return ETM_EUNSUPPORTED;
+}
+
+// dx = conv_transpose(dy) * (y_below > 0) for layers 2 / 3 (arguments as etm_conv_train_dgrad: C, H, W = the layer INPUT, w_b3 from
+// etm_conv_b3_pack with dgrad = 1).
+extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
+                                 int KH, int KW, int S, void *stream) {
+  (void)hipGetLastError();
+  if (!dy || !w_b3 || !dx || N <= 0) return ETM_EINVAL;
+  if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16) return ETM_EINVAL;
+  if (H != W || KH != KW) return ETM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  B3Args p{dy, nullptr, w_b3, nullptr, y_below, dx, N, 0};
+  EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
+  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<true, 32, 20, 4, 2, 64, 3>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);
+  return ETM_EUNSUPPORTED;
+}

@@ -1,7 +1,7 @@
 // ABI version + error strings of libetm_hip.so.
 #include "etm_common.h"
 
-extern "C" int etm_abi_version(void) { return 45; }
+extern "C" int etm_abi_version(void) { return 46; }
 
 extern "C" const char *etm_error_string(int code) {
   switch (code) {

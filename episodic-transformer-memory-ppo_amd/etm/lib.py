@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libetm_hip.so")     # (diagnostic tools that load another build assign this before load())
-ABI_VERSION = 45
+ABI_VERSION = 46
 
 _lib = None
 
@@ -106,6 +106,9 @@ SIGNATURES = {
     "etm_conv_train_wgrad_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "etm_conv_train_wgrad": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_relu_mask": (_I, [_P, _P, _P, _L, _P]),
+    "etm_conv_b3_pack": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "etm_conv_b3_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_b3_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_grouped_dw_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "etm_grouped_dw_max_problems": (_I, []),
     "etm_grouped_dw": (_I, [_P, _P, _P, _P, _I, _I, _P]),

@@ -545,6 +545,23 @@ int64_t etm_conv_train_wgrad_workspace_bytes(int N, int C, int H, int W, int Cou
 int etm_conv_train_wgrad(const float *x, const int64_t *x_index, const float *dy, float *dw_kc_dbias, float *workspace,
                          int64_t workspace_bytes, int N, int C, int H, int W, int Cout, int KH, int KW, int S, void *stream);
 int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *stream);
+/* ---------------------------------------------------------------------------------------------
+ * The same encoder passes on the bf16 matrix pipe at fp32 accuracy (round 6, csrc/conv_b3.hip; model.py:40-56, :90-92 and their
+ * autograd backward).  Every fp32 operand is split EXACTLY into three bf16 terms and every product accumulated in fp32 as six bf16
+ * MFMA products (v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 16 k against 8 x 64 for v_mfma_f32_32x32x2_f32); the error against
+ * float64 is at or below the fp32 MFMA chain's (tools/microbench/b3_gemm.hip).  x / y / dy / dx / dw stay fp32 NHWC tensors exactly
+ * as for etm_conv_train_*: the split is internal (images once per group at the LDS fill, weights once per step by etm_conv_b3_pack).
+ *   etm_conv_b3_pack : w[i] [Cout, C, KS, KS] -> out[i], 3 * numel bf16 in fragment order ([k / 16][channel tile][plane][lane][8]);
+ *                      dgrad[i] != 0: the backward-data operand of that layer (classes x channels as the output columns).
+ *   etm_conv_b3_fwd  : y = relu(conv(x) + bias), arguments as etm_conv_train_fwd (the three layers of model.py:29-31 on 84 x 84
+ *                      observations; ETM_EUNSUPPORTED otherwise -- the caller keeps the fp32 kernels).
+ *   etm_conv_b3_dgrad: dx = conv_transpose(dy) * (y_below > 0), arguments as etm_conv_train_dgrad (layers 2 / 3). */
+int etm_conv_b3_pack(const float *const *w, uint16_t *const *out, const int *dgrad, const int *Cout, const int *C, const int *KS,
+                     const int *S, int n, void *stream);
+int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, int N, int C, int H, int W,
+                    int Cout, int KH, int KW, int S, void *stream);
+int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
+                      int KH, int KW, int S, void *stream);
 
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */
