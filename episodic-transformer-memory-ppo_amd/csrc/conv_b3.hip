@@ -25,6 +25,7 @@
 // x, y, dy, dx are fp32 NHWC exactly as for etm_conv_train_fwd / _dgrad: the split is internal to the kernels.
 #include "etm_common.h"
 
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -40,6 +41,7 @@ struct B3Args {
   const float *ymask;             // backward-data: output of the layer below (NULL: no mask)
   float *out;
   int N, n_groups;
+  int dbg;                        // ablation switches of tools/conv_b3_check.py (ETM_B3_DBG; 0 in the product)
 };
 
 __device__ __forceinline__ unsigned b3_cvt_pk(float a, float b) {        // two floats -> two bf16 (a in the low half), round to nearest even
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
 
     u32x4 xa[2][3];
     read_x(xa[0], 0, std::integral_constant<int, 0>{});
+    if (!(p.dbg & 8))
     b3_for<KSTEPS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value, s = ks % PD;
       b3_for<TPW>([&](auto tc) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
       }
 #pragma unroll
       for (int u = ks * L::LPK; u < (ks + 1) * L::LPK; ++u)
-        if (u < NQ) fill_load(u, nrx);
+        if (u < NQ && !(p.dbg & 4)) fill_load(u, nrx);
       __builtin_amdgcn_sched_barrier(0);
     });
 
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
       const int m = T_ * 32 + col;
       const int g = m / L::PIX, r = m - g * L::PIX;
       const int n = grp * G + g;
-      if (T_ < L::MT && m < L::M && n < p.N) {
+      if (T_ < L::MT && m < L::M && n < p.N && !(p.dbg & 1)) {
         int o;                                             // byte offset of the lane's first quad
         if (DGRAD) {
           const int cls = ct / (C / 32), py = cls / S, px = cls - py * S;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
     }
 
     __syncthreads();                                       // every wave has read the planes: the next group's take their place
-    fill_to_lds();
+    if (!(p.dbg & 2)) fill_to_lds();
   }
 }
 
@@ -307,6 +310,7 @@ int launch_b3(const B3Args &p0, hipStream_t st) {
   if (G > 1 && p.img_index) return ETM_EUNSUPPORTED;
   if ((long long)p.N * L::HRES * L::HRES * L::CRES * 4 >= 0x7ffffff0ll) return ETM_EUNSUPPORTED;      // 32-bit byte offsets into the result
   p.n_groups = (p.N + G - 1) / G;
+  { const char *e = getenv("ETM_B3_DBG"); p.dbg = e ? atoi(e) : 0; }
   constexpr size_t lds = 3 * (size_t)L::PLANE;
   static_assert(lds <= 160 * 1024, "LDS of a CU");
   auto kern = conv_b3_kernel<L, DGRAD, C, S>;
@@ -386,7 +390,7 @@ extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uin
   if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)bias % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, y, N, 0};
+  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, y, N, 0, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
   if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1>(p, st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 1>(p, st);
@@ -403,7 +407,7 @@ extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const fl
   if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{dy, nullptr, w_b3, nullptr, y_below, dx, N, 0};
+  B3Args p{dy, nullptr, w_b3, nullptr, y_below, dx, N, 0, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<true, 32, 20, 4, 2, 64, 3>(p, st);
   if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);

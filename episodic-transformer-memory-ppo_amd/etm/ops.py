@@ -1131,6 +1131,35 @@ def encoder_train_supported(obs_shape, convs, batch=None):
     return True
 
 
+_encoder_products = "bf16x3"     # "bf16x3": the encoder's products on the bf16 matrix pipe at fp32 accuracy (csrc/conv_b3.hip, round 6);
+#                                    "fp32": v_mfma_f32_32x32x2_f32 (csrc/conv_train.hip and the LDS-resident forms)
+
+
+def set_encoder_products(kind):
+    """trainer.py: ``encoder_products`` ("bf16x3" default, "fp32")."""
+    global _encoder_products
+    if kind not in ("bf16x3", "fp32"):
+        raise ValueError(f"encoder_products must be 'bf16x3' or 'fp32', got {kind!r}")
+    _encoder_products = kind
+
+
+_B3_LAYERS = {(3, 84, 84, 32, 8, 4), (32, 20, 20, 64, 4, 2), (64, 9, 9, 64, 3, 1)}      # (C, H, W, Cout, K, S) of model.py:29-31 on 84 x 84
+
+
+def conv_b3_pack(weights, dgrad, strides):
+    """``weights[i]`` [Cout, C, K, K] -> the three bf16 planes of its forward (``dgrad[i]`` 0) or backward-data (1) operand in
+    fragment order (etm_conv_b3_pack, one launch for all entries): int16 tensors of 3 * numel."""
+    import ctypes
+    lib = _lib.load()
+    n = len(weights)
+    outs = [torch.empty(3 * w.numel(), dtype=torch.int16, device=w.device) for w in weights]
+    vp = lambda ts: (ctypes.c_void_p * n)(*[_ptr(t) for t in ts])
+    ia = lambda vs: (ctypes.c_int32 * n)(*vs)
+    _lib.check(lib.etm_conv_b3_pack(vp(weights), vp(outs), ia(dgrad), ia([w.shape[0] for w in weights]), ia([w.shape[1] for w in weights]),
+                                    ia([w.shape[2] for w in weights]), ia(strides), n, _stream()), "etm_conv_b3_pack")
+    return outs
+
+
 class _EncoderFn(torch.autograd.Function):
     """The three relu(conv2d) layers of model.py:90-92 on NHWC activations: 3 forward launches; backward = 1 mask/layout kernel,
     3 weight-gradient kernels (+ their fixed-order reductions) and 2 data-gradient kernels, with bias, ReLU, ReLU masks and
@@ -1153,20 +1182,34 @@ class _EncoderFn(torch.autograd.Function):
         import ctypes
         layers = ((w1, b1, strides[0]), (w2, b2, strides[1]), (w3, b3, strides[2]))
         wts = [_f32c(wt.detach(), "conv weight") for wt, _, _ in layers]
-        packs = [torch.empty(wt.numel(), dtype=torch.float32, device=x.device) for wt in wts]
-        dgrad_packs = [None] + [torch.empty(wt.numel(), dtype=torch.float32, device=x.device) for wt in wts[1:]]
-        vp = lambda ts: (ctypes.c_void_p * 3)(*[_ptr(t) for t in ts])
-        ia = lambda vs: (ctypes.c_int32 * 3)(*vs)
-        _lib.check(lib.etm_conv_pack_weights_grouped(vp(wts), vp(packs), vp(dgrad_packs), ia([wt.shape[0] for wt in wts]),
-                                                     ia([wt.shape[1] for wt in wts]), ia([wt.shape[2] for wt in wts]),
-                                                     ia([wt.shape[3] for wt in wts]), ia([l[2] for l in layers]), 3, st),
-                   "etm_conv_pack_weights_grouped")
+        geo, hh, ww = [], h, w
+        for wt, _, s in layers:
+            geo.append((wt.shape[1], hh, ww, wt.shape[0], wt.shape[2], s))
+            hh, ww = (hh - wt.shape[2]) // s + 1, (ww - wt.shape[3]) // s + 1
+        use_b3 = _encoder_products == "bf16x3" and all(g in _B3_LAYERS for g in geo) and all(wt.shape[2] == wt.shape[3] for wt in wts)
+        if use_b3:      # the five operands (three forward, two backward-data) split and packed in ONE launch
+            packs = conv_b3_pack(wts + wts[1:], [0, 0, 0, 1, 1], [l[2] for l in layers] + [l[2] for l in layers[1:]])
+            dgrad_packs = [None] + packs[3:]
+        else:
+            packs = [torch.empty(wt.numel(), dtype=torch.float32, device=x.device) for wt in wts]
+            dgrad_packs = [None] + [torch.empty(wt.numel(), dtype=torch.float32, device=x.device) for wt in wts[1:]]
+            vp = lambda ts: (ctypes.c_void_p * 3)(*[_ptr(t) for t in ts])
+            ia = lambda vs: (ctypes.c_int32 * 3)(*vs)
+            _lib.check(lib.etm_conv_pack_weights_grouped(vp(wts), vp(packs), vp(dgrad_packs), ia([wt.shape[0] for wt in wts]),
+                                                         ia([wt.shape[1] for wt in wts]), ia([wt.shape[2] for wt in wts]),
+                                                         ia([wt.shape[3] for wt in wts]), ia([l[2] for l in layers]), 3, st),
+                       "etm_conv_pack_weights_grouped")
+        ctx.b3 = use_b3
         for i, (wt, bs, s) in enumerate(layers):
             cout, _, kh, kw = wt.shape
             ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
             y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-            _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, x_images, _ptr(packs[i]),
-                                              _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s, 0, st), "etm_conv_train_fwd")
+            if use_b3:
+                _lib.check(lib.etm_conv_b3_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, _ptr(packs[i]), _ptr(_f32c(bs.detach(), "bias")),
+                                               _ptr(y), n, c, h, w, cout, kh, kw, s, st), "etm_conv_b3_fwd")
+            else:
+                _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, x_images, _ptr(packs[i]),
+                                                  _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s, 0, st), "etm_conv_train_fwd")
             shapes.append((c, h, w, cout, kh, kw, s, ho, wo))
             acts.append(y)
             h, w, c = ho, wo, cout
@@ -1215,8 +1258,12 @@ class _EncoderFn(torch.autograd.Function):
                 grads[2 * i + 1] = buf[K * cout:]
             if i > 0:
                 dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
-                _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
-                           "etm_conv_train_dgrad")
+                if ctx.b3:
+                    _lib.check(lib.etm_conv_b3_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
+                               "etm_conv_b3_dgrad")
+                else:
+                    _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
+                               "etm_conv_train_dgrad")
                 dy = dx
         if deferred:
             col.conv_wgrads.extend(deferred)

@@ -7,6 +7,8 @@ from yaml_parser import YamlParser
 from trainer import PPOTrainer
 cfg = YamlParser(os.path.join(REPO, "episodic-transformer-memory-ppo_amd", "configs", "synthetic_minigrid.yaml")).get_config()
 cfg["epochs"] = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if os.environ.get("ETM_ENCODER_PRODUCTS"):
+    cfg["encoder_products"] = os.environ["ETM_ENCODER_PRODUCTS"]      # (A/B of csrc/conv_b3.hip against the fp32-MFMA encoder kernels)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 tr = PPOTrainer(cfg, run_id="prof", device=dev, tensorboard=False)
