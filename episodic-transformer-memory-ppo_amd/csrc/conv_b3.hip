@@ -41,6 +41,7 @@ struct B3Args {
   const float *ymask;             // backward-data: output of the layer below (NULL: no mask)
   float *out;
   int N, n_groups;
+  long long *stamps;              // diagnostic: phase timestamps of wave 0 of workgroups 0 and 1 (ETM_B3_STAMPS; NULL in the product)
   int dbg;                        // ablation switches of tools/conv_b3_check.py (ETM_B3_DBG; 0 in the product)
 };
 
@@ -65,33 +66,43 @@ __device__ __forceinline__ void b3_for(F &&f) { b3_for_impl(f, std::make_integer
 
 // Geometry of one pass.  DGRAD false: forward of Conv2d(C, COUT, KS, S) on HW x HW inputs.  DGRAD true: backward-data of that layer
 // (the LDS image is the gradient of its output, the result its input gradient).
-template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G_>
+// BAND > 0 (forward): a unit of work is a band of BAND output rows of one image -- its (BAND - 1) S + KS input rows -- instead of the whole
+// image (layer 1: half an observation, 66.5 KB, so that two workgroups share a CU and one's fill / stores run under the other's MFMAs).
+// WPC: workgroups per CU the register allocation leaves room for.
+template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G_, int BAND = 0, int WPC_ = 1>
 struct B3Geo {
-  static constexpr int G = G_;
+  static constexpr int G = G_, WPC = WPC_;
   static constexpr int HOUT = (HW - KS) / S + 1;                 // output size of the layer
   static constexpr int T = KS / S;                               // backward-data: taps per dimension and class
   static constexpr int CI = DGRAD ? COUT : C;                    // channels of the LDS-resident image
   static constexpr int HI = DGRAD ? HOUT : HW;                   // its size in memory
   static constexpr bool THREE = CI == 3;                         // layer 1: 3 channels, the image stays in its memory order
   static constexpr int RS = DGRAD ? HI + T - 1 : HI;             // LDS row stride in pixel slots
-  static constexpr int SLOTS = DGRAD ? (HI + 2 * (T - 1) - 1) * RS + HI + 2 * (T - 1) : HI * HI;
+  static constexpr int NB = BAND > 0 ? HOUT / BAND : 1;          // units per image
+  static constexpr int HROWS = BAND > 0 ? (BAND - 1) * S + KS : HI;      // image rows of a unit in LDS
+  static constexpr int ROW0 = BAND * S;                          // first image row of unit b: b ROW0
+  static constexpr int SLOTS = DGRAD ? (HI + 2 * (T - 1) - 1) * RS + HI + 2 * (T - 1) : HROWS * HI;
   static constexpr int CPB = THREE ? 6 : (CI + 8) * 2;           // bytes per pixel slot and plane
   static constexpr int IMGB = (SLOTS * CPB + 15) / 16 * 16;      // bytes per image and plane
   static constexpr int PLANE = G * IMGB;
   static constexpr int HO = DGRAD ? HI + T - 1 : HOUT;           // result pixels per row (backward-data: per class)
-  static constexpr int PIX = HO * HO, M = G * PIX, MT = (M + 31) / 32;
+  static constexpr int PIXI = HO * HO;                           // result pixels per image (and class)
+  static constexpr int PIX = BAND > 0 ? BAND * HO : PIXI, M = G * PIX, MT = (M + 31) / 32;      // ... per unit, per group
   static constexpr int NOUT = DGRAD ? S * S * C : COUT;          // output channels of the GEMM (backward-data: class x channel)
   static constexpr int NT = NOUT / 32, RP = NT >= 4 ? 1 : 4 / NT, TPW = (MT + RP - 1) / RP;
   static constexpr int TAPS = DGRAD ? T : KS;                    // window size per dimension
   static constexpr int K = TAPS * TAPS * CI, KSTEPS = K / 16;
   static constexpr int KPT = THREE ? 1 : CI / 16;                // k steps per tap
   static constexpr int Q_IMG = HI * HI * CI / 4;                 // float4 per image in memory
-  static constexpr int NQ = (G * Q_IMG + 255) / 256;             // float4 per thread and group
+  static constexpr int Q_UNIT = HROWS * HI * CI / 4;             // ... per unit
+  static constexpr int Q_ROW0 = ROW0 * HI * CI / 4;              // first float4 of unit b inside its image: b Q_ROW0
+  static constexpr int NQ = (G * Q_UNIT + 255) / 256;            // float4 per thread and group
   static constexpr int LPK = (NQ + KSTEPS - 1) / KSTEPS;         // next-group loads issued per k step
   static constexpr int HRES = DGRAD ? S * HO : HO;               // result image size
   static constexpr int CRES = DGRAD ? C : COUT;                  // result channels
   static_assert(K % 16 == 0 && NOUT % 32 == 0 && (THREE || CI % 16 == 0) && (NT == 1 || NT == 2 || NT == 4), "layer geometry");
   static_assert(!DGRAD || (HW % S == 0 && KS % S == 0 && HI + T - 1 == HW / S), "backward-data: class grids tile the input");
+  static_assert(BAND == 0 || (!DGRAD && G == 1 && HOUT % BAND == 0 && (ROW0 * HI * CI) % 4 == 0 && (HROWS * HI * CI) % 4 == 0), "bands: forward, one unit per group");
 
   // pixel slot of memory pixel (y, x)
   static constexpr int slot(int y, int x) {
@@ -109,13 +120,18 @@ struct B3Geo {
 };
 
 template <class L, bool DGRAD, int C, int S>
-__global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
+__global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
   constexpr int G = L::G, TPW = L::TPW, NT = L::NT, RP = L::RP, KSTEPS = L::KSTEPS, NQ = L::NQ, PD = 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // three planes of [G] images
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave % NT, rp = wave / NT;
 
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (p.stamps && blockIdx.x < 2 && tid == 0 && n_stamp < 64) p.stamps[blockIdx.x * 64 + n_stamp++] = __builtin_readcyclecounter();
+  };
+  stamp();
   if (DGRAD) {                                             // the borders stay zero for the whole launch
     for (int e = tid; e < 3 * L::PLANE / 16; e += 256) reinterpret_cast<u32x4 *>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
   // ---- fill: this thread's float4 u of a group -> LDS byte offset inside a plane
   auto fill_dst = [&](int u) {
     const int q = tid + u * 256;
-    const int g = q / L::Q_IMG, qi = q - g * L::Q_IMG;
+    const int g = q / L::Q_UNIT, qi = q - g * L::Q_UNIT;
     if (L::THREE) return g * L::IMGB + qi * 8;
     const int pix = qi / (L::CI / 4), c4 = qi - pix * (L::CI / 4), y = pix / L::HI, x = pix - y * L::HI;
     return g * L::IMGB + L::slot(y, x) * L::CPB + c4 * 8;
@@ -150,16 +166,17 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
   // are still issued and return zeros without touching memory)
   auto group_rsrc = [&](int grp) {
     const bool exists = grp < p.n_groups;
-    const int n0 = exists ? grp * G : 0;
+    const int u0 = exists ? grp * G : 0;                   // first unit of the group; unit u = band u % NB of image u / NB
+    const int n0 = u0 / L::NB, b0 = u0 - n0 * L::NB;
     const long long src = (G == 1 && p.img_index) ? p.img_index[n0] : (long long)n0;
-    const int images = exists ? min(G, p.N - n0) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + src * (L::Q_IMG * 4)), 0, images * L::Q_IMG * 16, 0x00020000);
+    const int units = exists ? min(G, p.N * L::NB - u0) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + src * (L::Q_IMG * 4) + b0 * (L::Q_ROW0 * 4)), 0, units * L::Q_UNIT * 16, 0x00020000);
   };
   f32x4 fill[NQ];
   auto fill_to_lds = [&]() {
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      if (tid + u * 256 < G * L::Q_IMG) {
+      if (tid + u * 256 < G * L::Q_UNIT) {
         unsigned h0, m0, l0, h1, m1, l1;
         b3_split_pair(fill[u][0], fill[u][1], h0, m0, l0);
         b3_split_pair(fill[u][2], fill[u][3], h1, m1, l1);
@@ -179,7 +196,9 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
     const __amdgpu_buffer_rsrc_t rx = group_rsrc(grp);
 #pragma unroll
     for (int u = 0; u < NQ; ++u) fill_load(u, rx);
+    stamp();
     fill_to_lds();
+    stamp();
   }
   // bias of this lane's channels: accumulator quad j = channels ct * 32 + 8 j + 4 half + (0..3)
   f32x4 bias4[4];
@@ -196,6 +215,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
 
   for (; grp < p.n_groups; grp += gridDim.x) {
     __syncthreads();                                       // the group's planes are in LDS
+    stamp();
     const __amdgpu_buffer_rsrc_t nrx = group_rsrc(grp + gridDim.x);
     f32x16 acc[TPW];
 #pragma unroll
@@ -260,13 +280,14 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
       __builtin_amdgcn_sched_barrier(0);
     });
 
+    stamp();
     // ---- results: accumulator quad j of tile t = 4 consecutive channels of pixel (tile, col)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int T_ = rp + t * RP;
       const int m = T_ * 32 + col;
       const int g = m / L::PIX, r = m - g * L::PIX;
-      const int n = grp * G + g;
+      const int unit = grp * G + g, n = unit / L::NB, band = unit - n * L::NB;
       if (T_ < L::MT && m < L::M && n < p.N && !(p.dbg & 1)) {
         int o;                                             // byte offset of the lane's first quad
         if (DGRAD) {
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
           const int cy = r / L::HO, cx = r - cy * L::HO;
           o = ((((n * L::HRES + S * cy + py) * L::HRES + S * cx + px) * C + (ct % (C / 32)) * 32 + 4 * half)) * 4;
         } else {
-          o = ((n * L::PIX + r) * L::CRES + ct * 32 + 4 * half) * 4;
+          o = ((n * L::PIXI + band * L::PIX + r) * L::CRES + ct * 32 + 4 * half) * 4;
         }
         f32x4 mk[4];
         if (DGRAD && p.ymask) {
@@ -298,25 +319,29 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const B3Args p) {
       }
     }
 
+    stamp();
     __syncthreads();                                       // every wave has read the planes: the next group's take their place
+    stamp();
     if (!(p.dbg & 2)) fill_to_lds();
+    stamp();
   }
 }
 
-template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G>
+template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G, int BAND = 0, int WPC = 1>
 int launch_b3(const B3Args &p0, hipStream_t st) {
-  using L = B3Geo<DGRAD, C, HW, KS, S, COUT, G>;
+  using L = B3Geo<DGRAD, C, HW, KS, S, COUT, G, BAND, WPC>;
   B3Args p = p0;
   if (G > 1 && p.img_index) return ETM_EUNSUPPORTED;
   if ((long long)p.N * L::HRES * L::HRES * L::CRES * 4 >= 0x7ffffff0ll) return ETM_EUNSUPPORTED;      // 32-bit byte offsets into the result
-  p.n_groups = (p.N + G - 1) / G;
+  p.n_groups = (p.N * L::NB + G - 1) / G;
   { const char *e = getenv("ETM_B3_DBG"); p.dbg = e ? atoi(e) : 0; }
+  { const char *e = getenv("ETM_B3_STAMPS"); p.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
   constexpr size_t lds = 3 * (size_t)L::PLANE;
-  static_assert(lds <= 160 * 1024, "LDS of a CU");
+  static_assert(lds * WPC <= 160 * 1024, "LDS of a CU");
   auto kern = conv_b3_kernel<L, DGRAD, C, S>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  const int grid = p.n_groups < 256 ? p.n_groups : 256;
+  const int grid = p.n_groups < 256 * WPC ? p.n_groups : 256 * WPC;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
   return etm_launch_status();
 }
@@ -390,11 +415,12 @@ extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uin
   if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)bias % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, y, N, 0, 0};
+  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, y, N, 0, nullptr, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
-  if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1>(p, st);
+  static const int var = getenv("ETM_B3_VAR") ? atoi(getenv("ETM_B3_VAR")) : 1;
+  if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return (var & 1) ? launch_b3<false, 3, 84, 8, 4, 32, 1, 10, 2>(p, st) : launch_b3<false, 3, 84, 8, 4, 32, 1>(p, st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 1>(p, st);
-  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<false, 64, 9, 3, 1, 64, 4>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return (var & 2) ? launch_b3<false, 64, 9, 3, 1, 64, 2, 0, 2>(p, st) : launch_b3<false, 64, 9, 3, 1, 64, 4>(p, st);
   return ETM_EUNSUPPORTED;
 }
 
@@ -407,9 +433,10 @@ extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const fl
   if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{dy, nullptr, w_b3, nullptr, y_below, dx, N, 0, 0};
+  B3Args p{dy, nullptr, w_b3, nullptr, y_below, dx, N, 0, nullptr, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
-  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<true, 32, 20, 4, 2, 64, 3>(p, st);
-  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);
+  static const int var = getenv("ETM_B3_VAR") ? atoi(getenv("ETM_B3_VAR")) : 1;
+  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return (var & 4) ? launch_b3<true, 32, 20, 4, 2, 64, 1, 0, 2>(p, st) : launch_b3<true, 32, 20, 4, 2, 64, 3>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return (var & 8) ? launch_b3<true, 64, 9, 3, 1, 64, 1, 0, 3>(p, st) : (var & 16) ? launch_b3<true, 64, 9, 3, 1, 64, 2, 0, 1>(p, st) : launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);
   return ETM_EUNSUPPORTED;
 }

@@ -1243,16 +1243,32 @@ class _EncoderFn(torch.autograd.Function):
         for i in (2, 1, 0):
             c, h, w, cout, kh, kw, s, ho, wo = ctx.shapes[i]
             K = kh * kw * c
-            nbytes = lib.etm_conv_train_wgrad_workspace_bytes(n, c, h, w, cout, kh, kw, s)
+            if ctx.b3:
+                slices = lib.etm_conv_b3_wgrad_slices(n, c, h, w, cout, kh, kw, s)
+                nbytes = slices * (K * cout + cout) * 4
+            else:
+                slices = lib.etm_conv_train_wgrad_slices(n, c, h, w, cout, kh, kw, s)
+                nbytes = lib.etm_conv_train_wgrad_workspace_bytes(n, c, h, w, cout, kh, kw, s)
             if dests is not None:
                 ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)      # (lives until the collector's flush)
                 buf = None
-                deferred.append((ws, lib.etm_conv_train_wgrad_slices(n, c, h, w, cout, kh, kw, s), dests[2 * i], dests[2 * i + 1], cout, c, kh, kw))
+                deferred.append((ws, slices, dests[2 * i], dests[2 * i + 1], cout, c, kh, kw))
             else:
                 ws = workspace(nbytes, dev, "conv_wgrad")
                 buf = torch.empty(K * cout + cout, dtype=torch.float32, device=dev)
-            _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w,
-                                                cout, kh, kw, s, st), "etm_conv_train_wgrad")
+            if ctx.b3:      # the slices on the bf16 matrix pipe (csrc/conv_b3_wgrad.hip); without a collector their reduction follows at once
+                _lib.check(lib.etm_conv_b3_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(ws), nbytes, n, c, h, w,
+                                                 cout, kh, kw, s, st), "etm_conv_b3_wgrad")
+                if buf is not None:
+                    import ctypes
+                    one = lambda ct, v: (ct * 1)(v)
+                    _lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, _ptr(ws)), one(ctypes.c_int32, slices), one(ctypes.c_void_p, _ptr(buf)),
+                                                                 one(ctypes.c_void_p, buf.data_ptr() + K * cout * 4), one(ctypes.c_int32, cout),
+                                                                 one(ctypes.c_int32, c), one(ctypes.c_int32, kh), one(ctypes.c_int32, kw), 1, st),
+                               "etm_conv_wgrad_reduce_grouped")
+            else:
+                _lib.check(lib.etm_conv_train_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(buf), _ptr(ws), nbytes, n, c, h, w,
+                                                    cout, kh, kw, s, st), "etm_conv_train_wgrad")
             if buf is not None:
                 grads[2 * i] = buf[: K * cout].view(cout, c, kh, kw)
                 grads[2 * i + 1] = buf[K * cout:]

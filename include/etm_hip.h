@@ -562,6 +562,13 @@ int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3
                     int Cout, int KH, int KW, int S, void *stream);
 int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
                       int KH, int KW, int S, void *stream);
+/*   etm_conv_b3_wgrad: the weight-gradient slices of one layer (csrc/conv_b3_wgrad.hip: both images NHWC in LDS as bf16 planes, the
+ *                      pixel contraction fed by transposing LDS reads): workspace [etm_conv_b3_wgrad_slices(...)][K * Cout + Cout], dW in
+ *                      (k, co) order (k = (ky, kx, c)) followed by the column sums of dy -- the layout etm_conv_wgrad_reduce_grouped
+ *                      sums.  x / x_index / dy as etm_conv_train_wgrad. */
+int etm_conv_b3_wgrad_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
+int etm_conv_b3_wgrad(const float *x, const int64_t *x_index, const float *dy, float *workspace, int64_t workspace_bytes, int N, int C,
+                      int H, int W, int Cout, int KH, int KW, int S, void *stream);
 
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */

@@ -459,6 +459,7 @@ _ROLLOUT_PATHS = {
     "window_row_stats": {"bank_row_stats": False},      # norm_kv statistics per window row inside the passes (default: once per bank row)
     "generic_ln_grad": {"fused_ln_grad": False},
     "rows_ln_grad": {"fused_ln_grad": "rows"},           # norm_kv's gradients by round 5's pass over the window rows (default since round 6: from the passes' outputs)
+    "fp32_encoder": {"encoder_products": "fp32"},        # round 6: the fp32-MFMA encoder kernels in the optimisation phase (default: the bf16 matrix pipe at fp32 accuracy, csrc/conv_b3*.hip)
     "worker_processes": {"worker_processes": True},
     "worker_processes_k4": {"worker_processes": True, "envs_per_process": 4, "rollout_groups": 4, "rollout_min_group_size": 2},
     "worker_processes_eager": {"worker_processes": True, "envs_per_process": 2, "hip_graph_rollout": False},
@@ -473,7 +474,8 @@ _TF_CASES = [("vec", "default"), ("vec", "eager"), ("gtrxl", "default"), ("gtrxl
              ("img32", "separate_heads"), ("cfg3", "separate_heads"), ("img32", "four_groups"), ("cfg3", "four_groups"), ("img32", "uploaded_rows"), ("cfg3", "uploaded_rows"), ("cfg5", "uploaded_rows"),
              ("img32", "worker_processes"), ("img32", "worker_processes_k4"), ("cfg3", "worker_processes"), ("cfg3", "worker_processes_k4"),
              ("vec", "worker_processes"), ("img32", "worker_processes_eager"), ("cfg5", "worker_processes"),
-             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("cfg2", "window_row_stats"), ("cfg2", "generic_ln_grad"), ("cfg5", "rows_ln_grad"), ("gtrxl", "rows_ln_grad"), ("cfg5", "window_row_stats")]
+             ("img32", "kslice_hidden"), ("cfg3", "kslice_hidden"), ("cfg5", "kslice_hidden"), ("cfg2", "window_row_stats"), ("cfg2", "generic_ln_grad"), ("cfg5", "rows_ln_grad"), ("gtrxl", "rows_ln_grad"), ("cfg5", "window_row_stats"),
+             ("cfg3", "fp32_encoder"), ("cfg5", "fp32_encoder")]
 
 
 def movement_error(sd, z, tag, keys, prev):

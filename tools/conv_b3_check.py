@@ -89,5 +89,37 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
         etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), None, P(dxn), N, c, h, w, cout, k, k, s, st), "b3 dgrad nomask")
         refn = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1)
         print(f"conv{li + 1} bwd-data without mask: err vs float64 {rel(dxn[sel], refn):.2e}", flush=True)
+    # ---- backward-weight (slices + the grouped reduction, both paths)
+    K = k * k * c
+    buf32 = torch.empty(K * cout + cout, device=dev)
+    nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, h, w, cout, k, k, s)
+    ws32 = torch.empty(max(nbytes, 8) // 4, device=dev)
+    w32 = lambda: etm_lib.check(lib.etm_conv_train_wgrad(P(x), None, P(dy), P(buf32), P(ws32), nbytes, N, c, h, w, cout, k, k, s, st), "wgrad")
+    slices = lib.etm_conv_b3_wgrad_slices(N, c, h, w, cout, k, k, s)
+    ws3 = torch.full((slices * (K * cout + cout),), float("nan"), device=dev)
+    dw3 = torch.full((cout, c, k, k), float("nan"), device=dev); db3 = torch.full((cout,), float("nan"), device=dev)
+    one = lambda ct, v: (ct * 1)(v)
+    def wb3(xi=None):
+        etm_lib.check(lib.etm_conv_b3_wgrad(P(x), xi, P(dy), P(ws3), ws3.numel() * 4, N, c, h, w, cout, k, k, s, st), "b3 wgrad")
+        etm_lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, P(ws3)), one(ctypes.c_int32, slices), one(ctypes.c_void_p, P(dw3)),
+                                                        one(ctypes.c_void_p, P(db3)), one(ctypes.c_int32, cout), one(ctypes.c_int32, c),
+                                                        one(ctypes.c_int32, k), one(ctypes.c_int32, k), 1, st), "reduce")
+    w32(); wb3(); torch.cuda.synchronize()
+    cols = F.unfold(x.permute(0, 3, 1, 2).double(), k, stride=s)                       # [N, c k k, pixels], float64 on the device
+    ref_dw = torch.einsum("nkp,npo->ok", cols, dy.double().reshape(N, ho * wo, cout)).reshape(cout, c, k, k).cpu()
+    ref_db = dy.double().sum((0, 1, 2)).cpu()
+    del cols
+    dw32 = buf32[: K * cout].view(cout, c, k, k)
+    line = (f"conv{li + 1} bwd-weight: err vs float64  fp32 MFMA {rel(dw32, ref_dw):.2e}   bf16x3 {rel(dw3, ref_dw):.2e}   bias gradient fp32 {rel(buf32[K * cout:], ref_db):.2e}"
+            f"   bf16x3 path {rel(db3, ref_db):.2e}")
+    if "--no-time" not in sys.argv:
+        t0, t1 = timed(w32), timed(wb3); tot_old += t0; tot_new += t1
+        line += f"   {t0:6.1f} -> {t1:6.1f} us  ({fl / t1 / 1e6:5.1f} fp32-equivalent TFLOP/s, reductions included)"
+    print(line, flush=True)
+    if li == 0:
+        idx = torch.arange(N, device=dev)
+        keep = dw3.clone()
+        wb3(P(idx)); torch.cuda.synchronize()
+        print(f"conv1 bwd-weight through x_index (identity): identical {bool((dw3 == keep).all().item())}")
 if "--no-time" not in sys.argv:
     print(f"sum of the passes above: fp32 MFMA {tot_old:.1f} us -> bf16x3 {tot_new:.1f} us")

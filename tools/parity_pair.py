@@ -40,6 +40,8 @@ PATHS = {
     "multi_launch_blocks": {"fused_rollout_block": False},
     "window_row_stats": {"bank_row_stats": False},      # (optimisation phase: norm_kv statistics per window row)
     "window_row_stats_eager": {"bank_row_stats": False, "hip_graph_rollout": False},
+    "fp32_encoder": {"encoder_products": "fp32"},      # (optimisation phase: the fp32-MFMA encoder kernels instead of csrc/conv_b3*.hip)
+    "fp32_encoder_eager": {"encoder_products": "fp32", "hip_graph_rollout": False},
 }
 OUT = []
 
