@@ -38,7 +38,9 @@ struct B3Args {
   const long long *img_index;     // forward, optional (one image per group only): image n of the batch = x image img_index[n]
   const unsigned short *wp;       // etm_conv_b3_pack
   const float *bias;              // forward
-  const float *ymask;             // backward-data: output of the layer below (NULL: no mask)
+  const float *ymask;             // backward-data: output of the layer below (NULL: no mask, or the bits below)
+  const unsigned *bits_in;        // backward-data: its ReLU pattern as written by the forward pass (one bit per element), instead of ymask
+  unsigned *bits_out;             // forward, optional: bit c of word [n][y][x][c / 32] = (y[n, y, x, c] > 0)
   float *out;
   int N, n_groups;
   long long *stamps;              // diagnostic: phase timestamps of wave 0 of workgroups 0 and 1 (ETM_B3_STAMPS; NULL in the product)
@@ -154,6 +156,26 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
     }
   }
 
+  // ---- per tile: byte offset of the lane's first result quad inside its group's block of the result (-1: no such pixel) and the
+  // unit (image / band) of the group it belongs to
+  int o_t[TPW], g_t[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int T_ = rp + t * RP, m = T_ * 32 + col;
+    const int g = m / L::PIX, r = m - g * L::PIX;
+    int o;
+    if (DGRAD) {
+      constexpr int CT_ = C >= 32 ? C / 32 : 1;            // channel tiles per class
+      const int cls = ct / CT_, py = cls / S, px = cls - py * S;
+      const int cy = r / L::HO, cx = r - cy * L::HO;
+      o = (((g * L::HRES + S * cy + py) * L::HRES + S * cx + px) * C + (ct % CT_) * 32 + 4 * half) * 4;
+    } else {
+      o = (((L::NB > 1 ? 0 : g * L::PIXI) + r) * L::CRES + ct * 32 + 4 * half) * 4;
+    }
+    o_t[t] = (T_ < L::MT && m < L::M) ? o : -1;
+    g_t[t] = g;
+  }
+
   // ---- fill: this thread's float4 u of a group -> LDS byte offset inside a plane
   auto fill_dst = [&](int u) {
     const int q = tid + u * 256;
@@ -173,6 +195,9 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + src * (L::Q_IMG * 4) + b0 * (L::Q_ROW0 * 4)), 0, units * L::Q_UNIT * 16, 0x00020000);
   };
   f32x4 fill[NQ];
+  int fdst[NQ];                                            // (the decode costs ~ 20 vector-ALU operations per float4: once, not once per group)
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) fdst[u] = fill_dst(u);
   auto fill_to_lds = [&]() {
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
         unsigned h0, m0, l0, h1, m1, l1;
         b3_split_pair(fill[u][0], fill[u][1], h0, m0, l0);
         b3_split_pair(fill[u][2], fill[u][3], h1, m1, l1);
-        const int d = fill_dst(u);
+        const int d = fdst[u];
         *reinterpret_cast<u32x2 *>(lds + d) = u32x2{h0, h1};
         *reinterpret_cast<u32x2 *>(lds + L::PLANE + d) = u32x2{m0, m1};
         *reinterpret_cast<u32x2 *>(lds + 2 * L::PLANE + d) = u32x2{l0, l1};
@@ -212,16 +237,36 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)((long long)p.N * L::HRES * L::HRES * L::CRES * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ymask ? p.ymask : p.out), 0,
                                                                        p.ymask ? (int)((long long)p.N * L::HRES * L::HRES * L::CRES * 4) : 0, 0x00020000);
+  // ReLU pattern words: one per 32 channels of a pixel, i.e. word index = (byte offset of the lane's quad in the result) >> 7
+  const unsigned *bits_p = DGRAD ? p.bits_in : p.bits_out;
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(bits_p ? (const void *)bits_p : (const void *)p.out), 0,
+                                                                       bits_p ? (int)((long long)p.N * L::HRES * L::HRES * L::CRES / 8) : 0, 0x00020000);
 
   for (; grp < p.n_groups; grp += gridDim.x) {
     __syncthreads();                                       // the group's planes are in LDS
     stamp();
     const __amdgpu_buffer_rsrc_t nrx = group_rsrc(grp + gridDim.x);
-    f32x16 acc[TPW];
+    // byte offsets of the lane's results (outside the descriptors for what does not exist: stores dropped, loads return zeros)
+    int o[TPW];
+    unsigned relu_bits[TPW];
+    {
+      const int u0 = grp * G, units = min(G, p.N * L::NB - u0);
+      const int n0 = u0 / L::NB, b0 = u0 - n0 * L::NB;
+      const int gbase = DGRAD ? n0 * (L::HRES * L::HRES * C * 4) : (n0 * L::PIXI + b0 * L::PIX) * (L::CRES * 4);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) o[t] = (o_t[t] >= 0 && g_t[t] < units && !(p.dbg & 1)) ? o_t[t] + gbase : 0x7ffffff0;
+      if (DGRAD && p.bits_in) {                            // (requested in front of the k loop: nothing waits for them)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) relu_bits[t] = __builtin_amdgcn_raw_buffer_load_b32(rb, (o[t] >> 7) << 2, 0, 0);
+      }
+    }
+    // two accumulators per tile: the leading product w1 x1, and the five small products together (the bf16 MFMA's accumulate step
+    // does not round to nearest: kept out of the large sums, the small products cost no accuracy -- conv_b3_wgrad.hip)
+    f32x16 acc[TPW], acs[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[t][r] = acs[t][r] = 0.f;
     u32x4 b[PD][3];
 #pragma unroll
     for (int s = 0; s < PD; ++s)
@@ -261,11 +306,11 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 w1 = __builtin_bit_cast(bf16x8, b[s][0]), w2 = __builtin_bit_cast(bf16x8, b[s][1]), w3 = __builtin_bit_cast(bf16x8, b[s][2]);
         const bf16x8 x1 = __builtin_bit_cast(bf16x8, xa[cur][0]), x2 = __builtin_bit_cast(bf16x8, xa[cur][1]), x3 = __builtin_bit_cast(bf16x8, xa[cur][2]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc[t], 0, 0, 0);
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acs[t], 0, 0, 0);
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acs[t], 0, 0, 0);
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acs[t], 0, 0, 0);
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acs[t], 0, 0, 0);
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acs[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -281,40 +326,47 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
     });
 
     stamp();
-    // ---- results: accumulator quad j of tile t = 4 consecutive channels of pixel (tile, col)
+    // ---- results: accumulator quad j of tile t = 4 consecutive channels of pixel (tile, col).  Offsets outside the descriptors for what
+    // does not exist (stores dropped, mask loads return zeros); all mask loads of the group are requested before the first store (a
+    // load behind a store waits for the store: vmcnt is one in-order counter)
+    {
+      // (the mask loads run one tile ahead of the stores: a load behind a store would wait for the store -- vmcnt is one in-order counter --
+      // and a whole group's masks would be 16 registers per tile)
+      f32x4 mk[2][4];
+      auto mask_load = [&](int t) {
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int T_ = rp + t * RP;
-      const int m = T_ * 32 + col;
-      const int g = m / L::PIX, r = m - g * L::PIX;
-      const int unit = grp * G + g, n = unit / L::NB, band = unit - n * L::NB;
-      if (T_ < L::MT && m < L::M && n < p.N && !(p.dbg & 1)) {
-        int o;                                             // byte offset of the lane's first quad
-        if (DGRAD) {
-          const int cls = ct / (C / 32), py = cls / S, px = cls - py * S;
-          const int cy = r / L::HO, cx = r - cy * L::HO;
-          o = ((((n * L::HRES + S * cy + py) * L::HRES + S * cx + px) * C + (ct % (C / 32)) * 32 + 4 * half)) * 4;
-        } else {
-          o = ((n * L::PIXI + band * L::PIX + r) * L::CRES + ct * 32 + 4 * half) * 4;
-        }
-        f32x4 mk[4];
-        if (DGRAD && p.ymask) {
+        for (int j = 0; j < 4; ++j) mk[t & 1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, o[t] + 32 * j, 0, 0));
+      };
+      const bool by_values = DGRAD && p.ymask && !p.bits_in;
+      if (by_values) mask_load(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) mk[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, o + 32 * j, 0, 0));
-        }
+      for (int t = 0; t < TPW; ++t) {
+        if (by_values && t + 1 < TPW) mask_load(t + 1);
+        unsigned pattern = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 v{acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]};
+          f32x4 v{acc[t][4 * j] + acs[t][4 * j], acc[t][4 * j + 1] + acs[t][4 * j + 1], acc[t][4 * j + 2] + acs[t][4 * j + 2], acc[t][4 * j + 3] + acs[t][4 * j + 3]};
           if (DGRAD) {
-            if (p.ymask) {
+            if (p.bits_in) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = mk[j][q] > 0.f ? v[q] : 0.f;
+              for (int q = 0; q < 4; ++q) v[q] = ((relu_bits[t] >> (8 * j + 4 * half + q)) & 1u) ? v[q] : 0.f;
+            } else if (p.ymask) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = mk[t & 1][j][q] > 0.f ? v[q] : 0.f;
             }
           } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] + bias4[j][q], 0.f);
+            for (int q = 0; q < 4; ++q) {
+              v[q] = fmaxf(v[q] + bias4[j][q], 0.f);
+              pattern |= (v[q] > 0.f ? 1u : 0u) << (8 * j + q);
+            }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o + 32 * j, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, o[t] + 32 * j, 0, 0);
+        }
+        if (!DGRAD && p.bits_out) {                        // the two half-waves hold channels 8 j + (0..3) / 8 j + 4 + (0..3) of the same pixel
+          pattern <<= 4 * half;
+          pattern |= (unsigned)__shfl_xor((int)pattern, 32, 64);
+          __builtin_amdgcn_raw_buffer_store_b32(pattern, rb, half ? 0x7ffffff0 : ((o[t] >> 7) << 2), 0, 0);
         }
       }
     }
@@ -407,36 +459,37 @@ extern "C" int etm_conv_b3_pack(const float *const *w, uint16_t *const *out, con
 }
 
 // y = relu(conv(x) + bias) for the three layers of model.py:29-31 on 84 x 84 observations (arguments as etm_conv_train_fwd, w_b3 from
-// etm_conv_b3_pack); ETM_EUNSUPPORTED for any other geometry.
-extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, int N, int C, int H,
-                               int W, int Cout, int KH, int KW, int S, void *stream) {
+// etm_conv_b3_pack); ETM_EUNSUPPORTED for any other geometry.  relu_bits (optional): N * Ho * Wo * Cout / 32 words, bit c % 32 of word
+// [n][y][x][c / 32] = (y > 0) -- what etm_conv_b3_dgrad of the layer ABOVE needs of y (1 / 32 of the bytes).
+extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, uint32_t *relu_bits, int N,
+                               int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
   if (!x || !w_b3 || !bias || !y || N <= 0) return ETM_EINVAL;
   if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)bias % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, y, N, 0, nullptr, 0};
+  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, nullptr, relu_bits, y, N, 0, nullptr, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
-  static const int var = getenv("ETM_B3_VAR") ? atoi(getenv("ETM_B3_VAR")) : 1;
-  if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return (var & 1) ? launch_b3<false, 3, 84, 8, 4, 32, 1, 10, 2>(p, st) : launch_b3<false, 3, 84, 8, 4, 32, 1>(p, st);
+  static const int var = getenv("ETM_B3_VAR") ? atoi(getenv("ETM_B3_VAR")) : 0;      // (A/B switch of tools/conv_b3_check.py)
+  if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1, 10, 2>(p, st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 1>(p, st);
-  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return (var & 2) ? launch_b3<false, 64, 9, 3, 1, 64, 2, 0, 2>(p, st) : launch_b3<false, 64, 9, 3, 1, 64, 4>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return (var & 2) ? launch_b3<false, 64, 9, 3, 1, 64, 4>(p, st) : launch_b3<false, 64, 9, 3, 1, 64, 2, 0, 2>(p, st);
   return ETM_EUNSUPPORTED;
 }
 
 // dx = conv_transpose(dy) * (y_below > 0) for layers 2 / 3 (arguments as etm_conv_train_dgrad: C, H, W = the layer INPUT, w_b3 from
-// etm_conv_b3_pack with dgrad = 1).
-extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
-                                 int KH, int KW, int S, void *stream) {
+// etm_conv_b3_pack with dgrad = 1).  The ReLU pattern of the layer below: relu_bits (from its etm_conv_b3_fwd) if given, else y_below's
+// values, else none.
+extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, const uint32_t *relu_bits, float *dx, int N, int C,
+                                 int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
   if (!dy || !w_b3 || !dx || N <= 0) return ETM_EINVAL;
-  if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16) return ETM_EINVAL;
+  if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16 || (uintptr_t)relu_bits % 4) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{dy, nullptr, w_b3, nullptr, y_below, dx, N, 0, nullptr, 0};
+  B3Args p{dy, nullptr, w_b3, nullptr, y_below, relu_bits, nullptr, dx, N, 0, nullptr, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
-  static const int var = getenv("ETM_B3_VAR") ? atoi(getenv("ETM_B3_VAR")) : 1;
-  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return (var & 4) ? launch_b3<true, 32, 20, 4, 2, 64, 1, 0, 2>(p, st) : launch_b3<true, 32, 20, 4, 2, 64, 3>(p, st);
-  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return (var & 8) ? launch_b3<true, 64, 9, 3, 1, 64, 1, 0, 3>(p, st) : (var & 16) ? launch_b3<true, 64, 9, 3, 1, 64, 2, 0, 1>(p, st) : launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);
+  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<true, 32, 20, 4, 2, 64, 1, 0, 1>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);
   return ETM_EUNSUPPORTED;
 }

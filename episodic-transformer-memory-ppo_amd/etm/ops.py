@@ -1200,13 +1200,16 @@ class _EncoderFn(torch.autograd.Function):
                                                          ia([wt.shape[3] for wt in wts]), ia([l[2] for l in layers]), 3, st),
                        "etm_conv_pack_weights_grouped")
         ctx.b3 = use_b3
+        relu_bits = []      # (b3: the ReLU pattern of every layer's output, one bit per element -- what backward-data needs of it)
         for i, (wt, bs, s) in enumerate(layers):
             cout, _, kh, kw = wt.shape
             ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
             y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
             if use_b3:
+                bits = torch.empty((n, ho, wo, cout // 32), dtype=torch.int32, device=x.device) if i < 2 else None
+                relu_bits.append(bits)
                 _lib.check(lib.etm_conv_b3_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, _ptr(packs[i]), _ptr(_f32c(bs.detach(), "bias")),
-                                               _ptr(y), n, c, h, w, cout, kh, kw, s, st), "etm_conv_b3_fwd")
+                                               _ptr(y), _ptr(bits), n, c, h, w, cout, kh, kw, s, st), "etm_conv_b3_fwd")
             else:
                 _lib.check(lib.etm_conv_train_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, x_images, _ptr(packs[i]),
                                                   _ptr(_f32c(bs.detach(), "bias")), _ptr(y), n, c, h, w, cout, kh, kw, s, 0, st), "etm_conv_train_fwd")
@@ -1215,13 +1218,14 @@ class _EncoderFn(torch.autograd.Function):
             h, w, c = ho, wo, cout
         ctx.param_ptrs = tuple(t.data_ptr() for t in (w1, b1, w2, b2, w3, b3))
         ctx.shapes = shapes
-        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2], index)
+        ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2], index,
+                              *(relu_bits[:2] if use_b3 else (None, None)))
         return acts[3].view(n, -1)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x0, y1, y2, y3, pd2, pd3, index = ctx.saved_tensors
+        x0, y1, y2, y3, pd2, pd3, index, bits1, bits2 = ctx.saved_tensors
         st = _stream()
         dev = x0.device
         n = y1.shape[0]
@@ -1275,8 +1279,8 @@ class _EncoderFn(torch.autograd.Function):
             if i > 0:
                 dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
                 if ctx.b3:
-                    _lib.check(lib.etm_conv_b3_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
-                               "etm_conv_b3_dgrad")
+                    _lib.check(lib.etm_conv_b3_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr((None, bits1, bits2)[i]), _ptr(dx), n, c, h, w,
+                                                     cout, kh, kw, s, st), "etm_conv_b3_dgrad")
                 else:
                     _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
                                "etm_conv_train_dgrad")

@@ -555,13 +555,16 @@ int etm_relu_mask(const float *g, const float *y, float *out, int64_t n, void *s
  *                      dgrad[i] != 0: the backward-data operand of that layer (classes x channels as the output columns).
  *   etm_conv_b3_fwd  : y = relu(conv(x) + bias), arguments as etm_conv_train_fwd (the three layers of model.py:29-31 on 84 x 84
  *                      observations; ETM_EUNSUPPORTED otherwise -- the caller keeps the fp32 kernels).
- *   etm_conv_b3_dgrad: dx = conv_transpose(dy) * (y_below > 0), arguments as etm_conv_train_dgrad (layers 2 / 3). */
+ *                      relu_bits (optional): N * Ho * Wo * Cout / 32 words, bit c % 32 of word [n][y][x][c / 32] = (y > 0).
+ *   etm_conv_b3_dgrad: dx = conv_transpose(dy) * (y_below > 0), arguments as etm_conv_train_dgrad (layers 2 / 3); the ReLU pattern of
+ *                      the layer below comes from relu_bits (the words its etm_conv_b3_fwd wrote: 1 / 32 of y_below's bytes, requested
+ *                      in front of the k loop) if given, else from y_below's values, else there is none. */
 int etm_conv_b3_pack(const float *const *w, uint16_t *const *out, const int *dgrad, const int *Cout, const int *C, const int *KS,
                      const int *S, int n, void *stream);
-int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, int N, int C, int H, int W,
-                    int Cout, int KH, int KW, int S, void *stream);
-int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, float *dx, int N, int C, int H, int W, int Cout,
-                      int KH, int KW, int S, void *stream);
+int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, uint32_t *relu_bits, int N,
+                    int C, int H, int W, int Cout, int KH, int KW, int S, void *stream);
+int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, const uint32_t *relu_bits, float *dx, int N, int C,
+                      int H, int W, int Cout, int KH, int KW, int S, void *stream);
 /*   etm_conv_b3_wgrad: the weight-gradient slices of one layer (csrc/conv_b3_wgrad.hip: both images NHWC in LDS as bf16 planes, the
  *                      pixel contraction fed by transposing LDS reads): workspace [etm_conv_b3_wgrad_slices(...)][K * Cout + Cout], dW in
  *                      (k, co) order (k = (ky, kx, c)) followed by the column sums of dy -- the layout etm_conv_wgrad_reduce_grouped

@@ -55,7 +55,8 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
     wb3, = b3_pack([wt], [0], [s])
     y32 = torch.empty((N, ho, wo, cout), device=dev); yb3 = torch.full((N, ho, wo, cout), float("nan"), device=dev)
     f32 = lambda: etm_lib.check(lib.etm_conv_train_fwd(P(x), None, N, P(packed), P(b), P(y32), N, c, h, w, cout, k, k, s, 0, st), "fwd")
-    fb3 = lambda: etm_lib.check(lib.etm_conv_b3_fwd(P(x), None, P(wb3), P(b), P(yb3), N, c, h, w, cout, k, k, s, st), "b3 fwd")
+    ybits = torch.zeros((N, ho, wo, cout // 32), dtype=torch.int32, device=dev)
+    fb3 = lambda: etm_lib.check(lib.etm_conv_b3_fwd(P(x), None, P(wb3), P(b), P(yb3), P(ybits), N, c, h, w, cout, k, k, s, st), "b3 fwd")
     f32(); fb3(); torch.cuda.synchronize()
     nr = min(N, NREF)
     sel = torch.cat([torch.arange(nr // 2), torch.arange(N - (nr - nr // 2), N)])          # first and last images
@@ -65,11 +66,13 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
         t0, t1 = timed(f32), timed(fb3); tot_old += t0; tot_new += t1
         line += f"   {t0:6.1f} -> {t1:6.1f} us  ({fl / t1 / 1e6:5.1f} fp32-equivalent TFLOP/s)"
     print(line, flush=True)
+    yb = ((yb3 > 0).view(N, ho, wo, cout // 32, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
+    print(f"conv{li + 1} forward ReLU pattern words: identical to (y > 0) packed on the host: {bool((torch.where(yb >= 2 ** 31, yb - 2 ** 32, yb).to(torch.int32) == ybits).all().item())}")
     # ---- forward through the minibatch index (layer 1)
     if li == 0:
         idx = torch.randperm(N, device=dev)
         yi = torch.full((N, ho, wo, cout), float("nan"), device=dev)
-        etm_lib.check(lib.etm_conv_b3_fwd(P(x), P(idx), P(wb3), P(b), P(yi), N, c, h, w, cout, k, k, s, st), "b3 fwd idx")
+        etm_lib.check(lib.etm_conv_b3_fwd(P(x), P(idx), P(wb3), P(b), P(yi), None, N, c, h, w, cout, k, k, s, st), "b3 fwd idx")
         print(f"conv1 forward through x_index: identical to the gathered run: {bool((yi == yb3[idx]).all().item())}")
     # ---- backward-data
     if li > 0:
@@ -77,7 +80,12 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
         wd3, = b3_pack([wt], [1], [s])
         dx32 = torch.empty((N, h, w, c), device=dev); dxb3 = torch.full((N, h, w, c), float("nan"), device=dev)
         d32 = lambda: etm_lib.check(lib.etm_conv_train_dgrad(P(dy), P(pd), P(x), P(dx32), N, c, h, w, cout, k, k, s, st), "dgrad")
-        db3 = lambda: etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), P(x), P(dxb3), N, c, h, w, cout, k, k, s, st), "b3 dgrad")
+        # the ReLU pattern of the layer below as bits (what its forward pass writes): here built from x itself
+        xb = ((x > 0).view(N, h, w, c // 32, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
+        xbits = torch.where(xb >= 2 ** 31, xb - 2 ** 32, xb).to(torch.int32).contiguous()
+        db3 = lambda: etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), None, P(xbits), P(dxb3), N, c, h, w, cout, k, k, s, st), "b3 dgrad")
+        dxv = torch.full((N, h, w, c), float("nan"), device=dev)
+        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), P(x), None, P(dxv), N, c, h, w, cout, k, k, s, st), "b3 dgrad by values")
         d32(); db3(); torch.cuda.synchronize()
         ref = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1) * (x[sel].double().cpu() > 0)
         line = f"conv{li + 1} bwd-data  : err vs float64  fp32 MFMA {rel(dx32[sel], ref):.2e}   bf16x3 {rel(dxb3[sel], ref):.2e}   b3 vs fp32 (all N) {((dxb3 - dx32).norm() / dx32.norm()).item():.2e}"
@@ -86,9 +94,9 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
             line += f"   {t0:6.1f} -> {t1:6.1f} us  ({fl / t1 / 1e6:5.1f} fp32-equivalent TFLOP/s)"
         print(line, flush=True)
         dxn = torch.full((N, h, w, c), float("nan"), device=dev)
-        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), None, P(dxn), N, c, h, w, cout, k, k, s, st), "b3 dgrad nomask")
+        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), None, None, P(dxn), N, c, h, w, cout, k, k, s, st), "b3 dgrad nomask")
         refn = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1)
-        print(f"conv{li + 1} bwd-data without mask: err vs float64 {rel(dxn[sel], refn):.2e}", flush=True)
+        print(f"conv{li + 1} bwd-data without mask: err vs float64 {rel(dxn[sel], refn):.2e}; pattern from y_below's values identical to the bits form: {bool((dxv == dxb3).all().item())}", flush=True)
     # ---- backward-weight (slices + the grouped reduction, both paths)
     K = k * k * c
     buf32 = torch.empty(K * cout + cout, device=dev)
