@@ -2532,6 +2532,100 @@ def test_encoder_forward_with_lds_resident_images(N):
         close(outs[(True, 1)][:48], want.numpy(), atol=2e-5, rtol=1e-5, what=f"layer C={c} forward vs float64")
 
 
+@pytest.mark.parametrize("N", [7, 601, 2048])
+def test_encoder_passes_on_the_bf16_matrix_pipe_vs_float64(N):
+    """Round 6, csrc/conv_b3.hip + conv_b3_wgrad.hip (model.py:40-56, :90-92 and their backward): the eight encoder passes with every
+    fp32 product taken as six bf16 MFMA products of exactly split operands, through the C ABI, against float64 -- convolutions on the
+    host for the first / last images (forward, backward-data), the unfolded contraction in float64 on the device over ALL images (weight
+    and bias gradients) -- next to the fp32-MFMA kernels of rounds 2 - 3 on the same inputs.  The claim under test is "fp32 accuracy":
+    the error of every pass is at most the fp32-MFMA kernel's (measured 0.3 - 0.6 x: 8e-8 .. 1.3e-7 against 2.5e-7 .. 4.6e-7) and below
+    3e-7 of the result's norm.  Also: ragged last groups (7, 601), the fused minibatch gather (layer 1, forward and weight gradient),
+    the ReLU pattern words the forward pass writes and backward-data reads (identical to the mask taken from y_below's values)."""
+    import ctypes
+    import torch.nn.functional as F
+    from etm import lib as etm_lib
+    from etm import ops
+    dev = _dev()
+    lib = etm_lib.load()
+    torch.manual_seed(1000 + N)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()
+    rel = lambda a, ref: float((a.double().cpu() - ref).norm() / ref.norm())
+    one = lambda ct, v: (ct * 1)(v)
+    nref = min(N, 24)
+    sel = torch.cat([torch.arange(nref // 2), torch.arange(N - (nref - nref // 2), N)]) if N > nref else torch.arange(N)
+
+    def bits_of(t):      # bit c % 32 of word [..., c / 32] = (t > 0)
+        w = ((t > 0).view(*t.shape[:-1], t.shape[-1] // 32, 32).to(torch.int64) << torch.arange(32, device=t.device)).sum(-1)
+        return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+    for li, (c, hw, cout, k, s) in enumerate([(3, 84, 32, 8, 4), (32, 20, 64, 4, 2), (64, 9, 64, 3, 1)]):
+        ho = (hw - k) // s + 1
+        bank = torch.rand((N + 5, hw, hw, c), device=dev) if li == 0 else torch.relu(torch.randn((N + 5, hw, hw, c), device=dev))
+        index = torch.randperm(N + 5, device=dev)[:N].contiguous()
+        x = bank[index].contiguous()
+        wt = torch.randn((cout, c, k, k), device=dev) * 0.05
+        b = torch.randn(cout, device=dev) * 0.1
+        dy = torch.randn((N, ho, ho, cout), device=dev) * (torch.rand((N, ho, ho, cout), device=dev) > 0.5)
+        fwd_p, dg_p = ops.conv_b3_pack([wt, wt], [0, 1], [s, s]) if li else (ops.conv_b3_pack([wt], [0], [s])[0], None)
+        # ---- forward (+ pattern words), plain and through the index
+        y3 = torch.full((N, ho, ho, cout), float("nan"), device=dev)
+        ybits = torch.zeros((N, ho, ho, cout // 32), dtype=torch.int32, device=dev)
+        etm_lib.check(lib.etm_conv_b3_fwd(P(x), None, P(fwd_p), P(b), P(y3), P(ybits), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_fwd")
+        y32 = torch.empty_like(y3)
+        packed = ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+        etm_lib.check(lib.etm_conv_train_fwd(P(x), None, N, P(packed), P(b), P(y32), N, c, hw, hw, cout, k, k, s, 0, st), "etm_conv_train_fwd")
+        want = torch.relu(F.conv2d(x[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), b.double().cpu(), stride=s)).permute(0, 2, 3, 1)
+        e3, e32 = rel(y3[sel], want), rel(y32[sel], want)
+        assert bool(torch.isfinite(y3).all()) and e3 <= max(e32, 1e-7) and e3 < 3e-7, (li, "forward", e3, e32)
+        assert bool((bits_of(y3) == ybits).all()), (li, "ReLU pattern words")
+        if li == 0:
+            yi = torch.full_like(y3, float("nan"))
+            etm_lib.check(lib.etm_conv_b3_fwd(P(bank), P(index), P(fwd_p), P(b), P(yi), None, N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_fwd (index)")
+            assert bool((yi == y3).all()), "forward through the minibatch index"
+        # ---- backward-data: pattern from the words, from the values, none
+        if li:
+            dx3, dxv, dxn, dx32 = (torch.full((N, hw, hw, c), float("nan"), device=dev) for _ in range(4))
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(dg_p), None, P(bits_of(x)), P(dx3), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad")
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(dg_p), P(x), None, P(dxv), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (values)")
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(dg_p), None, None, P(dxn), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (no mask)")
+            etm_lib.check(lib.etm_conv_train_dgrad(P(dy), P(ops.conv_pack_dgrad_weights(wt, s)), P(x), P(dx32), N, c, hw, hw, cout, k, k, s, st), "etm_conv_train_dgrad")
+            full = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1)
+            want = full * (x[sel].double().cpu() > 0)
+            e3, e32 = rel(dx3[sel], want), rel(dx32[sel], want)
+            assert bool(torch.isfinite(dx3).all()) and e3 <= max(e32, 1e-7) and e3 < 3e-7, (li, "backward-data", e3, e32)
+            assert bool((dxv == dx3).all()) and rel(dxn[sel], full) < 3e-7, (li, "backward-data mask forms")
+        # ---- weight / bias gradients: slices + the grouped reduction, against the float64 contraction over all images
+        K = k * k * c
+        slices = lib.etm_conv_b3_wgrad_slices(N, c, hw, hw, cout, k, k, s)
+        assert 0 < slices <= 256
+        ws = torch.full((slices * (K * cout + cout),), float("nan"), device=dev)
+        dw3, db3 = torch.full((cout, c, k, k), float("nan"), device=dev), torch.full((cout,), float("nan"), device=dev)
+
+        def wgrad(src, idx):
+            assert lib.etm_conv_b3_wgrad(P(src), P(idx), P(dy), P(ws), ws.numel() * 4 - 4, N, c, hw, hw, cout, k, k, s, st) != 0, "a workspace that is too small is refused"
+            etm_lib.check(lib.etm_conv_b3_wgrad(P(src), P(idx), P(dy), P(ws), ws.numel() * 4, N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_wgrad")
+            etm_lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, P(ws)), one(ctypes.c_int32, slices), one(ctypes.c_void_p, P(dw3)),
+                                                            one(ctypes.c_void_p, P(db3)), one(ctypes.c_int32, cout), one(ctypes.c_int32, c),
+                                                            one(ctypes.c_int32, k), one(ctypes.c_int32, k), 1, st), "etm_conv_wgrad_reduce_grouped")
+        wgrad(x, None)
+        buf32 = torch.empty(K * cout + cout, device=dev)
+        nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, hw, hw, cout, k, k, s)
+        ws32 = torch.empty(max(nbytes, 8) // 4, device=dev)
+        etm_lib.check(lib.etm_conv_train_wgrad(P(x), None, P(dy), P(buf32), P(ws32), nbytes, N, c, hw, hw, cout, k, k, s, st), "etm_conv_train_wgrad")
+        cols = F.unfold(x.permute(0, 3, 1, 2).double(), k, stride=s)
+        ref_dw = torch.einsum("nkp,npo->ok", cols, dy.double().reshape(N, ho * ho, cout)).reshape(cout, c, k, k).cpu()
+        ref_db = dy.double().sum((0, 1, 2)).cpu()
+        del cols
+        e3, e32 = rel(dw3, ref_dw), rel(buf32[: K * cout].view(cout, c, k, k), ref_dw)
+        assert bool(torch.isfinite(dw3).all()) and e3 <= max(e32, 1e-7) and e3 < 3e-7, (li, "weight gradient", e3, e32)
+        assert rel(db3, ref_db) < 3e-7, (li, "bias gradient", rel(db3, ref_db))
+        if li == 0:
+            keep = dw3.clone()
+            wgrad(bank, index)
+            assert bool((dw3 == keep).all()), "weight gradient through the minibatch index"
+
+
 def test_train_encoder_minibatch_size_properties():
     """At the minibatch size of BASELINE config 3 (N = 2048, 3 x 84 x 84; too large for the float64 host reference): the features
     agree with the library convolutions, and the weight / bias gradients are ADDITIVE over the batch -- the gradient of the
