@@ -81,10 +81,11 @@ def kernel_work(name, N, L, D, H):
 
 # profile name of this build -> kernel symbol (prefix) in the rocprofv3 counter files
 PMC_SYMBOL = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel",
-              "conv_fwd_layer1": "conv_gemm_kernel<2, 1, false", "conv_fwd_layer2": "conv_fwd_lds_kernel<32, 20",
-              "conv_fwd_layer3": "conv_gemm_kernel<4, 2, false", "conv_dgrad_layer2": "conv_dgrad_lds_kernel<64, 9",
-              "conv_dgrad_layer3": "conv_gemm_kernel<1, 2, true", "conv_wgrad_layer1": "conv_wgrad_lds_kernel<3, 84",
-              "conv_wgrad_layer2": "conv_wgrad_kernel<4, 2>", "conv_wgrad_layer3": "conv_wgrad_kernel<3, 2>"}
+              # (round 6: the encoder passes on the bf16 matrix pipe, csrc/conv_b3.hip / conv_b3_wgrad.hip; B3Geo<DGRAD, C, HW, ...>)
+              "conv_fwd_layer1": "conv_b3_kernel<(anonymous namespace)::B3Geo<false, 3, 84", "conv_fwd_layer2": "conv_b3_kernel<(anonymous namespace)::B3Geo<false, 32, 20",
+              "conv_fwd_layer3": "conv_b3_kernel<(anonymous namespace)::B3Geo<false, 64, 9", "conv_dgrad_layer2": "conv_b3_kernel<(anonymous namespace)::B3Geo<true, 32, 20",
+              "conv_dgrad_layer3": "conv_b3_kernel<(anonymous namespace)::B3Geo<true, 64, 9", "conv_wgrad_layer1": "conv_b3_wgrad_kernel<(anonymous namespace)::W3Geo<3, 84",
+              "conv_wgrad_layer2": "conv_b3_wgrad_kernel<(anonymous namespace)::W3Geo<32, 20", "conv_wgrad_layer3": "conv_b3_wgrad_kernel<(anonymous namespace)::W3Geo<64, 9"}
 
 
 def pmc_traffic(kernel):
@@ -199,7 +200,7 @@ def _pick(d, keys):
 
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "avg_launch_ms", "launches", "bytes_per_launch",
                  "flops_per_launch", "unique_bytes_per_launch", "frac_unique", "hbm_side_frac", "mfma_busy_fraction_pmc", "est_region_ms",
-                 "us_per_dependent_phase", "dtype")
+                 "us_per_dependent_phase", "dtype", "pipe_achieved", "pipe_peak", "pipe_frac")
 
 
 def _flat_rooflines(r, prefix="", out=None):
@@ -208,7 +209,7 @@ def _flat_rooflines(r, prefix="", out=None):
     if not isinstance(r, dict):
         return out
     if "frac" in r and ("avg_launch_ms" in r or "ms" in r):
-        out[prefix.rstrip(".")] = [r.get("avg_launch_ms", r.get("ms")), r["frac"]]
+        out[prefix.rstrip(".")] = [r.get("avg_launch_ms", r.get("ms")), r["frac"]] + ([r["pipe_frac"]] if "pipe_frac" in r else [])      # (third: of the bf16 pipe's peak, kernels of csrc/conv_b3*.hip)
     for k, v in r.items():
         if isinstance(v, dict) and k not in ("shape", "model"):
             _flat_rooflines(v, prefix + k + ".", out)
@@ -245,7 +246,7 @@ def compact_line(full, full_path):
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data") if k in full}
     cfgf = full["config"]
-    line["config"] = dict(_pick(cfgf, ("env_pool", "observation_rows", "minibatch", "parallelism", "attention", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
+    line["config"] = dict(_pick(cfgf, ("env_pool", "observation_rows", "minibatch", "parallelism", "attention", "encoder_products", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
                                        "envs_per_process", "cgroup_cpu_quota")), workload=cfgf["workload"][:300])
     for k in ("value_worker_processes", "phase_s_per_step", "speedup_vs_cpu_baseline"):
         if full.get(k) is not None:
@@ -565,6 +566,9 @@ def main():
             kind, work = kernel_work(dom, N, L, D, H)
             if kind == "mfma":
                 ach, peak, unit, extra = kernels[dom]["tflops"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", {"flops_per_launch": work, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+                if dom.startswith("conv_") and etm_ops._encoder_products == "bf16x3":      # its products run on the bf16 pipe: both views
+                    import kernel_rooflines
+                    extra.update(kernel_rooflines.b3_fields(work, kernels[dom]["avg_ms"]))
             else:
                 ach, peak, unit, extra = kernels[dom]["gbs"], HBM_PEAK_GBS, "GB/s", {"bytes_per_launch": work, "dtype": "f32"}
             tr_pmc = pmc_traffic(dom)
@@ -628,6 +632,7 @@ def main():
                        "dp_step": (None if dp is None else "one_graph" if getattr(trainer, "_dp_one_graph", False) else "graph_a+allreduce+graph_b"),
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "encoder_products": etm_ops._encoder_products + (" (f32 products as 6 bf16 MFMA products of exactly split operands; error vs float64 below the fp32 MFMA kernels')" if etm_ops._encoder_products == "bf16x3" else ""),
                        "observation_rows": ("direct (host writes into device memory" + (", HDP flush register written)" if etm_ops._direct_mode.get(device.index) == 2 else ")")
                                             if getattr(trainer, "_direct_rows", False) else "pinned + upload"),
                        "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,

@@ -40,6 +40,10 @@ from etm import ops  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense (MI355X_MICROARCH.md): v_mfma_f32_32x32x16_bf16, 16 x the fp32 MFMA rate
+B3_DTYPE = "f32 results, every product as 6 x v_mfma_f32_32x32x16_bf16 of exactly split operands (3 bf16 terms each)"
+B3_NOTE = ("achieved / frac: the algorithmic fp32 flops against the fp32 MFMA peak (what a kernel on v_mfma_f32_32x32x2_f32 is bounded by -- "
+           "frac > 1 is past that bound); pipe_*: the bf16 products really issued (6 per fp32 product) against the dense bf16 MFMA peak")
 
 
 def _timed(fn, launches, warm=3):
@@ -66,10 +70,19 @@ def _hbm(name, nbytes, avg_ms, launches, **extra):
                 unit="GB/s", frac=gbs / HBM_PEAK_GBS, **extra)
 
 
-def _mfma(name, flops, avg_ms, launches, **extra):
+def b3_fields(flops, avg_ms):
+    """The bf16-pipe view of a kernel that takes its fp32 products as six bf16 MFMA products (csrc/conv_b3*.hip)."""
+    tf = 6.0 * flops / (avg_ms * 1e-3) / 1e12
+    return dict(dtype=B3_DTYPE, pipe_flops_per_launch=6.0 * flops, pipe_achieved=tf, pipe_peak=BF16_MFMA_PEAK_TFLOPS, pipe_frac=tf / BF16_MFMA_PEAK_TFLOPS, note=B3_NOTE)
+
+
+def _mfma(name, flops, avg_ms, launches, b3=False, **extra):
     tf = flops / (avg_ms * 1e-3) / 1e12
-    return dict(kernel=name, bound="mfma", flops_per_launch=flops, avg_launch_ms=avg_ms, launches=launches, achieved=tf,
-                peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_MFMA_PEAK_TFLOPS, dtype="f32 (v_mfma_f32_32x32x2_f32)", **extra)
+    d = dict(kernel=name, bound="mfma", flops_per_launch=flops, avg_launch_ms=avg_ms, launches=launches, achieved=tf,
+             peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_MFMA_PEAK_TFLOPS, dtype="f32 (v_mfma_f32_32x32x2_f32)", **extra)
+    if b3:
+        d.update(b3_fields(flops, avg_ms))
+    return d
 
 
 def window(mode, dev, launches=24, N=2048, L=64, D=384, H=4):
@@ -197,32 +210,57 @@ def encoder_flops(N, layers=ENCODER_LAYERS):
     return [2.0 * N * ((h - k) // s + 1) * ((w - k) // s + 1) * cout * k * k * c for (c, h, w, cout, k, s) in layers]
 
 
-def encoder(dev, launches=20, N=2048):
-    """Training-side encoder kernels (csrc/conv_train.hip) layer by layer and pass by pass through the C ABI at the minibatch
-    shape, against the fp32 MFMA peak.  Weight-gradient figures include the slice reduction launch."""
+def encoder(dev, launches=20, N=2048, products=None):
+    """Training-side encoder kernels layer by layer and pass by pass through the C ABI at the minibatch shape.  ``products``:
+    "bf16x3" (csrc/conv_b3.hip, conv_b3_wgrad.hip: the default of the trainer since round 6) or "fp32" (csrc/conv_train.hip and the
+    LDS-resident forms on v_mfma_f32_32x32x2_f32); None: what ops is set to.  Weight-gradient figures include the slice reduction."""
+    import ctypes
     lib = etm_lib.load()
     st = torch.cuda.current_stream().cuda_stream
-    P = lambda t: t.data_ptr()
+    P = lambda t: None if t is None else t.data_ptr()
+    products = products or ops._encoder_products
+    b3 = products == "bf16x3"
     torch.manual_seed(0)
     bufs = []
     for (c, h, w, cout, k, s) in ENCODER_LAYERS:
         ho, wo = (h - k) // s + 1, (w - k) // s + 1
         wt = torch.randn((cout, c, k, k), device=dev) * 0.05
-        nbytes = lib.etm_conv_train_wgrad_workspace_bytes(N, c, h, w, cout, k, k, s)
+        K = k * k * c
+        if b3:
+            slices = lib.etm_conv_b3_wgrad_slices(N, c, h, w, cout, k, k, s)
+            nbytes = slices * (K * cout + cout) * 4
+            packs = ops.conv_b3_pack([wt, wt] if c != 3 else [wt], [0, 1] if c != 3 else [0], [s, s] if c != 3 else [s])
+        else:
+            slices, nbytes = 0, lib.etm_conv_train_wgrad_workspace_bytes(N, c, h, w, cout, k, k, s)
+            packs = [ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1)), ops.conv_pack_dgrad_weights(wt, s) if c != 3 else None]
         bufs.append(dict(x=torch.rand((N, h, w, c), device=dev), b=torch.randn(cout, device=dev), y=torch.empty((N, ho, wo, cout), device=dev),
-                         dy=torch.randn((N, ho, wo, cout), device=dev), packed=ops.conv_pack_weights(wt.permute(0, 2, 3, 1).reshape(cout, -1)),
-                         pd=ops.conv_pack_dgrad_weights(wt, s) if c != 3 else None, dx=torch.empty((N, h, w, c), device=dev),
-                         dw=torch.empty(k * k * c * cout + cout, device=dev), ws=torch.empty(max(nbytes, 8) // 4, device=dev), nbytes=nbytes))
+                         dy=torch.randn((N, ho, wo, cout), device=dev), packed=packs[0], pd=packs[1] if len(packs) > 1 else None,
+                         dx=torch.empty((N, h, w, c), device=dev), dw=torch.empty(K * cout + cout, device=dev), ws=torch.empty(max(nbytes, 8) // 4, device=dev),
+                         nbytes=nbytes, slices=slices, ybits=torch.empty((N, ho, wo, cout // 32), dtype=torch.int32, device=dev),
+                         xbits=torch.randint(-2 ** 31, 2 ** 31 - 1, (N, h, w, max(c // 32, 1)), dtype=torch.int32, device=dev)))
+    one = lambda ct, v: (ct * 1)(v)
 
     def step_fn():
         for (c, h, w, cout, k, s), b in zip(ENCODER_LAYERS, bufs):
-            etm_lib.check(lib.etm_conv_train_fwd(P(b["x"]), None, N, P(b["packed"]), P(b["b"]), P(b["y"]), N, c, h, w, cout, k, k, s, 0, st), "fwd")
-            if b["pd"] is not None:
-                etm_lib.check(lib.etm_conv_train_dgrad(P(b["dy"]), P(b["pd"]), P(b["x"]), P(b["dx"]), N, c, h, w, cout, k, k, s, st), "dgrad")
-            etm_lib.check(lib.etm_conv_train_wgrad(P(b["x"]), None, P(b["dy"]), P(b["dw"]), P(b["ws"]), b["nbytes"], N, c, h, w, cout, k, k, s, st), "wgrad")
+            if b3:
+                etm_lib.check(lib.etm_conv_b3_fwd(P(b["x"]), None, P(b["packed"]), P(b["b"]), P(b["y"]), P(b["ybits"]) if c != 64 else None, N, c, h, w, cout, k, k, s, st), "fwd")
+                if b["pd"] is not None:
+                    etm_lib.check(lib.etm_conv_b3_dgrad(P(b["dy"]), P(b["pd"]), None, P(b["xbits"]), P(b["dx"]), N, c, h, w, cout, k, k, s, st), "dgrad")
+                etm_lib.check(lib.etm_conv_b3_wgrad(P(b["x"]), None, P(b["dy"]), P(b["ws"]), b["nbytes"], N, c, h, w, cout, k, k, s, st), "wgrad")
+                K = k * k * c
+                etm_lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, P(b["ws"])), one(ctypes.c_int32, b["slices"]), one(ctypes.c_void_p, P(b["dw"])),
+                                                                one(ctypes.c_void_p, b["dw"].data_ptr() + K * cout * 4), one(ctypes.c_int32, cout), one(ctypes.c_int32, c),
+                                                                one(ctypes.c_int32, k), one(ctypes.c_int32, k), 1, st), "reduce")
+            else:
+                etm_lib.check(lib.etm_conv_train_fwd(P(b["x"]), None, N, P(b["packed"]), P(b["b"]), P(b["y"]), N, c, h, w, cout, k, k, s, 0, st), "fwd")
+                if b["pd"] is not None:
+                    etm_lib.check(lib.etm_conv_train_dgrad(P(b["dy"]), P(b["pd"]), P(b["x"]), P(b["dx"]), N, c, h, w, cout, k, k, s, st), "dgrad")
+                etm_lib.check(lib.etm_conv_train_wgrad(P(b["x"]), None, P(b["dy"]), P(b["dw"]), P(b["ws"]), b["nbytes"], N, c, h, w, cout, k, k, s, st), "wgrad")
 
     t = _timed(step_fn, launches)
     fl = encoder_flops(N)
+    # b3: the three slice reductions are launches of the generic weight-gradient id (one per layer and call): their mean rides on every layer's figure
+    red = t.get("conv_train_wgrad_kernel", (0.0, 0))[0] if b3 else 0.0
     res, tot_ms, tot_fl = {}, 0.0, 0.0
     for li in range(3):
         for pas in ("fwd", "dgrad", "wgrad"):
@@ -230,12 +268,17 @@ def encoder(dev, launches=20, N=2048):
             if name not in t:
                 continue
             avg, cnt = t[name]
-            per_pass = avg * (2 if pas == "wgrad" else 1)          # wgrad: main kernel + slice reduction are two timed launches
-            res[name] = _mfma(name, fl[li], per_pass, cnt // (2 if pas == "wgrad" else 1), shape=dict(N=N, layer=ENCODER_LAYERS[li]))
+            if b3:
+                per_pass, n = avg + (red if pas == "wgrad" else 0.0), cnt
+            else:
+                per_pass, n = avg * (2 if pas == "wgrad" else 1), cnt // (2 if pas == "wgrad" else 1)      # wgrad: main kernel + slice reduction are two timed launches
+            res[name] = _mfma(name, fl[li], per_pass, n, b3=b3, shape=dict(N=N, layer=ENCODER_LAYERS[li]))
             tot_ms += per_pass
             tot_fl += fl[li]
     res["all_passes"] = dict(flops=tot_fl, ms=tot_ms, achieved=tot_fl / (tot_ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                             frac=tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, passes=8)
+                             frac=tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, passes=8, products=products)
+    if b3:
+        res["all_passes"].update({k: v for k, v in b3_fields(tot_fl, tot_ms).items() if k != "pipe_flops_per_launch"})
     return res
 
 
@@ -359,7 +402,9 @@ def all_rooflines(dev, quick=False):
     out["gae"] = {"config_size": gae(dev, 32, 512, n), "scaled": gae(dev, 65536, 512, n)}
     out["ppo_loss"] = {"config_size": ppo(dev, 2048, 3, n), "scaled": ppo(dev, 1 << 24, 3, n)}
     torch.cuda.empty_cache()
-    out["encoder"] = encoder(dev, n)
+    out["encoder"] = encoder(dev, n, products="bf16x3")         # (the trainer's default since round 6)
+    torch.cuda.empty_cache()
+    out["encoder_fp32_mfma"] = encoder(dev, n, products="fp32")  # (rounds 2 - 3: encoder_products: fp32)
     torch.cuda.empty_cache()
     out["block_weight_gradients"] = grouped_dw(dev, n)
     torch.cuda.empty_cache()
@@ -405,8 +450,8 @@ if __name__ == "__main__":
         res = {"config_size": gae(dev, 32, 512, n), "scaled": gae(dev, 65536, 512, n)}
     elif what == "ppo":
         res = {"config_size": ppo(dev, 2048, 3, n), "scaled": ppo(dev, 1 << 24, 3, n)}
-    elif what == "encoder":
-        res = encoder(dev, n)
+    elif what in ("encoder", "encoder_fp32"):
+        res = encoder(dev, n, products="fp32" if what == "encoder_fp32" else "bf16x3")
     elif what == "grouped_dw":
         res = grouped_dw(dev, n)
     elif what == "rollout_step":
