@@ -25,7 +25,6 @@
 // x, y, dy, dx are fp32 NHWC exactly as for etm_conv_train_fwd / _dgrad: the split is internal to the kernels.
 #include "etm_common.h"
 
-#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -43,8 +42,6 @@ struct B3Args {
   unsigned *bits_out;             // forward, optional: bit c of word [n][y][x][c / 32] = (y[n, y, x, c] > 0)
   float *out;
   int N, n_groups;
-  long long *stamps;              // diagnostic: phase timestamps of wave 0 of workgroups 0 and 1 (ETM_B3_STAMPS; NULL in the product)
-  int dbg;                        // ablation switches of tools/conv_b3_check.py (ETM_B3_DBG; 0 in the product)
 };
 
 __device__ __forceinline__ unsigned b3_cvt_pk(float a, float b) {        // two floats -> two bf16 (a in the low half), round to nearest even
@@ -129,11 +126,6 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave % NT, rp = wave / NT;
 
-  int n_stamp = 0;
-  auto stamp = [&]() {
-    if (p.stamps && blockIdx.x < 2 && tid == 0 && n_stamp < 64) p.stamps[blockIdx.x * 64 + n_stamp++] = __builtin_readcyclecounter();
-  };
-  stamp();
   if (DGRAD) {                                             // the borders stay zero for the whole launch
     for (int e = tid; e < 3 * L::PLANE / 16; e += 256) reinterpret_cast<u32x4 *>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
@@ -221,9 +213,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
     const __amdgpu_buffer_rsrc_t rx = group_rsrc(grp);
 #pragma unroll
     for (int u = 0; u < NQ; ++u) fill_load(u, rx);
-    stamp();
     fill_to_lds();
-    stamp();
   }
   // bias of this lane's channels: accumulator quad j = channels ct * 32 + 8 j + 4 half + (0..3)
   f32x4 bias4[4];
@@ -244,7 +234,6 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
 
   for (; grp < p.n_groups; grp += gridDim.x) {
     __syncthreads();                                       // the group's planes are in LDS
-    stamp();
     const __amdgpu_buffer_rsrc_t nrx = group_rsrc(grp + gridDim.x);
     // byte offsets of the lane's results (outside the descriptors for what does not exist: stores dropped, loads return zeros)
     int o[TPW];
@@ -254,7 +243,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
       const int n0 = u0 / L::NB, b0 = u0 - n0 * L::NB;
       const int gbase = DGRAD ? n0 * (L::HRES * L::HRES * C * 4) : (n0 * L::PIXI + b0 * L::PIX) * (L::CRES * 4);
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) o[t] = (o_t[t] >= 0 && g_t[t] < units && !(p.dbg & 1)) ? o_t[t] + gbase : 0x7ffffff0;
+      for (int t = 0; t < TPW; ++t) o[t] = (o_t[t] >= 0 && g_t[t] < units) ? o_t[t] + gbase : 0x7ffffff0;
       if (DGRAD && p.bits_in) {                            // (requested in front of the k loop: nothing waits for them)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) relu_bits[t] = __builtin_amdgcn_raw_buffer_load_b32(rb, (o[t] >> 7) << 2, 0, 0);
@@ -295,7 +284,6 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
 
     u32x4 xa[2][3];
     read_x(xa[0], 0, std::integral_constant<int, 0>{});
-    if (!(p.dbg & 8))
     b3_for<KSTEPS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value, s = ks % PD;
       b3_for<TPW>([&](auto tc) {
@@ -321,11 +309,10 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
       }
 #pragma unroll
       for (int u = ks * L::LPK; u < (ks + 1) * L::LPK; ++u)
-        if (u < NQ && !(p.dbg & 4)) fill_load(u, nrx);
+        if (u < NQ) fill_load(u, nrx);
       __builtin_amdgcn_sched_barrier(0);
     });
 
-    stamp();
     // ---- results: accumulator quad j of tile t = 4 consecutive channels of pixel (tile, col).  Offsets outside the descriptors for what
     // does not exist (stores dropped, mask loads return zeros); all mask loads of the group are requested before the first store (a
     // load behind a store waits for the store: vmcnt is one in-order counter)
@@ -371,11 +358,8 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
       }
     }
 
-    stamp();
     __syncthreads();                                       // every wave has read the planes: the next group's take their place
-    stamp();
-    if (!(p.dbg & 2)) fill_to_lds();
-    stamp();
+    fill_to_lds();
   }
 }
 
@@ -386,8 +370,6 @@ int launch_b3(const B3Args &p0, hipStream_t st) {
   if (G > 1 && p.img_index) return ETM_EUNSUPPORTED;
   if ((long long)p.N * L::HRES * L::HRES * L::CRES * 4 >= 0x7ffffff0ll) return ETM_EUNSUPPORTED;      // 32-bit byte offsets into the result
   p.n_groups = (p.N * L::NB + G - 1) / G;
-  { const char *e = getenv("ETM_B3_DBG"); p.dbg = e ? atoi(e) : 0; }
-  { const char *e = getenv("ETM_B3_STAMPS"); p.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
   constexpr size_t lds = 3 * (size_t)L::PLANE;
   static_assert(lds * WPC <= 160 * 1024, "LDS of a CU");
   auto kern = conv_b3_kernel<L, DGRAD, C, S>;
@@ -468,12 +450,11 @@ extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uin
   if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)bias % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, nullptr, relu_bits, y, N, 0, nullptr, 0};
+  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, nullptr, relu_bits, y, N, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
-  static const int var = getenv("ETM_B3_VAR") ? atoi(getenv("ETM_B3_VAR")) : 0;      // (A/B switch of tools/conv_b3_check.py)
   if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1, 10, 2>(p, st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 1>(p, st);
-  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return (var & 2) ? launch_b3<false, 64, 9, 3, 1, 64, 4>(p, st) : launch_b3<false, 64, 9, 3, 1, 64, 2, 0, 2>(p, st);
+  if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<false, 64, 9, 3, 1, 64, 2, 0, 2>(p, st);
   return ETM_EUNSUPPORTED;
 }
 
@@ -487,7 +468,7 @@ extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const fl
   if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16 || (uintptr_t)relu_bits % 4) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{dy, nullptr, w_b3, nullptr, y_below, relu_bits, nullptr, dx, N, 0, nullptr, 0};
+  B3Args p{dy, nullptr, w_b3, nullptr, y_below, relu_bits, nullptr, dx, N, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<true, 32, 20, 4, 2, 64, 1, 0, 1>(p, st);
   if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);

@@ -16,7 +16,6 @@
 //   * the bias gradient is summed from the fp32 values at the fill (a thread always holds the same 4 channels).
 #include "etm_common.h"
 
-#include <cstdlib>
 #include <utility>
 
 namespace {
