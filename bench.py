@@ -82,10 +82,10 @@ def kernel_work(name, N, L, D, H):
 # profile name of this build -> kernel symbol (prefix) in the rocprofv3 counter files
 PMC_SYMBOL = {"window_fwd_kernel": "window_pass_kernel", "window_bwd_kernel": "window_pass_kernel",
               # (round 6: the encoder passes on the bf16 matrix pipe, csrc/conv_b3.hip / conv_b3_wgrad.hip; B3Geo<DGRAD, C, HW, ...>)
-              "conv_fwd_layer1": "conv_b3_kernel<(anonymous namespace)::B3Geo<false, 3, 84", "conv_fwd_layer2": "conv_b3_kernel<(anonymous namespace)::B3Geo<false, 32, 20",
-              "conv_fwd_layer3": "conv_b3_kernel<(anonymous namespace)::B3Geo<false, 64, 9", "conv_dgrad_layer2": "conv_b3_kernel<(anonymous namespace)::B3Geo<true, 32, 20",
-              "conv_dgrad_layer3": "conv_b3_kernel<(anonymous namespace)::B3Geo<true, 64, 9", "conv_wgrad_layer1": "conv_b3_wgrad_kernel<(anonymous namespace)::W3Geo<3, 84",
-              "conv_wgrad_layer2": "conv_b3_wgrad_kernel<(anonymous namespace)::W3Geo<32, 20", "conv_wgrad_layer3": "conv_b3_wgrad_kernel<(anonymous namespace)::W3Geo<64, 9"}
+              "conv_fwd_layer1": "conv_b3_kernel<B3Geo<false, 3, 84", "conv_fwd_layer2": "conv_b3_kernel<B3Geo<false, 32, 20",
+              "conv_fwd_layer3": "conv_b3_kernel<B3Geo<false, 64, 9", "conv_dgrad_layer2": "conv_b3_kernel<B3Geo<true, 32, 20",
+              "conv_dgrad_layer3": "conv_b3_kernel<B3Geo<true, 64, 9", "conv_wgrad_layer1": "conv_b3_wgrad_kernel<W3Geo<3, 84",
+              "conv_wgrad_layer2": "conv_b3_wgrad_kernel<W3Geo<32, 20", "conv_wgrad_layer3": "conv_b3_wgrad_kernel<W3Geo<64, 9"}
 
 
 def pmc_traffic(kernel):

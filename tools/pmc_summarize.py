@@ -13,8 +13,21 @@ for target in sorted(os.listdir(src)):
     for f in glob.glob(os.path.join(src, target, "*", "counters.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            short = name.split("::")[-1].split("(")[0] if "<" not in name else name.split("::")[1].split("(")[0]
-            short = short.replace("(anonymous namespace)", "").strip()
+            # kernel symbol without namespaces, return type and parameter list; template arguments kept (they may hold "::" and
+            # parentheses themselves: conv_b3_kernel<B3Geo<false, 3, 84, ...>, ...>)
+            short = name.replace("(anonymous namespace)::", "")
+            short = short[5:] if short.startswith("void ") else short
+            if "<" in short.split("(")[0]:
+                depth = 0
+                for i, ch in enumerate(short):
+                    depth += ch == "<"
+                    depth -= ch == ">"
+                    if ch == ">" and depth == 0:
+                        short = short[: i + 1]
+                        break
+            else:
+                short = short.split("(")[0]
+            short = short.strip()
             acc.setdefault(short, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     res = {}
     for k, cs in acc.items():
