@@ -7,10 +7,11 @@
 // gradient image, filled by coalesced 16-byte fp32 loads and split once, as in the forward kernel) and ds_read_b64_tr_b16 does the
 // transposition on the way to the registers: per 16-lane group, lane i supplies the address of 4 consecutive channels of pixel
 // (i >> 2) and receives channel i of the four pixels (tools/microbench/tr_read.hip) -- two such reads per plane make an operand.
-//   * a workgroup is persistent over its units (layer 1: bands of 10 output rows, 66.5 + 48 KB; layer 2: one image; layer 3: two
-//     images) and keeps ALL of dW in its accumulators (weights-stationary): wave w owns a channel tile and half of the k tiles (layers
-//     2 / 3: 8 / 9 accumulator tiles) or half of the k tiles and every second 16-pixel step (layer 1: 3 tiles, one cross-wave sum at
-//     the very end); no vector-memory instruction in the loop but the next unit's loads, requested up front into registers;
+//   * a workgroup is persistent over its units (layer 1: bands of 5 output rows = 24 input rows, 36 + 27 KB, two workgroups per CU --
+//     measured 106.5 -> 90.6 us against bands of 10 rows on one workgroup; layer 2: one image; layer 3: two images) and keeps ALL of dW in
+//     its accumulators (weights-stationary): layers 2 / 3 on eight waves = channel tile x k part (4 - 5 accumulator tiles, leading and
+//     small products apart), layer 1 on four waves = k half x pixel-step parity (3 tiles, one cross-wave sum at the very end); no
+//     vector-memory instruction in the loop but the next unit's loads, requested up front into registers;
 //   * one partial result per workgroup goes to the workspace in the layout of etm_conv_train_wgrad ([slices][K Cout + Cout], dW in
 //     (k, co) order, then the column sums of dY): etm_conv_wgrad_reduce_grouped sums the slices in a fixed order -- deterministic;
 //   * the bias gradient is summed from the fp32 values at the fill (a thread always holds the same 4 channels).
@@ -60,9 +61,9 @@ __device__ __forceinline__ void w3_for(F &&f) { w3_for_impl(f, std::make_integer
 // Conv2d(C, COUT, KS, S) on HW x HW inputs; G units per group; BAND > 0: a unit is a band of BAND output rows (G = 1).
 // PSPLIT: 1 = the waves split (channel tile, k half); 2 = (k half, every second pixel step).
 // NW waves per workgroup (4 or 8).
-template <int C, int HW, int KS, int S, int COUT, int G_, int BAND, int PSPLIT_, int NW_>
+template <int C, int HW, int KS, int S, int COUT, int G_, int BAND, int PSPLIT_, int NW_, int WPC_ = 1>
 struct W3Geo {
-  static constexpr int G = G_, PSPLIT = PSPLIT_, NW = NW_, NTH = NW_ * 64;
+  static constexpr int G = G_, PSPLIT = PSPLIT_, NW = NW_, NTH = NW_ * 64, WPC = WPC_;      // WPC: workgroups per CU
   static constexpr int HOUT = (HW - KS) / S + 1;
   static constexpr bool THREE = C == 3;
   static constexpr int NB = BAND > 0 ? HOUT / BAND : 1;
@@ -97,7 +98,7 @@ struct W3Geo {
 };
 
 template <class L, int C, int HW, int S, int COUT>
-__global__ __launch_bounds__(L::NTH) void conv_b3_wgrad_kernel(const W3Args p) {
+__global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kernel(const W3Args p) {
   constexpr int G = L::G, KTW = L::KTW, CTW = L::CTW, STEPS = L::STEPS, NQX = L::NQX, NQD = L::NQD, NTH = L::NTH;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // input planes [3][G][IMGB], gradient planes [3][MPAD][CPBD]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -335,13 +336,13 @@ __global__ __launch_bounds__(L::NTH) void conv_b3_wgrad_kernel(const W3Args p) {
   }
 }
 
-template <int C, int HW, int KS, int S, int COUT, int G, int BAND, int PSPLIT, int NW>
+template <int C, int HW, int KS, int S, int COUT, int G, int BAND, int PSPLIT, int NW, int WPC = 1>
 struct W3 {
-  using L = W3Geo<C, HW, KS, S, COUT, G, BAND, PSPLIT, NW>;
-  static_assert(L::LDS <= 160 * 1024, "LDS of a CU");
+  using L = W3Geo<C, HW, KS, S, COUT, G, BAND, PSPLIT, NW, WPC>;
+  static_assert(L::LDS * WPC <= 160 * 1024, "LDS of a CU");
   static int slices(int N) {
     const int groups = (N * L::NB + G - 1) / G;
-    return groups < 256 ? groups : 256;
+    return groups < 256 * WPC ? groups : 256 * WPC;
   }
   static int launch(const W3Args &p0, hipStream_t st) {
     W3Args p = p0;
@@ -355,7 +356,7 @@ struct W3 {
   }
 };
 //              C  HW KS S COUT G BAND PSPLIT NW
-using W3L1 = W3<3, 84, 8, 4, 32, 1, 10, 2, 4>;
+using W3L1 = W3<3, 84, 8, 4, 32, 1, 5, 2, 4, 2>;
 using W3L2 = W3<32, 20, 4, 2, 64, 1, 0, 1, 8>;
 using W3L3 = W3<64, 9, 3, 1, 64, 2, 0, 1, 8>;
 
