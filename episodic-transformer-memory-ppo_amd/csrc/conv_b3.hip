@@ -9,8 +9,9 @@
 // b3_gemm.txt: 3.6e-7 against 4.3e-7 of the result norm at K = 576; 344 fp32-equivalent TFLOP/s measured on register operands).
 //
 // All five passes are one kernel: a "forward-like" convolution over images that are RESIDENT IN LDS as three bf16 planes,
-//   * forward: the layer input (layer 1: the 84 x 84 x 3 observation, 127 KB; layer 2: one 20 x 20 x 32 image, its columns de-interleaved
-//     by parity so that the stride-2 windows of neighbouring output pixels are neighbours in LDS; layer 3: four 9 x 9 x 64 images);
+//   * forward: the layer input (layer 1: a band of 10 output rows = 44 rows of the 84 x 84 x 3 observation, 66.5 KB, two workgroups per CU;
+//     layer 2: two 20 x 20 x 32 images, their columns de-interleaved by parity so that the stride-2 windows of neighbouring output pixels
+//     are neighbours in LDS, unpadded 64-byte pixels with swizzled chunks (B3Geo::SWZ); layer 3: two 9 x 9 x 64 images, two workgroups per CU);
 //   * backward-data: the gradient image, zero-bordered (rows share their border pixels: row stride = width + taps - 1), walked per
 //     stride-parity class as a dense T x T convolution -- the classes are more output-channel tiles of the same GEMM;
 //   * every input element crosses the memory system once per group as coalesced 16-byte fp32 loads (the NEXT group's are requested
@@ -68,9 +69,14 @@ __device__ __forceinline__ void b3_for(F &&f) { b3_for_impl(f, std::make_integer
 // BAND > 0 (forward): a unit of work is a band of BAND output rows of one image -- its (BAND - 1) S + KS input rows -- instead of the whole
 // image (layer 1: half an observation, 66.5 KB, so that two workgroups share a CU and one's fill / stores run under the other's MFMAs).
 // WPC: workgroups per CU the register allocation leaves room for.
-template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G_, int BAND = 0, int WPC_ = 1>
+// SWZ: pixel slots without padding (2 CI bytes), their 16-byte chunks XOR-swizzled with the slot index instead -- layer 2's forward, where two
+// images only fit unpadded (153.6 KB) and two images are what fills the four waves evenly (162 pixels = 6 tiles = 3 per wave; one image:
+// 3 tiles on 2 + 1): chunk c of slot q sits at chunk position c ^ ((q >> 2) & 3), so that 16 consecutive slots x one chunk index cover
+// the 16 chunk columns of the banks.  The address of a fragment read is then computed per (tile, k step): 5 vector-ALU operations.
+template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G_, int BAND = 0, int WPC_ = 1, bool SWZ_ = false>
 struct B3Geo {
   static constexpr int G = G_, WPC = WPC_;
+  static constexpr bool SWZ = SWZ_;
   static constexpr int HOUT = (HW - KS) / S + 1;                 // output size of the layer
   static constexpr int T = KS / S;                               // backward-data: taps per dimension and class
   static constexpr int CI = DGRAD ? COUT : C;                    // channels of the LDS-resident image
@@ -81,7 +87,7 @@ struct B3Geo {
   static constexpr int HROWS = BAND > 0 ? (BAND - 1) * S + KS : HI;      // image rows of a unit in LDS
   static constexpr int ROW0 = BAND * S;                          // first image row of unit b: b ROW0
   static constexpr int SLOTS = DGRAD ? (HI + 2 * (T - 1) - 1) * RS + HI + 2 * (T - 1) : HROWS * HI;
-  static constexpr int CPB = THREE ? 6 : (CI + 8) * 2;           // bytes per pixel slot and plane
+  static constexpr int CPB = THREE ? 6 : SWZ ? CI * 2 : (CI + 8) * 2;      // bytes per pixel slot and plane
   static constexpr int IMGB = (SLOTS * CPB + 15) / 16 * 16;      // bytes per image and plane
   static constexpr int PLANE = G * IMGB;
   static constexpr int HO = DGRAD ? HI + T - 1 : HOUT;           // result pixels per row (backward-data: per class)
@@ -101,6 +107,7 @@ struct B3Geo {
   static constexpr int CRES = DGRAD ? C : COUT;                  // result channels
   static_assert(K % 16 == 0 && NOUT % 32 == 0 && (THREE || CI % 16 == 0) && (NT == 1 || NT == 2 || NT == 4), "layer geometry");
   static_assert(!DGRAD || (HW % S == 0 && KS % S == 0 && HI + T - 1 == HW / S), "backward-data: class grids tile the input");
+  static_assert(!SWZ || (!DGRAD && CI == 32 && SLOTS % 16 == 0 && IMGB == SLOTS * CPB), "swizzled slots: 64-byte pixels of four chunks");
   static_assert(BAND == 0 || (!DGRAD && G == 1 && HOUT % BAND == 0 && (ROW0 * HI * CI) % 4 == 0 && (HROWS * HI * CI) % 4 == 0), "bands: forward, one unit per group");
 
   // pixel slot of memory pixel (y, x)
@@ -108,6 +115,12 @@ struct B3Geo {
     if (DGRAD) return (y + T - 1) * RS + (x + T - 1);
     if (S == 2) return y * HI + (x & 1) * (HI / 2) + (x >> 1);
     return y * HI + x;
+  }
+  // slot offset of k step ks's tap relative to the window's first pixel
+  static constexpr int tap_slot(int ks) {
+    const int tap = ks / KPT, ty = tap / TAPS, tx = tap % TAPS;
+    if (!DGRAD && S == 2) return ty * HI + (tx & 1) * (HI / 2) + (tx >> 1);
+    return ty * RS + tx;
   }
   // byte offset (inside a plane's image) of k step ks relative to the window's first element (layers with CI % 16 == 0)
   static constexpr int tap_bytes(int ks) {
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
       a_offb[t] = g * L::IMGB + e0 * 2 + half * ((L::HI * 3 - 16) * 2);      // ... or the second one at the start of the next row
     } else {
       const int q0 = DGRAD ? oy * L::RS + ox : (S == 2 ? (2 * oy) * L::HI + ox : (oy * S) * L::HI + ox * S);
-      a_off[t] = g * L::IMGB + q0 * L::CPB + half * 16;
+      a_off[t] = L::SWZ ? g * L::SLOTS + q0 : g * L::IMGB + q0 * L::CPB + half * 16;      // (swizzled: the slot index; bytes per read)
       a_offb[t] = 0;
     }
   }
@@ -174,6 +187,10 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
     const int g = q / L::Q_UNIT, qi = q - g * L::Q_UNIT;
     if (L::THREE) return g * L::IMGB + qi * 8;
     const int pix = qi / (L::CI / 4), c4 = qi - pix * (L::CI / 4), y = pix / L::HI, x = pix - y * L::HI;
+    if (L::SWZ) {
+      const int q = g * L::SLOTS + L::slot(y, x);
+      return q * L::CPB + (((c4 >> 1) ^ ((q >> 2) & 3)) << 4) + (c4 & 1) * 8;
+    }
     return g * L::IMGB + L::slot(y, x) * L::CPB + c4 * 8;
   };
   // buffer descriptor of a group's images: the float4 it really has (ragged last group; a group that does not exist: none -- the loads
@@ -275,6 +292,12 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
           const u32x2 hi = *reinterpret_cast<const u32x2 *>(lds + pl * L::PLANE + base + 8);
           xf[pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
+      } else if constexpr (L::SWZ) {
+        constexpr int chunk0 = (ks % L::KPT) * 2;          // this k step's 16 channels = chunks chunk0 (lanes 0 - 31) and chunk0 + 1 (lanes 32 - 63)
+        const int q = a_off[t] + L::tap_slot(ks);
+        const int off = q * L::CPB + (((chunk0 | half) ^ ((q >> 2) & 3)) << 4);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[pl] = *reinterpret_cast<const u32x4 *>(lds + pl * L::PLANE + off);
       } else {
         constexpr int off = L::tap_bytes(ks);
 #pragma unroll
@@ -363,9 +386,9 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
   }
 }
 
-template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G, int BAND = 0, int WPC = 1>
+template <bool DGRAD, int C, int HW, int KS, int S, int COUT, int G, int BAND = 0, int WPC = 1, bool SWZ = false>
 int launch_b3(const B3Args &p0, hipStream_t st) {
-  using L = B3Geo<DGRAD, C, HW, KS, S, COUT, G, BAND, WPC>;
+  using L = B3Geo<DGRAD, C, HW, KS, S, COUT, G, BAND, WPC, SWZ>;
   B3Args p = p0;
   if (G > 1 && p.img_index) return ETM_EUNSUPPORTED;
   if ((long long)p.N * L::HRES * L::HRES * L::CRES * 4 >= 0x7ffffff0ll) return ETM_EUNSUPPORTED;      // 32-bit byte offsets into the result
@@ -453,7 +476,7 @@ extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uin
   B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, nullptr, relu_bits, y, N, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
   if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1, 10, 2>(p, st);
-  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 1>(p, st);
+  if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 2, 0, 1, true>(p, st);      // (one padded image per group: 93.5 us; two swizzled ones: 76)
   if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<false, 64, 9, 3, 1, 64, 2, 0, 2>(p, st);
   return ETM_EUNSUPPORTED;
 }
