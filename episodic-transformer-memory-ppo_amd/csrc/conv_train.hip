@@ -589,39 +589,45 @@ struct WgradReduceGroup {
 };
 // conv_wgrad_reduce_kernel for several layers: same fixed summation order; the weight part goes to dw (native [Cout, C, KH, KW]
 // layout), the bias part to db.
+// (round 6: four consecutive elements per lane, 16-byte loads -- a wave-instruction moves 1 KB instead of 256 bytes; every element is
+// still summed in the order above: 32.5 -> 24.8 us for the three layers' 84 MB of slices)
 __global__ __launch_bounds__(1024) void conv_wgrad_reduce_grouped_kernel(const WgradReduceGroup g) {
-  __shared__ float red[16][64];
+  __shared__ f32x4 red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;      // uniform
   const float *__restrict__ partial = g.partial[i];
   const int splits = g.splits[i], Cout = g.Cout[i], C = g.C[i], KH = g.KH[i], KW = g.KW[i];
-  const long long KC = (long long)KH * KW * C * Cout, elems = KC + Cout;
-  const long long e = (long long)((int)blockIdx.x - g.first_block[i]) * 64 + lane;
-  float acc[8];
+  const long long KC = (long long)KH * KW * C * Cout, elems = KC + Cout;   // (a multiple of 4: Cout % 32 == 0)
+  const long long e = ((long long)((int)blockIdx.x - g.first_block[i]) * 64 + lane) * 4;
+  f32x4 acc[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (e < elems) {
     for (int s0 = wave; s0 < splits; s0 += 16 * 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int sl = s0 + 16 * u;
-        if (sl < splits) acc[u] += partial[(long long)sl * elems + e];
+        if (sl < splits) acc[u] += *reinterpret_cast<const f32x4 *>(partial + (long long)sl * elems + e);
       }
     }
   }
   red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (wave == 0 && e < elems) {
-    float t = 0.f;
+    f32x4 t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += red[w][lane];
-    if (e < KC) {
-      const int co = (int)(e % Cout), k = (int)(e / Cout);
-      const int c = k % C, kx = (k / C) % KW, ky = k / (C * KW);
-      g.dw[i][(((long long)co * C + c) * KH + ky) * KW + kx] = t;
-    } else {
-      g.db[i][e - KC] = t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long eq = e + q;
+      if (eq < KC) {
+        const int co = (int)(eq % Cout), k = (int)(eq / Cout);
+        const int c = k % C, kx = (k / C) % KW, ky = k / (C * KW);
+        g.dw[i][(((long long)co * C + c) * KH + ky) * KW + kx] = t[q];
+      } else {
+        g.db[i][eq - KC] = t[q];
+      }
     }
   }
 }
@@ -960,7 +966,8 @@ extern "C" int etm_conv_wgrad_reduce_grouped(const float *const *partial, const 
     g.partial[i] = partial[i]; g.dw[i] = dw[i]; g.db[i] = db[i]; g.splits[i] = slices[i];
     g.Cout[i] = Cout[i]; g.C[i] = C[i]; g.KH[i] = KH[i]; g.KW[i] = KW[i];
     g.first_block[i] = blocks;
-    blocks += (int)(((long long)KH[i] * KW[i] * C[i] * Cout[i] + Cout[i] + 63) / 64);
+    if (Cout[i] % 4 != 0 || ((uintptr_t)partial[i] % 16) != 0) return ETM_EUNSUPPORTED;      // 16-byte loads of four consecutive elements
+    blocks += (int)(((long long)KH[i] * KW[i] * C[i] * Cout[i] + Cout[i] + 255) / 256);
   }
   g.first_block[n] = blocks;
   g.n = n;
