@@ -566,7 +566,7 @@ def main():
             kind, work = kernel_work(dom, N, L, D, H)
             if kind == "mfma":
                 ach, peak, unit, extra = kernels[dom]["tflops"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", {"flops_per_launch": work, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
-                if dom.startswith("conv_") and etm_ops._encoder_products == "bf16x3":      # its products run on the bf16 pipe: both views
+                if dom.startswith("conv_") and trainer.model.encoder_products == "bf16x3":      # its products run on the bf16 pipe: both views
                     import kernel_rooflines
                     extra.update(kernel_rooflines.b3_fields(work, kernels[dom]["avg_ms"]))
             else:
@@ -632,7 +632,7 @@ def main():
                        "dp_step": (None if dp is None else "one_graph" if getattr(trainer, "_dp_one_graph", False) else "graph_a+allreduce+graph_b"),
                        "numa_pinned_cpus": len(numa_cpus) if numa_cpus else None,
                        "rollout_groups": len(getattr(trainer, "_groups", None) or []) or 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "encoder_products": etm_ops._encoder_products + (" (f32 products as 6 bf16 MFMA products of exactly split operands; error vs float64 below the fp32 MFMA kernels')" if etm_ops._encoder_products == "bf16x3" else ""),
+                       "encoder_products": trainer.model.encoder_products + (" (f32 products as 6 bf16 MFMA products of exactly split operands; error vs float64 below the fp32 MFMA kernels')" if trainer.model.encoder_products == "bf16x3" else ""),
                        "observation_rows": ("direct (host writes into device memory" + (", HDP flush register written)" if etm_ops._direct_mode.get(device.index) == 2 else ")")
                                             if getattr(trainer, "_direct_rows", False) else "pinned + upload"),
                        "worker_processes": bool(cfg.get("worker_processes", False)), "envs_per_process": trainer._host_plan["envs_per_process"] if cfg.get("worker_processes", False) else None,

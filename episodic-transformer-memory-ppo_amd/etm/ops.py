@@ -1131,12 +1131,13 @@ def encoder_train_supported(obs_shape, convs, batch=None):
     return True
 
 
-_encoder_products = "bf16x3"     # "bf16x3": the encoder's products on the bf16 matrix pipe at fp32 accuracy (csrc/conv_b3.hip, round 6);
-#                                    "fp32": v_mfma_f32_32x32x2_f32 (csrc/conv_train.hip and the LDS-resident forms)
+_encoder_products = "bf16x3"     # default of encoder_train for callers that name none: "bf16x3" = the encoder's products on the bf16 matrix
+#                                    pipe at fp32 accuracy (csrc/conv_b3.hip, round 6); "fp32" = v_mfma_f32_32x32x2_f32 (csrc/conv_train.hip and
+#                                    the LDS-resident forms).  The model passes its own ``encoder_products`` with every call.
 
 
 def set_encoder_products(kind):
-    """trainer.py: ``encoder_products`` ("bf16x3" default, "fp32")."""
+    """Default product form of ``encoder_train`` calls that pass none ("bf16x3" / "fp32"); tools use it, the trainer does not."""
     global _encoder_products
     if kind not in ("bf16x3", "fp32"):
         raise ValueError(f"encoder_products must be 'bf16x3' or 'fp32', got {kind!r}")
@@ -1168,7 +1169,7 @@ class _EncoderFn(torch.autograd.Function):
     flatten order (model.py:94) and back."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, w1, b1, w2, b2, w3, b3, strides, index=None):
+    def forward(ctx, x_nhwc, w1, b1, w2, b2, w3, b3, strides, index=None, products=None):
         lib = _lib.load()
         _need_dev(x_nhwc, w1, b1, w2, b2, w3, b3)
         x = _f32c(x_nhwc, "obs")
@@ -1186,7 +1187,7 @@ class _EncoderFn(torch.autograd.Function):
         for wt, _, s in layers:
             geo.append((wt.shape[1], hh, ww, wt.shape[0], wt.shape[2], s))
             hh, ww = (hh - wt.shape[2]) // s + 1, (ww - wt.shape[3]) // s + 1
-        use_b3 = _encoder_products == "bf16x3" and all(g in _B3_LAYERS for g in geo) and all(wt.shape[2] == wt.shape[3] for wt in wts)
+        use_b3 = (products or _encoder_products) == "bf16x3" and all(g in _B3_LAYERS for g in geo) and all(wt.shape[2] == wt.shape[3] for wt in wts)
         if use_b3:      # the five operands (three forward, two backward-data) split and packed in ONE launch
             packs = conv_b3_pack(wts + wts[1:], [0, 0, 0, 1, 1], [l[2] for l in layers] + [l[2] for l in layers[1:]])
             dgrad_packs = [None] + packs[3:]
@@ -1288,16 +1289,18 @@ class _EncoderFn(torch.autograd.Function):
         if deferred:
             col.conv_wgrads.extend(deferred)
             col.written.update(ctx.param_ptrs)
-        return (None, *grads, None, None)
+        return (None, *grads, None, None, None)
 
 
-def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None):
+def encoder_train(obs_nhwc, conv1, conv2, conv3, index=None, products=None):
     """Differentiable encoder forward on an NHWC observation batch [N, H, W, C] -- or, with ``index`` (int64 [n]), on the images
     ``obs_nhwc[index]`` without gathering them first: features [N, Ho * Wo * Cout], NHWC-flattened
     (``linear_relu_nhwc`` is the following linear layer on that column order).  Gradients flow to the
     convolution weights and biases (observations need none)."""
+    if products not in (None, "bf16x3", "fp32"):
+        raise ValueError(f"products must be 'bf16x3' or 'fp32', got {products!r}")
     return _EncoderFn.apply(obs_nhwc, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias,
-                            (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index)
+                            (conv1.stride[0], conv2.stride[0], conv3.stride[0]), index, products)
 
 
 class ReplayAfterWarmup:

@@ -36,6 +36,11 @@ class ActorCriticModel(nn.Module):
         self.channels_last = True          # visual observations are kept NHWC for the optimisation phase (trainer._observations_channels_last)
         self.fused_encoder = bool(config.get("fused_rollout_encoder", True))
         self.train_encoder = bool(config.get("fused_train_encoder", True))     # False: library convolutions in the optimisation phase
+        # round 6: "bf16x3" = the encoder's fp32 products as six bf16 MFMA products of exactly split operands (csrc/conv_b3*.hip; error
+        # against float64 below the fp32-MFMA kernels'), "fp32" = the fp32-MFMA kernels of rounds 2 - 3.  Per model, handed to every call.
+        self.encoder_products = str(config.get("encoder_products", "bf16x3"))
+        if self.encoder_products not in ("bf16x3", "fp32"):
+            raise ValueError(f"encoder_products must be 'bf16x3' or 'fp32', got {self.encoder_products!r}")
         self.fused_rollout_block = bool(config.get("fused_rollout_block", True))   # False: one launch per GEMM / LayerNorm / attention
         # round 5: GRU-gated layouts -- the step kernel of a worker GROUP (csrc/rollout_group.hip: workers as the rows of every product,
         # every matrix read once per group and step); False keeps the per-worker teams of csrc/rollout_fused.hip
@@ -305,7 +310,7 @@ class ActorCriticModel(nn.Module):
                     self._train_encoder_ok = ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3))
                 if self._train_encoder_ok and ops.encoder_train_supported(self.observation_space_shape, (self.conv1, self.conv2, self.conv3),
                                                                             batch=int(obs.index.numel())):
-                    feats = ops.encoder_train(obs.bank, self.conv1, self.conv2, self.conv3, index=obs.index)
+                    feats = ops.encoder_train(obs.bank, self.conv1, self.conv2, self.conv3, index=obs.index, products=self.encoder_products)
                     if getattr(self, "_keep_encoder_features", False):      # data-parallel overlap: the backward pass is cut here
                         self._encoder_features = feats                      # (trainer._train_body_a1; released by _train_body_a2)
                     return ops.linear_relu_nhwc(feats, self.lin_hidden.weight, self.lin_hidden.bias, self.conv3.out_channels)
@@ -324,7 +329,7 @@ class ActorCriticModel(nn.Module):
                                                                         batch=int(obs.shape[0])):
                 # optimisation phase: the three relu(conv2d) layers forward and backward on the hand-written MFMA kernels
                 # (NHWC activations; the trainer hands over an NCHW view of NHWC memory, which permutes back for free)
-                feats = ops.encoder_train(obs.permute(0, 2, 3, 1), self.conv1, self.conv2, self.conv3)      # (h, w, c) flatten order
+                feats = ops.encoder_train(obs.permute(0, 2, 3, 1), self.conv1, self.conv2, self.conv3, products=self.encoder_products)      # (h, w, c) flatten order
                 return ops.linear_relu_nhwc(feats, self.lin_hidden.weight, self.lin_hidden.bias, self.conv3.out_channels)
         if self.visual:
             if self.channels_last and h.is_cuda:

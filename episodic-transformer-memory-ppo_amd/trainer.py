@@ -196,7 +196,6 @@ class PPOTrainer(_DataParallelStep, _NativeRolloutDrive, _RunOutputs):
         if self._host_plan["polite_wait"]:
             hostcpu.set_timer_slack_ns(1000)
         self._flag_wait_ema = 0.0
-        ops.set_encoder_products(config.get("encoder_products", "bf16x3"))      # ("fp32": the fp32-MFMA encoder kernels of rounds 2 - 3 -- a tested option)
         ops.set_ln_grad_kernel(config.get("fused_ln_grad", True))      # (true / "outputs": from the window passes' outputs; "rows": round 5's pass over the window rows; false: the generic dX kernel -- tested options)
         # worker_processes (round 4; upstream trainer.py:62-66, worker.py): the environments live in worker PROCESSES over one shared,
         # HIP-registered segment (environments/shm_env.py): they take their actions straight from the device and step concurrently;
