@@ -40,6 +40,8 @@ struct B3Args {
   const float *bias;              // forward
   const float *ymask;             // backward-data: output of the layer below (NULL: no mask, or the bits below)
   const unsigned *bits_in;        // backward-data: its ReLU pattern as written by the forward pass (one bit per element), instead of ymask
+  const unsigned *src_bits;       // backward-data, optional: ReLU pattern of the layer's OWN output -- x is then the gradient of the activation
+                                  // and the pre-activation gradient x * (y > 0) is formed at the fill (no etm_relu_mask launch)
   unsigned *bits_out;             // forward, optional: bit c of word [n][y][x][c / 32] = (y[n, y, x, c] > 0)
   float *out;
   int N, n_groups;
@@ -106,7 +108,7 @@ struct B3Geo {
   static constexpr int HRES = DGRAD ? S * HO : HO;               // result image size
   static constexpr int CRES = DGRAD ? C : COUT;                  // result channels
   static_assert(K % 16 == 0 && NOUT % 32 == 0 && (THREE || CI % 16 == 0) && (NT == 1 || NT == 2 || NT == 4), "layer geometry");
-  static_assert(!DGRAD || (HW % S == 0 && KS % S == 0 && HI + T - 1 == HW / S), "backward-data: class grids tile the input");
+  static_assert(!DGRAD || (HW % S == 0 && KS % S == 0 && HI + T - 1 == HW / S && Q_IMG % 8 == 0), "backward-data: class grids tile the input");
   static_assert(!SWZ || (!DGRAD && CI == 32 && SLOTS % 16 == 0 && IMGB == SLOTS * CPB), "swizzled slots: 64-byte pixels of four chunks");
   static_assert(BAND == 0 || (!DGRAD && G == 1 && HOUT % BAND == 0 && (ROW0 * HI * CI) % 4 == 0 && (HROWS * HI * CI) % 4 == 0), "bands: forward, one unit per group");
 
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + src * (L::Q_IMG * 4) + b0 * (L::Q_ROW0 * 4)), 0, units * L::Q_UNIT * 16, 0x00020000);
   };
   f32x4 fill[NQ];
+  unsigned fbits[DGRAD ? NQ : 1];                          // (backward-data with src_bits: the pattern word of every float4)
   int fdst[NQ];                                            // (the decode costs ~ 20 vector-ALU operations per float4: once, not once per group)
 #pragma unroll
   for (int u = 0; u < NQ; ++u) fdst[u] = fill_dst(u);
@@ -211,6 +214,11 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
       if (tid + u * 256 < G * L::Q_UNIT) {
+        if (DGRAD && p.src_bits) {                          // float4 q = elements 4 q .. 4 q + 3 of the group: bits 4 (q & 7) .. of its word
+          const unsigned nib = fbits[DGRAD ? u : 0] >> (((tid + u * 256) & 7) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fill[u][e] = (nib >> e) & 1u ? fill[u][e] : 0.f;
+        }
         unsigned h0, m0, l0, h1, m1, l1;
         b3_split_pair(fill[u][0], fill[u][1], h0, m0, l0);
         b3_split_pair(fill[u][2], fill[u][3], h1, m1, l1);
@@ -221,15 +229,24 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
       }
     }
   };
-  auto fill_load = [&](int u, __amdgpu_buffer_rsrc_t rx) {
+  // pattern words of a group's images (32 elements per word, the same linear order as the fp32 tensor)
+  auto group_bits_rsrc = [&](int grp) {
+    const bool exists = DGRAD && p.src_bits && grp < p.n_groups;
+    const int n0 = exists ? grp * G : 0;
+    const int images = exists ? min(G, p.N - n0) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)((p.src_bits ? p.src_bits : (const unsigned *)p.x) + (long long)n0 * (L::Q_IMG / 8)), 0,
+                                             images * (L::Q_IMG / 8) * 4, 0x00020000);
+  };
+  auto fill_load = [&](int u, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rbits) {
     fill[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, tid * 16, u * 4096, 0));
+    if (DGRAD && p.src_bits) fbits[DGRAD ? u : 0] = __builtin_amdgcn_raw_buffer_load_b32(rbits, ((tid + u * 256) >> 3) * 4, 0, 0);
   };
 
   int grp = blockIdx.x;
   {
-    const __amdgpu_buffer_rsrc_t rx = group_rsrc(grp);
+    const __amdgpu_buffer_rsrc_t rx = group_rsrc(grp), rxb = group_bits_rsrc(grp);
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) fill_load(u, rx);
+    for (int u = 0; u < NQ; ++u) fill_load(u, rx, rxb);
     fill_to_lds();
   }
   // bias of this lane's channels: accumulator quad j = channels ct * 32 + 8 j + 4 half + (0..3)
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
 
   for (; grp < p.n_groups; grp += gridDim.x) {
     __syncthreads();                                       // the group's planes are in LDS
-    const __amdgpu_buffer_rsrc_t nrx = group_rsrc(grp + gridDim.x);
+    const __amdgpu_buffer_rsrc_t nrx = group_rsrc(grp + gridDim.x), nrxb = group_bits_rsrc(grp + gridDim.x);
     // byte offsets of the lane's results (outside the descriptors for what does not exist: stores dropped, loads return zeros)
     int o[TPW];
     unsigned relu_bits[TPW];
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(256, L::WPC) void conv_b3_kernel(const B3Args p) {
       }
 #pragma unroll
       for (int u = ks * L::LPK; u < (ks + 1) * L::LPK; ++u)
-        if (u < NQ) fill_load(u, nrx);
+        if (u < NQ) fill_load(u, nrx, nrxb);
       __builtin_amdgcn_sched_barrier(0);
     });
 
@@ -473,7 +490,7 @@ extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uin
   if ((uintptr_t)x % 16 || (uintptr_t)y % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)bias % 16) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, nullptr, relu_bits, y, N, 0};
+  B3Args p{x, (const long long *)x_index, w_b3, bias, nullptr, nullptr, nullptr, relu_bits, y, N, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_FWD, ETM_K_CONV_FWD_L1, ETM_K_CONV_FWD_L2, ETM_K_CONV_FWD_L3, KH), st);
   if (C == 3 && H == 84 && KH == 8 && S == 4 && Cout == 32) return launch_b3<false, 3, 84, 8, 4, 32, 1, 10, 2>(p, st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<false, 32, 20, 4, 2, 64, 2, 0, 1, true>(p, st);      // (one padded image per group: 93.5 us; two swizzled ones: 76)
@@ -483,15 +500,16 @@ extern "C" int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uin
 
 // dx = conv_transpose(dy) * (y_below > 0) for layers 2 / 3 (arguments as etm_conv_train_dgrad: C, H, W = the layer INPUT, w_b3 from
 // etm_conv_b3_pack with dgrad = 1).  The ReLU pattern of the layer below: relu_bits (from its etm_conv_b3_fwd) if given, else y_below's
-// values, else none.
-extern "C" int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, const uint32_t *relu_bits, float *dx, int N, int C,
-                                 int H, int W, int Cout, int KH, int KW, int S, void *stream) {
+// values, else none.  dy_relu_bits (optional): the pattern words of this layer's OWN output -- dy is then the gradient of the activation and
+// dy * (y > 0) is formed while the gradient images are filled (the last layer: no etm_relu_mask launch in front of the backward pass).
+extern "C" int etm_conv_b3_dgrad(const float *dy, const uint32_t *dy_relu_bits, const uint16_t *w_b3, const float *y_below, const uint32_t *relu_bits,
+                                 float *dx, int N, int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
   if (!dy || !w_b3 || !dx || N <= 0) return ETM_EINVAL;
-  if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16 || (uintptr_t)relu_bits % 4) return ETM_EINVAL;
+  if ((uintptr_t)dy % 16 || (uintptr_t)dx % 16 || (uintptr_t)w_b3 % 16 || (uintptr_t)y_below % 16 || (uintptr_t)relu_bits % 4 || (uintptr_t)dy_relu_bits % 4) return ETM_EINVAL;
   if (H != W || KH != KW) return ETM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  B3Args p{dy, nullptr, w_b3, nullptr, y_below, relu_bits, nullptr, dx, N, 0};
+  B3Args p{dy, nullptr, w_b3, nullptr, y_below, relu_bits, dy_relu_bits, nullptr, dx, N, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_DGRAD, -1, ETM_K_CONV_DGRAD_L2, ETM_K_CONV_DGRAD_L3, KH), st);
   if (C == 32 && H == 20 && KH == 4 && S == 2 && Cout == 64) return launch_b3<true, 32, 20, 4, 2, 64, 1, 0, 1>(p, st);
   if (C == 64 && H == 9 && KH == 3 && S == 1 && Cout == 64) return launch_b3<true, 64, 9, 3, 1, 64, 3>(p, st);

@@ -28,6 +28,7 @@ struct W3Args {
   const float *x;                 // NHWC layer input
   const long long *img_index;     // optional: image n of the batch = x image img_index[n]
   const float *dy;                // NHWC pre-activation gradient of the layer output
+  const unsigned *dy_bits;        // optional: ReLU pattern words of the layer's output -- dy is then the gradient of the activation, masked at the fill
   float *partial;                 // [gridDim.x][K * COUT + COUT]
   int N, n_groups;
 };
@@ -87,6 +88,7 @@ struct W3Geo {
   static constexpr int NQX = (G * QX + NTH - 1) / NTH, NQD = (G * QD + NTH - 1) / NTH;
   static_assert(K % 64 == 0 && COUT % 32 == 0 && NTH % (COUT / 4) == 0 && (THREE || C % 32 == 0), "layer geometry");
   static_assert(PSPLIT == 1 ? CT == 2 : (CT == 1 && PSPLIT == NW / 2 && KT % 2 == 0), "wave split");
+  static_assert(QD_IMG % 8 == 0 && QD % 8 == 0, "pattern words: 32 elements each");
   static_assert(BAND == 0 || (G == 1 && HOUT % BAND == 0 && (ROW0 * HW * C) % 4 == 0 && (HROWS * HW * C) % 4 == 0 && (PIX * COUT) % 4 == 0), "bands");
   static constexpr int slot(int y, int x) { return S == 2 ? y * HW + (x & 1) * (HW / 2) + (x >> 1) : y * HW + x; }
   // byte offset of k tile kt relative to a window's first element (layers with C % 32 == 0)
@@ -117,19 +119,23 @@ __global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kern
   // 16-column half (lane >> 4) & 1 of a 32-wide tile; the half-wave (lane >> 5) takes pixels 8 .. 15 of a 16-pixel step
   const int prow = (lane & 15) >> 2, cofs = ((lane >> 4) & 1) * 16 + (lane & 3) * 4, p8 = (lane >> 5) * 8;
   const unsigned lds0 = (unsigned)(size_t)lds;
-  unsigned tab[STEPS][2];                                  // input planes: byte address of (step, read)'s pixel window + the lane's columns
+  // input planes: byte address of (step, read)'s pixel window + the lane's columns -- a function of the lane alone, kept as a table behind
+  // the planes ([STEPS][2][64]; 2 x STEPS registers per lane were what pushed the eight-wave forms over 256) and read once per step
+  unsigned *tabl = reinterpret_cast<unsigned *>(lds + L::LDS);
+  if (wave == 0) {
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s)
+    for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int m = 16 * s + p8 + 4 * j + prow;
-      if (m >= L::M) m = 0;                                // (its gradient row is zero; any finite input will do)
-      const int g = m / L::PIX, r = m - g * L::PIX, oy = r / L::HOUT, ox = r - oy * L::HOUT;
-      int b;
-      if (L::THREE) b = g * L::IMGB + ((oy * S * HW + ox * S) * 3) * 2;
-      else b = g * L::IMGB + (S == 2 ? (2 * oy) * HW + ox : (oy * S) * HW + ox * S) * L::CPB + cofs * 2;
-      tab[s][j] = lds0 + (unsigned)b;
-    }
+      for (int j = 0; j < 2; ++j) {
+        int m = 16 * s + p8 + 4 * j + prow;
+        if (m >= L::M) m = 0;                              // (its gradient row is zero; any finite input will do)
+        const int g = m / L::PIX, r = m - g * L::PIX, oy = r / L::HOUT, ox = r - oy * L::HOUT;
+        int b;
+        if (L::THREE) b = g * L::IMGB + ((oy * S * HW + ox * S) * 3) * 2;
+        else b = g * L::IMGB + (S == 2 ? (2 * oy) * HW + ox : (oy * S) * HW + ox * S) * L::CPB + cofs * 2;
+        tabl[(2 * s + j) * 64 + lane] = lds0 + (unsigned)b;
+      }
+  }
   // byte offset of owned k tile i inside a window.  Layer 1 (per lane): its 4 elements start at k0 = 32 kt + cofs = (ky, offset in the
   // window row of 24); the other layers (wave-uniform): (tap, channel half) of the tile
   int koff[KTW];
@@ -170,11 +176,21 @@ __global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kern
     return __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + src * (L::QX_IMG * 4) + b0 * (L::QX_ROW0 * 4)), 0, units * L::QX * 16, 0x00020000);
   };
   f32x4 fx[NQX], fd[NQD];
+  unsigned fdb[NQD];                                       // (with dy_bits: the pattern word of every gradient float4)
   f32x4 bsum{0.f, 0.f, 0.f, 0.f};                           // channels 4 (tid % (COUT / 4)) .. + 3 over this thread's gradient pixels
   auto issue_fill = [&](int grp) {
     const __amdgpu_buffer_rsrc_t rx = unit_rsrc(grp, false), rd = unit_rsrc(grp, true);
 #pragma unroll
     for (int u = 0; u < NQD; ++u) fd[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, tid * 16, u * (NTH * 16), 0));
+    if (p.dy_bits) {                                       // 32 elements per word, the fp32 tensor's linear order
+      const bool exists = grp < p.n_groups;
+      const int u0 = exists ? grp * G : 0, n0 = u0 / L::NB, b0 = u0 - n0 * L::NB;
+      const int units = exists ? min(G, p.N * L::NB - u0) : 0;
+      const __amdgpu_buffer_rsrc_t rdb = __builtin_amdgcn_make_buffer_rsrc((void *)(p.dy_bits + (long long)n0 * (L::QD_IMG / 8) + b0 * (L::QD / 8)), 0,
+                                                                            units * (L::QD / 8) * 4, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < NQD; ++u) fdb[u] = __builtin_amdgcn_raw_buffer_load_b32(rdb, ((tid + u * NTH) >> 3) * 4, 0, 0);
+    }
 #pragma unroll
     for (int u = 0; u < NQX; ++u) fx[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, tid * 16, u * (NTH * 16), 0));
   };
@@ -190,6 +206,11 @@ __global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kern
 #pragma unroll
     for (int u = 0; u < NQD; ++u)
       if (tid + u * NTH < G * L::QD) {
+        if (p.dy_bits) {
+          const unsigned nib = fdb[u] >> (((tid + u * NTH) & 7) * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fd[u][q] = (nib >> q) & 1u ? fd[u][q] : 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) bsum[q] += fd[u][q];
         put(fd[u], d_dst(u), L::DPLANE);
@@ -221,9 +242,10 @@ __global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kern
     // operand of one (step, tile): three planes x two transposing reads
     // (the plane is the instruction's immediate offset; one address addition per read pair, made where it is used: the table is
     // laundered once per group so that the sums are not all hoisted out of the loop into registers)
+    unsigned t0 = 0, t1 = 0;                               // this step's two table entries
     auto read_a = [&](u32x4(&a)[3], auto sc, auto ic) {
-      constexpr int s = decltype(sc)::value, i = decltype(ic)::value;
-      const unsigned a0 = tab[s][0] + (unsigned)koff[i], a1 = tab[s][1] + (unsigned)koff[i];
+      constexpr int i = decltype(ic)::value;
+      const unsigned a0 = t0 + (unsigned)koff[i], a1 = t1 + (unsigned)koff[i];
       w3_for<3>([&](auto plc) {
         constexpr int pl = decltype(plc)::value;
         const u32x2 lo = w3_tr_read<pl * L::XPLANE>(a0), hi = w3_tr_read<pl * L::XPLANE>(a1);
@@ -238,11 +260,11 @@ __global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kern
         b[pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
       });
     };
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) asm volatile("" : "+v"(tab[s][0]), "+v"(tab[s][1]));
+
     w3_for<STEPS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if (L::PSPLIT > 1 && (s % L::PSPLIT) != sp) return;   // (wave-uniform)
+      t0 = tabl[(2 * s) * 64 + lane]; t1 = tabl[(2 * s + 1) * 64 + lane];
       u32x4 bf[CTW][3];
       static_assert(CTW == 1, "one channel tile per wave");
       read_b(bf[0], sc);
@@ -339,7 +361,8 @@ __global__ __launch_bounds__(L::NTH, L::WPC * L::NW / 4) void conv_b3_wgrad_kern
 template <int C, int HW, int KS, int S, int COUT, int G, int BAND, int PSPLIT, int NW, int WPC = 1>
 struct W3 {
   using L = W3Geo<C, HW, KS, S, COUT, G, BAND, PSPLIT, NW, WPC>;
-  static_assert(L::LDS * WPC <= 160 * 1024, "LDS of a CU");
+  static constexpr int LDS_ALL = L::LDS + L::STEPS * 2 * 64 * 4;      // planes + the address table
+  static_assert(LDS_ALL * WPC <= 160 * 1024, "LDS of a CU");
   static int slices(int N) {
     const int groups = (N * L::NB + G - 1) / G;
     return groups < 256 * WPC ? groups : 256 * WPC;
@@ -350,8 +373,8 @@ struct W3 {
     p.n_groups = (p.N * L::NB + G - 1) / G;
     auto kern = conv_b3_wgrad_kernel<L, C, HW, S, COUT>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::LDS); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)slices(p.N)), dim3(L::NTH), L::LDS, st, p);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ALL); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)slices(p.N)), dim3(L::NTH), LDS_ALL, st, p);
     return etm_launch_status();
   }
 };
@@ -382,9 +405,10 @@ extern "C" int etm_conv_b3_wgrad_slices(int N, int C, int H, int W, int Cout, in
 
 // Weight-gradient slices of the three layers of model.py:29-31 on 84 x 84 observations: workspace [slices][K Cout + Cout] (dW in
 // (k, co) order, k = (ky, kx, c); then the column sums of dy), to be summed by etm_conv_wgrad_reduce_grouped.  x / x_index / dy as
-// etm_conv_train_wgrad.  ETM_EUNSUPPORTED for any other geometry.
-extern "C" int etm_conv_b3_wgrad(const float *x, const int64_t *x_index, const float *dy, float *workspace, int64_t workspace_bytes, int N,
-                                 int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
+// etm_conv_train_wgrad; dy_relu_bits (optional): ReLU pattern words of the layer's output (etm_conv_b3_fwd) -- dy is then the gradient of
+// the ACTIVATION and dy * (y > 0) is formed at the fill, bias gradient included.  ETM_EUNSUPPORTED for any other geometry.
+extern "C" int etm_conv_b3_wgrad(const float *x, const int64_t *x_index, const float *dy, const uint32_t *dy_relu_bits, float *workspace,
+                                 int64_t workspace_bytes, int N, int C, int H, int W, int Cout, int KH, int KW, int S, void *stream) {
   (void)hipGetLastError();
   if (!x || !dy || !workspace || N <= 0) return ETM_EINVAL;
   if ((uintptr_t)x % 16 || (uintptr_t)dy % 16 || (uintptr_t)workspace % 16) return ETM_EINVAL;
@@ -393,7 +417,7 @@ extern "C" int etm_conv_b3_wgrad(const float *x, const int64_t *x_index, const f
   const int slices = etm_conv_b3_wgrad_slices(N, C, H, W, Cout, KH, KW, S);
   if (workspace_bytes < (int64_t)slices * ((int64_t)KH * KW * C * Cout + Cout) * (int64_t)sizeof(float)) return ETM_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  W3Args p{x, (const long long *)x_index, dy, workspace, N, 0};
+  W3Args p{x, (const long long *)x_index, dy, dy_relu_bits, workspace, N, 0};
   EtmProfScope prof(etm_conv_layer_kid(ETM_K_CONV_TRAIN_WGRAD, ETM_K_CONV_WGRAD_L1, ETM_K_CONV_WGRAD_L2, ETM_K_CONV_WGRAD_L3, KH), st);
   switch (layer) {
     case 1: return W3L1::launch(p, st);

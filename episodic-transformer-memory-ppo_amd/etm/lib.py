@@ -108,9 +108,9 @@ SIGNATURES = {
     "etm_relu_mask": (_I, [_P, _P, _P, _L, _P]),
     "etm_conv_b3_pack": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "etm_conv_b3_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "etm_conv_b3_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_b3_dgrad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_conv_b3_wgrad_slices": (_I, [_I] * 8),
-    "etm_conv_b3_wgrad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "etm_conv_b3_wgrad": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "etm_grouped_dw_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "etm_grouped_dw_max_problems": (_I, []),
     "etm_grouped_dw": (_I, [_P, _P, _P, _P, _I, _I, _P]),

@@ -1207,7 +1207,7 @@ class _EncoderFn(torch.autograd.Function):
             ho, wo = (h - kh) // s + 1, (w - kw) // s + 1
             y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
             if use_b3:
-                bits = torch.empty((n, ho, wo, cout // 32), dtype=torch.int32, device=x.device) if i < 2 else None
+                bits = torch.empty((n, ho, wo, cout // 32), dtype=torch.int32, device=x.device)
                 relu_bits.append(bits)
                 _lib.check(lib.etm_conv_b3_fwd(_ptr(acts[-1]), _ptr(index) if i == 0 else None, _ptr(packs[i]), _ptr(_f32c(bs.detach(), "bias")),
                                                _ptr(y), _ptr(bits), n, c, h, w, cout, kh, kw, s, st), "etm_conv_b3_fwd")
@@ -1220,20 +1220,23 @@ class _EncoderFn(torch.autograd.Function):
         ctx.param_ptrs = tuple(t.data_ptr() for t in (w1, b1, w2, b2, w3, b3))
         ctx.shapes = shapes
         ctx.save_for_backward(acts[0], acts[1], acts[2], acts[3], dgrad_packs[1], dgrad_packs[2], index,
-                              *(relu_bits[:2] if use_b3 else (None, None)))
+                              *(relu_bits if use_b3 else (None, None, None)))
         return acts[3].view(n, -1)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x0, y1, y2, y3, pd2, pd3, index, bits1, bits2 = ctx.saved_tensors
+        x0, y1, y2, y3, pd2, pd3, index, bits1, bits2, bits3 = ctx.saved_tensors
         st = _stream()
         dev = x0.device
         n = y1.shape[0]
         g = _f32c(g, "d_features")
         c3, h3, w3_, cout3, _, _, _, ho3, wo3 = ctx.shapes[2]
-        dy = torch.empty((n, ho3, wo3, cout3), dtype=torch.float32, device=dev)
-        _lib.check(lib.etm_relu_mask(_ptr(g), _ptr(y3), _ptr(dy), dy.numel(), st), "etm_relu_mask")
+        if ctx.b3:      # the last layer's ReLU backward rides in the fills of its two consumers (pattern words of y3 from the forward pass)
+            dy, dy_bits = g, bits3
+        else:
+            dy, dy_bits = torch.empty((n, ho3, wo3, cout3), dtype=torch.float32, device=dev), None
+            _lib.check(lib.etm_relu_mask(_ptr(g), _ptr(y3), _ptr(dy), dy.numel(), st), "etm_relu_mask")
         grads = [None] * 6
         inputs = (x0, y1, y2)
         dgrad_packs = (None, pd2, pd3)
@@ -1262,7 +1265,7 @@ class _EncoderFn(torch.autograd.Function):
                 ws = workspace(nbytes, dev, "conv_wgrad")
                 buf = torch.empty(K * cout + cout, dtype=torch.float32, device=dev)
             if ctx.b3:      # the slices on the bf16 matrix pipe (csrc/conv_b3_wgrad.hip); without a collector their reduction follows at once
-                _lib.check(lib.etm_conv_b3_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(ws), nbytes, n, c, h, w,
+                _lib.check(lib.etm_conv_b3_wgrad(_ptr(inputs[i]), _ptr(index) if i == 0 else None, _ptr(dy), _ptr(dy_bits), _ptr(ws), nbytes, n, c, h, w,
                                                  cout, kh, kw, s, st), "etm_conv_b3_wgrad")
                 if buf is not None:
                     import ctypes
@@ -1280,12 +1283,12 @@ class _EncoderFn(torch.autograd.Function):
             if i > 0:
                 dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
                 if ctx.b3:
-                    _lib.check(lib.etm_conv_b3_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr((None, bits1, bits2)[i]), _ptr(dx), n, c, h, w,
+                    _lib.check(lib.etm_conv_b3_dgrad(_ptr(dy), _ptr(dy_bits), _ptr(dgrad_packs[i]), None, _ptr((None, bits1, bits2)[i]), _ptr(dx), n, c, h, w,
                                                      cout, kh, kw, s, st), "etm_conv_b3_dgrad")
                 else:
                     _lib.check(lib.etm_conv_train_dgrad(_ptr(dy), _ptr(dgrad_packs[i]), _ptr(inputs[i]), _ptr(dx), n, c, h, w, cout, kh, kw, s, st),
                                "etm_conv_train_dgrad")
-                dy = dx
+                dy, dy_bits = dx, None      # (the data gradient comes out masked: a pre-activation gradient)
         if deferred:
             col.conv_wgrads.extend(deferred)
             col.written.update(ctx.param_ptrs)

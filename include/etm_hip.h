@@ -563,15 +563,18 @@ int etm_conv_b3_pack(const float *const *w, uint16_t *const *out, const int *dgr
                      const int *S, int n, void *stream);
 int etm_conv_b3_fwd(const float *x, const int64_t *x_index, const uint16_t *w_b3, const float *bias, float *y, uint32_t *relu_bits, int N,
                     int C, int H, int W, int Cout, int KH, int KW, int S, void *stream);
-int etm_conv_b3_dgrad(const float *dy, const uint16_t *w_b3, const float *y_below, const uint32_t *relu_bits, float *dx, int N, int C,
-                      int H, int W, int Cout, int KH, int KW, int S, void *stream);
+int etm_conv_b3_dgrad(const float *dy, const uint32_t *dy_relu_bits, const uint16_t *w_b3, const float *y_below, const uint32_t *relu_bits,
+                      float *dx, int N, int C, int H, int W, int Cout, int KH, int KW, int S, void *stream);
 /*   etm_conv_b3_wgrad: the weight-gradient slices of one layer (csrc/conv_b3_wgrad.hip: both images NHWC in LDS as bf16 planes, the
  *                      pixel contraction fed by transposing LDS reads): workspace [etm_conv_b3_wgrad_slices(...)][K * Cout + Cout], dW in
  *                      (k, co) order (k = (ky, kx, c)) followed by the column sums of dy -- the layout etm_conv_wgrad_reduce_grouped
- *                      sums.  x / x_index / dy as etm_conv_train_wgrad. */
+ *                      sums.  x / x_index / dy as etm_conv_train_wgrad.
+ *   dy_relu_bits (etm_conv_b3_dgrad, etm_conv_b3_wgrad; optional): the ReLU pattern words of the layer's OWN output.  dy is then the
+ *                      gradient of the ACTIVATION and dy * (y > 0) is formed while the gradient images are filled -- for the last layer
+ *                      this replaces the etm_relu_mask launch in front of the backward pass (and its 77 MB of traffic). */
 int etm_conv_b3_wgrad_slices(int N, int C, int H, int W, int Cout, int KH, int KW, int S);
-int etm_conv_b3_wgrad(const float *x, const int64_t *x_index, const float *dy, float *workspace, int64_t workspace_bytes, int N, int C,
-                      int H, int W, int Cout, int KH, int KW, int S, void *stream);
+int etm_conv_b3_wgrad(const float *x, const int64_t *x_index, const float *dy, const uint32_t *dy_relu_bits, float *workspace,
+                      int64_t workspace_bytes, int N, int C, int H, int W, int Cout, int KH, int KW, int S, void *stream);
 
 /* hipMemcpyAsync(dst, src, bytes, host-to-device) on `stream`: pinned observation rows are streamed into the time-major
  * staging array while the environments still step (trainer.py:190 of the reference uploads per worker, synchronously). */

@@ -2586,15 +2586,27 @@ def test_encoder_passes_on_the_bf16_matrix_pipe_vs_float64(N):
         # ---- backward-data: pattern from the words, from the values, none
         if li:
             dx3, dxv, dxn, dx32 = (torch.full((N, hw, hw, c), float("nan"), device=dev) for _ in range(4))
-            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(dg_p), None, P(bits_of(x)), P(dx3), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad")
-            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(dg_p), P(x), None, P(dxv), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (values)")
-            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(dg_p), None, None, P(dxn), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (no mask)")
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), None, P(dg_p), None, P(bits_of(x)), P(dx3), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad")
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), None, P(dg_p), P(x), None, P(dxv), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (values)")
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), None, P(dg_p), None, None, P(dxn), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (no mask)")
             etm_lib.check(lib.etm_conv_train_dgrad(P(dy), P(ops.conv_pack_dgrad_weights(wt, s)), P(x), P(dx32), N, c, hw, hw, cout, k, k, s, st), "etm_conv_train_dgrad")
             full = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1)
             want = full * (x[sel].double().cpu() > 0)
             e3, e32 = rel(dx3[sel], want), rel(dx32[sel], want)
             assert bool(torch.isfinite(dx3).all()) and e3 <= max(e32, 1e-7) and e3 < 3e-7, (li, "backward-data", e3, e32)
             assert bool((dxv == dx3).all()) and rel(dxn[sel], full) < 3e-7, (li, "backward-data mask forms")
+            # the layer's OWN ReLU backward at the fill: (gradient of the activation, pattern words of y) == the pre-masked gradient, bit for bit
+            gact = torch.randn((N, ho, ho, cout), device=dev)
+            dym = gact * (y3 > 0)
+            dxa, dxb = torch.full_like(dx3, float("nan")), torch.full_like(dx3, float("nan"))
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(dym), None, P(dg_p), None, P(bits_of(x)), P(dxa), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (pre-masked)")
+            etm_lib.check(lib.etm_conv_b3_dgrad(P(gact), P(ybits), P(dg_p), None, P(bits_of(x)), P(dxb), N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_dgrad (dy_relu_bits)")
+            assert bool((dxa == dxb).all()), (li, "backward-data with the layer's own ReLU pattern at the fill")
+            wsa, wsb = torch.full_like(ws_probe := torch.empty(lib.etm_conv_b3_wgrad_slices(N, c, hw, hw, cout, k, k, s) * (k * k * c * cout + cout), device=dev), float("nan")), None
+            wsb = torch.full_like(wsa, float("nan"))
+            etm_lib.check(lib.etm_conv_b3_wgrad(P(x), None, P(dym), None, P(wsa), wsa.numel() * 4, N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_wgrad (pre-masked)")
+            etm_lib.check(lib.etm_conv_b3_wgrad(P(x), None, P(gact), P(ybits), P(wsb), wsb.numel() * 4, N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_wgrad (dy_relu_bits)")
+            assert bool((wsa == wsb).all()), (li, "weight / bias gradient slices with the layer's own ReLU pattern at the fill")
         # ---- weight / bias gradients: slices + the grouped reduction, against the float64 contraction over all images
         K = k * k * c
         slices = lib.etm_conv_b3_wgrad_slices(N, c, hw, hw, cout, k, k, s)
@@ -2603,8 +2615,8 @@ def test_encoder_passes_on_the_bf16_matrix_pipe_vs_float64(N):
         dw3, db3 = torch.full((cout, c, k, k), float("nan"), device=dev), torch.full((cout,), float("nan"), device=dev)
 
         def wgrad(src, idx):
-            assert lib.etm_conv_b3_wgrad(P(src), P(idx), P(dy), P(ws), ws.numel() * 4 - 4, N, c, hw, hw, cout, k, k, s, st) != 0, "a workspace that is too small is refused"
-            etm_lib.check(lib.etm_conv_b3_wgrad(P(src), P(idx), P(dy), P(ws), ws.numel() * 4, N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_wgrad")
+            assert lib.etm_conv_b3_wgrad(P(src), P(idx), P(dy), None, P(ws), ws.numel() * 4 - 4, N, c, hw, hw, cout, k, k, s, st) != 0, "a workspace that is too small is refused"
+            etm_lib.check(lib.etm_conv_b3_wgrad(P(src), P(idx), P(dy), None, P(ws), ws.numel() * 4, N, c, hw, hw, cout, k, k, s, st), "etm_conv_b3_wgrad")
             etm_lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, P(ws)), one(ctypes.c_int32, slices), one(ctypes.c_void_p, P(dw3)),
                                                             one(ctypes.c_void_p, P(db3)), one(ctypes.c_int32, cout), one(ctypes.c_int32, c),
                                                             one(ctypes.c_int32, k), one(ctypes.c_int32, k), 1, st), "etm_conv_wgrad_reduce_grouped")

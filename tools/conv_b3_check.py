@@ -83,9 +83,9 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
         # the ReLU pattern of the layer below as bits (what its forward pass writes): here built from x itself
         xb = ((x > 0).view(N, h, w, c // 32, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
         xbits = torch.where(xb >= 2 ** 31, xb - 2 ** 32, xb).to(torch.int32).contiguous()
-        db3 = lambda: etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), None, P(xbits), P(dxb3), N, c, h, w, cout, k, k, s, st), "b3 dgrad")
+        db3 = lambda: etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), None, P(wd3), None, P(xbits), P(dxb3), N, c, h, w, cout, k, k, s, st), "b3 dgrad")
         dxv = torch.full((N, h, w, c), float("nan"), device=dev)
-        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), P(x), None, P(dxv), N, c, h, w, cout, k, k, s, st), "b3 dgrad by values")
+        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), None, P(wd3), P(x), None, P(dxv), N, c, h, w, cout, k, k, s, st), "b3 dgrad by values")
         d32(); db3(); torch.cuda.synchronize()
         ref = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1) * (x[sel].double().cpu() > 0)
         line = f"conv{li + 1} bwd-data  : err vs float64  fp32 MFMA {rel(dx32[sel], ref):.2e}   bf16x3 {rel(dxb3[sel], ref):.2e}   b3 vs fp32 (all N) {((dxb3 - dx32).norm() / dx32.norm()).item():.2e}"
@@ -94,7 +94,7 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
             line += f"   {t0:6.1f} -> {t1:6.1f} us  ({fl / t1 / 1e6:5.1f} fp32-equivalent TFLOP/s)"
         print(line, flush=True)
         dxn = torch.full((N, h, w, c), float("nan"), device=dev)
-        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), P(wd3), None, None, P(dxn), N, c, h, w, cout, k, k, s, st), "b3 dgrad nomask")
+        etm_lib.check(lib.etm_conv_b3_dgrad(P(dy), None, P(wd3), None, None, P(dxn), N, c, h, w, cout, k, k, s, st), "b3 dgrad nomask")
         refn = F.conv_transpose2d(dy[sel].double().cpu().permute(0, 3, 1, 2), wt.double().cpu(), stride=s).permute(0, 2, 3, 1)
         print(f"conv{li + 1} bwd-data without mask: err vs float64 {rel(dxn[sel], refn):.2e}; pattern from y_below's values identical to the bits form: {bool((dxv == dxb3).all().item())}", flush=True)
     # ---- backward-weight (slices + the grouped reduction, both paths)
@@ -108,7 +108,7 @@ for li, (c, h, w, cout, k, s) in enumerate(layers):
     dw3 = torch.full((cout, c, k, k), float("nan"), device=dev); db3 = torch.full((cout,), float("nan"), device=dev)
     one = lambda ct, v: (ct * 1)(v)
     def wb3(xi=None):
-        etm_lib.check(lib.etm_conv_b3_wgrad(P(x), xi, P(dy), P(ws3), ws3.numel() * 4, N, c, h, w, cout, k, k, s, st), "b3 wgrad")
+        etm_lib.check(lib.etm_conv_b3_wgrad(P(x), xi, P(dy), None, P(ws3), ws3.numel() * 4, N, c, h, w, cout, k, k, s, st), "b3 wgrad")
         etm_lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, P(ws3)), one(ctypes.c_int32, slices), one(ctypes.c_void_p, P(dw3)),
                                                         one(ctypes.c_void_p, P(db3)), one(ctypes.c_int32, cout), one(ctypes.c_int32, c),
                                                         one(ctypes.c_int32, k), one(ctypes.c_int32, k), 1, st), "reduce")

@@ -245,8 +245,8 @@ def encoder(dev, launches=20, N=2048, products=None):
             if b3:
                 etm_lib.check(lib.etm_conv_b3_fwd(P(b["x"]), None, P(b["packed"]), P(b["b"]), P(b["y"]), P(b["ybits"]) if c != 64 else None, N, c, h, w, cout, k, k, s, st), "fwd")
                 if b["pd"] is not None:
-                    etm_lib.check(lib.etm_conv_b3_dgrad(P(b["dy"]), P(b["pd"]), None, P(b["xbits"]), P(b["dx"]), N, c, h, w, cout, k, k, s, st), "dgrad")
-                etm_lib.check(lib.etm_conv_b3_wgrad(P(b["x"]), None, P(b["dy"]), P(b["ws"]), b["nbytes"], N, c, h, w, cout, k, k, s, st), "wgrad")
+                    etm_lib.check(lib.etm_conv_b3_dgrad(P(b["dy"]), None, P(b["pd"]), None, P(b["xbits"]), P(b["dx"]), N, c, h, w, cout, k, k, s, st), "dgrad")
+                etm_lib.check(lib.etm_conv_b3_wgrad(P(b["x"]), None, P(b["dy"]), None, P(b["ws"]), b["nbytes"], N, c, h, w, cout, k, k, s, st), "wgrad")
                 K = k * k * c
                 etm_lib.check(lib.etm_conv_wgrad_reduce_grouped(one(ctypes.c_void_p, P(b["ws"])), one(ctypes.c_int32, b["slices"]), one(ctypes.c_void_p, P(b["dw"])),
                                                                 one(ctypes.c_void_p, b["dw"].data_ptr() + K * cout * 4), one(ctypes.c_int32, cout), one(ctypes.c_int32, c),
