@@ -244,7 +244,7 @@ def compact_line(full, full_path):
     ONE {kernel: [avg_ms, frac]} summary of the micro-benchmarks.  Everything else (per-kernel tables, models, prose) is in
     the side file ``full_path``."""
     line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                 "vs_baseline", "dtype", "data") if k in full}
+                                 "vs_baseline", "dtype", "dtype_note", "data") if k in full}
     cfgf = full["config"]
     line["config"] = dict(_pick(cfgf, ("env_pool", "observation_rows", "minibatch", "parallelism", "attention", "encoder_products", "dp_collective", "dp_step", "rollout_groups", "worker_processes",
                                        "envs_per_process", "cgroup_cpu_quota")), workload=cfgf["workload"][:300])
@@ -608,6 +608,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": ("f32 tensors and results throughout; the encoder's products of the optimisation phase are taken as six bf16 MFMA products of "
+                           "exactly split f32 operands (error vs float64 below the f32 MFMA kernels'; config.encoder_products)"
+                           if getattr(trainer.model, "encoder_products", "fp32") == "bf16x3" else "f32 throughout"),
             "data": "synthetic",
             "config": {"workload": (("BASELINE config (3)/(4)" if CONFIG_NAME == "synthetic_minigrid" else
                                      "shape of BASELINE config (5)" if CONFIG_NAME == "synthetic_mortar_gtrxl" else
