@@ -41,6 +41,36 @@ struct GdParams {
 
 static_assert(sizeof(GdParams) <= 4096, "kernel arguments of one launch");
 
+// Workgroup b runs on XCD b % 8 (the dispatcher deals consecutive workgroups round the eight dies, each with an L2 of its own), and the
+// 9 - 12 tiles of one problem read the SAME two operands: dealt round the dies as they come, every tile pulls its operand columns
+// through its die's L2 by itself (PMC rounds 5 / 6: 397 MB fetched per launch against 226 MB of operands even without any sharing).  So
+// the tiles are renumbered: die x takes the contiguous run [x T / 8, (x + 1) T / 8) of the launch's tiles -- the tiles of a problem sit on
+// one die (two at a run's ends) and walk the sample rows together through its L2.  A bijection for every T (checked on the host for
+// T <= 2000); the few blocks of a die that has one workgroup more than its run has tiles take the tiles left over on other dies.
+__device__ __forceinline__ int gd_tile_of_block(int b, int n_tiles) {
+  const int x = b & 7, slot = b >> 3;
+  const int lo = (int)(((long long)x * n_tiles) >> 3), hi = (int)(((long long)(x + 1) * n_tiles) >> 3);      // this die's run
+  const int full = n_tiles >> 3;
+  const int wgs = full + (x < (n_tiles & 7) ? 1 : 0);        // workgroups the dispatcher gives die x
+  const int run = hi - lo;
+  if (slot < (run < wgs ? run : wgs)) return lo + slot;
+  int k = 0;                                                 // index of this block among the leftover blocks
+  for (int y = 0; y < x; ++y) {
+    const int wy = full + (y < (n_tiles & 7) ? 1 : 0), ry = (int)(((long long)(y + 1) * n_tiles) >> 3) - (int)(((long long)y * n_tiles) >> 3);
+    if (wy > ry) k += wy - ry;
+  }
+  k += slot - run;
+  for (int y = 0; y < 8; ++y) {
+    const int ly = (int)(((long long)y * n_tiles) >> 3), ry = (int)(((long long)(y + 1) * n_tiles) >> 3) - ly;
+    const int wy = full + (y < (n_tiles & 7) ? 1 : 0);
+    if (ry > wy) {
+      if (k < ry - wy) return ly + wy + k;
+      k -= ry - wy;
+    }
+  }
+  return b;                                                  // (not reached: leftover blocks and leftover tiles are equally many)
+}
+
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -68,7 +98,7 @@ __global__ __launch_bounds__(256) void grouped_dw_kernel(const GdParams P) {
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the descriptors below depend on it
   // tile -> problem (uniform; <= GD_MAXP compares on the scalar unit)
-  const int tile = blockIdx.x;
+  const int tile = gd_tile_of_block(blockIdx.x, P.n_tiles);
   int pi = 0;
   for (int q = 1; q < P.n_problems; ++q)
     if (tile >= P.p[q].tile_start) pi = q;
